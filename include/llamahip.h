@@ -1,0 +1,174 @@
+/* llamahip.h -- C ABI of libllamahip.so: the MI355X (gfx950) drop-in for the quantized-LLaMA hot
+ * path of alexrozanski/llama.swift.
+ *
+ * The two entry points the reference's Objective-C++ bridge binds are
+ *     llama_model_load()  Sources/llamaObjCxx/bridge/LlamaPredictOperation.mm:98
+ *     llama_eval()        Sources/llamaObjCxx/bridge/LlamaPredictOperation.mm:510-518
+ * (called from -[LlamaPredictOperation main], .mm:790, :822, :840; model released at :900).
+ * Everything else here is either an accessor the caller needs because the model is now an opaque
+ * handle (vocab, hparams), the host-side text utilities the same caller uses
+ * (Sources/cpp/utils.cpp:275-311 tokenizer, :345-428 sampler), or measurement / debug hooks.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types cross this boundary;
+ *   - return 0 on success, LLAMAHIP_ERR_LOAD (-1000) / LLAMAHIP_ERR_PREDICT (-1001) on failure --
+ *     the values of LlamaErrorCodeFailedToLoadModel / LlamaErrorCodePredictionFailed
+ *     (Sources/llamaObjCxx/headers/LlamaError.h:14-19); a UTF-8 message is written to `err`;
+ *   - calls are synchronous; a handle is used by one thread at a time; distinct handles are
+ *     independent (no process-wide scratch, unlike the reference's static buffer, .mm:532-533);
+ *   - the library never falls back to a CPU path: without a HIP device every compute entry point
+ *     fails with an error.
+ *
+ * Numerics: results are computed with the arithmetic order of the reference's x86 AVX2+FMA+F16C
+ * build, so logits are expected to be bit-identical to that build for the same
+ * `n_threads` (the reference's attention V*P product depends on its thread count,
+ * Sources/cpp/ggml.c:5619-5665 / 5553-5577; `n_threads` selects the same split here).
+ */
+#ifndef LLAMAHIP_H
+#define LLAMAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLAMAHIP_OK            0
+#define LLAMAHIP_ERR_UNKNOWN   (-1)      /* LlamaErrorCodeUnknown            (LlamaError.h:15) */
+#define LLAMAHIP_ERR_LOAD      (-1000)   /* LlamaErrorCodeFailedToLoadModel  (LlamaError.h:17) */
+#define LLAMAHIP_ERR_PREDICT   (-1001)   /* LlamaErrorCodePredictionFailed   (LlamaError.h:18) */
+
+typedef struct llamahip_model llamahip_model;
+
+/* Optional load-time options (pass NULL for defaults).  Not part of the reference surface: these
+ * are the knobs SURVEY.md section 5 "Config / flags" routes through an extended struct so the
+ * Swift API stays unchanged. */
+typedef struct llamahip_opts {
+    int32_t struct_size;   /* sizeof(llamahip_opts) */
+    int32_t device;        /* HIP device ordinal; -1 = current device */
+    int32_t layer_begin;   /* pipeline stage: first layer held by this handle (0) */
+    int32_t layer_end;     /* one past the last layer; -1 = n_layer */
+    int32_t n_parts;       /* 0 = by n_embd as the reference (.mm:33-38; unknown widths -> 1) */
+    int32_t flags;         /* LLAMAHIP_FLAG_* */
+} llamahip_opts;
+
+#define LLAMAHIP_FLAG_NO_GRAPH   1   /* launch decode kernels eagerly instead of via hipGraph */
+#define LLAMAHIP_FLAG_UNFUSED    2   /* use the separate prepare+GEMV kernels for decode */
+#define LLAMAHIP_FLAG_HOST_ONLY  4   /* parse + validate the file and vocab only (no device work): the
+                                        handle serves tokenize / token_text / tensor_bytes / sampler;
+                                        every compute call on it fails with LLAMAHIP_ERR_PREDICT */
+
+/* ---- the drop-in boundary ------------------------------------------------------------------ */
+
+/* Replaces llama_model_load(fname, model, vocab, n_ctx, &error)  (.mm:98).
+ * Parses ggml-model-q4_0.bin[.1 ...] (magic 0x67676d6c, 7 int32 hparams, vocab, tensors; multi-part
+ * shards merged as .mm:312-495), uploads and repacks the weights, allocates the fp32 KV cache
+ * (.mm:290-304) on the device. */
+int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
+                        llamahip_model **out, char *err, size_t err_cap);
+
+/* Replaces llama_eval(model, n_threads, n_past, embd_inp, embd_w, mem_per_token, &error) (.mm:510).
+ * Runs `n_tokens` tokens at context offset `n_past`; writes the n_vocab fp32 logits of the LAST
+ * token to `logits_out` (.mm:724-725).  Fails (PREDICT) if n_past + n_tokens > n_ctx. */
+int llamahip_eval(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                  const int32_t *tokens, int32_t n_tokens, float *logits_out,
+                  char *err, size_t err_cap);
+
+/* Replaces ggml_free(model.ctx)  (.mm:900). */
+void llamahip_model_free(llamahip_model *m);
+
+/* ---- accessors (the reference reads these fields off llama_model / gpt_vocab directly) ------ */
+int32_t llamahip_n_vocab(const llamahip_model *m);
+int32_t llamahip_n_ctx(const llamahip_model *m);
+int32_t llamahip_n_embd(const llamahip_model *m);
+int32_t llamahip_n_head(const llamahip_model *m);
+int32_t llamahip_n_layer(const llamahip_model *m);
+int32_t llamahip_n_ff(const llamahip_model *m);
+int32_t llamahip_n_parts(const llamahip_model *m);
+/* vocab.id_to_token[id] (utils.h:49-55); returns NULL for an id out of range */
+const char *llamahip_token_text(const llamahip_model *m, int32_t id, uint32_t *len);
+
+/* ---- host-side text utilities used by the same caller --------------------------------------- */
+/* llama_tokenize(vocab, text, bos)  (utils.cpp:275-311).  Returns the token count (may exceed cap). */
+int32_t llamahip_tokenize(const llamahip_model *m, const char *text, int32_t bos,
+                          int32_t *out, int32_t cap);
+
+/* Sampler state = std::mt19937 rng(seed) + the last_n_tokens window (.mm:773, :827-829). */
+typedef struct llamahip_sampler llamahip_sampler;
+llamahip_sampler *llamahip_sampler_new(int32_t seed, int32_t repeat_last_n);
+void              llamahip_sampler_free(llamahip_sampler *s);
+void              llamahip_sampler_accept(llamahip_sampler *s, int32_t id);   /* .mm:867-868, 882-883 */
+/* llama_sample_top_p_top_k  (utils.cpp:345-428) */
+int32_t llamahip_sample_top_p_top_k(const llamahip_model *m, llamahip_sampler *s, const float *logits,
+                                    double repeat_penalty, int32_t top_k, double top_p, double temp);
+
+/* ---- extensions -------------------------------------------------------------------------------- */
+
+/* Greedy decode loop kept on the device: step i evaluates one token at n_past + i, takes
+ * argmax(logits) (lowest index on ties -- the harness' definition of "temperature 0", SURVEY.md
+ * fact 8) and feeds it to step i+1 without a host round trip.  out_tokens[i] = token produced by
+ * step i.  If logits_last is non-NULL it receives the final step's logits. */
+int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token,
+                           int32_t n_steps, int32_t *out_tokens, float *logits_last,
+                           char *err, size_t err_cap);
+
+/* llamahip_eval + every token's logits (n_tokens * n_vocab) and, for dump_layer >= 0, that layer's
+ * 17 intermediates in the order documented in DESIGN.md ("debug dump order").  Parity tooling. */
+int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                        const int32_t *tokens, int32_t n_tokens, float *logits_last, float *logits_all,
+                        int32_t dump_layer, float *dump, int64_t dump_cap, int64_t *dump_sizes,
+                        char *err, size_t err_cap);
+
+/* Pipeline-stage evaluation for layer-sharded models (handle loaded with layer_begin/layer_end).
+ * hidden_in / hidden_out are DEVICE pointers to n_tokens * n_embd fp32 (the residual stream that
+ * crosses layers, .mm:563-564, 687-690).  The first stage ignores hidden_in and embeds `tokens`;
+ * the last stage also writes logits (host pointer, may be NULL) . */
+int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                        const int32_t *tokens, int32_t n_tokens,
+                        const void *hidden_in, void *hidden_out, float *logits_out,
+                        char *err, size_t err_cap);
+
+/* Raw fp32 KV rows of layer il, positions [0, n_pos) copied to host (n_pos * n_embd floats each). */
+int llamahip_kv_read(llamahip_model *m, int32_t il, int32_t n_pos, float *out_k, float *out_v,
+                     char *err, size_t err_cap);
+
+/* Copy a weight tensor's merged file-format bytes (Q4_0 blocks or fp32) back to the host:
+ * loader / multi-part merge parity.  Returns the byte count, or -1 for an unknown name. */
+int64_t llamahip_tensor_bytes(llamahip_model *m, const char *name, void *out, int64_t cap);
+
+/* ---- single-op entry points (parity tests and kernel benchmarks; host buffers in/out) ---------- */
+/* y[n][m] = W . quantize_q4_0(x[n])  with W = M rows of K/32 Q4_0 blocks in file layout
+ * (replaces ggml_compute_forward_mul_mat_q4_0_f32, ggml.c:5987-6285). */
+int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const float *x, int32_t N,
+                             float *y, char *err, size_t err_cap);
+/* runtime activation quantizer (ggml.c:456-523): x[k] -> k/32 blocks of 20 bytes */
+int llamahip_op_quantize_row_q4_0(const float *x, int32_t k, void *y, char *err, size_t err_cap);
+
+typedef struct llamahip_gemv_bench {
+    int32_t M, K;            /* shape */
+    int32_t iters;           /* timed launches */
+    float   ms_total;        /* HIP-event time over the timed launches, on the launch stream */
+    double  algo_bytes;      /* M*(K/32)*20 + (K/32)*20 + 4*M  per launch */
+} llamahip_gemv_bench;
+/* Times the decode GEMV kernel on one of the model's resident matrices:
+ * which = 0 fused wq|wk|wv, 1 wo, 2 fused w1|w3, 3 w2, 4 output; layer = layer index (ignored for 4). */
+int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t warmup, int32_t iters,
+                        llamahip_gemv_bench *out, char *err, size_t err_cap);
+
+typedef struct llamahip_stats {
+    int32_t struct_size;
+    int64_t weight_bytes_device;   /* repacked Q4_0 bytes resident in HBM */
+    int64_t kv_bytes_device;
+    int64_t n_evals;
+    double  t_load_ms;             /* the reference measures t_load_us/t_predict_us and drops them (.mm:778,845) */
+    double  t_eval_ms_total;
+} llamahip_stats;
+int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out);
+
+const char *llamahip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAMAHIP_H */

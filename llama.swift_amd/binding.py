@@ -1,0 +1,307 @@
+"""ctypes binding of include/llamahip.h (no torch types cross the boundary)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libllamahip.so")
+INCLUDE = os.path.join(ROOT, "include")
+
+ERR_LOAD, ERR_PREDICT = -1000, -1001
+DUMP_NAMES = [
+    "layer_in", "attn_normed", "q", "k", "v", "q_roped", "kq_softmax", "kqv", "kqv_merged",
+    "wo_out", "ffn_in", "ffn_normed", "w3_out", "w1_out", "silu_mul", "w2_out", "layer_out",
+]
+bench_gemv_names = {0: "wq|wk|wv", 1: "wo", 2: "w1|w3", 3: "w2", 4: "output"}
+
+
+class LlamaHipError(RuntimeError):
+    """Mirrors NSError(domain LlamaErrorDomain, code) (Sources/llamaObjCxx/headers/LlamaError.h:12-19)."""
+
+    domain = "com.alexrozanski.llama.error"
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{self.domain} {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libllamahip.so + tools in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "all"], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libllamahip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    return LIB_PATH
+
+
+_lib = None
+
+
+class _Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("layer_begin", C.c_int32),
+                ("layer_end", C.c_int32), ("n_parts", C.c_int32), ("flags", C.c_int32)]
+
+
+class _GemvBench(C.Structure):
+    _fields_ = [("M", C.c_int32), ("K", C.c_int32), ("iters", C.c_int32), ("ms_total", C.c_float),
+                ("algo_bytes", C.c_double)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("weight_bytes_device", C.c_int64), ("kv_bytes_device", C.c_int64),
+                ("n_evals", C.c_int64), ("t_load_ms", C.c_double), ("t_eval_ms_total", C.c_double)]
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, cp, sz = C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t
+    L.llamahip_version.restype = cp
+    L.llamahip_model_load.argtypes = [cp, i32, C.POINTER(_Opts), C.POINTER(vp), cp, sz]
+    L.llamahip_eval.argtypes = [vp, i32, i32, vp, i32, vp, cp, sz]
+    L.llamahip_model_free.argtypes = [vp]
+    for fn in ("n_vocab", "n_ctx", "n_embd", "n_head", "n_layer", "n_ff", "n_parts"):
+        getattr(L, "llamahip_" + fn).argtypes = [vp]
+        getattr(L, "llamahip_" + fn).restype = i32
+    L.llamahip_token_text.argtypes = [vp, i32, C.POINTER(C.c_uint32)]
+    L.llamahip_token_text.restype = vp
+    L.llamahip_tokenize.argtypes = [vp, cp, i32, vp, i32]
+    L.llamahip_tokenize.restype = i32
+    L.llamahip_sampler_new.argtypes = [i32, i32]
+    L.llamahip_sampler_new.restype = vp
+    L.llamahip_sampler_free.argtypes = [vp]
+    L.llamahip_sampler_accept.argtypes = [vp, i32]
+    L.llamahip_sample_top_p_top_k.argtypes = [vp, vp, vp, C.c_double, i32, C.c_double, C.c_double]
+    L.llamahip_sample_top_p_top_k.restype = i32
+    L.llamahip_decode_greedy.argtypes = [vp, i32, i32, i32, i32, vp, vp, cp, sz]
+    L.llamahip_eval_debug.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, C.c_int64, vp, cp, sz]
+    L.llamahip_eval_stage.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, cp, sz]
+    L.llamahip_kv_read.argtypes = [vp, i32, i32, vp, vp, cp, sz]
+    L.llamahip_tensor_bytes.argtypes = [vp, cp, vp, C.c_int64]
+    L.llamahip_tensor_bytes.restype = C.c_int64
+    L.llamahip_op_mul_mat_q4_0.argtypes = [vp, i32, i32, vp, i32, vp, cp, sz]
+    L.llamahip_op_quantize_row_q4_0.argtypes = [vp, i32, vp, cp, sz]
+    L.llamahip_bench_gemv.argtypes = [vp, i32, i32, i32, i32, C.POINTER(_GemvBench), cp, sz]
+    L.llamahip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    _lib = L
+    return L
+
+
+def version() -> str:
+    return lib().llamahip_version().decode()
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/*.h (used by the CPU-side ABI test)."""
+    names: list[str] = []
+    for h in sorted(os.listdir(INCLUDE)):
+        if not h.endswith(".h"):
+            continue
+        text = open(os.path.join(INCLUDE, h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(llamahip_[a-z0-9_]+|llama_runner_[a-z0-9_]+)\s*\(", text)
+    seen, out = set(), []
+    for n in names:
+        if n not in seen and n not in ("llamahip_opts", "llamahip_model", "llamahip_sampler", "llamahip_stats", "llamahip_gemv_bench"):
+            seen.add(n)
+            out.append(n)
+    return out
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc: int, err) -> None:
+    if rc != 0:
+        raise LlamaHipError(rc, err.value.decode(errors="replace"))
+
+
+class Model:
+    """Opaque model handle (llama_model + gpt_vocab of the reference, .mm:71-88, utils.h:49-55)."""
+
+    def __init__(self, path: str, n_ctx: int = 512, device: int = -1, layer_begin: int = 0,
+                 layer_end: int = -1, n_parts: int = 0, flags: int = 0):
+        L = lib()
+        err = C.create_string_buffer(1024)
+        h = C.c_void_p()
+        opts = _Opts(C.sizeof(_Opts), device, layer_begin, layer_end, n_parts, flags)
+        rc = L.llamahip_model_load(path.encode(), n_ctx, C.byref(opts), C.byref(h), err, len(err))
+        _check(rc, err)
+        self._h = h
+        self.path = path
+        self.n_vocab = L.llamahip_n_vocab(h)
+        self.n_ctx = L.llamahip_n_ctx(h)
+        self.n_embd = L.llamahip_n_embd(h)
+        self.n_head = L.llamahip_n_head(h)
+        self.n_layer = L.llamahip_n_layer(h)
+        self.n_ff = L.llamahip_n_ff(h)
+        self.n_parts = L.llamahip_n_parts(h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().llamahip_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # --- llama_eval ---------------------------------------------------------------------------
+    def eval(self, tokens, n_past: int, n_threads: int = 8) -> np.ndarray:
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        logits = np.empty(self.n_vocab, np.float32)
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_eval(self._h, n_threads, n_past, _ptr(tokens), tokens.size, _ptr(logits), err, len(err))
+        _check(rc, err)
+        return logits
+
+    def eval_debug(self, tokens, n_past: int, n_threads: int = 8, all_logits: bool = True, dump_layer: int = -1) -> dict:
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        N = tokens.size
+        last = np.empty(self.n_vocab, np.float32)
+        allb = np.empty((N, self.n_vocab), np.float32) if all_logits else None
+        dump = sizes = None
+        cap = 0
+        if dump_layer >= 0:
+            T = n_past + N
+            cap = N * (14 * self.n_embd + 3 * self.n_ff) + T * N * self.n_head + 1024
+            dump = np.zeros(cap, np.float32)
+            sizes = np.zeros(len(DUMP_NAMES), np.int64)
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_eval_debug(self._h, n_threads, n_past, _ptr(tokens), N, _ptr(last), _ptr(allb),
+                                       dump_layer, _ptr(dump), cap, _ptr(sizes), err, len(err))
+        _check(rc, err)
+        res = {"logits": last}
+        if all_logits:
+            res["logits_all"] = allb
+        if dump is not None:
+            off = 0
+            for i, name in enumerate(DUMP_NAMES):
+                n = int(sizes[i])
+                res[name] = dump[off:off + n].copy()
+                off += n
+        return res
+
+    def decode_greedy(self, first_token: int, n_past: int, n_steps: int, n_threads: int = 8, want_logits: bool = False):
+        out = np.empty(n_steps, np.int32)
+        logits = np.empty(self.n_vocab, np.float32) if want_logits else None
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_decode_greedy(self._h, n_threads, n_past, int(first_token), n_steps, _ptr(out), _ptr(logits), err, len(err))
+        _check(rc, err)
+        return (out, logits) if want_logits else out
+
+    def kv(self, il: int, n_pos: int):
+        k = np.empty((n_pos, self.n_embd), np.float32)
+        v = np.empty((n_pos, self.n_embd), np.float32)
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_kv_read(self._h, il, n_pos, _ptr(k), _ptr(v), err, len(err))
+        _check(rc, err)
+        return k, v
+
+    def tensor_bytes(self, name: str) -> np.ndarray:
+        n = lib().llamahip_tensor_bytes(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n, np.uint8)
+        if lib().llamahip_tensor_bytes(self._h, name.encode(), _ptr(out), n) != n:
+            raise LlamaHipError(ERR_LOAD, f"failed to read tensor {name}")
+        return out
+
+    # --- vocab / text -------------------------------------------------------------------------
+    def token_text(self, tid: int) -> bytes:
+        ln = C.c_uint32(0)
+        p = lib().llamahip_token_text(self._h, tid, C.byref(ln))
+        if not p:
+            raise IndexError(tid)
+        return C.string_at(p, ln.value)
+
+    def tokenize(self, text: str | bytes, bos: bool = True) -> np.ndarray:
+        raw = text.encode() if isinstance(text, str) else text
+        cap = len(raw) + 2
+        out = np.empty(cap, np.int32)
+        n = lib().llamahip_tokenize(self._h, raw, int(bos), _ptr(out), cap)
+        return out[:n].copy()
+
+    # --- measurement ----------------------------------------------------------------------------
+    def bench_gemv(self, which: int, layer: int = 0, warmup: int = 5, iters: int = 50) -> dict:
+        b = _GemvBench()
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_bench_gemv(self._h, which, layer, warmup, iters, C.byref(b), err, len(err))
+        _check(rc, err)
+        us = b.ms_total * 1e3 / b.iters
+        return {"name": bench_gemv_names[which], "M": b.M, "K": b.K, "iters": b.iters, "us_per_launch": us,
+                "algo_bytes": b.algo_bytes, "GBps": b.algo_bytes / (us * 1e-6) / 1e9}
+
+    def stats(self) -> dict:
+        s = _Stats()
+        lib().llamahip_get_stats(self._h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_ if k != "struct_size"}
+
+
+class Sampler:
+    """mt19937 + last_n_tokens window (LlamaPredictOperation.mm:773, 827-829)."""
+
+    def __init__(self, seed: int = -1, repeat_last_n: int = 64):
+        self._s = C.c_void_p(lib().llamahip_sampler_new(seed, repeat_last_n))
+
+    def accept(self, tid: int) -> None:
+        lib().llamahip_sampler_accept(self._s, int(tid))
+
+    def sample(self, model: Model, logits: np.ndarray, repeat_penalty: float = 1.3, top_k: int = 40,
+               top_p: float = float(np.float32(0.95)), temp: float = float(np.float32(0.8))) -> int:
+        logits = np.ascontiguousarray(logits, np.float32)
+        return int(lib().llamahip_sample_top_p_top_k(model._h, self._s, _ptr(logits), repeat_penalty, top_k, top_p, temp))
+
+    def __del__(self):
+        try:
+            if self._s:
+                lib().llamahip_sampler_free(self._s)
+                self._s = None
+        except Exception:
+            pass
+
+
+def op_mul_mat_q4_0(wq: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """wq uint8 [M, K/32, 20] (file layout), x f32 [N, K] -> f32 [N, M] on the GPU."""
+    wq = np.ascontiguousarray(wq, np.uint8)
+    M, nb, _ = wq.shape
+    K = nb * 32
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, K)
+    N = x.shape[0]
+    y = np.empty((N, M), np.float32)
+    err = C.create_string_buffer(1024)
+    rc = lib().llamahip_op_mul_mat_q4_0(_ptr(wq), M, K, _ptr(x), N, _ptr(y), err, len(err))
+    _check(rc, err)
+    return y
+
+
+def op_quantize_row_q4_0(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    out = np.empty(x.size // 32 * 20, np.uint8)
+    err = C.create_string_buffer(1024)
+    rc = lib().llamahip_op_quantize_row_q4_0(_ptr(x), x.size, _ptr(out), err, len(err))
+    _check(rc, err)
+    return out

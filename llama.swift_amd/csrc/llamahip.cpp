@@ -1,0 +1,767 @@
+// llamahip.cpp -- C ABI of libllamahip.so (include/llamahip.h): loader, device residency, forward
+// pass schedule.  Replaces llama_model_load / llama_eval of the reference bridge
+// (Sources/llamaObjCxx/bridge/LlamaPredictOperation.mm:98-498, 510-735).  There is no CPU
+// fallback: every compute entry point needs a HIP device and fails loudly without one.
+#include "../../include/llamahip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "llamahip_internal.h"
+#include "model_file.h"
+
+using namespace lh;
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+void set_err(char *err, size_t cap, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+void set_err(char *err, size_t cap, const char *fmt, ...) {
+    if (!err || !cap) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, cap, fmt, ap);
+    va_end(ap);
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+#define HIP_TRY(expr, code)                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            set_err(err, err_cap, "HIP error: %s (%s) at %s:%d", hipGetErrorString(e_), #expr, __FILE__, __LINE__); \
+            return (code);                                                                           \
+        }                                                                                            \
+    } while (0)
+
+struct Layer {
+    float *attention_norm = nullptr, *ffn_norm = nullptr;   // fp32 [d]
+    QMat qkv;    // rows [wq; wk; wv]  (3d x d)
+    QMat wo;     // d x d
+    QMat w13;    // rows [w1; w3]      (2F x d)
+    QMat w2;     // d x F
+};
+
+// fp16 lookup tables, built on the host with the host libm exactly as ggml_init does
+// (ggml.c:2376-2389): silu(x) = x/(1+exp(-x)) in double -> float -> fp16 ; exp(x) likewise.
+uint16_t f32_to_f16_rne(float f) {
+    // portable round-to-nearest-even conversion (same result as F16C _cvtss_sh(x, 0))
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) return (uint16_t) (sign | (ax > 0x7F800000u ? 0x7E00u | ((ax >> 13) & 0x3FFu) : 0x7C00u));   // nan / inf
+    if (ax >= 0x477FF000u) return (uint16_t) (sign | 0x7C00u);            // rounds to inf (>= 65520)
+    if (ax < 0x33000001u) return (uint16_t) sign;                        // rounds to zero (<= 2^-25)
+    int32_t exp = (int32_t) (ax >> 23) - 127;
+    uint32_t mant = (ax & 0x7FFFFFu) | 0x800000u;
+    uint32_t half;
+    if (exp < -14) {                                                      // subnormal half
+        const int shift = -14 - exp + 13;                                 // 14..24
+        const uint32_t rem_mask = (1u << shift) - 1;
+        const uint32_t rem = mant & rem_mask, halfway = 1u << (shift - 1);
+        half = mant >> shift;
+        if (rem > halfway || (rem == halfway && (half & 1))) half++;
+    } else {
+        const uint32_t rem = mant & 0x1FFFu;
+        half = ((uint32_t) (exp + 15) << 10) | ((mant >> 13) & 0x3FFu);
+        if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) half++;      // carry may bump the exponent: still correct
+    }
+    return (uint16_t) (sign | half);
+}
+
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1F, mant = h & 0x3FFu;
+    uint32_t out;
+    if (exp == 0) {
+        if (mant == 0) out = sign;
+        else {
+            int e = -1;
+            uint32_t m = mant;
+            do { e++; m <<= 1; } while (!(m & 0x400u));
+            out = sign | ((uint32_t) (127 - 15 - e) << 23) | ((m & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) {
+        out = sign | 0x7F800000u | (mant << 13);
+    } else {
+        out = sign | ((exp + 112) << 23) | (mant << 13);
+    }
+    float f;
+    memcpy(&f, &out, 4);
+    return f;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// the model handle
+// ------------------------------------------------------------------------------------------------
+struct llamahip_model {
+    ModelFile file;
+    HParams hp;
+    int device = 0;
+    int l0 = 0, l1 = 0;                  // layers [l0, l1) live on this handle
+    bool first_stage = true, last_stage = true;
+    int flags = 0;
+    bool host_only = false;
+    hipStream_t stream = nullptr;
+
+    // weights
+    uint8_t *tok_emb = nullptr;          // file-layout Q4_0 rows (gathered, never streamed)
+    float *norm_w = nullptr;
+    QMat output;
+    std::vector<Layer> layers;           // index il - l0
+
+    // KV cache: fp32 [layer][n_ctx][d] each (.mm:290-304)
+    float *Kc = nullptr, *Vc = nullptr;
+
+    // tables
+    uint16_t *T_silu = nullptr, *T_exp = nullptr;
+    double *sincos = nullptr;            // [n_ctx][dh/2][2]
+
+    // workspace (sized for ws_cap tokens)
+    int ws_cap = 0;
+    int32_t *d_tokens = nullptr;
+    float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *qr = nullptr, *merged = nullptr, *gu = nullptr;
+    float *tmp = nullptr;                // debug: un-fused residual operand
+    float *logits = nullptr;             // [ws_cap][V] (all rows only in debug evals)
+    uint32_t *qa_A = nullptr;
+    float *qa_d = nullptr;
+    float *dbg_y = nullptr, *dbg_p = nullptr, *dbg_kqv = nullptr;
+    int32_t *d_out_tokens = nullptr;     // greedy decode results
+    int out_tokens_cap = 0;
+
+    // stats
+    int64_t weight_bytes = 0, kv_bytes = 0, n_evals = 0;
+    double t_load_ms = 0, t_eval_ms = 0;
+
+    ~llamahip_model();
+};
+
+static void free_dev(void *p) { if (p) (void) hipFree(p); }
+
+llamahip_model::~llamahip_model() {
+    if (host_only) return;
+    (void) hipSetDevice(device);
+    free_dev(tok_emb); free_dev(norm_w); free_dev(output.tiles);
+    for (auto &l : layers) {
+        free_dev(l.attention_norm); free_dev(l.ffn_norm);
+        free_dev(l.qkv.tiles); free_dev(l.wo.tiles); free_dev(l.w13.tiles); free_dev(l.w2.tiles);
+    }
+    free_dev(Kc); free_dev(Vc); free_dev(T_silu); free_dev(T_exp); free_dev(sincos);
+    free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
+    free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
+    free_dev(d_out_tokens);
+    if (stream) (void) hipStreamDestroy(stream);
+}
+
+namespace {
+
+// upload one Q4_0 tensor (file layout) and repack it into rows [row0, row0 + M) of `dst`
+int upload_q4(llamahip_model *m, const std::string &name, QMat &dst, int row0, uint8_t *d_stage, std::vector<uint8_t> &h_stage,
+              char *err, size_t err_cap) {
+    const TensorInfo &t = m->file.tensors.at(name);
+    h_stage.resize((size_t) t.nbytes());
+    std::string e;
+    if (!m->file.read_tensor(name, h_stage.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
+    HIP_TRY(hipMemcpyAsync(d_stage, h_stage.data(), h_stage.size(), hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_LOAD);
+    uint8_t *out = dst.tiles + (size_t) (row0 / 8) * (dst.nchunks + 1) * TILE_BYTES;
+    HIP_TRY(launch_repack(d_stage, out, (int) t.ne1, (int) t.ne0, m->stream), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_LOAD);      // h_stage / d_stage are reused
+    return 0;
+}
+
+int alloc_qmat(QMat &q, int M, int K, llamahip_model *m, char *err, size_t err_cap) {
+    q.M = M; q.K = K;
+    q.ngroups = (M + 7) / 8;
+    q.nchunks = (K + 255) / 256;
+    HIP_TRY(hipMalloc((void **) &q.tiles, q.bytes()), LLAMAHIP_ERR_LOAD);
+    m->weight_bytes += (int64_t) q.bytes();
+    return 0;
+}
+
+int upload_f32(llamahip_model *m, const std::string &name, float **dst, char *err, size_t err_cap) {
+    const TensorInfo &t = m->file.tensors.at(name);
+    std::vector<uint8_t> h((size_t) t.nbytes());
+    std::string e;
+    if (!m->file.read_tensor(name, h.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
+    HIP_TRY(hipMalloc((void **) dst, h.size()), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipMemcpy(*dst, h.data(), h.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+    return 0;
+}
+
+int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
+    if (N <= m->ws_cap) return 0;
+    const HParams &hp = m->hp;
+    const size_t d = hp.n_embd, F = hp.n_ff, V = hp.n_vocab, C = hp.n_ctx, H = hp.n_head;
+    const size_t KpMax = ((std::max(d, F) + 255) / 256) * 256;
+    float **bufs[] = { &m->x, &m->x1, &m->qkv, &m->qr, &m->merged, &m->gu, &m->tmp, &m->logits, &m->qa_d, &m->dbg_y, &m->dbg_p, &m->dbg_kqv };
+    for (auto b : bufs) { free_dev(*b); *b = nullptr; }
+    free_dev(m->qa_A); m->qa_A = nullptr;
+    free_dev(m->d_tokens); m->d_tokens = nullptr;
+    m->ws_cap = 0;
+    const size_t n = (size_t) N;
+    HIP_TRY(hipMalloc((void **) &m->d_tokens, n * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->x, n * d * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->x1, n * d * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->qkv, n * 3 * d * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->qr, n * d * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->merged, n * d * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->gu, n * 2 * F * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->tmp, n * std::max(d, F) * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->logits, n * V * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->qa_A, n * KpMax), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->qa_d, n * (KpMax / 32) * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->dbg_y, n * std::max(d, F) * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->dbg_p, H * n * C * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->dbg_kqv, n * d * 4), LLAMAHIP_ERR_PREDICT);
+    m->ws_cap = N;
+    return 0;
+}
+
+struct DumpSink {
+    float *dump = nullptr;
+    int64_t cap = 0, used = 0;
+    int64_t *sizes = nullptr;
+    hipStream_t st = nullptr;
+    bool put(int idx, const float *dev, int64_t count) {
+        if (!dump || !sizes) return true;
+        if (used + count > cap) return true;        // silently truncated, size stays 0
+        if (hipMemcpyAsync(dump + used, dev, (size_t) count * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        sizes[idx] = count;
+        used += count;
+        return true;
+    }
+};
+
+// The forward pass for N tokens at n_past on this handle's layers (.mm:510-735).
+//   hidden_in  : device fp32 [N][d] residual stream from the previous stage (nullptr on the first stage)
+//   want_all   : compute logits for every token (debug) instead of only the last (.mm:724-725)
+int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool tokens_on_device,
+            bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap) {
+    const HParams &hp = m->hp;
+    const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx;
+    const int nth = std::max(1, std::min(n_threads, 64));
+    hipStream_t st = m->stream;
+    (void) tokens_on_device;
+    const bool debug = dump_layer >= 0 && sink;
+    const bool fused = (N == 1) && !debug && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
+
+    if (m->first_stage) {
+        HIP_TRY(launch_embed(m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
+    } else {
+        HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
+    }
+
+    for (int il = m->l0; il < m->l1; il++) {
+        const Layer &L = m->layers[il - m->l0];
+        float *Kl = m->Kc + (size_t) (il - m->l0) * C * d, *Vl = m->Vc + (size_t) (il - m->l0) * C * d;
+        const bool dmp = debug && il == dump_layer;
+
+        if (fused) {
+            // ---- decode: 5 launches per layer, activation prep fused into each GEMV prologue
+            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, L.attention_norm, m->qkv, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, 1, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, 1, d, H, nth, m->T_exp, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.wo, PREP_PLAIN, EPI_RESID, nullptr, nullptr, m->merged, nullptr, m->x1, m->x, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, m->x, m->x1, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            continue;
+        }
+
+        // ---- general path (prompt chunks, debug dumps): prepare -> GEMM per mat-mul
+        if (dmp && !sink->put(0, m->x, (int64_t) N * d)) goto dump_fail;
+        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
+        if (dmp && !sink->put(1, m->dbg_y, (int64_t) N * d)) goto dump_fail;
+        HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
+        if (dmp) {
+            for (int which = 0; which < 3; which++) {           // q, k, v are column slices of qkv[N][3d]
+                HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) d * 4, m->qkv + (size_t) which * d, (size_t) 3 * d * 4, (size_t) d * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
+                if (!sink->put(2 + which, m->tmp, (int64_t) N * d)) goto dump_fail;
+            }
+        }
+        HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);        // .mm:586-611
+        if (dmp && !sink->put(5, m->qr, (int64_t) N * d)) goto dump_fail;
+        HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, dmp ? m->dbg_p : nullptr, dmp ? m->dbg_kqv : nullptr, n_past, N, d, H, nth, m->T_exp, st), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
+        if (dmp) {
+            if (!sink->put(6, m->dbg_p, (int64_t) H * N * (n_past + N))) goto dump_fail;
+            if (!sink->put(7, m->dbg_kqv, (int64_t) N * d)) goto dump_fail;
+            if (!sink->put(8, m->merged, (int64_t) N * d)) goto dump_fail;
+        }
+        HIP_TRY(launch_prep(PREP_PLAIN, m->merged, nullptr, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+        if (dmp) {
+            HIP_TRY(launch_gemm(L.wo, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);      // .mm:649-651
+            if (!sink->put(9, m->tmp, (int64_t) N * d)) goto dump_fail;
+            HIP_TRY(launch_add(m->tmp, m->x, m->x1, (long) N * d, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:654
+            if (!sink->put(10, m->x1, (int64_t) N * d)) goto dump_fail;
+        } else {
+            HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, N, m->x1, d, m->x, d, st), LLAMAHIP_ERR_PREDICT);
+        }
+        HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
+        if (dmp && !sink->put(11, m->dbg_y, (int64_t) N * d)) goto dump_fail;
+        HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, N, m->gu, 2L * F, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);     // .mm:668-675
+        if (dmp) {
+            HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) F * 4, m->gu + F, (size_t) 2 * F * 4, (size_t) F * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
+            if (!sink->put(12, m->tmp, (int64_t) N * F)) goto dump_fail;       // w3 output ("tmp" in the reference)
+            HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) F * 4, m->gu, (size_t) 2 * F * 4, (size_t) F * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
+            if (!sink->put(13, m->tmp, (int64_t) N * F)) goto dump_fail;       // w1 output
+        }
+        HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
+        if (dmp && !sink->put(14, m->dbg_y, (int64_t) N * F)) goto dump_fail;
+        if (dmp) {
+            HIP_TRY(launch_gemm(L.w2, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);      // .mm:682-684
+            if (!sink->put(15, m->tmp, (int64_t) N * d)) goto dump_fail;
+            HIP_TRY(launch_add(m->tmp, m->x1, m->x, (long) N * d, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:687
+            if (!sink->put(16, m->x, (int64_t) N * d)) goto dump_fail;
+        } else {
+            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qa_A, m->qa_d, N, m->x, d, m->x1, d, st), LLAMAHIP_ERR_PREDICT);
+        }
+    }
+
+    if (m->last_stage) {
+        // final norm + lm head (.mm:695-705).  The reference multiplies all N rows and keeps the
+        // last (.mm:724-725); only the last row is computed here unless every row is requested.
+        const int V = hp.n_vocab;
+        if (fused) {
+            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+        } else if (want_all) {
+            HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, N, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
+        } else {
+            HIP_TRY(launch_prep(PREP_NORM, m->x + (size_t) (N - 1) * d, m->norm_w, d, 0, d, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, 1, m->logits + (size_t) (N - 1) * V, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
+        }
+    }
+    return 0;
+
+dump_fail:
+    set_err(err, err_cap, "HIP error while copying debug dump");
+    return LLAMAHIP_ERR_PREDICT;
+}
+
+int check_eval_args(llamahip_model *m, int n_past, const int32_t *tokens, int N, bool need_tokens, char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    if (m->host_only) { set_err(err, err_cap, "model was loaded with LLAMAHIP_FLAG_HOST_ONLY: no device state, cannot evaluate"); return LLAMAHIP_ERR_PREDICT; }
+    if (N < 1) { set_err(err, err_cap, "llamahip_eval: n_tokens must be >= 1 (got %d)", N); return LLAMAHIP_ERR_PREDICT; }
+    if (n_past < 0 || n_past + N > m->hp.n_ctx) {
+        // the reference has no bounds check and writes past its cache (.mm:586-590); refuse instead
+        set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (%d) > n_ctx (%d)", n_past, N, m->hp.n_ctx);
+        return LLAMAHIP_ERR_PREDICT;
+    }
+    if (need_tokens) {
+        if (!tokens) { set_err(err, err_cap, "null tokens"); return LLAMAHIP_ERR_PREDICT; }
+        for (int i = 0; i < N; i++) {
+            if (tokens[i] < 0 || tokens[i] >= m->hp.n_vocab) {
+                set_err(err, err_cap, "token id %d out of range [0, %d)", tokens[i], m->hp.n_vocab);
+                return LLAMAHIP_ERR_PREDICT;
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *llamahip_version(void) { return "llamahip 0.1 (gfx950)"; }
+
+int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
+                        llamahip_model **out, char *err, size_t err_cap) {
+    const double t0 = now_ms();
+    if (!out || !path) { set_err(err, err_cap, "null argument"); return LLAMAHIP_ERR_LOAD; }
+    *out = nullptr;
+    if (n_ctx < 1) { set_err(err, err_cap, "n_ctx must be >= 1"); return LLAMAHIP_ERR_LOAD; }
+    std::unique_ptr<llamahip_model> m(new llamahip_model());
+    int force_parts = 0, layer_begin = 0, layer_end = -1, device = -1;
+    if (opts && opts->struct_size >= (int32_t) sizeof(llamahip_opts)) {
+        force_parts = opts->n_parts; layer_begin = opts->layer_begin; layer_end = opts->layer_end;
+        device = opts->device; m->flags = opts->flags;
+    }
+    std::string e;
+    if (!m->file.open(path, n_ctx, force_parts, e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
+    m->hp = m->file.hp;
+    const HParams &hp = m->hp;
+    const int d = hp.n_embd, F = hp.n_ff, V = hp.n_vocab, H = hp.n_head;
+    if (d % H != 0 || (d / H) % 32 != 0 || 256 % (d / H) != 0) {
+        set_err(err, err_cap, "unsupported head size %d (n_embd %d / n_head %d): must be 32, 64, 128 or 256", H ? d / H : 0, d, H);
+        return LLAMAHIP_ERR_LOAD;
+    }
+    if (F % 8 != 0) { set_err(err, err_cap, "unsupported n_ff %d (must be a multiple of 8)", F); return LLAMAHIP_ERR_LOAD; }
+    if (layer_end < 0) layer_end = hp.n_layer;
+    if (layer_begin < 0 || layer_begin >= layer_end || layer_end > hp.n_layer) {
+        set_err(err, err_cap, "bad layer range [%d, %d) for n_layer %d", layer_begin, layer_end, hp.n_layer);
+        return LLAMAHIP_ERR_LOAD;
+    }
+    m->l0 = layer_begin; m->l1 = layer_end;
+    m->first_stage = (m->l0 == 0);
+    m->last_stage = (m->l1 == hp.n_layer);
+    if (m->flags & LLAMAHIP_FLAG_HOST_ONLY) {
+        m->host_only = true;
+        m->t_load_ms = now_ms() - t0;
+        *out = m.release();
+        return LLAMAHIP_OK;
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_err(err, err_cap, "no HIP device available: libllamahip has no CPU fallback");
+        return LLAMAHIP_ERR_LOAD;
+    }
+    if (device >= 0) HIP_TRY(hipSetDevice(device), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipGetDevice(&m->device), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipStreamCreate(&m->stream), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(init_kernel_attrs(), LLAMAHIP_ERR_LOAD);
+
+    // ---- lookup tables (ggml.c:2376-2389) and the RoPE angle table (ggml.c:7113-7116), host libm
+    {
+        std::vector<uint16_t> ts(1 << 16), te(1 << 16);
+        for (int i = 0; i < (1 << 16); i++) {
+            const float f = f16_to_f32((uint16_t) i);
+            ts[i] = f32_to_f16_rne((float) ((double) f / (1.0 + exp((double) -f))));
+            te[i] = f32_to_f16_rne((float) exp((double) f));
+        }
+        HIP_TRY(hipMalloc((void **) &m->T_silu, ts.size() * 2), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->T_exp, te.size() * 2), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemcpy(m->T_silu, ts.data(), ts.size() * 2, hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemcpy(m->T_exp, te.data(), te.size() * 2, hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+        const int dh = d / H;
+        std::vector<double> sc((size_t) n_ctx * dh);
+        for (int p = 0; p < n_ctx; p++) {
+            for (int i0 = 0; i0 < dh; i0 += 2) {
+                const double theta = pow(10000.0, ((double) -i0) / dh);
+                double sn, cs;
+                sincos(p * theta, &sn, &cs);                  // the reference's -O3 build calls sincos()
+                sc[(size_t) p * dh + i0] = cs;
+                sc[(size_t) p * dh + i0 + 1] = sn;
+            }
+        }
+        HIP_TRY(hipMalloc((void **) &m->sincos, sc.size() * 8), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemcpy(m->sincos, sc.data(), sc.size() * 8, hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+    }
+
+    // ---- weights
+    size_t max_bytes = 0;
+    for (const auto &kv : m->file.tensors) if (kv.second.q4) max_bytes = std::max(max_bytes, (size_t) kv.second.nbytes());
+    uint8_t *d_stage = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_stage, max_bytes), LLAMAHIP_ERR_LOAD);
+    std::vector<uint8_t> h_stage;
+    int rc = 0;
+#define LOAD_TRY(x) do { rc = (x); if (rc != 0) { (void) hipFree(d_stage); return rc; } } while (0)
+
+    if (m->first_stage) {
+        const TensorInfo &t = m->file.tensors.at("tok_embeddings.weight");
+        h_stage.resize((size_t) t.nbytes());
+        if (!m->file.read_tensor(t.name, h_stage.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); (void) hipFree(d_stage); return LLAMAHIP_ERR_LOAD; }
+        HIP_TRY(hipMalloc((void **) &m->tok_emb, h_stage.size()), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemcpy(m->tok_emb, h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+        m->weight_bytes += (int64_t) h_stage.size();
+    }
+    if (m->last_stage) {
+        LOAD_TRY(upload_f32(m.get(), "norm.weight", &m->norm_w, err, err_cap));
+        LOAD_TRY(alloc_qmat(m->output, V, d, m.get(), err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), "output.weight", m->output, 0, d_stage, h_stage, err, err_cap));
+    }
+    m->layers.resize(m->l1 - m->l0);
+    for (int il = m->l0; il < m->l1; il++) {
+        Layer &L = m->layers[il - m->l0];
+        const std::string p = "layers." + std::to_string(il) + ".";
+        LOAD_TRY(upload_f32(m.get(), p + "attention_norm.weight", &L.attention_norm, err, err_cap));
+        LOAD_TRY(upload_f32(m.get(), p + "ffn_norm.weight", &L.ffn_norm, err, err_cap));
+        LOAD_TRY(alloc_qmat(L.qkv, 3 * d, d, m.get(), err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), p + "attention.wq.weight", L.qkv, 0, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), p + "attention.wk.weight", L.qkv, d, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), p + "attention.wv.weight", L.qkv, 2 * d, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(alloc_qmat(L.wo, d, d, m.get(), err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), p + "attention.wo.weight", L.wo, 0, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(alloc_qmat(L.w13, 2 * F, d, m.get(), err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w1.weight", L.w13, 0, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w3.weight", L.w13, F, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(alloc_qmat(L.w2, d, F, m.get(), err, err_cap));
+        LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w2.weight", L.w2, 0, d_stage, h_stage, err, err_cap));
+    }
+#undef LOAD_TRY
+    (void) hipFree(d_stage);
+
+    // ---- KV cache (.mm:290-304); zero-initialised (the reference leaves malloc garbage)
+    const size_t kv_elems = (size_t) (m->l1 - m->l0) * n_ctx * d;
+    HIP_TRY(hipMalloc((void **) &m->Kc, kv_elems * 4), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipMalloc((void **) &m->Vc, kv_elems * 4), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipMemset(m->Kc, 0, kv_elems * 4), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipMemset(m->Vc, 0, kv_elems * 4), LLAMAHIP_ERR_LOAD);
+    m->kv_bytes = (int64_t) kv_elems * 8;
+
+    rc = ensure_workspace(m.get(), 16, err, err_cap);
+    if (rc != 0) return LLAMAHIP_ERR_LOAD;
+    HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_LOAD);
+    m->t_load_ms = now_ms() - t0;
+    *out = m.release();
+    return LLAMAHIP_OK;
+}
+
+void llamahip_model_free(llamahip_model *m) { delete m; }
+
+int32_t llamahip_n_vocab(const llamahip_model *m) { return m ? m->hp.n_vocab : 0; }
+int32_t llamahip_n_ctx(const llamahip_model *m) { return m ? m->hp.n_ctx : 0; }
+int32_t llamahip_n_embd(const llamahip_model *m) { return m ? m->hp.n_embd : 0; }
+int32_t llamahip_n_head(const llamahip_model *m) { return m ? m->hp.n_head : 0; }
+int32_t llamahip_n_layer(const llamahip_model *m) { return m ? m->hp.n_layer : 0; }
+int32_t llamahip_n_ff(const llamahip_model *m) { return m ? m->hp.n_ff : 0; }
+int32_t llamahip_n_parts(const llamahip_model *m) { return m ? m->hp.n_parts : 0; }
+
+const char *llamahip_token_text(const llamahip_model *m, int32_t id, uint32_t *len) {
+    if (!m || id < 0 || id >= (int32_t) m->file.id_to_token.size()) { if (len) *len = 0; return nullptr; }
+    const std::string &s = m->file.id_to_token[id];
+    if (len) *len = (uint32_t) s.size();
+    return s.c_str();
+}
+
+int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                        const int32_t *tokens, int32_t N, float *logits_last, float *logits_all,
+                        int32_t dump_layer, float *dump, int64_t dump_cap, int64_t *dump_sizes,
+                        char *err, size_t err_cap) {
+    int rc = check_eval_args(m, n_past, tokens, N, true, err, err_cap);
+    if (rc) return rc;
+    if (!m->first_stage || !m->last_stage) { set_err(err, err_cap, "llamahip_eval on a pipeline-stage handle: use llamahip_eval_stage"); return LLAMAHIP_ERR_PREDICT; }
+    const double t0 = now_ms();
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    rc = ensure_workspace(m, N, err, err_cap);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    DumpSink sink;
+    if (dump_layer >= 0 && dump && dump_sizes) {
+        sink.dump = dump; sink.cap = dump_cap; sink.sizes = dump_sizes; sink.st = m->stream;
+        for (int i = 0; i < 17; i++) dump_sizes[i] = 0;
+    }
+    const bool want_all = logits_all != nullptr;
+    rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap);
+    if (rc) return rc;
+    const size_t V = m->hp.n_vocab;
+    if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    if (logits_all) HIP_TRY(hipMemcpyAsync(logits_all, m->logits, (size_t) N * V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    m->n_evals++;
+    m->t_eval_ms += now_ms() - t0;
+    return LLAMAHIP_OK;
+}
+
+int llamahip_eval(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                  const int32_t *tokens, int32_t n_tokens, float *logits_out, char *err, size_t err_cap) {
+    return llamahip_eval_debug(m, n_threads, n_past, tokens, n_tokens, logits_out, nullptr, -1, nullptr, 0, nullptr, err, err_cap);
+}
+
+int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                        const int32_t *tokens, int32_t N, const void *hidden_in, void *hidden_out,
+                        float *logits_out, char *err, size_t err_cap) {
+    int rc = check_eval_args(m, n_past, tokens, N, m && m->first_stage, err, err_cap);
+    if (rc) return rc;
+    if (!m->first_stage && !hidden_in) { set_err(err, err_cap, "stage [%d,%d) needs hidden_in", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
+    const double t0 = now_ms();
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    rc = ensure_workspace(m, N, err, err_cap);
+    if (rc) return rc;
+    if (m->first_stage) HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    rc = forward(m, n_threads, n_past, N, (const float *) hidden_in, false, false, -1, nullptr, err, err_cap);
+    if (rc) return rc;
+    const size_t d = m->hp.n_embd, V = m->hp.n_vocab;
+    if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t) N * d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    if (m->last_stage && logits_out) HIP_TRY(hipMemcpyAsync(logits_out, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    m->n_evals++;
+    m->t_eval_ms += now_ms() - t0;
+    return LLAMAHIP_OK;
+}
+
+int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token,
+                           int32_t n_steps, int32_t *out_tokens, float *logits_last, char *err, size_t err_cap) {
+    int rc = check_eval_args(m, n_past, &first_token, 1, true, err, err_cap);
+    if (rc) return rc;
+    if (n_steps < 1 || n_past + n_steps > m->hp.n_ctx) {
+        set_err(err, err_cap, "context overflow: n_past (%d) + n_steps (%d) > n_ctx (%d)", n_past, n_steps, m->hp.n_ctx);
+        return LLAMAHIP_ERR_PREDICT;
+    }
+    if (!m->first_stage || !m->last_stage) { set_err(err, err_cap, "greedy decode needs a whole-model handle"); return LLAMAHIP_ERR_PREDICT; }
+    const double t0 = now_ms();
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    rc = ensure_workspace(m, 1, err, err_cap);
+    if (rc) return rc;
+    if (m->out_tokens_cap < n_steps) {
+        free_dev(m->d_out_tokens); m->d_out_tokens = nullptr; m->out_tokens_cap = 0;
+        HIP_TRY(hipMalloc((void **) &m->d_out_tokens, (size_t) n_steps * 4), LLAMAHIP_ERR_PREDICT);
+        m->out_tokens_cap = n_steps;
+    }
+    HIP_TRY(hipMemcpyAsync(m->d_tokens, &first_token, 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    for (int i = 0; i < n_steps; i++) {
+        rc = forward(m, n_threads, n_past + i, 1, nullptr, true, false, -1, nullptr, err, err_cap);
+        if (rc) return rc;
+        // argmax feeds the next step's token slot on the device: no host round trip
+        HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, i, m->d_tokens, m->stream), LLAMAHIP_ERR_PREDICT);
+    }
+    if (out_tokens) HIP_TRY(hipMemcpyAsync(out_tokens, m->d_out_tokens, (size_t) n_steps * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    m->n_evals += n_steps;
+    m->t_eval_ms += now_ms() - t0;
+    return LLAMAHIP_OK;
+}
+
+int llamahip_kv_read(llamahip_model *m, int32_t il, int32_t n_pos, float *out_k, float *out_v, char *err, size_t err_cap) {
+    if (!m || m->host_only || il < m->l0 || il >= m->l1 || n_pos < 0 || n_pos > m->hp.n_ctx) { set_err(err, err_cap, "bad kv_read arguments"); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    const size_t d = m->hp.n_embd, off = (size_t) (il - m->l0) * m->hp.n_ctx * d;
+    HIP_TRY(hipMemcpy(out_k, m->Kc + off, (size_t) n_pos * d * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMemcpy(out_v, m->Vc + off, (size_t) n_pos * d * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    return LLAMAHIP_OK;
+}
+
+int64_t llamahip_tensor_bytes(llamahip_model *m, const char *name, void *out, int64_t cap) {
+    if (!m || !name) return -1;
+    auto it = m->file.tensors.find(name);
+    if (it == m->file.tensors.end()) return -1;
+    const int64_t n = it->second.nbytes();
+    if (out && cap >= n) {
+        std::string e;
+        if (!m->file.read_tensor(name, (uint8_t *) out, e)) return -1;
+    }
+    return n;
+}
+
+int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out) {
+    if (!m || !out) return LLAMAHIP_ERR_UNKNOWN;
+    out->struct_size = (int32_t) sizeof(*out);
+    out->weight_bytes_device = m->weight_bytes;
+    out->kv_bytes_device = m->kv_bytes;
+    out->n_evals = m->n_evals;
+    out->t_load_ms = m->t_load_ms;
+    out->t_eval_ms_total = m->t_eval_ms;
+    return LLAMAHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-op entry points
+// ------------------------------------------------------------------------------------------------
+static int need_device(char *err, size_t err_cap) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_err(err, err_cap, "no HIP device available: libllamahip has no CPU fallback");
+        return LLAMAHIP_ERR_PREDICT;
+    }
+    return 0;
+}
+
+int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const float *x, int32_t N,
+                             float *y, char *err, size_t err_cap) {
+    if (need_device(err, err_cap)) return LLAMAHIP_ERR_PREDICT;
+    if (!w_q4_0 || !x || !y || M < 1 || N < 1 || K < 64 || K % 64 != 0) { set_err(err, err_cap, "bad mul_mat arguments (K must be a positive multiple of 64)"); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(init_kernel_attrs(), LLAMAHIP_ERR_PREDICT);
+    QMat q;
+    q.M = M; q.K = K; q.ngroups = (M + 7) / 8; q.nchunks = (K + 255) / 256;
+    const size_t wbytes = (size_t) M * (K / 32) * 20, Kp = (size_t) q.nchunks * 256;
+    uint8_t *d_w = nullptr; float *d_x = nullptr, *d_y = nullptr, *d_qd = nullptr; uint32_t *d_qA = nullptr;
+    hipStream_t st = nullptr;
+    int rc = LLAMAHIP_ERR_PREDICT;
+    do {
+        if (hipMalloc((void **) &d_w, wbytes) != hipSuccess) break;
+        if (hipMalloc((void **) &q.tiles, q.bytes()) != hipSuccess) break;
+        if (hipMalloc((void **) &d_x, (size_t) N * K * 4) != hipSuccess) break;
+        if (hipMalloc((void **) &d_y, (size_t) N * M * 4) != hipSuccess) break;
+        if (hipMalloc((void **) &d_qA, (size_t) N * Kp) != hipSuccess) break;
+        if (hipMalloc((void **) &d_qd, (size_t) N * (Kp / 32) * 4) != hipSuccess) break;
+        if (hipStreamCreate(&st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_w, w_q4_0, wbytes, hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_x, x, (size_t) N * K * 4, hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (launch_repack(d_w, q.tiles, M, K, st) != hipSuccess) break;
+        if (launch_prep(PREP_PLAIN, d_x, nullptr, K, 0, K, N, d_qA, d_qd, nullptr, nullptr, nullptr, 0, 0, st) != hipSuccess) break;
+        if (launch_gemm(q, EPI_STORE, d_qA, d_qd, N, d_y, M, nullptr, 0, st) != hipSuccess) break;
+        if (hipMemcpyAsync(y, d_y, (size_t) N * M * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+        if (hipStreamSynchronize(st) != hipSuccess) break;
+        rc = LLAMAHIP_OK;
+    } while (0);
+    if (rc != LLAMAHIP_OK) set_err(err, err_cap, "HIP error in llamahip_op_mul_mat_q4_0: %s", hipGetErrorString(hipGetLastError()));
+    if (st) (void) hipStreamDestroy(st);
+    free_dev(d_w); free_dev(q.tiles); free_dev(d_x); free_dev(d_y); free_dev(d_qA); free_dev(d_qd);
+    return rc;
+}
+
+int llamahip_op_quantize_row_q4_0(const float *x, int32_t k, void *y, char *err, size_t err_cap) {
+    if (need_device(err, err_cap)) return LLAMAHIP_ERR_PREDICT;
+    if (!x || !y || k < 32 || k % 32 != 0) { set_err(err, err_cap, "bad quantize arguments"); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(init_kernel_attrs(), LLAMAHIP_ERR_PREDICT);
+    const size_t Kp = ((size_t) k + 255) / 256 * 256;
+    float *d_x = nullptr, *d_qd = nullptr; uint32_t *d_qA = nullptr; uint8_t *d_raw = nullptr;
+    int rc = LLAMAHIP_ERR_PREDICT;
+    do {
+        if (hipMalloc((void **) &d_x, (size_t) k * 4) != hipSuccess) break;
+        if (hipMalloc((void **) &d_qA, Kp) != hipSuccess) break;
+        if (hipMalloc((void **) &d_qd, (Kp / 32) * 4) != hipSuccess) break;
+        if (hipMalloc((void **) &d_raw, (size_t) (k / 32) * 20) != hipSuccess) break;
+        if (hipMemcpy(d_x, x, (size_t) k * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (launch_prep(PREP_PLAIN, d_x, nullptr, k, 0, k, 1, d_qA, d_qd, nullptr, d_raw, nullptr, 0, 0, nullptr) != hipSuccess) break;
+        if (hipMemcpy(y, d_raw, (size_t) (k / 32) * 20, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = LLAMAHIP_OK;
+    } while (0);
+    if (rc != LLAMAHIP_OK) set_err(err, err_cap, "HIP error in llamahip_op_quantize_row_q4_0: %s", hipGetErrorString(hipGetLastError()));
+    free_dev(d_x); free_dev(d_qA); free_dev(d_qd); free_dev(d_raw);
+    return rc;
+}
+
+int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t warmup, int32_t iters,
+                        llamahip_gemv_bench *out, char *err, size_t err_cap) {
+    if (!m || m->host_only || !out || iters < 1) { set_err(err, err_cap, "bad bench arguments"); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    const QMat *q = nullptr;
+    if (which == 4) { if (m->last_stage) q = &m->output; }
+    else if (layer >= m->l0 && layer < m->l1) {
+        const Layer &L = m->layers[layer - m->l0];
+        q = which == 0 ? &L.qkv : which == 1 ? &L.wo : which == 2 ? &L.w13 : which == 3 ? &L.w2 : nullptr;
+    }
+    if (!q) { set_err(err, err_cap, "no such matrix (which=%d layer=%d)", which, layer); return LLAMAHIP_ERR_PREDICT; }
+    int rc = ensure_workspace(m, 1, err, err_cap);
+    if (rc) return rc;
+    // a deterministic activation row, quantized once; the timed region is the decode GEMV kernel alone
+    std::vector<float> hx(q->K);
+    for (int i = 0; i < q->K; i++) hx[i] = (float) ((i * 2654435761u) >> 8 & 0xFFFF) / 32768.0f - 1.0f;
+    HIP_TRY(hipMemcpyAsync(m->tmp, hx.data(), (size_t) q->K * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(launch_prep(PREP_PLAIN, m->tmp, nullptr, q->K, 0, q->K, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
+    float *yout = m->gu;     // large enough for every matrix except output
+    if (which == 4) yout = m->logits;
+    for (int i = 0; i < warmup; i++)
+        HIP_TRY(launch_gemv(*q, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipEventCreate(&e1), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipEventRecord(e0, m->stream), LLAMAHIP_ERR_PREDICT);
+    for (int i = 0; i < iters; i++)
+        HIP_TRY(launch_gemv(*q, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipEventRecord(e1, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipEventSynchronize(e1), LLAMAHIP_ERR_PREDICT);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1), LLAMAHIP_ERR_PREDICT);
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    out->M = q->M; out->K = q->K; out->iters = iters; out->ms_total = ms;
+    out->algo_bytes = (double) q->M * (q->K / 32) * 20 + (double) (q->K / 32) * 20 + 4.0 * q->M;
+    return LLAMAHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// runner.cpp -- host-side text utilities and the generation driver above the C ABI.
+//
+//   llamahip_tokenize            <- llama_tokenize              Sources/cpp/utils.cpp:275-311
+//   llamahip_sample_top_p_top_k  <- llama_sample_top_p_top_k    Sources/cpp/utils.cpp:345-428
+//   llama_runner_bridge_run      <- -[LlamaPredictOperation main]
+//                                   Sources/llamaObjCxx/bridge/LlamaPredictOperation.mm:768-901
+//
+// The sampler deliberately uses the same standard-library facilities as the reference
+// (std::partial_sort, std::discrete_distribution, std::mt19937): the draw sequence of
+// discrete_distribution is implementation-defined, so parity is pinned against libstdc++.
+#include "../../include/llama_runner.h"
+#include "../../include/llamahip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct llamahip_sampler {
+    std::mt19937 rng;
+    std::vector<int32_t> last_n_tokens;
+};
+
+struct llama_runner_bridge {
+    std::string model_path;
+};
+
+extern "C" {
+
+int32_t llamahip_tokenize(const llamahip_model *m, const char *text_c, int32_t bos, int32_t *out, int32_t cap) {
+    if (!m || !text_c) return 0;
+    const std::string text(text_c);
+    const int32_t n_vocab = llamahip_n_vocab(m);
+    std::vector<int32_t> res;
+    if (bos) res.push_back(1);
+    // longest match at every position; among equally long matches the highest id wins because the
+    // reference walks id_to_token in ascending id order and only skips strictly shorter tokens
+    size_t pos = 0;
+    for (;;) {
+        size_t best_len = 0;
+        int32_t best_id = 0;
+        for (int32_t id = 0; id < n_vocab; id++) {
+            uint32_t len = 0;
+            const char *tok = llamahip_token_text(m, id, &len);
+            if (len < best_len) continue;
+            if (len > text.size() - pos) continue;
+            if (text.compare(pos, len, tok, len) == 0) { best_len = len; best_id = id; }
+        }
+        if (best_len == 0) break;
+        res.push_back(best_id);
+        pos += best_len;
+    }
+    for (size_t i = 0; i < res.size() && (int32_t) i < cap; i++) out[i] = res[i];
+    return (int32_t) res.size();
+}
+
+llamahip_sampler *llamahip_sampler_new(int32_t seed, int32_t repeat_last_n) {
+    llamahip_sampler *s = new llamahip_sampler();
+    s->rng = std::mt19937(seed);                                   // .mm:773 (seed -1 -> 4294967295)
+    s->last_n_tokens.assign(repeat_last_n > 0 ? repeat_last_n : 0, 0);   // .mm:827-829
+    return s;
+}
+
+void llamahip_sampler_free(llamahip_sampler *s) { delete s; }
+
+void llamahip_sampler_accept(llamahip_sampler *s, int32_t id) {
+    if (!s || s->last_n_tokens.empty()) return;
+    s->last_n_tokens.erase(s->last_n_tokens.begin());
+    s->last_n_tokens.push_back(id);
+}
+
+int32_t llamahip_sample_top_p_top_k(const llamahip_model *m, llamahip_sampler *s, const float *logits,
+                                    double repeat_penalty, int32_t top_k, double top_p, double temp) {
+    const int n_logits = llamahip_n_vocab(m);
+    std::vector<std::pair<double, int32_t>> cand;
+    cand.reserve(n_logits);
+    const double scale = 1.0 / temp;
+    for (int i = 0; i < n_logits; i++) {
+        const bool seen = std::find(s->last_n_tokens.begin(), s->last_n_tokens.end(), i) != s->last_n_tokens.end();
+        if (seen) {
+            // CTRL-style repetition penalty: negative scores are multiplied, positive ones divided
+            if (logits[i] < 0.0) cand.emplace_back(logits[i] * scale * repeat_penalty, i);
+            else                 cand.emplace_back(logits[i] * scale / repeat_penalty, i);
+        } else {
+            cand.emplace_back(logits[i] * scale, i);
+        }
+    }
+    std::partial_sort(cand.begin(), cand.begin() + top_k, cand.end(),
+                      [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
+    cand.resize(top_k);
+
+    double maxl = -INFINITY;
+    for (const auto &c : cand) maxl = std::max(maxl, c.first);
+    std::vector<double> probs;
+    probs.reserve(cand.size());
+    double sum = 0.0;
+    for (const auto &c : cand) {
+        const double p = exp(c.first - maxl);
+        probs.push_back(p);
+        sum += p;
+    }
+    for (auto &p : probs) p /= sum;
+
+    if (top_p < 1.0f) {
+        double cumsum = 0.0f;
+        for (int i = 0; i < (int) probs.size(); i++) {
+            cumsum += probs[i];
+            if (cumsum >= top_p) {
+                probs.resize(i + 1);
+                cand.resize(i + 1);
+                break;
+            }
+        }
+        cumsum = 1.0 / cumsum;
+        for (auto &p : probs) p *= cumsum;
+    }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    const int idx = dist(s->rng);
+    return cand[idx].second;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bridge + generation driver
+// ------------------------------------------------------------------------------------------------
+void llama_runner_config_default(llama_runner_config *c) {
+    if (!c) return;
+    c->numberOfThreads = 8;       // LlamaRunner.swift:17
+    c->numberOfTokens = 512;
+    c->reversePrompt = nullptr;
+    c->n_ctx = 0;
+    c->greedy = 0;
+    c->seed = -1;                 // utils.h:16
+}
+
+llama_runner_bridge *llama_runner_bridge_new(const char *model_path) {
+    llama_runner_bridge *b = new llama_runner_bridge();
+    b->model_path = model_path ? model_path : "";
+    return b;
+}
+void llama_runner_bridge_free(llama_runner_bridge *b) { delete b; }
+const char *llama_runner_bridge_model_path(const llama_runner_bridge *b) { return b ? b->model_path.c_str() : nullptr; }
+
+int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, const llama_runner_config *config,
+                                llama_event_handler handler, void *user) {
+    llama_runner_config cfg;
+    llama_runner_config_default(&cfg);
+    if (config) cfg = *config;
+    auto post = [&](llama_event_type t, const char *text, uint32_t len, int32_t code) {
+        if (handler) handler(user, t, text, len, code);
+    };
+    // gpt_params defaults that the bridge does not override (utils.h:15-37)
+    const int32_t repeat_last_n = 64, top_k = 40, n_batch = 8;
+    const double top_p = 0.95f, temp = 0.80f, repeat_penalty = 1.30f;
+    const int32_t n_ctx = cfg.n_ctx > 0 ? cfg.n_ctx : 512;                          // .mm:790
+    const int32_t n_threads = (int32_t) cfg.numberOfThreads;
+    std::string prompt = prompt_c ? prompt_c : "";
+
+    char err[512] = { 0 };
+    post(LLAMA_EVENT_STARTED_LOADING_MODEL, nullptr, 0, 0);                         // .mm:785
+    llamahip_model *model = nullptr;
+    int rc = llamahip_model_load(b->model_path.c_str(), n_ctx, nullptr, &model, err, sizeof(err));
+    if (rc != 0) {                                                                  // .mm:790-793
+        post(LLAMA_EVENT_FAILED, err, (uint32_t) strlen(err), LLAMAHIP_ERR_LOAD);
+        return LLAMAHIP_ERR_LOAD;
+    }
+    post(LLAMA_EVENT_FINISHED_LOADING_MODEL, nullptr, 0, 0);                        // .mm:797
+    post(LLAMA_EVENT_STARTED_GENERATING_OUTPUT, nullptr, 0, 0);                     // .mm:800
+
+    const int32_t n_vocab = llamahip_n_vocab(model);
+    std::vector<int32_t> embd_inp(prompt.size() + 2);
+    const int32_t n_inp = llamahip_tokenize(model, prompt.c_str(), 1, embd_inp.data(), (int32_t) embd_inp.size());   // .mm:810
+    embd_inp.resize(n_inp);
+    int32_t n_predict = std::min((int32_t) cfg.numberOfTokens, n_ctx - n_inp);     // .mm:812
+    if (cfg.reversePrompt) {                                                        // .mm:815 (result unused there too)
+        std::vector<int32_t> anti(strlen(cfg.reversePrompt) + 2);
+        (void) llamahip_tokenize(model, cfg.reversePrompt, 0, anti.data(), (int32_t) anti.size());
+    }
+
+    std::vector<float> logits(n_vocab);
+    auto fail = [&](void) {
+        post(LLAMA_EVENT_FAILED, err, (uint32_t) strlen(err), LLAMAHIP_ERR_PREDICT);
+        llamahip_model_free(model);
+        return (int32_t) LLAMAHIP_ERR_PREDICT;
+    };
+    {   // warm-up eval that sizes the reference's scratch buffer (.mm:820-825); kept because it
+        // writes KV rows 0..3 of every layer exactly as the reference does
+        const int32_t warm[4] = { 0, 1, 2, 3 };
+        if (n_ctx >= 4 && llamahip_eval(model, n_threads, 0, warm, 4, logits.data(), err, sizeof(err)) != 0) return fail();
+    }
+
+    llamahip_sampler *sampler = llamahip_sampler_new(cfg.seed, repeat_last_n);
+    std::vector<int32_t> embd;
+    int32_t n_past = 0, remaining = n_predict;
+    size_t consumed = 0;
+    while (remaining > 0) {                                                         // .mm:834
+        if (!embd.empty()) {
+            if (llamahip_eval(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), logits.data(), err, sizeof(err)) != 0) {
+                llamahip_sampler_free(sampler);
+                return fail();
+            }
+        }
+        n_past += (int32_t) embd.size();
+        embd.clear();
+        if (embd_inp.size() <= consumed) {                                          // .mm:851
+            int32_t id;
+            if (cfg.greedy) {
+                id = (int32_t) (std::max_element(logits.begin(), logits.end()) - logits.begin());   // first maximum = lowest index
+            } else {
+                id = llamahip_sample_top_p_top_k(model, sampler, logits.data(), repeat_penalty, top_k, top_p, temp);
+            }
+            llamahip_sampler_accept(sampler, id);
+            embd.push_back(id);
+            --remaining;
+        } else {
+            while (embd_inp.size() > consumed) {                                    // .mm:880-888 (chunks of n_batch + 1)
+                embd.push_back(embd_inp[consumed]);
+                llamahip_sampler_accept(sampler, embd_inp[consumed]);
+                ++consumed;
+                if ((int32_t) embd.size() > n_batch) break;
+            }
+        }
+        for (int32_t id : embd) {                                                   // .mm:892-895
+            uint32_t len = 0;
+            const char *tok = llamahip_token_text(model, id, &len);
+            post(LLAMA_EVENT_OUTPUT_TOKEN, tok, len, 0);
+        }
+    }
+    llamahip_sampler_free(sampler);
+    post(LLAMA_EVENT_COMPLETED, nullptr, 0, 0);                                     // .mm:898
+    llamahip_model_free(model);                                                     // .mm:900
+    return 0;
+}
+
+}  // extern "C"
