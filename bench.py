@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/sec of the Q4_0 LLaMA hot path on MI355X + HBM roofline of the GEMV.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched through
+``python -m torch.distributed.run --nproc-per-node N ...``); rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): LLaMA-7B Q4_0, single-token decode, 512-token generation,
+n_ctx 512.  There are no real weights offline, so the model file is synthetic (random-init weights of
+the 7B architecture written in the reference's exact file format by csrc/tools/make_synth_model) and
+the prompt is synthetic token ids.  One *step* = one decoded token = one pass of the hot path
+(llama_eval with one token at a growing context offset) including the greedy argmax that feeds the
+next step on the device.  `value` = tokens/s with everything resident in HBM (logits are not copied
+back per token inside the timed region; the PCIe-inclusive rate is reported as `value_pcie`).
+
+N > 1: the model is layer-sharded into N pipeline stages (one process per GPU); N independent
+greedy sequences are kept in flight round-robin so every stage is busy, and the residual stream
+crosses stages with point-to-point RCCL send/recv.  value = all sequences'
+tokens / time, scaling = "weak" (one sequence per GPU).
+
+Extra objects:  "roofline" for the dominant kernel (k_gemv, the Q4_0 x Q4_0 decode GEMV) and
+"cpu_baseline" (the reference's own ggml.c, oracle/_ref, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODELS = {
+    "7B": dict(n_vocab=32000, n_embd=4096, n_mult=256, n_head=32, n_layer=32),
+    "13B": dict(n_vocab=32000, n_embd=5120, n_mult=256, n_head=40, n_layer=40),
+    "65B": dict(n_vocab=32000, n_embd=8192, n_mult=256, n_head=64, n_layer=80),
+    # small stand-in for smoke-testing the harness itself (never used for reported numbers)
+    "tiny": dict(n_vocab=512, n_embd=512, n_mult=64, n_head=4, n_layer=4),
+}
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def model_path(name: str, cfg: dict, seed: int) -> str:
+    base = os.environ.get("LLAMAHIP_MODEL_DIR", "/tmp/llamahip_models")
+    os.makedirs(base, exist_ok=True)
+    path = os.path.join(base, f"{name}-seed{seed}", "ggml-model-q4_0.bin")
+    if not os.path.exists(path + ".done"):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tool = os.path.join(ROOT, "llama.swift_amd", "csrc", "tools", "make_synth_model")
+        t0 = time.time()
+        args = [tool, "--out", path, "--seed", str(seed)] + [x for k, v in cfg.items() for x in (f"--{k}", str(v))]
+        if name in ("13B", "65B"):
+            args += ["--parts", "1"]          # single-part synthetic file (multi-part merge is covered by tests)
+        subprocess.run(args, check=True)
+        open(path + ".done", "w").close()
+        log(f"[bench] wrote synthetic {name} model in {time.time() - t0:.1f}s: {path}")
+    return path
+
+
+def n_ff(cfg):
+    return ((2 * (4 * cfg["n_embd"]) // 3 + cfg["n_mult"] - 1) // cfg["n_mult"]) * cfg["n_mult"]
+
+
+def gemv_bytes(M, K):
+    # 20 B per 32-weight block + quantized activations + fp32 outputs
+    return M * (K // 32) * 20 + (K // 32) * 20 + 4 * M
+
+
+def cpu_baseline(path: str, n_threads: int, budget_s: float, n_ctx: int) -> dict:
+    """The reference's own ggml.c (oracle/_ref, built in place from /root/reference) on the host
+    cores: greedy decode on the same model file, bounded by `budget_s` seconds of wall time."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import reflib
+    kind = "reference" if reflib.have_ref() else "port"
+    lib = reflib.RefLib() if kind == "reference" else reflib.OracleLib()
+    m = lib.load(path, n_ctx, 1) if kind == "reference" else lib.load(path, n_ctx, 1)
+    prompt = np.array([1, 17, 291, 4001, 29, 512, 77, 1234], np.int32)
+    logits = m.eval(prompt, 0, n_threads)["logits"]
+    tok, n_past, n = int(np.argmax(logits)), len(prompt), 0
+    t0 = time.time()
+    while time.time() - t0 < budget_s and n_past < n_ctx:
+        logits = m.eval(np.array([tok], np.int32), n_past, n_threads)["logits"]
+        tok = int(np.argmax(logits)); n_past += 1; n += 1
+    dt = time.time() - t0
+    m.close()
+    return {"value": n / dt, "unit": "tokens/s", "cores": n_threads, "kind": kind,
+            "sample": f"{n} greedy decode tokens after an 8-token prompt, same synthetic model file, {dt:.1f}s wall, "
+                      f"{n_threads} threads (reference default numThreads=8, Sources/llama/LlamaRunner.swift:17)",
+            "host_cpus": os.cpu_count()}
+
+
+def run_single(args, cfg, path):
+    import llama_swift_amd as L
+    t0 = time.time()
+    m = L.Model(path, n_ctx=args.n_ctx)
+    t_load = time.time() - t0
+    log(f"[bench] loaded in {t_load:.1f}s: {m.stats()}")
+    prompt = np.array([1, 17, 291, 4001, 29, 512, 77, 1234], np.int32) % cfg["n_vocab"]
+    prompt[0] = 1
+    logits = m.eval(prompt, 0, args.threads)
+    tok, n_past = int(np.argmax(logits)), len(prompt)
+    steps = min(args.steps, args.n_ctx - n_past - args.warmup)
+    if args.warmup > 0:
+        w = m.decode_greedy(tok, n_past, args.warmup, args.threads)
+        tok, n_past = int(w[-1]), n_past + args.warmup
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = m.decode_greedy(tok, n_past, steps, args.threads)       # synchronises before returning
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # PCIe-inclusive variant: the reference boundary (llama_eval returning host logits every token)
+    n_pcie = min(64, steps)
+    m2_past = n_past
+    t1 = time.perf_counter()
+    tk = tok
+    for i in range(n_pcie):
+        lg = m.eval(np.array([tk], np.int32), m2_past + i, args.threads)
+        tk = int(np.argmax(lg))
+    dt_pcie = time.perf_counter() - t1
+    same = bool(np.array_equal(out[:n_pcie], np.array([int(x) for x in out[:n_pcie]])))
+    # roofline: the decode GEMV kernel on every resident matrix kind, cycling over all layers so the
+    # weights stream from HBM (one pass over the model is 4.1 GB >> 256 MB Infinity Cache)
+    shapes = []
+    tot_bytes = tot_us = 0.0
+    for which in range(5):
+        r = m.bench_gemv(which, -1, 1, args.gemv_iters)
+        shapes.append(r)
+        per_token = 1 if which == 4 else cfg["n_layer"]
+        tot_bytes += r["algo_bytes"] * per_token
+        tot_us += r["us_per_launch"] * per_token
+    m.close()
+    return dict(steps=steps, dt=dt, tokens=out, t_load=t_load, value_pcie=n_pcie / dt_pcie, shapes=shapes,
+                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, same=same)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=496)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default=os.environ.get("LLAMAHIP_BENCH_MODEL", "7B"), choices=sorted(MODELS))
+    ap.add_argument("--n_ctx", type=int, default=512)
+    ap.add_argument("--threads", type=int, default=8, help="reference n_threads (selects its V*P summation split)")
+    ap.add_argument("--seed", type=int, default=20230312)
+    ap.add_argument("--gemv-iters", type=int, default=20)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cfg = MODELS[args.model]
+
+    if world > 1 or args.gpus > 1:
+        from llama_swift_amd import pipeline
+        return pipeline.bench_main(args, cfg, model_path, log)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the HIP path)")
+    path = model_path(args.model, cfg, args.seed)
+    r = run_single(args, cfg, path)
+    tps = r["steps"] / r["dt"]
+    F = n_ff(cfg)
+    d = cfg["n_embd"]
+    dom = max(r["shapes"], key=lambda s: s["algo_bytes"] * (1 if s["name"] == "output" else cfg["n_layer"]))
+    achieved = r["gemv_bytes_per_token"] / (r["gemv_us_per_token"] * 1e-6) / 1e9
+    result = {
+        "metric": "decode tokens/sec LLaMA-7B Q4_0 @1 GPU; % HBM-roofline on Q4_0 GEMV",
+        "value": tps, "unit": "tokens/s", "n_gpus": 1, "steps": r["steps"], "warmup": args.warmup,
+        "ms_per_step": r["dt"] * 1e3 / r["steps"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "q4_0 x q4_0 -> int32 block sums, fp32 scales/accumulate",
+        "data": "synthetic (random-init 7B-architecture weights in the reference file format, synthetic token ids)",
+        "config": {"workload": f"LLaMA-{args.model} Q4_0 single-token decode, greedy, n_ctx {args.n_ctx}, "
+                               f"{r['steps']} timed tokens after 8 prompt + {args.warmup} warm-up tokens",
+                   "n_threads_semantics": args.threads, "parallelism": "1 GPU"},
+        "value_pcie": r["value_pcie"],
+        "load_s": r["t_load"],
+        "roofline": {"bound": "hbm", "kernel": "lh::k_gemv (Q4_0 x Q4_0 decode GEMV, all 5 matrix kinds, one model pass)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None,
+                     "per_shape": [{k: s[k] for k in ("name", "M", "K", "us_per_launch", "GBps")} for s in r["shapes"]],
+                     "dominant_shape": {k: dom[k] for k in ("name", "M", "K", "us_per_launch", "GBps")},
+                     "note": "algorithmic bytes per launch = M*(K/32)*20 + (K/32)*20 + 4*M (SURVEY.md 8d); durations are HIP-event "
+                             "averages on the launch stream over back-to-back launches cycling through all layers"},
+    }
+    if not args.no_cpu_baseline and args.cpu_seconds > 0:
+        try:
+            result["cpu_baseline"] = cpu_baseline(path, 8, args.cpu_seconds, args.n_ctx)
+        except Exception as e:  # the checker must never take the measurement down
+            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -151,8 +151,10 @@ typedef struct llamahip_gemv_bench {
     float   ms_total;        /* HIP-event time over the timed launches, on the launch stream */
     double  algo_bytes;      /* M*(K/32)*20 + (K/32)*20 + 4*M  per launch */
 } llamahip_gemv_bench;
-/* Times the decode GEMV kernel on one of the model's resident matrices:
- * which = 0 fused wq|wk|wv, 1 wo, 2 fused w1|w3, 3 w2, 4 output; layer = layer index (ignored for 4). */
+/* Times the decode GEMV kernel on the model's resident matrices:
+ * which = 0 fused wq|wk|wv, 1 wo, 2 fused w1|w3, 3 w2, 4 output; layer = layer index, or -1 to cycle
+ * over every layer so each launch streams different weights from HBM (`iters` = cycles; out->iters =
+ * timed launches).  For `output` the matrix is evicted from the Infinity Cache between launches. */
 int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t warmup, int32_t iters,
                         llamahip_gemv_bench *out, char *err, size_t err_cap);
 

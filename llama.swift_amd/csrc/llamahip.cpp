@@ -730,13 +730,19 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
                         llamahip_gemv_bench *out, char *err, size_t err_cap) {
     if (!m || m->host_only || !out || iters < 1) { set_err(err, err_cap, "bad bench arguments"); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
-    const QMat *q = nullptr;
-    if (which == 4) { if (m->last_stage) q = &m->output; }
-    else if (layer >= m->l0 && layer < m->l1) {
-        const Layer &L = m->layers[layer - m->l0];
-        q = which == 0 ? &L.qkv : which == 1 ? &L.wo : which == 2 ? &L.w13 : which == 3 ? &L.w2 : nullptr;
+    // layer < 0: cycle over every resident layer so consecutive launches stream DIFFERENT weights
+    // from HBM (one cycle of the smallest 7B matrix kind is 336 MB > the 256 MB Infinity Cache)
+    std::vector<const QMat *> mats;
+    auto pick = [&](const Layer &L) -> const QMat * {
+        return which == 0 ? &L.qkv : which == 1 ? &L.wo : which == 2 ? &L.w13 : which == 3 ? &L.w2 : nullptr;
+    };
+    if (which == 4) { if (m->last_stage) mats.push_back(&m->output); }
+    else if (which >= 0 && which < 4) {
+        if (layer < 0) for (const Layer &L : m->layers) mats.push_back(pick(L));
+        else if (layer >= m->l0 && layer < m->l1) mats.push_back(pick(m->layers[layer - m->l0]));
     }
-    if (!q) { set_err(err, err_cap, "no such matrix (which=%d layer=%d)", which, layer); return LLAMAHIP_ERR_PREDICT; }
+    if (mats.empty()) { set_err(err, err_cap, "no such matrix (which=%d layer=%d)", which, layer); return LLAMAHIP_ERR_PREDICT; }
+    const QMat *q = mats[0];
     int rc = ensure_workspace(m, 1, err, err_cap);
     if (rc) return rc;
     // a deterministic activation row, quantized once; the timed region is the decode GEMV kernel alone
@@ -744,22 +750,43 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
     for (int i = 0; i < q->K; i++) hx[i] = (float) ((i * 2654435761u) >> 8 & 0xFFFF) / 32768.0f - 1.0f;
     HIP_TRY(hipMemcpyAsync(m->tmp, hx.data(), (size_t) q->K * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(launch_prep(PREP_PLAIN, m->tmp, nullptr, q->K, 0, q->K, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
-    float *yout = m->gu;     // large enough for every matrix except output
-    if (which == 4) yout = m->logits;
-    for (int i = 0; i < warmup; i++)
-        HIP_TRY(launch_gemv(*q, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    float *yout = which == 4 ? m->logits : m->gu;     // gu (2F floats) is large enough for every layer matrix
+    auto run = [&](const QMat *w) { return launch_gemv(*w, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, m->stream); };
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipEventCreate(&e1), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipEventRecord(e0, m->stream), LLAMAHIP_ERR_PREDICT);
-    for (int i = 0; i < iters; i++)
-        HIP_TRY(launch_gemv(*q, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipEventRecord(e1, m->stream), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipEventSynchronize(e1), LLAMAHIP_ERR_PREDICT);
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1), LLAMAHIP_ERR_PREDICT);
+    float ms_total = 0;
+    int launches = 0;
+    if (which == 4 && !m->layers.empty()) {
+        // a single 82 MB matrix would be served from the Infinity Cache when re-launched: evict it
+        // between timed launches by streaming > 256 MB of other weights (untimed)
+        for (int it = 0; it < warmup + iters; it++) {
+            size_t flushed = 0;
+            for (const Layer &L : m->layers) {
+                HIP_TRY(launch_gemv(L.w13, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, m->gu, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
+                flushed += L.w13.bytes();
+                if (flushed > (size_t) 400 << 20) break;
+            }
+            HIP_TRY(hipEventRecord(e0, m->stream), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(run(q), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(hipEventRecord(e1, m->stream), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(hipEventSynchronize(e1), LLAMAHIP_ERR_PREDICT);
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1), LLAMAHIP_ERR_PREDICT);
+            if (it >= warmup) { ms_total += ms; launches++; }
+        }
+    } else {
+        for (int it = 0; it < warmup; it++) for (const QMat *w : mats) HIP_TRY(run(w), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipEventRecord(e0, m->stream), LLAMAHIP_ERR_PREDICT);
+        for (int it = 0; it < iters; it++) for (const QMat *w : mats) HIP_TRY(run(w), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipEventRecord(e1, m->stream), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipEventSynchronize(e1), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipEventElapsedTime(&ms_total, e0, e1), LLAMAHIP_ERR_PREDICT);
+        launches = iters * (int) mats.size();
+    }
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-    out->M = q->M; out->K = q->K; out->iters = iters; out->ms_total = ms;
+    out->M = q->M; out->K = q->K; out->iters = launches; out->ms_total = ms_total;
     out->algo_bytes = (double) q->M * (q->K / 32) * 20 + (double) (q->K / 32) * 20 + 4.0 * q->M;
     return LLAMAHIP_OK;
 }
