@@ -29,6 +29,7 @@ namespace lh {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef float    f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -38,6 +39,11 @@ __device__ __forceinline__ uint16_t f2h_bits(float f) {          // _cvtss_sh(x,
 }
 __device__ __forceinline__ float h2f_bits(uint16_t h) {          // _cvtsh_ss / table_f32_f16 (ggml.c:161,263-267)
     return __half2float(__ushort_as_half(h));
+}
+
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {           // lane Q of every quad (DPP quad_perm:[Q,Q,Q,Q])
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q | (Q << 2) | (Q << 4) | (Q << 6), 0xF, 0xF, true));
 }
 
 template <int J>
@@ -53,22 +59,64 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     return __hiloint2double(hi, lo);
 }
 
+// DPP lane permutations (VALU-only, a few cycles; __shfl goes through the LDS pipe)
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i within each 8
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i within each 16
+
+// sum over the 64 lanes of a wave (any association order: callers only use it where the order is
+// immaterial, i.e. double accumulation of fp32 data, see DESIGN.md "norm")
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<DPP_QUAD_XOR1>(v);
+    v += dpp_d<DPP_QUAD_XOR2>(v);
+    v += dpp_d<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_d<DPP_ROW_MIRROR>(v);                       // every lane of a 16-lane row holds its row sum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // block-wide sums / max; `red` is LDS scratch of >= 32 doubles.  All threads get the result.
-__device__ double block_sum_d(double v, double *red) {
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+// Successive calls alternate between the two halves of `red`, so one barrier per call suffices
+// (a slot is rewritten only two calls later, after every wave passed the barrier in between).
+__device__ double block_sum_d(double v, double *red, int phase = 0) {
+    v = wave_sum_d(v);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[w] = v;
+    double *r = red + (phase & 1) * 16;
+    if ((threadIdx.x & 63) == 0) r[w] = v;
     __syncthreads();
     double s = 0.0;
-    for (int i = 0; i < nw; i++) s += red[i];
+    for (int i = 0; i < nw; i++) s += r[i];
     return s;
 }
-__device__ float block_max_f(float v, double *red) {
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+__device__ float block_max_f(float v, double *red, int phase = 0) {
+    v = wave_max_f(v);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    float *r = (float *) red;
-    __syncthreads();
+    float *r = (float *) (red + (phase & 1) * 16);
     if ((threadIdx.x & 63) == 0) r[w] = v;
     __syncthreads();
     float s = r[0];
@@ -80,8 +128,11 @@ __device__ float block_max_f(float v, double *red) {
 // repack: file-layout Q4_0 rows -> chain-major tiles (load time only)
 // ------------------------------------------------------------------------------------------------
 // one thread per (row-group, chunk, lane); src = M rows of nb blocks of 20 bytes (unaligned floats)
+// gmap: tile group of logical row-group lg is  (lg / 4) * 8 + goff + lg % 4  when gmap != 0 (the
+// w1|w3 interleave: every 8 consecutive tile groups hold 32 rows of w1 then the same 32 rows of w3,
+// so one 8-wave workgroup owns gate and up of one whole Q4_0 block of the FFN activation), else lg.
 __global__ void k_repack_q4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                            int M, int nb, int ngroups, int nchunks) {
+                            int M, int nb, int ngroups, int nchunks, int gmap, int goff) {
     const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long) ngroups * nchunks * 64;
     if (gid >= total) return;
@@ -109,7 +160,8 @@ __global__ void k_repack_q4(const uint8_t *__restrict__ src, uint8_t *__restrict
         }
         out[i] = dw;
     }
-    uint8_t *t = dst + ((size_t) g * (nchunks + 1) + c) * TILE_BYTES;
+    const int tg = gmap ? (g >> 2) * 8 + goff + (g & 3) : g;
+    uint8_t *t = dst + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
     u32x4 v = { out[0], out[1], out[2], out[3] };
     *(u32x4 *) (t + lane * 16) = v;
     // scale of block c*8 + k of row m
@@ -120,9 +172,12 @@ __global__ void k_repack_q4(const uint8_t *__restrict__ src, uint8_t *__restrict
         uint32_t bits = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t) p[3] << 24);
         d = __builtin_bit_cast(float, bits);
     }
-    *(float *) (t + 1024 + lane * 4) = d;
+    // scales of a row are stored as [s0,s4,s1,s5,s2,s6,s3,s7]: lane (r,k) later loads the pair
+    // (s[k&3], s[4+(k&3)]), so every QUAD of lanes holds all 8 scales of its row and the per-block
+    // scale is one v_mul_f32 with a quad_perm DPP broadcast (no LDS-pipe swizzle)
+    *(float *) (t + 1024 + (r * 8 + (k & 3) * 2 + (k >> 2)) * 4) = d;
     if (c == 0) {   // the zero tile closing this row-group (nibbles 8 = value 0, scales 0)
-        uint8_t *z = dst + ((size_t) g * (nchunks + 1) + nchunks) * TILE_BYTES;
+        uint8_t *z = dst + ((size_t) tg * (nchunks + 1) + nchunks) * TILE_BYTES;
         u32x4 zv = { 0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u };
         *(u32x4 *) (z + lane * 16) = zv;
         *(float *) (z + 1024 + lane * 4) = 0.0f;
@@ -184,68 +239,161 @@ __device__ __forceinline__ int pidx(int i) { return i + (i >> 5); }
 //   PREP_NORM     y = w * ((float)(x - mean) * scale)          ggml_norm + ggml_mul, ggml.c:5327-5385, :4555
 //   PREP_SILU_MUL y = silu_lut(in0) * in1                      ggml.c:1956-1963 + ggml_mul (.mm:678-680)
 //   PREP_SUM      y = in0[0] + in0[1] + ... (in order)         attention partial buffers, ggml.c:5553-5577
-template <int MODE>
+// Global loads are issued in batches of LB float4 per thread before anything consumes them (indices
+// clamped, never branched around), so a prologue costs a couple of L2 round trips instead of one per
+// element: these prologues run inside the GEMV kernels, in front of the weight stream.
+constexpr int LB_DEFAULT = 8;
+
+template <int MODE, int LB = LB_DEFAULT>
 __device__ void make_y(float *ybuf, double *red, const float *__restrict__ in0, const float *__restrict__ in1,
                        int K, const uint16_t *__restrict__ T_silu, int nsum, long sum_stride) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int n4 = K >> 2;                                   // K is a multiple of 32
+    const f32x4 *a4 = (const f32x4 *) in0;
+    const f32x4 *b4 = (const f32x4 *) in1;
     if (MODE == PREP_PLAIN) {
-        for (int i = tid; i < K; i += nt) ybuf[pidx(i)] = in0[i];
+        for (int base = tid; base < n4; base += nt * LB) {
+            f32x4 v[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) v[u] = a4[min(base + u * nt, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int g = base + u * nt;
+                if (g < n4) { float *o = ybuf + pidx(4 * g); o[0] = v[u].x; o[1] = v[u].y; o[2] = v[u].z; o[3] = v[u].w; }
+            }
+        }
     } else if (MODE == PREP_SILU_MUL) {
-        for (int i = tid; i < K; i += nt) {
-            const float s = h2f_bits(T_silu[f2h_bits(in0[i])]);
-            ybuf[pidx(i)] = s * in1[i];
+        for (int base = tid; base < n4; base += nt * LB) {
+            f32x4 ga[LB], up[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) { const int g = min(base + u * nt, n4 - 1); ga[u] = a4[g]; up[u] = b4[g]; }
+            uint16_t lut[LB][4];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                lut[u][0] = T_silu[f2h_bits(ga[u].x)]; lut[u][1] = T_silu[f2h_bits(ga[u].y)];
+                lut[u][2] = T_silu[f2h_bits(ga[u].z)]; lut[u][3] = T_silu[f2h_bits(ga[u].w)];
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int g = base + u * nt;
+                if (g < n4) {
+                    float *o = ybuf + pidx(4 * g);
+                    o[0] = h2f_bits(lut[u][0]) * up[u].x; o[1] = h2f_bits(lut[u][1]) * up[u].y;
+                    o[2] = h2f_bits(lut[u][2]) * up[u].z; o[3] = h2f_bits(lut[u][3]) * up[u].w;
+                }
+            }
         }
     } else if (MODE == PREP_SUM) {
-        for (int i = tid; i < K; i += nt) {
-            float s = in0[i];
-            for (int j = 1; j < nsum; j++) s += in0[(size_t) j * sum_stride + i];
-            ybuf[pidx(i)] = s;
+        for (int base = tid; base < n4; base += nt * LB) {
+            f32x4 acc[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) acc[u] = a4[min(base + u * nt, n4 - 1)];
+            for (int j = 1; j < nsum; j++) {
+                const f32x4 *p4 = (const f32x4 *) (in0 + (size_t) j * sum_stride);
+                f32x4 v[LB];
+#pragma unroll
+                for (int u = 0; u < LB; u++) v[u] = p4[min(base + u * nt, n4 - 1)];
+#pragma unroll
+                for (int u = 0; u < LB; u++) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int g = base + u * nt;
+                if (g < n4) { float *o = ybuf + pidx(4 * g); o[0] = acc[u].x; o[1] = acc[u].y; o[2] = acc[u].z; o[3] = acc[u].w; }
+            }
         }
     } else {  // PREP_NORM
         double s = 0.0;
-        for (int i = tid; i < K; i += nt) s += (double) in0[i];
-        const double mean = block_sum_d(s, red) / (double) K;
+        for (int base = tid; base < n4; base += nt * LB) {
+            f32x4 v[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) v[u] = a4[min(base + u * nt, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int g = base + u * nt;
+                if (g < n4) {
+                    float *o = ybuf + pidx(4 * g);
+                    o[0] = v[u].x; o[1] = v[u].y; o[2] = v[u].z; o[3] = v[u].w;
+                    s += (double) v[u].x; s += (double) v[u].y; s += (double) v[u].z; s += (double) v[u].w;
+                }
+            }
+        }
+        const double mean = block_sum_d(s, red, 0) / (double) K;      // (block_sum_d syncs: ybuf is visible)
         double s2 = 0.0;
         for (int i = tid; i < K; i += nt) {
-            const double v = (double) in0[i] - mean;
+            const double v = (double) ybuf[pidx(i)] - mean;
             ybuf[pidx(i)] = (float) v;
             s2 += v * v;
         }
-        const double sum2 = block_sum_d(s2, red);
+        const double sum2 = block_sum_d(s2, red, 1);
         const float scale = (float) (1.0 / sqrt(sum2 / (double) K + (double) 1e-5f));
-        for (int i = tid; i < K; i += nt) {
-            const float yv = ybuf[pidx(i)] * scale;
-            ybuf[pidx(i)] = in1[i] * yv;
+        for (int base = tid; base < n4; base += nt * LB) {
+            f32x4 w[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) w[u] = b4[min(base + u * nt, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int g = base + u * nt;
+                if (g < n4) {
+                    float *o = ybuf + pidx(4 * g);
+                    o[0] = w[u].x * (o[0] * scale); o[1] = w[u].y * (o[1] * scale);
+                    o[2] = w[u].z * (o[2] * scale); o[3] = w[u].w * (o[3] * scale);
+                }
+            }
         }
     }
     __syncthreads();
 }
 
-// Quantize ybuf[K] into QA operands at (A, da) -- generic pointers (global or LDS).
+// cooperative global -> LDS copy of n4 16-byte granules, all loads of a batch in flight together
+__device__ __forceinline__ void copy_g2l(uint32_t *dst, const uint32_t *__restrict__ src, int n4) {
+    constexpr int LB = LB_DEFAULT;
+    const u32x4 *s4 = (const u32x4 *) src;
+    u32x4 *d4 = (u32x4 *) dst;
+    for (int base = threadIdx.x; base < n4; base += blockDim.x * LB) {
+        u32x4 v[LB];
+#pragma unroll
+        for (int u = 0; u < LB; u++) v[u] = s4[min(base + u * (int) blockDim.x, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < LB; u++) { const int g = base + u * (int) blockDim.x; if (g < n4) d4[g] = v[u]; }
+    }
+}
+
+// Quantize ybuf[K] into QA operands at (A, da) -- generic pointers (global or LDS).  One thread per
+// block; values are re-read from LDS (once for amax, once per chain) instead of being held in 64
+// registers, because this runs inside the GEMV kernels while the weight ring is live.
 __device__ void quantize_y(const float *ybuf, int K, int Kp, uint32_t *A, float *da, uint8_t *raw_out) {
     const int nb = K / 32, nbp = Kp / 32;
     for (int b = threadIdx.x; b < nbp; b += blockDim.x) {
         const int c = b >> 3, j = b & 7;
-        uint32_t chain[8];
-        float d = 0.0f;
+        const float *v = ybuf + b * 33;
+        float d = 0.0f, id = 0.0f;
         if (b < nb) {
-            float v[32];
-#pragma unroll
-            for (int l = 0; l < 32; l++) v[l] = ybuf[b * 33 + l];
-            uint8_t raw[16];
-            d = quant_block(v, j & 1, chain, raw_out ? raw : nullptr);
-            if (raw_out) {
-                uint8_t *o = raw_out + (size_t) b * 20;
-                const uint32_t bits = __builtin_bit_cast(uint32_t, d);
-                o[0] = bits & 0xFF; o[1] = (bits >> 8) & 0xFF; o[2] = (bits >> 16) & 0xFF; o[3] = bits >> 24;
-                for (int t = 0; t < 16; t++) o[4 + t] = raw[t];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) chain[k] = 0;
+            float amax = 0.0f;
+#pragma unroll 8
+            for (int l = 0; l < 32; l++) amax = fmaxf(amax, fabsf(v[l]));
+            d = amax / 7.0f;                                   // ggml.c:479
+            id = (amax != 0.0f) ? 7.0f / amax : 0.0f;          // ggml.c:482
+        }
+        uint8_t *o = raw_out ? raw_out + (size_t) b * 20 : nullptr;
+        if (o && b < nb) {
+            const uint32_t bits = __builtin_bit_cast(uint32_t, d);
+            o[0] = bits & 0xFF; o[1] = (bits >> 8) & 0xFF; o[2] = (bits >> 16) & 0xFF; o[3] = bits >> 24;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) A[(c * 8 + k) * 8 + j] = chain[k];
+        for (int k = 0; k < 8; k++) {
+            uint32_t dw = 0;
+            if (b < nb) {
+                const int q0 = (int) __builtin_rintf(v[2 * k] * id), q1 = (int) __builtin_rintf(v[2 * k + 1] * id);
+                const int q2 = (int) __builtin_rintf(v[16 + 2 * k] * id), q3 = (int) __builtin_rintf(v[17 + 2 * k] * id);
+                dw = ((uint32_t) (q0 & 0xF) | ((uint32_t) (q1 & 0xF) << 8) | ((uint32_t) (q2 & 0xF) << 16) | ((uint32_t) (q3 & 0xF) << 24)) << (4 * (j & 1));
+                if (o) {            // file-layout bytes: qs[k] = elements (2k, 2k+1), qs[8+k] = (16+2k, 17+2k), each q + 8
+                    o[4 + k] = (uint8_t) ((q0 + 8) | ((q1 + 8) << 4));
+                    o[12 + k] = (uint8_t) ((q2 + 8) | ((q3 + 8) << 4));
+                }
+            }
+            A[(c * 8 + k) * 8 + j] = dw;
+        }
         da[b] = d;
     }
 }
@@ -278,7 +426,7 @@ __global__ void k_prep_qa(const float *__restrict__ in0, const float *__restrict
 // ------------------------------------------------------------------------------------------------
 #define LH_STEP(J, WD, AD, DA)                                                                     \
     {                                                                                              \
-        const float sc_ = bcast8<J>(sw) * (DA);                                                    \
+        const float sc_ = quad_bcast<((J) & 3)>((J) < 4 ? sw.x : sw.y) * (DA);                     \
         const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, false);                   \
         acc = fmaf(sc_, (float) p_, acc);                                                          \
     }
@@ -301,13 +449,21 @@ __device__ __forceinline__ float fold8(float acc) {
 // that closes every row-group (scale 0 -> fma(0*da, p, acc) == acc), never branched around, so the compiler's waitcnt
 // pass sees no control-flow merges and emits counted vmcnt waits (2*(D-1) loads stay in flight).
 // dynamic LDS: [A: Kp bytes][da: Kp/32 floats] (+ prologue scratch for fused modes)
-template <int PRE, int EPI, int D, bool RING>
-__global__ void __launch_bounds__(256)
-k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
+//   gmapF8 : 0, or F/8 for the interleaved w1|w3 matrix (tile group -> logical row-group, see k_repack_q4)
+//   EPI_SILU_QA (w1|w3 only, 8 waves per workgroup = 32 gate rows + the same 32 up rows): the
+//         workgroup applies silu_lut(gate)*up (ggml.c:1956-1963, .mm:678-680) to its 32 outputs and
+//         quantizes them as one Q4_0 activation block (ggml.c:456-523) straight into the QA operand of
+//         the following w2 mat-vec: out_A / out_d.  y, if non-null, receives silu*up as fp32.
+//   PG  : prologue granules (16 B) kept in registers per thread; the host sizes the workgroup so
+//         that PG * blockDim covers the activation row (fp32 modes) or the QA "A" array (PRE_QA)
+template <int PRE, int EPI, int D, bool RING, int PG>
+__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256, EPI == EPI_SILU_QA ? 4 : 1)
+k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
        const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d,
        const float *__restrict__ in0, const float *__restrict__ in1, int K,
        float *__restrict__ y, const float *__restrict__ resid,
-       const uint16_t *__restrict__ T_silu, int nsum, long sum_stride) {
+       const uint16_t *__restrict__ T_silu, int nsum, long sum_stride,
+       uint32_t *__restrict__ out_A, float *__restrict__ out_d) {
     extern __shared__ double smem_d[];
     uint32_t *ldsA = (uint32_t *) smem_d;
     float *ldsD = (float *) (ldsA + nchunks * 64);
@@ -318,25 +474,94 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
     const int last = nchunks - 1;
 
     u32x4 wq[D];
-    float ws[D];
+    f32x2 ws[D];
 #define LH_LOADW(SLOT, CH)                                                                                   \
     {                                                                                                        \
         const int ch_ = min((CH), nchunks);   /* tile `nchunks` of every row-group is the zero tile */      \
         const uint8_t *tp_ = wbase + (size_t) ch_ * TILE_BYTES;                                              \
         wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + lane * 16));                            \
-        ws[SLOT] = __builtin_nontemporal_load((const float *) (tp_ + 1024 + lane * 4));                      \
+        ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + 1024 + ((lane >> 3) * 8 + (lane & 3) * 2) * 4)); \
     }
-    // weights do not depend on the activations: put the first D chunks in flight before the
-    // prologue so the HBM latency overlaps it
+    // ---- phase 1: the prologue's own (small, L2-resident) loads go out FIRST.  vmcnt retires in
+    // order, so anything issued behind the weight prefetch would have to wait for all of it.
+    constexpr bool REGPRE = (PRE == PRE_QA || PRE == PREP_NORM || PRE == PREP_PLAIN);
+    constexpr int MAXG = (PRE == PREP_NORM || PRE == PREP_PLAIN) ? PG : 1;   // fp32 float4 granules per thread
+    constexpr int MAXQA = (PRE == PRE_QA) ? PG : 1, MAXQD = (PG + 7) / 8;    // QA granules per thread (da is 1/8 of A)
+    f32x4 xa[MAXG], xb[MAXG];
+    u32x4 qg[MAXQA], qh[MAXQD];
+    const int nt = blockDim.x;
+    const int n4 = K >> 2;
+    // (trip counts are wave-uniform; a skipped load only makes the compiler's vmcnt for these
+    //  prologue loads stricter -- they are all older than the weight loads, which stay in flight)
+    if (PRE == PREP_NORM || PRE == PREP_PLAIN) {
+        const int ng = (n4 + nt - 1) / nt;
+#pragma unroll
+        for (int u = 0; u < MAXG; u++) {
+            if (u < ng) {
+                const int gi = min(tid + u * nt, n4 - 1);
+                xa[u] = ((const f32x4 *) in0)[gi];
+                if (PRE == PREP_NORM) xb[u] = ((const f32x4 *) in1)[gi];
+            }
+        }
+    }
+    if (PRE == PRE_QA) {
+        const int nqa = (nchunks * 16 + nt - 1) / nt, nqd = (nchunks * 2 + nt - 1) / nt;
+#pragma unroll
+        for (int u = 0; u < MAXQA; u++) if (u < nqa) qg[u] = ((const u32x4 *) qa_A)[min(tid + u * nt, nchunks * 16 - 1)];
+#pragma unroll
+        for (int u = 0; u < MAXQD; u++) if (u < nqd) qh[u] = ((const u32x4 *) qa_d)[min(tid + u * nt, nchunks * 2 - 1)];
+    }
+    // ---- phase 2: put the first D weight chunks in flight (they do not depend on the activations).
+    // The scheduling barriers pin the issue order phase 1 -> phase 2 -> phase 3.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < D; i++) LH_LOADW(i, i)
+    __builtin_amdgcn_sched_barrier(0);
 
+    // ---- phase 3: prologue arithmetic while the weights stream in
+    double *red = (double *) (ldsD + nchunks * 8);
     if (PRE == PRE_QA) {
-        for (int i = tid; i < nchunks * 64; i += blockDim.x) ldsA[i] = qa_A[i];
-        for (int i = tid; i < nchunks * 8; i += blockDim.x) ldsD[i] = qa_d[i];
+#pragma unroll
+        for (int u = 0; u < MAXQA; u++) { const int gi = tid + u * nt; if (gi < nchunks * 16) ((u32x4 *) ldsA)[gi] = qg[u]; }
+#pragma unroll
+        for (int u = 0; u < MAXQD; u++) { const int gi = tid + u * nt; if (gi < nchunks * 2) ((u32x4 *) ldsD)[gi] = qh[u]; }
+        __syncthreads();
+    } else if (REGPRE) {
+        float *ybuf = (float *) (red + 32);
+        if (PRE == PREP_NORM) {
+            // ggml_norm + ggml_mul (ggml.c:5327-5385, :4555) on register-resident x
+            double s1 = 0.0;
+#pragma unroll
+            for (int u = 0; u < MAXG; u++)
+                if (tid + u * nt < n4) { s1 += (double) xa[u].x; s1 += (double) xa[u].y; s1 += (double) xa[u].z; s1 += (double) xa[u].w; }
+            const double mean = block_sum_d(s1, red, 0) / (double) K;
+            double s2 = 0.0;
+#pragma unroll
+            for (int u = 0; u < MAXG; u++)
+                if (tid + u * nt < n4) {
+                    const double v0 = (double) xa[u].x - mean, v1 = (double) xa[u].y - mean;
+                    const double v2 = (double) xa[u].z - mean, v3 = (double) xa[u].w - mean;
+                    xa[u].x = (float) v0; xa[u].y = (float) v1; xa[u].z = (float) v2; xa[u].w = (float) v3;
+                    s2 += v0 * v0; s2 += v1 * v1; s2 += v2 * v2; s2 += v3 * v3;
+                }
+            const double sum2 = block_sum_d(s2, red, 1);
+            const float scale = (float) (1.0 / sqrt(sum2 / (double) K + (double) 1e-5f));
+#pragma unroll
+            for (int u = 0; u < MAXG; u++)
+                if (tid + u * nt < n4) {
+                    xa[u].x = xb[u].x * (xa[u].x * scale); xa[u].y = xb[u].y * (xa[u].y * scale);
+                    xa[u].z = xb[u].z * (xa[u].z * scale); xa[u].w = xb[u].w * (xa[u].w * scale);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXG; u++) {
+            const int gi = tid + u * nt;
+            if (gi < n4) { float *o = ybuf + pidx(4 * gi); o[0] = xa[u].x; o[1] = xa[u].y; o[2] = xa[u].z; o[3] = xa[u].w; }
+        }
+        __syncthreads();
+        quantize_y(ybuf, K, nchunks * 256, ldsA, ldsD, nullptr);
         __syncthreads();
     } else {
-        double *red = (double *) (ldsD + nchunks * 8);
         float *ybuf = (float *) (red + 32);
         make_y<PRE>(ybuf, red, in0, in1, K, T_silu, nsum, sum_stride);
         quantize_y(ybuf, K, nchunks * 256, ldsA, ldsD, nullptr);
@@ -349,7 +574,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
     {                                                                                              \
         const int cl_ = min((CH), last);                                                           \
         const u32x4 w = wq[SLOT];                                                                  \
-        const float sw = ws[SLOT];                                                                 \
+        const f32x2 sw = ws[SLOT];                                                                 \
         const u32x4 *pa = (const u32x4 *) (ldsA + (cl_ * 8 + k) * 8);                              \
         const u32x4 a0 = pa[0], a1 = pa[1];                                                        \
         const f32x4 *pd = (const f32x4 *) (ldsD + cl_ * 8);                                        \
@@ -382,8 +607,34 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
 #undef LH_LOADW
 
     acc = fold8(acc);
-    const int m = g * 8 + (lane >> 3);
-    if (valid && k == 0 && m < M) {
+    int lg = g;
+    if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+    const int m = lg * 8 + (lane >> 3);
+    if (EPI == EPI_SILU_QA) {
+        // 8 waves: waves 0-3 hold gate rows b*32 .. b*32+31, waves 4-7 the matching up rows (b = blockIdx.x)
+        float *gu = (float *) red;                      // prologue scratch is free again
+        __syncthreads();
+        if (k == 0) gu[wave * 8 + (lane >> 3)] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            const int i = lane & 31;
+            const float act = h2f_bits(T_silu[f2h_bits(gu[i])]) * gu[32 + i];
+            float amax = fabsf(act);
+            amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
+            amax = fmaxf(amax, __shfl_xor(amax, 4));  amax = fmaxf(amax, __shfl_xor(amax, 2));
+            amax = fmaxf(amax, __shfl_xor(amax, 1));
+            const float dd = amax / 7.0f;
+            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+            const uint32_t nib = ((uint32_t) ((int) __builtin_rintf(act * id) + 8) - 8) & 0xF;     // signed nibble of (q - 8)
+            const int kk = lane & 7;
+            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+            const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+            const int b = blockIdx.x, c = b >> 3, j = b & 7;
+            if (lane < 8) out_A[(c * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+            if (lane == 0) out_d[b] = dd;
+            if (y && lane < 32) y[b * 32 + i] = act;
+        }
+    } else if (valid && k == 0 && m < M) {
         if (EPI == EPI_RESID) acc = acc + resid[m];
         y[m] = acc;
     }
@@ -393,7 +644,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
 // from global memory (L1/L2 resident: NC * 288 B per chunk), no LDS, no barriers.
 template <int NC, int EPI>
 __global__ void __launch_bounds__(256)
-k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
+k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
           const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d,
           float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -406,19 +657,20 @@ k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
 #pragma unroll
     for (int n = 0; n < NC; n++) accs[n] = 0.0f;
 
+    const int soff = 1024 + ((lane >> 3) * 8 + (lane & 3) * 2) * 4;
     u32x4 w_next = __builtin_nontemporal_load((const u32x4 *) (wbase + lane * 16));
-    float s_next = __builtin_nontemporal_load((const float *) (wbase + 1024 + lane * 4));
+    f32x2 s_next = __builtin_nontemporal_load((const f32x2 *) (wbase + soff));
     for (int c = 0; c < nchunks; c++) {
         const u32x4 w = w_next;
-        const float sw = s_next;
+        const f32x2 sw = s_next;
         if (c + 1 < nchunks) {
             w_next = __builtin_nontemporal_load((const u32x4 *) (wbase + (size_t) (c + 1) * TILE_BYTES + lane * 16));
-            s_next = __builtin_nontemporal_load((const float *) (wbase + (size_t) (c + 1) * TILE_BYTES + 1024 + lane * 4));
+            s_next = __builtin_nontemporal_load((const f32x2 *) (wbase + (size_t) (c + 1) * TILE_BYTES + soff));
         }
         const uint32_t w0 = w.x ^ 0x88888888u, w1 = w.y ^ 0x88888888u;
         const uint32_t w2 = w.z ^ 0x88888888u, w3 = w.w ^ 0x88888888u;
-        const float s0 = bcast8<0>(sw), s1 = bcast8<1>(sw), s2 = bcast8<2>(sw), s3 = bcast8<3>(sw);
-        const float s4 = bcast8<4>(sw), s5 = bcast8<5>(sw), s6 = bcast8<6>(sw), s7 = bcast8<7>(sw);
+        const float s0 = quad_bcast<0>(sw.x), s1 = quad_bcast<1>(sw.x), s2 = quad_bcast<2>(sw.x), s3 = quad_bcast<3>(sw.x);
+        const float s4 = quad_bcast<0>(sw.y), s5 = quad_bcast<1>(sw.y), s6 = quad_bcast<2>(sw.y), s7 = quad_bcast<3>(sw.y);
 #pragma unroll
         for (int n = 0; n < NC; n++) {
             const u32x4 *pa = (const u32x4 *) (qa_A + n * strideA + (c * 8 + k) * 8);
@@ -435,7 +687,9 @@ k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M,
             accs[n] = acc;
         }
     }
-    const int m = g * 8 + (lane >> 3);
+    int lg = g;
+    if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+    const int m = lg * 8 + (lane >> 3);
 #pragma unroll
     for (int n = 0; n < NC; n++) {
         float acc = fold8(accs[n]);
@@ -526,14 +780,14 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
     // ---- soft_max over keys 0..tmax (masked keys are -inf -> 0)
     float mx = -INFINITY;
     for (int t = tid; t <= tmax; t += blockDim.x) mx = fmaxf(mx, sc[t]);
-    mx = block_max_f(mx, red);
+    mx = block_max_f(mx, red, 0);
     double sum = 0.0;
     for (int t = tid; t <= tmax; t += blockDim.x) {
         const float e = h2f_bits(T_exp[f2h_bits(sc[t] - mx)]);
         sc[t] = e;
         sum += (double) e;
     }
-    sum = block_sum_d(sum, red);
+    sum = block_sum_d(sum, red, 1);
     const float inv = (float) (1.0 / sum);
     for (int t = tid; t <= tmax; t += blockDim.x) sc[t] *= inv;
     __syncthreads();
@@ -565,10 +819,164 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 }
 
 // ------------------------------------------------------------------------------------------------
+// Decode attention (one query row), split so that every CU works and replayable from a hipGraph:
+// the context position lives in device memory (st[0] = n_past), never in a kernel argument.
+//
+//   k_dec_scores  grid (H, ceil(n_ctx/32)): RoPE of q (every workgroup, 64 pairs), RoPE + append of
+//                 the new K row and copy of the new V row (the workgroup whose key slice contains
+//                 n_past), then KQ*scale for its 32 keys            -> sc[H][n_ctx]
+//   k_dec_pv_blk  grid (H, dh/32), nth*32 threads: soft_max over the head's row (exact in any order, see
+//                 k_attn), the nth partial V*P sums of the reference's nth-way key split, their
+//                 addition in thread order (ggml.c:5553-5577) and the quantization of the head's dh
+//                 outputs to Q4_0 activation blocks for the wo mat-vec -> QA (and fp32 merged row)
+// Arithmetic is identical to k_attn / k_rope_kv; only the work distribution differs.
+// ------------------------------------------------------------------------------------------------
+constexpr int DEC_TS = 32;      // keys per workgroup: 8 half-waves x 4 keys
+
+__global__ void __launch_bounds__(256)
+k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restrict__ sincos_tab,
+             float *__restrict__ Kc, float *__restrict__ Vc, float *__restrict__ sc, int n_ctx,
+             float kq_scale, const int32_t *__restrict__ st) {
+    extern __shared__ double smem_d[];
+    float *qs = (float *) smem_d;          // roped q of this head
+    float *kn = qs + dh;                   // roped new k of this head
+    const int h = blockIdx.x;
+    const int n_past = st[0];
+    const int t0 = blockIdx.y * DEC_TS;
+    if (t0 > n_past) return;
+    const int tid = threadIdx.x;
+    const bool owns_new = n_past < t0 + DEC_TS;          // this slice contains key n_past
+    const double *tab = sincos_tab + (size_t) n_past * dh;
+    const float *q = qkv + h * dh, *kk = qkv + d + h * dh, *vv = qkv + 2 * d + h * dh;
+    if (tid < dh / 2) {
+        const int e = 2 * tid;
+        const double cs = tab[e], sn = tab[e + 1];
+        const double x0 = (double) q[e], x1 = (double) q[e + 1];
+        qs[e] = (float) (x0 * cs - x1 * sn);
+        qs[e + 1] = (float) (x0 * sn + x1 * cs);
+        if (owns_new) {
+            const double k0 = (double) kk[e], k1 = (double) kk[e + 1];
+            const float r0 = (float) (k0 * cs - k1 * sn), r1 = (float) (k0 * sn + k1 * cs);
+            kn[e] = r0; kn[e + 1] = r1;
+            Kc[(size_t) n_past * d + h * dh + e] = r0;
+            Kc[(size_t) n_past * d + h * dh + e + 1] = r1;
+            Vc[(size_t) n_past * d + h * dh + e] = vv[e];
+            Vc[(size_t) n_past * d + h * dh + e + 1] = vv[e + 1];
+        }
+    }
+    __syncthreads();
+    // each half-wave owns DEC_TS/8 consecutive keys and keeps all their loads in flight at once
+    const int hw = tid >> 5, l = tid & 31;
+    constexpr int KPH = DEC_TS / 8;
+    const int tb = t0 + hw * KPH;
+    float kv[KPH][8];
+#pragma unroll
+    for (int u = 0; u < KPH; u++) {
+        const int t = min(tb + u, n_past);
+        const float *kr = Kc + (size_t) t * d + h * dh;
+#pragma unroll
+        for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < KPH; u++) {
+        const int t = tb + u;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (i * 32 < dh) {
+                const float kval = (t == n_past) ? kn[i * 32 + l] : kv[u][i];   // own row from LDS: the global store above is not yet visible
+                s = fmaf(kval, qs[i * 32 + l], s);
+            }
+        }
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (l == 0 && t <= n_past) sc[(size_t) h * n_ctx + t] = s * kq_scale;
+    }
+}
+
+// One workgroup per (head, 32-column block of the head): soft_max of the head's score row
+// (recomputed by each of the head's dh/32 workgroups -- exact in any order), the nth partial V*P sums
+// for its 32 columns (one sequential FMA chain per (chunk, column), all nth*32 chains in parallel),
+// their addition in thread order, and the Q4_0 quantization of exactly one activation block.
+// Splitting a head by columns needs no cross-workgroup hand-off: the ordered combine is per column.
+// block = 32 * min(nth, 32) threads; dynamic LDS: [32 doubles][n_ctx p][nth*32 partials]
+__global__ void __launch_bounds__(1024)
+k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth,
+             float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
+             const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st) {
+    extern __shared__ double smem_d[];
+    double *red = smem_d;
+    float *p = (float *) (smem_d + 32);
+    float *part = p + n_ctx;
+    const int h = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int n_past = st[0];
+    const int T = n_past + 1;
+    const float *row = sc + (size_t) h * n_ctx;
+    float mx = -INFINITY;
+    for (int t = tid; t < T; t += nt) { const float v = row[t]; p[t] = v; mx = fmaxf(mx, v); }
+    mx = block_max_f(mx, red, 0);
+    double sum = 0.0;
+    for (int t = tid; t < T; t += nt) {
+        const float e = h2f_bits(T_exp[f2h_bits(p[t] - mx)]);
+        p[t] = e;
+        sum += (double) e;
+    }
+    sum = block_sum_d(sum, red, 1);
+    const float inv = (float) (1.0 / sum);
+    for (int t = tid; t < T; t += nt) p[t] *= inv;
+    __syncthreads();
+
+    const int c = tid & 31, sub = tid >> 5, nsub = nt >> 5;
+    const int dc = (T + nth - 1) / nth;
+    const int col = h * dh + cb * 32 + c;
+    const float *vcol = Vc + col;
+    for (int th = sub; th < nth; th += nsub) {
+        const int t0 = dc * th, t1 = min(t0 + dc, T);
+        float acc = 0.0f;
+        for (int tb = t0; tb < t1; tb += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = vcol[(size_t) min(tb + u, t1 - 1) * d];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float pe = (tb + u < t1) ? p[min(tb + u, T - 1)] : 0.0f;      // fma(v, 0, acc) == acc
+                acc = fmaf(v[u], pe, acc);
+            }
+        }
+        part[th * 32 + c] = acc;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = part[tid];
+        for (int th = 1; th < nth; th++) s += part[th * 32 + tid];          // thread order (ggml.c:5553-5577)
+        if (merged) merged[col] = s;
+        // quantize this 32-element block (ggml.c:456-523), one element per lane
+        float amax = fabsf(s);
+        amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));  amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        const float dd = amax / 7.0f;
+        const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+        const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
+        const int kk = tid & 7;
+        const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+        const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+        const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
+        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+        if (tid == 0) qa_d[b] = dd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // greedy argmax, lowest index on ties (harness definition of temperature 0)
 // ------------------------------------------------------------------------------------------------
+// st (optional): st[0] = n_past, st[1] = decode step index -- both advanced here so a captured
+// decode graph can be replayed without touching kernel arguments; out[st[1]] receives the token.
 __global__ void k_argmax(const float *__restrict__ logits, int V, int32_t *__restrict__ out, int out_idx,
-                         int32_t *__restrict__ next_token) {
+                         int32_t *__restrict__ next_token, int32_t *__restrict__ st) {
     __shared__ float bv[1024];
     __shared__ int bi[1024];
     float best = -INFINITY;
@@ -588,8 +996,9 @@ __global__ void k_argmax(const float *__restrict__ logits, int V, int32_t *__res
     }
     if (threadIdx.x == 0) {
         const int r = bi[0] == 0x7fffffff ? 0 : bi[0];
-        out[out_idx] = r;
+        out[st ? st[1] : out_idx] = r;
         if (next_token) *next_token = r;
+        if (st) { st[0] += 1; st[1] += 1; }
     }
 }
 
@@ -610,12 +1019,14 @@ hipError_t init_kernel_attrs() {
     const int cap = 160 * 1024;
 #define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
     LH_ATTR(k_prep_qa<PREP_PLAIN>); LH_ATTR(k_prep_qa<PREP_NORM>); LH_ATTR(k_prep_qa<PREP_SILU_MUL>); LH_ATTR(k_prep_qa<PREP_SUM>);
-#define LH_ATTR_G(PRE, EPI) LH_ATTR((k_gemv<PRE, EPI, 16, false>)); LH_ATTR((k_gemv<PRE, EPI, 16, true>)); LH_ATTR((k_gemv<PRE, EPI, 13, true>)); \
-    LH_ATTR((k_gemv<PRE, EPI, 11, true>)); LH_ATTR((k_gemv<PRE, EPI, 10, true>)); LH_ATTR((k_gemv<PRE, EPI, 8, true>))
+#define LH_ATTR_G1(PRE, EPI, PG) LH_ATTR((k_gemv<PRE, EPI, 16, false, PG>)); LH_ATTR((k_gemv<PRE, EPI, 16, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 13, true, PG>)); \
+    LH_ATTR((k_gemv<PRE, EPI, 11, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 10, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 8, true, PG>))
+#define LH_ATTR_G(PRE, EPI) LH_ATTR_G1(PRE, EPI, 4); LH_ATTR_G1(PRE, EPI, 12)
     LH_ATTR_G(PRE_QA, EPI_STORE); LH_ATTR_G(PRE_QA, EPI_RESID); LH_ATTR_G(PREP_NORM, EPI_STORE);
-    LH_ATTR_G(PREP_PLAIN, EPI_RESID); LH_ATTR_G(PREP_SILU_MUL, EPI_RESID); LH_ATTR_G(PREP_SUM, EPI_RESID);
+    LH_ATTR_G(PREP_PLAIN, EPI_RESID); LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 2);
+#undef LH_ATTR_G1
 #undef LH_ATTR_G
-    LH_ATTR(k_attn);
+    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk);
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -626,11 +1037,11 @@ hipError_t launch_add(const float *a, const float *b, float *c, long n, hipStrea
     return hipSuccess;
 }
 
-hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, hipStream_t st) {
+hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int gmap, int goff, hipStream_t st) {
     const int nb = K / 32, ngroups = (M + 7) / 8, nchunks = (nb + 7) / 8;
     const long total = (long) ngroups * nchunks * 64;
     const int bs = 256;
-    hipLaunchKernelGGL(k_repack_q4, dim3((unsigned) ((total + bs - 1) / bs)), dim3(bs), 0, st, src_aos, dst, M, nb, ngroups, nchunks);
+    hipLaunchKernelGGL(k_repack_q4, dim3((unsigned) ((total + bs - 1) / bs)), dim3(bs), 0, st, src_aos, dst, M, nb, ngroups, nchunks, gmap, goff);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -681,18 +1092,22 @@ static int pick_depth(int nchunks) {
     return best;
 }
 
-template <int PRE, int EPI>
-static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float *qa_d,
-                                const float *in0, const float *in1, float *y, const float *resid,
-                                const uint16_t *T_silu, int nsum, long sum_stride, hipStream_t st) {
-    const int nw = pick_waves(w.ngroups);
+template <int PRE, int EPI, int PG>
+static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, const float *qa_d,
+                                 const float *in0, const float *in1, float *y, const float *resid,
+                                 const uint16_t *T_silu, int nsum, long sum_stride,
+                                 uint32_t *out_A, float *out_d, hipStream_t st) {
     const int grid = (w.ngroups + nw - 1) / nw;
-    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4;
+    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     if (PRE != PRE_QA) lds += prep_lds_bytes(w.K);
     lds = (lds + 15) & ~(size_t) 15;
-#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING>), dim3(grid), dim3(nw * 64), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, nsum, sum_stride)
-    if (w.nchunks <= 16) {
+#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, nsum, sum_stride, out_A, out_d)
+    // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
+    // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
+    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) {
         LH_GO(16, false);
+    } else if (w.nchunks <= 16) {
+        LH_GO(8, true);
     } else {
         switch (pick_depth(w.nchunks)) {
             case 8:  LH_GO(8, true); break;
@@ -707,17 +1122,49 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
     return hipSuccess;
 }
 
+// Workgroup size and prologue register budget.  fp32 prologues (norm / plain) keep K/4 float4
+// granules in registers, PRE_QA keeps the nchunks*16 granules of the A array: small budgets (PG 4)
+// keep the kernel near 128 VGPRs so 4 waves per SIMD stay resident; the large budget covers wide rows.
+template <int PRE, int EPI>
+static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float *qa_d,
+                                const float *in0, const float *in1, float *y, const float *resid,
+                                const uint16_t *T_silu, int nsum, long sum_stride,
+                                uint32_t *out_A, float *out_d, hipStream_t st) {
+#define LH_PGARGS w, nw, qa_A, qa_d, in0, in1, y, resid, T_silu, nsum, sum_stride, out_A, out_d, st
+    if constexpr (EPI == EPI_SILU_QA) {
+        // 8 waves = 4 gate row-groups + the 4 matching up row-groups (interleaved layout)
+        const int nw = 8;
+        if (!w.gmapF8 || w.ngroups % 8 != 0 || w.K / 4 > 2 * 512) return hipErrorInvalidValue;
+        return launch_gemv_pg<PRE, EPI, 2>(LH_PGARGS);
+    } else if constexpr (PRE == PREP_SILU_MUL || PRE == PREP_SUM) {
+        const int nw = pick_waves(w.ngroups);
+        return launch_gemv_pg<PRE, EPI, 1>(LH_PGARGS);
+    } else {
+        int nw = pick_waves(w.ngroups);
+        const int need = (PRE == PRE_QA) ? w.nchunks * 16 : w.K / 4;
+        // prefer the small budget; grow the workgroup (up to 4 waves) before growing the budget
+        while (nw < 4 && need > 4 * nw * 64) nw *= 2;
+        if (need <= 4 * nw * 64) return launch_gemv_pg<PRE, EPI, 4>(LH_PGARGS);
+        nw = pick_waves(w.ngroups);
+        while (nw < 4 && need > 12 * nw * 64) nw *= 2;
+        if (need <= 12 * nw * 64) return launch_gemv_pg<PRE, EPI, 12>(LH_PGARGS);
+        return hipErrorInvalidValue;          // caller falls back to the unfused path
+    }
+#undef LH_PGARGS
+}
+
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
-                       const uint16_t *T_silu, int nsum, long sum_stride, hipStream_t st) {
-#define LH_ARGS w, qa_A, qa_d, in0, in1, y, resid, T_silu, nsum, sum_stride, st
+                       const uint16_t *T_silu, int nsum, long sum_stride,
+                       uint32_t *out_A, float *out_d, hipStream_t st) {
+#define LH_ARGS w, qa_A, qa_d, in0, in1, y, resid, T_silu, nsum, sum_stride, out_A, out_d, st
     // only the (prologue, epilogue) pairs the forward pass uses are instantiated
     if (pre == PRE_QA && epi == EPI_STORE)        return launch_gemv_t<PRE_QA, EPI_STORE>(LH_ARGS);
     if (pre == PRE_QA && epi == EPI_RESID)        return launch_gemv_t<PRE_QA, EPI_RESID>(LH_ARGS);
     if (pre == PREP_NORM && epi == EPI_STORE)     return launch_gemv_t<PREP_NORM, EPI_STORE>(LH_ARGS);
+    if (pre == PREP_NORM && epi == EPI_SILU_QA)   return launch_gemv_t<PREP_NORM, EPI_SILU_QA>(LH_ARGS);
     if (pre == PREP_PLAIN && epi == EPI_RESID)    return launch_gemv_t<PREP_PLAIN, EPI_RESID>(LH_ARGS);
     if (pre == PREP_SILU_MUL && epi == EPI_RESID) return launch_gemv_t<PREP_SILU_MUL, EPI_RESID>(LH_ARGS);
-    if (pre == PREP_SUM && epi == EPI_RESID)      return launch_gemv_t<PREP_SUM, EPI_RESID>(LH_ARGS);
 #undef LH_ARGS
     return hipErrorInvalidValue;
 }
@@ -728,9 +1175,9 @@ static hipError_t launch_gemm_nc_t(const QMat &w, int epi, const uint32_t *qa_A,
     const int nw = pick_waves(w.ngroups);
     const int grid = (w.ngroups + nw - 1) / nw;
     if (epi == EPI_RESID)
-        hipLaunchKernelGGL((k_gemm_nc<NC, EPI_RESID>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, qa_A, qa_d, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_gemm_nc<NC, EPI_RESID>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, y, y_stride, resid, resid_stride);
     else
-        hipLaunchKernelGGL((k_gemm_nc<NC, EPI_STORE>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, qa_A, qa_d, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_gemm_nc<NC, EPI_STORE>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, y, y_stride, resid, resid_stride);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -752,7 +1199,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         else if (rem >= 8) { step = 8;  e = launch_gemm_nc_t<8>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
         else if (rem >= 4) { step = 4;  e = launch_gemm_nc_t<4>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
         else if (rem >= 2) { step = 2;  e = launch_gemm_nc_t<2>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-        else               { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, 0, 0, st); }
+        else               { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, 0, 0, nullptr, nullptr, st); }
         if (e != hipSuccess) return e;
         n0 += step;
     }
@@ -776,8 +1223,23 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
     return hipSuccess;
 }
 
-hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, hipStream_t st) {
-    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, V, out, out_idx, next_token);
+hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
+                           float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
+                           const uint16_t *T_exp, const int32_t *state, hipStream_t st) {
+    const int dh = d / H;
+    const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
+    const int nsl = (n_ctx + DEC_TS - 1) / DEC_TS;
+    hipLaunchKernelGGL(k_dec_scores, dim3(H, nsl), dim3(256), 2 * dh * sizeof(float), st, qkv, d, dh, tab, Kc, Vc, sc, n_ctx, kq_scale, state);
+    LH_LAUNCH_CHECK();
+    const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;      // whole waves: the DPP reductions need every lane live
+    const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
+    hipLaunchKernelGGL(k_dec_pv_blk, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st) {
+    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, V, out, out_idx, next_token, state);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

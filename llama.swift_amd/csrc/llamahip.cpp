@@ -148,6 +148,15 @@ struct llamahip_model {
     int32_t *d_out_tokens = nullptr;     // greedy decode results
     int out_tokens_cap = 0;
 
+    // decode-path state (device resident so a captured graph can be replayed unchanged)
+    int32_t *d_state = nullptr;          // [0] n_past, [1] decode step index
+    float *sc = nullptr;                 // attention scores [H][n_ctx]
+    float *part = nullptr;               // V*P partial sums [H][64][dh]
+    uint32_t *qa1_A = nullptr, *qa2_A = nullptr;   // QA operands: attention output (K = d), FFN activation (K = F)
+    float *qa1_d = nullptr, *qa2_d = nullptr;
+    bool w13_interleaved = false;
+    std::map<int, hipGraphExec_t> decode_graphs;   // keyed by n_threads semantics (nth)
+
     // stats
     int64_t weight_bytes = 0, kv_bytes = 0, n_evals = 0;
     double t_load_ms = 0, t_eval_ms = 0;
@@ -169,6 +178,8 @@ llamahip_model::~llamahip_model() {
     free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(d_out_tokens);
+    free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
+    for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
     if (stream) (void) hipStreamDestroy(stream);
 }
 
@@ -176,14 +187,14 @@ namespace {
 
 // upload one Q4_0 tensor (file layout) and repack it into rows [row0, row0 + M) of `dst`
 int upload_q4(llamahip_model *m, const std::string &name, QMat &dst, int row0, uint8_t *d_stage, std::vector<uint8_t> &h_stage,
-              char *err, size_t err_cap) {
+              char *err, size_t err_cap, int gmap = 0, int goff = 0) {
     const TensorInfo &t = m->file.tensors.at(name);
     h_stage.resize((size_t) t.nbytes());
     std::string e;
     if (!m->file.read_tensor(name, h_stage.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
     HIP_TRY(hipMemcpyAsync(d_stage, h_stage.data(), h_stage.size(), hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_LOAD);
     uint8_t *out = dst.tiles + (size_t) (row0 / 8) * (dst.nchunks + 1) * TILE_BYTES;
-    HIP_TRY(launch_repack(d_stage, out, (int) t.ne1, (int) t.ne0, m->stream), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(launch_repack(d_stage, out, (int) t.ne1, (int) t.ne0, gmap, goff, m->stream), LLAMAHIP_ERR_LOAD);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_LOAD);      // h_stage / d_stage are reused
     return 0;
 }
@@ -209,6 +220,9 @@ int upload_f32(llamahip_model *m, const std::string &name, float **dst, char *er
 
 int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N <= m->ws_cap) return 0;
+    // captured decode graphs hold the old workspace pointers
+    for (auto &kv : m->decode_graphs) (void) hipGraphExecDestroy(kv.second);
+    m->decode_graphs.clear();
     const HParams &hp = m->hp;
     const size_t d = hp.n_embd, F = hp.n_ff, V = hp.n_vocab, C = hp.n_ctx, H = hp.n_head;
     const size_t KpMax = ((std::max(d, F) + 255) / 256) * 256;
@@ -255,15 +269,19 @@ struct DumpSink {
 // The forward pass for N tokens at n_past on this handle's layers (.mm:510-735).
 //   hidden_in  : device fp32 [N][d] residual stream from the previous stage (nullptr on the first stage)
 //   want_all   : compute logits for every token (debug) instead of only the last (.mm:724-725)
-int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool tokens_on_device,
+int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool state_on_device,
             bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap) {
     const HParams &hp = m->hp;
     const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx;
     const int nth = std::max(1, std::min(n_threads, 64));
     hipStream_t st = m->stream;
-    (void) tokens_on_device;
     const bool debug = dump_layer >= 0 && sink;
     const bool fused = (N == 1) && !debug && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
+    if (fused && !state_on_device) {
+        // host-driven single-token eval: publish the position to the device-resident state
+        const int32_t hs[2] = { n_past, 0 };
+        HIP_TRY(hipMemcpyAsync(m->d_state, hs, sizeof(hs), hipMemcpyHostToDevice, st), LLAMAHIP_ERR_PREDICT);
+    }
 
     if (m->first_stage) {
         HIP_TRY(launch_embed(m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
@@ -277,13 +295,18 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         const bool dmp = debug && il == dump_layer;
 
         if (fused) {
-            // ---- decode: 5 launches per layer, activation prep fused into each GEMV prologue
-            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, L.attention_norm, m->qkv, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, 1, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, 1, d, H, nth, m->T_exp, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_gemv(L.wo, PREP_PLAIN, EPI_RESID, nullptr, nullptr, m->merged, nullptr, m->x1, m->x, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, m->x, m->x1, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            // ---- decode: activation preparation lives in GEMV prologues / producer epilogues;
+            // the context position is read from m->d_state by the attention kernels
+            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, L.attention_norm, m->qkv, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, m->d_state, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, m->x, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            if (m->w13_interleaved) {
+                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, 0, 0, m->qa2_A, m->qa2_d, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, m->x, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            } else {
+                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, m->x, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            }
             continue;
         }
 
@@ -341,7 +364,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         // last (.mm:724-725); only the last row is computed here unless every row is requested.
         const int V = hp.n_vocab;
         if (fused) {
-            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
         } else if (want_all) {
             HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, N, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
@@ -484,6 +507,7 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
         LOAD_TRY(upload_q4(m.get(), "output.weight", m->output, 0, d_stage, h_stage, err, err_cap));
     }
     m->layers.resize(m->l1 - m->l0);
+    m->w13_interleaved = (F % 32 == 0);
     for (int il = m->l0; il < m->l1; il++) {
         Layer &L = m->layers[il - m->l0];
         const std::string p = "layers." + std::to_string(il) + ".";
@@ -496,8 +520,15 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
         LOAD_TRY(alloc_qmat(L.wo, d, d, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "attention.wo.weight", L.wo, 0, d_stage, h_stage, err, err_cap));
         LOAD_TRY(alloc_qmat(L.w13, 2 * F, d, m.get(), err, err_cap));
-        LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w1.weight", L.w13, 0, d_stage, h_stage, err, err_cap));
-        LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w3.weight", L.w13, F, d_stage, h_stage, err, err_cap));
+        if (m->w13_interleaved) {
+            // every 8 tile groups = 32 rows of w1 followed by the same 32 rows of w3 (k_repack_q4)
+            L.w13.gmapF8 = F / 8;
+            LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w1.weight", L.w13, 0, d_stage, h_stage, err, err_cap, 1, 0));
+            LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w3.weight", L.w13, 0, d_stage, h_stage, err, err_cap, 1, 4));
+        } else {
+            LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w1.weight", L.w13, 0, d_stage, h_stage, err, err_cap));
+            LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w3.weight", L.w13, F, d_stage, h_stage, err, err_cap));
+        }
         LOAD_TRY(alloc_qmat(L.w2, d, F, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w2.weight", L.w2, 0, d_stage, h_stage, err, err_cap));
     }
@@ -511,6 +542,22 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
     HIP_TRY(hipMemset(m->Kc, 0, kv_elems * 4), LLAMAHIP_ERR_LOAD);
     HIP_TRY(hipMemset(m->Vc, 0, kv_elems * 4), LLAMAHIP_ERR_LOAD);
     m->kv_bytes = (int64_t) kv_elems * 8;
+    {
+        const size_t Kp_d = ((size_t) d + 255) / 256 * 256, Kp_F = ((size_t) F + 255) / 256 * 256, dh = d / H;
+        HIP_TRY(hipMalloc((void **) &m->d_state, 2 * sizeof(int32_t)), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->d_state, 0, 2 * sizeof(int32_t)), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->sc, (size_t) H * n_ctx * 4), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->part, (size_t) H * 64 * dh * 4), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->qa1_A, Kp_d), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->qa1_d, Kp_d / 32 * 4), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->qa2_A, Kp_F), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->qa2_d, Kp_F / 32 * 4), LLAMAHIP_ERR_LOAD);
+        // blocks past K/32 (padding up to a multiple of 256 columns) are never written again: keep them zero
+        HIP_TRY(hipMemset(m->qa1_A, 0, Kp_d), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->qa1_d, 0, Kp_d / 32 * 4), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->qa2_A, 0, Kp_F), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->qa2_d, 0, Kp_F / 32 * 4), LLAMAHIP_ERR_LOAD);
+    }
 
     rc = ensure_workspace(m.get(), 16, err, err_cap);
     if (rc != 0) return LLAMAHIP_ERR_LOAD;
@@ -606,17 +653,45 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     rc = ensure_workspace(m, 1, err, err_cap);
     if (rc) return rc;
-    if (m->out_tokens_cap < n_steps) {
-        free_dev(m->d_out_tokens); m->d_out_tokens = nullptr; m->out_tokens_cap = 0;
-        HIP_TRY(hipMalloc((void **) &m->d_out_tokens, (size_t) n_steps * 4), LLAMAHIP_ERR_PREDICT);
-        m->out_tokens_cap = n_steps;
+    if (!m->d_out_tokens) {      // sized once for the whole context: captured graphs hold this pointer
+        HIP_TRY(hipMalloc((void **) &m->d_out_tokens, (size_t) m->hp.n_ctx * 4), LLAMAHIP_ERR_PREDICT);
+        m->out_tokens_cap = m->hp.n_ctx;
     }
     HIP_TRY(hipMemcpyAsync(m->d_tokens, &first_token, 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
-    for (int i = 0; i < n_steps; i++) {
-        rc = forward(m, n_threads, n_past + i, 1, nullptr, true, false, -1, nullptr, err, err_cap);
-        if (rc) return rc;
-        // argmax feeds the next step's token slot on the device: no host round trip
-        HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, i, m->d_tokens, m->stream), LLAMAHIP_ERR_PREDICT);
+    {
+        const int32_t hs[2] = { n_past, 0 };
+        HIP_TRY(hipMemcpyAsync(m->d_state, hs, sizeof(hs), hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    }
+    const int nth = std::max(1, std::min(n_threads, 64));
+    const bool fusable = !(m->flags & LLAMAHIP_FLAG_UNFUSED);
+    if (fusable && !(m->flags & LLAMAHIP_FLAG_NO_GRAPH)) {
+        // One decode step (embed -> layers -> lm head -> argmax) captured once per n_threads value.
+        // Nothing in it depends on the step: position and token slots live in device memory and
+        // k_argmax advances them, so the same executable graph is replayed n_steps times.
+        auto it = m->decode_graphs.find(nth);
+        if (it == m->decode_graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal), LLAMAHIP_ERR_PREDICT);
+            rc = forward(m, nth, 0, 1, nullptr, true, false, -1, nullptr, err, err_cap);
+            hipError_t e1 = rc ? hipErrorUnknown : launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, 0, m->d_tokens, m->d_state, m->stream);
+            hipError_t e2 = hipStreamEndCapture(m->stream, &graph);
+            if (rc) return rc;
+            HIP_TRY(e1, LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(e2, LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), LLAMAHIP_ERR_PREDICT);
+            (void) hipGraphDestroy(graph);
+            it = m->decode_graphs.emplace(nth, exec).first;
+        }
+        for (int i = 0; i < n_steps; i++) HIP_TRY(hipGraphLaunch(it->second, m->stream), LLAMAHIP_ERR_PREDICT);
+    } else {
+        for (int i = 0; i < n_steps; i++) {
+            rc = forward(m, n_threads, n_past + i, 1, nullptr, fusable, false, -1, nullptr, err, err_cap);
+            if (rc) return rc;
+            // argmax feeds the next step's token slot (and advances the position) on the device
+            HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, i, m->d_tokens, m->d_state, m->stream), LLAMAHIP_ERR_PREDICT);
+        }
     }
     if (out_tokens) HIP_TRY(hipMemcpyAsync(out_tokens, m->d_out_tokens, (size_t) n_steps * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
@@ -691,7 +766,7 @@ int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const flo
         if (hipStreamCreate(&st) != hipSuccess) break;
         if (hipMemcpyAsync(d_w, w_q4_0, wbytes, hipMemcpyHostToDevice, st) != hipSuccess) break;
         if (hipMemcpyAsync(d_x, x, (size_t) N * K * 4, hipMemcpyHostToDevice, st) != hipSuccess) break;
-        if (launch_repack(d_w, q.tiles, M, K, st) != hipSuccess) break;
+        if (launch_repack(d_w, q.tiles, M, K, 0, 0, st) != hipSuccess) break;
         if (launch_prep(PREP_PLAIN, d_x, nullptr, K, 0, K, N, d_qA, d_qd, nullptr, nullptr, nullptr, 0, 0, st) != hipSuccess) break;
         if (launch_gemm(q, EPI_STORE, d_qA, d_qd, N, d_y, M, nullptr, 0, st) != hipSuccess) break;
         if (hipMemcpyAsync(y, d_y, (size_t) N * M * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
@@ -752,7 +827,7 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
     HIP_TRY(launch_prep(PREP_PLAIN, m->tmp, nullptr, q->K, 0, q->K, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
     float *yout = which == 4 ? m->logits : m->gu;     // gu (2F floats) is large enough for every layer matrix
-    auto run = [&](const QMat *w) { return launch_gemv(*w, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, m->stream); };
+    auto run = [&](const QMat *w) { return launch_gemv(*w, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, nullptr, nullptr, m->stream); };
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipEventCreate(&e1), LLAMAHIP_ERR_PREDICT);
@@ -764,7 +839,7 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
         for (int it = 0; it < warmup + iters; it++) {
             size_t flushed = 0;
             for (const Layer &L : m->layers) {
-                HIP_TRY(launch_gemv(L.w13, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, m->gu, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w13, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, m->gu, nullptr, m->T_silu, 0, 0, nullptr, nullptr, m->stream), LLAMAHIP_ERR_PREDICT);
                 flushed += L.w13.bytes();
                 if (flushed > (size_t) 400 << 20) break;
             }

@@ -10,7 +10,7 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
 enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_SUM = 4 };
-enum { EPI_STORE = 0, EPI_RESID = 1 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2 };
 
 // a Q4_0 weight matrix resident in HBM in chain-major tile layout
 struct QMat {
@@ -18,6 +18,7 @@ struct QMat {
     int M = 0, K = 0;           // logical rows / columns
     int ngroups = 0;            // ceil(M / 8)
     int nchunks = 0;            // ceil(K / 256)
+    int gmapF8 = 0;             // F/8 for the interleaved w1|w3 matrix, else 0 (see k_repack_q4)
     size_t bytes() const { return (size_t) ngroups * (nchunks + 1) * TILE_BYTES; }
     int Kp() const { return nchunks * 256; }
 };
@@ -25,20 +26,24 @@ struct QMat {
 hipError_t init_kernel_attrs();
 
 hipError_t launch_add(const float *a, const float *b, float *c, long n, hipStream_t st);
-hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, hipStream_t st);
+hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int gmap, int goff, hipStream_t st);
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st);
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
                        int nsum, long sum_stride, hipStream_t st);
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
-                       const uint16_t *T_silu, int nsum, long sum_stride, hipStream_t st);
+                       const uint16_t *T_silu, int nsum, long sum_stride,
+                       uint32_t *out_A, float *out_d, hipStream_t st);
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st);
 hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, const double *tab,
                           float *qr, float *Kc, float *Vc, int n_past, int N, hipStream_t st);
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, hipStream_t st);
-hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, hipStream_t st);
+hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
+                           float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
+                           const uint16_t *T_exp, const int32_t *state, hipStream_t st);
+hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st);
 
 }  // namespace lh

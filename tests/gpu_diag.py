@@ -76,6 +76,16 @@ def main():
                 gk, gv = gm.kv(il, n_past); ok, ov = om.kv(il, n_past)
                 report(f"nth={nth} K cache layer {il}", gk, ok); report(f"nth={nth} V cache layer {il}", gv, ov)
             first = tok
+            for flags, label in ((1, "eager"), (3, "eager+unfused")):
+                g2 = L.Model(path, n_ctx=64, flags=flags)
+                g2.eval(toks, 0, nth); g2.eval(np.array([7], np.int32), 9, nth)
+                tk = 11
+                for step in range(6):
+                    gl = g2.eval(np.array([tk], np.int32), 10 + step, nth)
+                    wl = om2[step] if False else None
+                    tk = int(np.argmax(gl))
+                report(f"nth={nth} {label} greedy tokens vs graph model", g2.decode_greedy(first, n_past, 8, nth), gm.decode_greedy(first, n_past, 8, nth))
+                g2.close()
             gt = gm.decode_greedy(first, n_past, 8, nth)
             ot = []
             for i in range(8):
