@@ -1,0 +1,150 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares; loader validation and
+error strings (file parsing happens before any device work); host-only handles: multi-part merge,
+tokenizer and sampler against the golden vectors; the runner's event order on failure.
+No compute call is made (there is no GPU here)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HOST_ONLY = 4
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = L.lib()
+    missing = [s for s in L.declared_symbols() if not hasattr(lib, s)]
+    assert not missing
+    assert len(L.declared_symbols()) >= 25
+    assert L.version().startswith("llamahip")
+
+
+def test_load_errors_follow_the_reference_messages(L, tmp_path):
+    with pytest.raises(L.LlamaHipError) as e:
+        L.Model(str(tmp_path / "nope.bin"))
+    assert e.value.code == -1000 and "failed to open" in e.value.message           # .mm:101-102
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"\x00" * 64)
+    with pytest.raises(L.LlamaHipError) as e:
+        L.Model(str(bad))
+    assert e.value.code == -1000 and "bad magic" in e.value.message                 # .mm:111-112
+    f16 = tmp_path / "f16.bin"
+    f16.write_bytes(struct.pack("<I7i", synth.MAGIC, 4, 64, 32, 1, 1, 64, 7) + b"\x00" * 64)
+    with pytest.raises(L.LlamaHipError) as e:
+        L.Model(str(f16))
+    assert "bad f16 value 7" in e.value.message                                      # .mm:176-177
+
+
+def _write(tmp_path, hp, parts=1, mutate=None, seed=3):
+    path = str(tmp_path / "m.bin")
+    t = synth.random_tensors(hp, seed=seed)
+    synth.write_model(path, hp, t, n_parts=parts)
+    if mutate:
+        mutate(path)
+    return path, t
+
+
+def test_unknown_and_misshapen_tensors_are_rejected(L, tmp_path):
+    hp = synth.HParams(n_vocab=32, n_embd=128, n_mult=64, n_head=1, n_layer=1)
+    path, _ = _write(tmp_path, hp)
+    raw = bytearray(open(path, "rb").read())
+    at = raw.find(b"norm.weight")
+    raw[at:at + 4] = b"nor_"
+    open(path, "wb").write(raw)
+    with pytest.raises(L.LlamaHipError) as e:
+        L.Model(path, flags=HOST_ONLY)
+    assert "unknown tensor 'nor_.weight' in model file" in e.value.message         # .mm:353-354
+    path, _ = _write(tmp_path, hp)
+    raw = bytearray(open(path, "rb").read())
+    at = raw.find(b"tok_embeddings.weight")
+    ne0 = struct.unpack_from("<i", raw, at - 8)[0]
+    assert ne0 == 128
+    struct.pack_into("<i", raw, at - 8, 64)
+    open(path, "wb").write(raw)
+    with pytest.raises(L.LlamaHipError) as e:
+        L.Model(path, flags=HOST_ONLY)
+    assert "has wrong size in model file" in e.value.message                        # .mm:394-395
+
+
+@pytest.mark.parametrize("parts", [1, 2, 4])
+def test_multipart_merge_matches_the_reference_loader(L, ref, tmp_path, parts):
+    hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=256, n_head=2, n_layer=2)      # n_ff 768: shards stay multiples of 64
+    path, _ = _write(tmp_path, hp, parts=parts, seed=11)
+    m = L.Model(path, n_ctx=32, n_parts=parts, flags=HOST_ONLY)
+    r = ref.load(path, 32, parts)
+    assert (m.n_vocab, m.n_embd, m.n_head, m.n_layer, m.n_ff, m.n_parts) == (r.n_vocab, r.n_embd, r.n_head, r.n_layer, r.n_ff, parts)
+    for name in ("tok_embeddings.weight", "output.weight", "norm.weight", "layers.0.attention.wq.weight",
+                 "layers.1.attention.wo.weight", "layers.0.feed_forward.w1.weight", "layers.1.feed_forward.w2.weight",
+                 "layers.1.feed_forward.w3.weight", "layers.0.ffn_norm.weight"):
+        assert np.array_equal(m.tensor_bytes(name), r.tensor_bytes(name)), name
+    with pytest.raises(L.LlamaHipError) as e:          # no device state behind a host-only handle
+        m.eval([1], 0)
+    assert e.value.code == -1001
+
+
+def test_multipart_equals_single_part(L, tmp_path):
+    hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=256, n_head=2, n_layer=1)
+    t = synth.random_tensors(hp, seed=5)
+    p1, p2 = str(tmp_path / "one.bin"), str(tmp_path / "two.bin")
+    synth.write_model(p1, hp, t, 1)
+    synth.write_model(p2, hp, t, 2)
+    a = L.Model(p1, flags=HOST_ONLY)
+    b = L.Model(p2, n_parts=2, flags=HOST_ONLY)
+    # row-sharded tensors quantize identically per shard; column shards too (32-aligned slices)
+    for name in ("layers.0.attention.wq.weight", "layers.0.attention.wo.weight", "layers.0.feed_forward.w2.weight", "output.weight", "tok_embeddings.weight"):
+        assert np.array_equal(a.tensor_bytes(name), b.tensor_bytes(name)), name
+
+
+def _golden_model(L, tmp_path):
+    g = np.load(os.path.join(G, "tiny_model.npz"))
+    path = str(tmp_path / "tiny.bin")
+    g["model_file"].tofile(path)
+    return L.Model(path, n_ctx=64, flags=HOST_ONLY), g
+
+
+def test_tokenizer_matches_reference_vectors(L, tmp_path):
+    m, _ = _golden_model(L, tmp_path)
+    t = np.load(os.path.join(G, "text.npz"))
+    prompts = bytes(t["prompts_joined"]).split(b"\x00")
+    for i, p in enumerate(prompts):
+        assert np.array_equal(m.tokenize(p, True), t[f"tok_{i}_bos"]), p
+        assert np.array_equal(m.tokenize(p, False), t[f"tok_{i}_nobos"]), p
+    assert m.token_text(3) == b"a" and m.token_text(1) == b""
+    with pytest.raises(IndexError):
+        m.token_text(10 ** 6)
+
+
+def test_sampler_matches_reference_sequence(L, tmp_path):
+    m, _ = _golden_model(L, tmp_path)
+    t = np.load(os.path.join(G, "text.npz"))
+    s = L.Sampler(seed=-1, repeat_last_n=64)
+    for tok in t["sampler_window_init"]:
+        s.accept(int(tok))
+    got = []
+    for lg in t["sampler_logits"]:
+        tid = s.sample(m, lg)
+        s.accept(tid)
+        got.append(tid)
+    assert got == t["sampler_ids"].tolist()
+
+
+def test_runner_reports_load_failure_like_the_bridge(L, tmp_path):
+    states, tokens = [], []
+    r = L.LlamaRunner(str(tmp_path / "missing.bin"))
+    with pytest.raises(L.LlamaHipError) as e:
+        r.run("hello", L.Config(numThreads=8, numTokens=4), tokens.append, lambda s, err: states.append(s))
+    assert e.value.code == -1000 and e.value.domain == "com.alexrozanski.llama.error"
+    assert states == [L.RunState.notStarted, L.RunState.initializing, L.RunState.failed] and tokens == []
+    assert L.Config.default == L.Config(8, 512, None)
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(L.LlamaHipError) as e:
+        L.op_quantize_row_q4_0(np.zeros(32, np.float32))
+    assert "no CPU fallback" in e.value.message
