@@ -51,6 +51,7 @@ typedef struct llamahip_opts {
     int32_t layer_end;     /* one past the last layer; -1 = n_layer */
     int32_t n_parts;       /* 0 = by n_embd as the reference (.mm:33-38; unknown widths -> 1) */
     int32_t flags;         /* LLAMAHIP_FLAG_* */
+    int32_t n_seq;         /* independent KV caches held by this handle (pipeline micro-batching); 0 = 1 */
 } llamahip_opts;
 
 #define LLAMAHIP_FLAG_NO_GRAPH   1   /* launch decode kernels eagerly instead of via hipGraph */
@@ -128,6 +129,9 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
                         const int32_t *tokens, int32_t n_tokens,
                         const void *hidden_in, void *hidden_out, float *logits_out,
                         char *err, size_t err_cap);
+
+/* Select which of the handle's n_seq KV caches subsequent evals read and write (default 0). */
+int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap);
 
 /* Raw fp32 KV rows of layer il, positions [0, n_pos) copied to host (n_pos * n_embd floats each). */
 int llamahip_kv_read(llamahip_model *m, int32_t il, int32_t n_pos, float *out_k, float *out_v,

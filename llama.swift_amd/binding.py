@@ -46,7 +46,7 @@ _lib = None
 
 class _Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("layer_begin", C.c_int32),
-                ("layer_end", C.c_int32), ("n_parts", C.c_int32), ("flags", C.c_int32)]
+                ("layer_end", C.c_int32), ("n_parts", C.c_int32), ("flags", C.c_int32), ("n_seq", C.c_int32)]
 
 
 class _GemvBench(C.Structure):
@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
     L.llamahip_eval_debug.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, C.c_int64, vp, cp, sz]
     L.llamahip_eval_stage.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, cp, sz]
     L.llamahip_kv_read.argtypes = [vp, i32, i32, vp, vp, cp, sz]
+    L.llamahip_set_seq.argtypes = [vp, i32, cp, sz]
     L.llamahip_tensor_bytes.argtypes = [vp, cp, vp, C.c_int64]
     L.llamahip_tensor_bytes.restype = C.c_int64
     L.llamahip_op_mul_mat_q4_0.argtypes = [vp, i32, i32, vp, i32, vp, cp, sz]
@@ -135,11 +136,12 @@ class Model:
     """Opaque model handle (llama_model + gpt_vocab of the reference, .mm:71-88, utils.h:49-55)."""
 
     def __init__(self, path: str, n_ctx: int = 512, device: int = -1, layer_begin: int = 0,
-                 layer_end: int = -1, n_parts: int = 0, flags: int = 0):
+                 layer_end: int = -1, n_parts: int = 0, flags: int = 0, n_seq: int = 1):
         L = lib()
         err = C.create_string_buffer(1024)
         h = C.c_void_p()
-        opts = _Opts(C.sizeof(_Opts), device, layer_begin, layer_end, n_parts, flags)
+        opts = _Opts(C.sizeof(_Opts), device, layer_begin, layer_end, n_parts, flags, n_seq)
+        self.layer_begin, self.n_seq = layer_begin, n_seq
         rc = L.llamahip_model_load(path.encode(), n_ctx, C.byref(opts), C.byref(h), err, len(err))
         _check(rc, err)
         self._h = h
@@ -204,6 +206,23 @@ class Model:
                 res[name] = dump[off:off + n].copy()
                 off += n
         return res
+
+    def set_seq(self, seq: int) -> None:
+        err = C.create_string_buffer(1024)
+        _check(lib().llamahip_set_seq(self._h, seq, err, len(err)), err)
+
+    def eval_stage(self, n_past: int, tokens=None, n_tokens: int = 0, hidden_in: int = 0, hidden_out: int = 0,
+                   want_logits: bool = False, n_threads: int = 8):
+        """Pipeline-stage eval.  hidden_in / hidden_out are DEVICE addresses (e.g. torch tensor
+        .data_ptr()) of n_tokens * n_embd fp32; tokens is given on the first stage only."""
+        tk = np.ascontiguousarray(tokens, np.int32) if tokens is not None else None
+        N = tk.size if tk is not None else n_tokens
+        logits = np.empty(self.n_vocab, np.float32) if want_logits else None
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_eval_stage(self._h, n_threads, n_past, _ptr(tk), N, C.c_void_p(hidden_in), C.c_void_p(hidden_out),
+                                       _ptr(logits), err, len(err))
+        _check(rc, err)
+        return logits
 
     def decode_greedy(self, first_token: int, n_past: int, n_steps: int, n_threads: int = 8, want_logits: bool = False):
         out = np.empty(n_steps, np.int32)

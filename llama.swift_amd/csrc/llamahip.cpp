@@ -155,7 +155,8 @@ struct llamahip_model {
     uint32_t *qa1_A = nullptr, *qa2_A = nullptr;   // QA operands: attention output (K = d), FFN activation (K = F)
     float *qa1_d = nullptr, *qa2_d = nullptr;
     bool w13_interleaved = false;
-    std::map<int, hipGraphExec_t> decode_graphs;   // keyed by n_threads semantics (nth)
+    int n_seq = 1, cur_seq = 0;          // KV caches: [seq][layer][n_ctx][d]
+    std::map<int, hipGraphExec_t> decode_graphs;   // keyed by nth * 4096 + seq
 
     // stats
     int64_t weight_bytes = 0, kv_bytes = 0, n_evals = 0;
@@ -291,7 +292,8 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
 
     for (int il = m->l0; il < m->l1; il++) {
         const Layer &L = m->layers[il - m->l0];
-        float *Kl = m->Kc + (size_t) (il - m->l0) * C * d, *Vl = m->Vc + (size_t) (il - m->l0) * C * d;
+        const size_t kv_at = ((size_t) m->cur_seq * (m->l1 - m->l0) + (il - m->l0)) * C * d;
+        float *Kl = m->Kc + kv_at, *Vl = m->Vc + kv_at;
         const bool dmp = debug && il == dump_layer;
 
         if (fused) {
@@ -418,9 +420,10 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
     if (n_ctx < 1) { set_err(err, err_cap, "n_ctx must be >= 1"); return LLAMAHIP_ERR_LOAD; }
     std::unique_ptr<llamahip_model> m(new llamahip_model());
     int force_parts = 0, layer_begin = 0, layer_end = -1, device = -1;
-    if (opts && opts->struct_size >= (int32_t) sizeof(llamahip_opts)) {
+    if (opts && opts->struct_size >= 24) {             // fields up to `flags`
         force_parts = opts->n_parts; layer_begin = opts->layer_begin; layer_end = opts->layer_end;
         device = opts->device; m->flags = opts->flags;
+        if (opts->struct_size >= (int32_t) sizeof(llamahip_opts) && opts->n_seq > 0) m->n_seq = opts->n_seq;
     }
     std::string e;
     if (!m->file.open(path, n_ctx, force_parts, e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
@@ -536,7 +539,7 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
     (void) hipFree(d_stage);
 
     // ---- KV cache (.mm:290-304); zero-initialised (the reference leaves malloc garbage)
-    const size_t kv_elems = (size_t) (m->l1 - m->l0) * n_ctx * d;
+    const size_t kv_elems = (size_t) m->n_seq * (m->l1 - m->l0) * n_ctx * d;
     HIP_TRY(hipMalloc((void **) &m->Kc, kv_elems * 4), LLAMAHIP_ERR_LOAD);
     HIP_TRY(hipMalloc((void **) &m->Vc, kv_elems * 4), LLAMAHIP_ERR_LOAD);
     HIP_TRY(hipMemset(m->Kc, 0, kv_elems * 4), LLAMAHIP_ERR_LOAD);
@@ -668,7 +671,8 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         // One decode step (embed -> layers -> lm head -> argmax) captured once per n_threads value.
         // Nothing in it depends on the step: position and token slots live in device memory and
         // k_argmax advances them, so the same executable graph is replayed n_steps times.
-        auto it = m->decode_graphs.find(nth);
+        const int gkey = nth * 4096 + m->cur_seq;
+        auto it = m->decode_graphs.find(gkey);
         if (it == m->decode_graphs.end()) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
@@ -682,7 +686,7 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
             HIP_TRY(e2, LLAMAHIP_ERR_PREDICT);
             HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), LLAMAHIP_ERR_PREDICT);
             (void) hipGraphDestroy(graph);
-            it = m->decode_graphs.emplace(nth, exec).first;
+            it = m->decode_graphs.emplace(gkey, exec).first;
         }
         for (int i = 0; i < n_steps; i++) HIP_TRY(hipGraphLaunch(it->second, m->stream), LLAMAHIP_ERR_PREDICT);
     } else {
@@ -701,10 +705,16 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
     return LLAMAHIP_OK;
 }
 
+int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap) {
+    if (!m || seq < 0 || seq >= m->n_seq) { set_err(err, err_cap, "sequence slot %d out of range [0, %d)", seq, m ? m->n_seq : 0); return LLAMAHIP_ERR_PREDICT; }
+    m->cur_seq = seq;
+    return LLAMAHIP_OK;
+}
+
 int llamahip_kv_read(llamahip_model *m, int32_t il, int32_t n_pos, float *out_k, float *out_v, char *err, size_t err_cap) {
     if (!m || m->host_only || il < m->l0 || il >= m->l1 || n_pos < 0 || n_pos > m->hp.n_ctx) { set_err(err, err_cap, "bad kv_read arguments"); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
-    const size_t d = m->hp.n_embd, off = (size_t) (il - m->l0) * m->hp.n_ctx * d;
+    const size_t d = m->hp.n_embd, off = ((size_t) m->cur_seq * (m->l1 - m->l0) + (il - m->l0)) * m->hp.n_ctx * d;
     HIP_TRY(hipMemcpy(out_k, m->Kc + off, (size_t) n_pos * d * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMemcpy(out_v, m->Vc + off, (size_t) n_pos * d * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
     return LLAMAHIP_OK;

@@ -499,10 +499,14 @@ static void norm_mul(const float *x, const float *w, float *y, int d, int N) {
 #define DUMP(idx, ptr, count) do { if (dmp && dump && dump_sizes) { const long c_ = (long) (count); \
     if (dump_used + c_ <= dump_cap) { memcpy(dump + dump_used, (ptr), sizeof(float) * c_); dump_sizes[idx] = c_; dump_used += c_; } } } while (0)
 
-int orc_eval(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int N,
-             float *logits_last, float *logits_all,
-             int dump_layer, float *dump, long dump_cap, long *dump_sizes) {
-    const int d = m->n_embd, L = m->n_layer, C = m->n_ctx, H = m->n_head, V = m->n_vocab, F = m->n_ff;
+/* layers [l0, l1): a pipeline stage.  The first stage embeds `tokens`, later stages start from
+ * hidden_in (the fp32 residual stream, .mm:563-564, 687-690); the last stage applies the final norm
+ * and lm head, earlier stages return the residual stream in hidden_out. */
+static int eval_range(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int N, int l0, int l1,
+                      const float *hidden_in, float *hidden_out,
+                      float *logits_last, float *logits_all,
+                      int dump_layer, float *dump, long dump_cap, long *dump_sizes) {
+    const int d = m->n_embd, C = m->n_ctx, H = m->n_head, V = m->n_vocab, F = m->n_ff;
     const int dh = d / H, T = n_past + N;
     const int nth = n_threads < 1 ? 1 : n_threads;
     if (T > C || N < 1) return -1001;
@@ -518,11 +522,15 @@ int orc_eval(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int
     uint8_t *qa = (uint8_t *) malloc((size_t) N * ((F > d ? F : d) / QK) * BLK);
     const float kq_scale = 1.0f / sqrtf((float) d / H);         /* .mm:620 */
 
-    /* ggml_get_rows on a Q4_0 matrix (ggml.c:6760-6785) */
-    for (int n = 0; n < N; n++)
-        orc_dequantize_row_q4_0(m->tok_embeddings->data + (size_t) tokens[n] * (d / QK) * BLK, x + (size_t) n * d, d);
+    if (l0 == 0) {
+        /* ggml_get_rows on a Q4_0 matrix (ggml.c:6760-6785) */
+        for (int n = 0; n < N; n++)
+            orc_dequantize_row_q4_0(m->tok_embeddings->data + (size_t) tokens[n] * (d / QK) * BLK, x + (size_t) n * d, d);
+    } else {
+        memcpy(x, hidden_in, Nd * 4);
+    }
 
-    for (int il = 0; il < L; il++) {
+    for (int il = l0; il < l1; il++) {
         const orc_layer *l = &m->layers[il];
         const int dmp = (il == dump_layer);
         float *Kc = m->memory_k + (size_t) il * C * d, *Vc = m->memory_v + (size_t) il * C * d;
@@ -608,14 +616,32 @@ int orc_eval(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int
         DUMP(16, x, Nd);
     }
 
-    norm_mul(x, (const float *) m->norm->data, cur, d, N);                        /* .mm:695-700 */
-    quantize_rows(cur, qa, d, N);
-    float *logits = (float *) malloc((size_t) N * V * 4);
-    matmul_q4(m->output, qa, logits, N, nth);                                     /* .mm:705 */
-    if (logits_last) memcpy(logits_last, logits + (size_t) (N - 1) * V, (size_t) V * 4);   /* .mm:724-725 */
-    if (logits_all) memcpy(logits_all, logits, (size_t) N * V * 4);
+    float *logits = NULL;
+    if (l1 == m->n_layer) {
+        norm_mul(x, (const float *) m->norm->data, cur, d, N);                    /* .mm:695-700 */
+        quantize_rows(cur, qa, d, N);
+        logits = (float *) malloc((size_t) N * V * 4);
+        matmul_q4(m->output, qa, logits, N, nth);                                 /* .mm:705 */
+        if (logits_last) memcpy(logits_last, logits + (size_t) (N - 1) * V, (size_t) V * 4);   /* .mm:724-725 */
+        if (logits_all) memcpy(logits_all, logits, (size_t) N * V * 4);
+    } else if (hidden_out) {
+        memcpy(hidden_out, x, Nd * 4);
+    }
 
     free(logits); free(x); free(cur); free(q); free(k); free(v); free(ffin); free(merged);
     free(up); free(gate); free(kq); free(kqv); free(part); free(qa);
     return 0;
+}
+
+int orc_eval(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int N,
+             float *logits_last, float *logits_all,
+             int dump_layer, float *dump, long dump_cap, long *dump_sizes) {
+    return eval_range(m, n_threads, n_past, tokens, N, 0, m->n_layer, NULL, NULL, logits_last, logits_all,
+                      dump_layer, dump, dump_cap, dump_sizes);
+}
+
+int orc_eval_range(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int N, int l0, int l1,
+                   const float *hidden_in, float *hidden_out, float *logits_last) {
+    if (l0 < 0 || l1 > m->n_layer || l0 >= l1) return -1001;
+    return eval_range(m, n_threads, n_past, tokens, N, l0, l1, hidden_in, hidden_out, logits_last, NULL, -1, NULL, 0, NULL);
 }

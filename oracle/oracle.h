@@ -47,6 +47,10 @@ int        orc_eval(orc_model *m, int n_threads, int n_past, const int32_t *toke
                     float *logits_last, float *logits_all,
                     int dump_layer, float *dump, long dump_cap, long *dump_sizes);
 
+/* layers [l0, l1) only -- emulates one stage of the layer pipeline */
+int        orc_eval_range(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int N, int l0, int l1,
+                          const float *hidden_in, float *hidden_out, float *logits_last);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,6 +234,8 @@ class OracleLib:
         L.orc_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p]
         L.orc_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_void_p, C.c_long, C.c_void_p]
+        L.orc_eval_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_tables_init()
 
     def tables(self):
@@ -335,6 +337,20 @@ class OracleModel:
         v = np.empty((n_pos, self.n_embd), np.float32)
         self.lib.L.orc_kv(self.h, il, n_pos, k, v)
         return k, v
+
+    def eval_range(self, l0, l1, n_past, tokens=None, hidden_in=None, n_threads=8):
+        """One pipeline stage: returns (hidden_out or None, logits or None)."""
+        tk = np.ascontiguousarray(tokens, np.int32) if tokens is not None else None
+        hin = np.ascontiguousarray(hidden_in, np.float32) if hidden_in is not None else None
+        N = tk.size if tk is not None else hin.size // self.n_embd
+        last = l1 == self.n_layer
+        hout = None if last else np.empty(N * self.n_embd, np.float32)
+        logits = np.empty(self.n_vocab, np.float32) if last else None
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        rc = self.lib.L.orc_eval_range(self.h, n_threads, n_past, p(tk), N, l0, l1, p(hin), p(hout), p(logits))
+        if rc != 0:
+            raise RuntimeError(f"orc_eval_range failed: {rc}")
+        return hout, logits
 
     def eval(self, tokens, n_past, n_threads=8, all_logits=False, dump_layer=-1):
         tokens = np.ascontiguousarray(tokens, np.int32)

@@ -1,0 +1,124 @@
+"""The N > 1 path of bench.py: the layer-pipeline schedule (llama.swift_amd/pipeline.py).
+
+CPU (world_size 2 and 3, gloo): the schedule itself -- ordering, non-blocking hand-off, token
+feedback, per-sequence KV slots -- with oracle-backed stages standing in for the GPUs; the pipelined
+tokens must equal the monolithic greedy decode of every sequence.
+GPU (-m gpu, single device): the product stage (llamahip_eval_stage + KV sequence slots) split in two
+on one GPU must reproduce the whole-model logits bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_layer_range_partitions_every_layer_once(L):
+    from llama_swift_amd.pipeline import layer_range
+    for n_layer, world in [(32, 1), (32, 8), (80, 8), (40, 3), (5, 4), (60, 7)]:
+        got = [layer_range(n_layer, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == n_layer
+        assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+        assert max(hi - lo for lo, hi in got) - min(hi - lo for lo, hi in got) <= 1
+
+
+class OracleStage:
+    """CPU stand-in for a GPU stage: layers [lo, hi) evaluated by the oracle, one model instance per
+    in-flight sequence (= one KV cache per sequence)."""
+
+    def __init__(self, path, n_ctx, rank, world, n_seq, n_layer):
+        import reflib
+        from llama_swift_amd.pipeline import layer_range
+        self.lo, self.hi = layer_range(n_layer, rank, world)
+        lib = reflib.OracleLib()
+        self.models = [lib.load(path, n_ctx) for _ in range(n_seq)]
+        self.is_first, self.is_last = self.lo == 0, self.hi == n_layer
+        self.n_embd, self.n_vocab = self.models[0].n_embd, self.models[0].n_vocab
+        self.device = "cpu"
+
+    def run(self, seq, n_past, tokens, hidden):
+        import torch
+        hin = None if self.is_first else hidden.numpy()
+        hout, logits = self.models[seq].eval_range(self.lo, self.hi, n_past, tokens=tokens if self.is_first else None, hidden_in=hin, n_threads=8)
+        return logits if self.is_last else torch.from_numpy(hout)
+
+
+def _worker(rank, world, path, n_layer, init_file, rounds, out_file):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    from llama_swift_amd.pipeline import pipeline_rounds
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    S = world + 1                                  # more sequences than stages also has to work
+    stage = OracleStage(path, 64, rank, world, S, n_layer)
+    prompts = [synth.synth_prompt(5 + s, 96, seed=10 + s) for s in range(S)]
+    toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, rounds)
+    toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, [np.array([toks[s, -1]], np.int32) for s in range(S)], n_past, 3)
+    if rank == 0:
+        np.savez(out_file, toks=np.concatenate([toks, toks2], axis=1), n_past=np.array(n_past))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_schedule_gloo(built, tmp_path, world):
+    import torch.multiprocessing as mp
+    n_layer = 3
+    hp = synth.HParams(n_vocab=96, n_embd=256, n_mult=64, n_head=2, n_layer=n_layer)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=31))
+    rounds = 4
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(world, path, n_layer, str(tmp_path / "rdv"), rounds, out), nprocs=world, join=True)
+    got = np.load(out)
+    import reflib
+    lib = reflib.OracleLib()
+    S = world + 1
+    for s in range(S):
+        m = lib.load(path, 64)
+        prompt = synth.synth_prompt(5 + s, 96, seed=10 + s)
+        lg = m.eval(prompt, 0, 8)["logits"]
+        n_past, want = len(prompt), []
+        for _ in range(rounds + 3):
+            t = int(np.argmax(lg)); want.append(t)
+            lg = m.eval(np.array([t], np.int32), n_past, 8)["logits"]; n_past += 1
+        assert got["toks"][s].tolist() == want, f"sequence {s}"
+        assert int(got["n_past"][s]) == len(prompt) + rounds - 1 + 3
+
+
+@pytest.mark.gpu
+def test_two_stages_on_one_gpu_equal_the_whole_model(L, tmp_path):
+    import torch
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=4)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=9))
+    whole = L.Model(path, n_ctx=64)
+    a = L.Model(path, n_ctx=64, layer_begin=0, layer_end=1, n_seq=2)        # uneven split on purpose
+    b = L.Model(path, n_ctx=64, layer_begin=1, layer_end=4, n_seq=2)
+    d = hp.n_embd
+    prompts = [synth.synth_prompt(9, hp.n_vocab, seed=1), synth.synth_prompt(6, hp.n_vocab, seed=2)]
+    n_past = [0, 0]
+    for step in range(5):
+        for s in (1, 0):                                                     # interleave the two sequences
+            toks = prompts[s] if step == 0 else np.array([nxt[s]], np.int32)
+            if step == 0 and s == 1:
+                nxt = [0, 0]
+            h = torch.empty(len(toks) * d, dtype=torch.float32, device="cuda")
+            a.set_seq(s); b.set_seq(s)
+            a.eval_stage(n_past[s], tokens=toks, hidden_out=h.data_ptr())
+            lg = b.eval_stage(n_past[s], n_tokens=len(toks), hidden_in=h.data_ptr(), want_logits=True)
+            n_past[s] += len(toks)
+            nxt[s] = int(np.argmax(lg))
+            if s == 0:                                                       # the whole model follows sequence 0 only
+                want = whole.eval(toks, n_past[0] - len(toks), 8)
+                assert np.array_equal(lg.view(np.uint32), want.view(np.uint32)), f"step {step}"
+    with pytest.raises(L.LlamaHipError):
+        a.set_seq(2)
+    with pytest.raises(L.LlamaHipError):
+        b.eval([1], 0)                                                        # a stage handle is not a whole model
+    for m in (whole, a, b):
+        m.close()
