@@ -68,6 +68,15 @@ def lib() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the HIP path)")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 + libhsa-runtime64; whichever HIP runtime is
+    # loaded first serves the whole process (same SONAME).  If this library pulled in the system
+    # runtime first, a later torch.cuda init would pair it with torch's bundled HSA runtime and find
+    # no GPUs -- so when torch is installed, let it load its runtime first (torch is only plumbing
+    # here: device tensors for the pipeline hand-off and torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, cp, sz = C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t
     L.llamahip_version.restype = cp
