@@ -162,6 +162,12 @@ typedef struct llamahip_gemv_bench {
 int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t warmup, int32_t iters,
                         llamahip_gemv_bench *out, char *err, size_t err_cap);
 
+/* In-kernel phase probe of the decode GEMVs: runs n_steps greedy decode steps with the probe armed;
+ * one record of 8 uint64 per GEMV launch {s_memtime at entry, loads issued, prologue done, weights
+ * consumed, exit; ngroups; nchunks; PRE*16+EPI}.  Returns the record count.  Measurement tooling only. */
+int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t first_token, int32_t n_steps,
+                                     uint64_t *records, int64_t cap, char *err, size_t err_cap);
+
 typedef struct llamahip_stats {
     int32_t struct_size;
     int64_t weight_bytes_device;   /* repacked Q4_0 bytes resident in HBM */

@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libllamahip.so")
+LIB_PATH = os.path.join(CSRC, os.environ.get("LLAMAHIP_LIB", "libllamahip.so"))     # LLAMAHIP_LIB=libllamahip_probe.so: measurement build
 INCLUDE = os.path.join(ROOT, "include")
 
 ERR_LOAD, ERR_PREDICT = -1000, -1001

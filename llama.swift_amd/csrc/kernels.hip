@@ -14,7 +14,8 @@
 //     _mm256_madd_epi16 gives lane k of its 8-float accumulator the elements
 //     {2k, 2k+1, 16+2k, 17+2k} of every block (ggml.c:1443-1452); a GPU lane owns exactly that
 //     chain, so its fp32 FMA sequence over the blocks is the reference's.
-//     dword i of a lane covers blocks (2i, 2i+1) of the chunk: byte p = e_p(block 2i) | e_p(block 2i+1) << 4.
+//     dword i of a lane covers blocks (2i, 2i+1) of the chunk: byte p = e_p(block 2i) | e_p(block 2i+1) << 4,
+//     each e stored as the signed nibble (q - 8) & 0xF.
 //   Quantized activations ("QA") for one row x[K]:
 //       A  : uint32 [chunk c][chain k][block j]  4 signed nibbles (q-8) of chain k, in the LOW nibble
 //            of each byte for even j, HIGH nibble for odd j  -> one v_dot8_i32_i4 per block
@@ -162,7 +163,8 @@ __global__ void k_repack_q4(const uint8_t *__restrict__ src, uint8_t *__restrict
     }
     const int tg = gmap ? (g >> 2) * 8 + goff + (g & 3) : g;
     uint8_t *t = dst + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
-    u32x4 v = { out[0], out[1], out[2], out[3] };
+    // stored as signed 4-bit values: (q - 8) & 0xF == q ^ 8, i.e. the dword ^ 0x88888888 -- ready for v_dot8_i32_i4
+    u32x4 v = { out[0] ^ 0x88888888u, out[1] ^ 0x88888888u, out[2] ^ 0x88888888u, out[3] ^ 0x88888888u };
     *(u32x4 *) (t + lane * 16) = v;
     // scale of block c*8 + k of row m
     const int bs = c * 8 + k;
@@ -176,9 +178,9 @@ __global__ void k_repack_q4(const uint8_t *__restrict__ src, uint8_t *__restrict
     // (s[k&3], s[4+(k&3)]), so every QUAD of lanes holds all 8 scales of its row and the per-block
     // scale is one v_mul_f32 with a quad_perm DPP broadcast (no LDS-pipe swizzle)
     *(float *) (t + 1024 + (r * 8 + (k & 3) * 2 + (k >> 2)) * 4) = d;
-    if (c == 0) {   // the zero tile closing this row-group (nibbles 8 = value 0, scales 0)
+    if (c == 0) {   // the zero tile closing this row-group (values 0, scales 0)
         uint8_t *z = dst + ((size_t) tg * (nchunks + 1) + nchunks) * TILE_BYTES;
-        u32x4 zv = { 0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u };
+        u32x4 zv = { 0u, 0u, 0u, 0u };
         *(u32x4 *) (z + lane * 16) = zv;
         *(float *) (z + 1024 + lane * 4) = 0.0f;
     }
@@ -243,6 +245,19 @@ __device__ __forceinline__ int pidx(int i) { return i + (i >> 5); }
 // clamped, never branched around), so a prologue costs a couple of L2 round trips instead of one per
 // element: these prologues run inside the GEMV kernels, in front of the weight stream.
 constexpr int LB_DEFAULT = 8;
+
+// Optional phase-timing probe (tools/gemv_phases.py), compiled in only with -DLH_PHASE_PROBE=1
+// (`make probe` -> libllamahip_probe.so): one thread of the middle workgroup of every k_gemv launch
+// stores s_memtime at the phase boundaries.  It is NOT in the product build: merely carrying the
+// probe pointer through the kernel cost the 22-deep ring variant 60 VGPRs and pushed it into scratch.
+// layout: [0] = launch counter, [1] = capacity, entry e at 8*(1+e): {5 stamps, ngroups, nchunks, PRE*16+EPI}
+__device__ unsigned long long *g_phase_probe = nullptr;
+#if LH_PHASE_PROBE
+#define LH_STAMP(IDX) do { if (probe_e) probe_e[IDX] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LH_STAMP(IDX) do { } while (0)
+#endif
+
 
 template <int MODE, int LB = LB_DEFAULT>
 __device__ void make_y(float *ybuf, double *red, const float *__restrict__ in0, const float *__restrict__ in1,
@@ -427,7 +442,7 @@ __global__ void k_prep_qa(const float *__restrict__ in0, const float *__restrict
 #define LH_STEP(J, WD, AD, DA)                                                                     \
     {                                                                                              \
         const float sc_ = quad_bcast<((J) & 3)>((J) < 4 ? sw.x : sw.y) * (DA);                     \
-        const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, false);                   \
+        const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, true);  /* clamp: one VOP3P op, |isum| <= 512 never saturates */ \
         acc = fmaf(sc_, (float) p_, acc);                                                          \
     }
 
@@ -472,6 +487,15 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     const bool valid = g < ngroups;
     const uint8_t *wbase = wt + (size_t) (valid ? g : 0) * (nchunks + 1) * TILE_BYTES;
     const int last = nchunks - 1;
+#if LH_PHASE_PROBE
+    unsigned long long *probe_e = nullptr;
+    if (g_phase_probe && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+        unsigned long long *pb = g_phase_probe;
+        const unsigned long long slot = atomicAdd(pb, 1ull);
+        if (slot < pb[1]) { probe_e = pb + 8 * (1 + slot); probe_e[5] = ngroups; probe_e[6] = nchunks; probe_e[7] = PRE * 16 + EPI; }
+    }
+#endif
+    LH_STAMP(0);
 
     u32x4 wq[D];
     f32x2 ws[D];
@@ -484,23 +508,31 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     }
     // ---- phase 1: the prologue's own (small, L2-resident) loads go out FIRST.  vmcnt retires in
     // order, so anything issued behind the weight prefetch would have to wait for all of it.
+    // fp32 prologues own the row in HALF-BLOCK granules (16 contiguous elements = 4 float4): granule
+    // h belongs to thread h % blockDim, so the two halves of a Q4_0 block sit in lanes t and t^1 and the
+    // whole norm -> quantize pipeline stays in registers (no LDS staging of y, no one-thread-per-block
+    // serial quantizer: the prologue is VALU work repeated by every workgroup, so its instruction
+    // count matters as much as the mat-vec's).
     constexpr bool REGPRE = (PRE == PRE_QA || PRE == PREP_NORM || PRE == PREP_PLAIN);
-    constexpr int MAXG = (PRE == PREP_NORM || PRE == PREP_PLAIN) ? PG : 1;   // fp32 float4 granules per thread
+    constexpr int MAXH = (PRE == PREP_NORM || PRE == PREP_PLAIN) ? PG : 1;   // half-block granules per thread
     constexpr int MAXQA = (PRE == PRE_QA) ? PG : 1, MAXQD = (PG + 7) / 8;    // QA granules per thread (da is 1/8 of A)
-    f32x4 xa[MAXG], xb[MAXG];
+    f32x4 xa[MAXH][4], xb[MAXH][4];
     u32x4 qg[MAXQA], qh[MAXQD];
     const int nt = blockDim.x;
-    const int n4 = K >> 2;
+    const int nh = K >> 4;                                   // half-blocks in the row
     // (trip counts are wave-uniform; a skipped load only makes the compiler's vmcnt for these
     //  prologue loads stricter -- they are all older than the weight loads, which stay in flight)
     if (PRE == PREP_NORM || PRE == PREP_PLAIN) {
-        const int ng = (n4 + nt - 1) / nt;
+        const int ng = (nh + nt - 1) / nt;
 #pragma unroll
-        for (int u = 0; u < MAXG; u++) {
+        for (int u = 0; u < MAXH; u++) {
             if (u < ng) {
-                const int gi = min(tid + u * nt, n4 - 1);
-                xa[u] = ((const f32x4 *) in0)[gi];
-                if (PRE == PREP_NORM) xb[u] = ((const f32x4 *) in1)[gi];
+                const int hi = min(tid + u * nt, nh - 1);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    xa[u][v] = ((const f32x4 *) in0)[hi * 4 + v];
+                    if (PRE == PREP_NORM) xb[u][v] = ((const f32x4 *) in1)[hi * 4 + v];
+                }
             }
         }
     }
@@ -519,6 +551,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- phase 3: prologue arithmetic while the weights stream in
+    LH_STAMP(1);
     double *red = (double *) (ldsD + nchunks * 8);
     if (PRE == PRE_QA) {
 #pragma unroll
@@ -527,39 +560,80 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         for (int u = 0; u < MAXQD; u++) { const int gi = tid + u * nt; if (gi < nchunks * 2) ((u32x4 *) ldsD)[gi] = qh[u]; }
         __syncthreads();
     } else if (REGPRE) {
-        float *ybuf = (float *) (red + 32);
         if (PRE == PREP_NORM) {
             // ggml_norm + ggml_mul (ggml.c:5327-5385, :4555) on register-resident x
             double s1 = 0.0;
 #pragma unroll
-            for (int u = 0; u < MAXG; u++)
-                if (tid + u * nt < n4) { s1 += (double) xa[u].x; s1 += (double) xa[u].y; s1 += (double) xa[u].z; s1 += (double) xa[u].w; }
+            for (int u = 0; u < MAXH; u++)
+                if (tid + u * nt < nh) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++) { s1 += (double) xa[u][v].x; s1 += (double) xa[u][v].y; s1 += (double) xa[u][v].z; s1 += (double) xa[u][v].w; }
+                }
             const double mean = block_sum_d(s1, red, 0) / (double) K;
             double s2 = 0.0;
 #pragma unroll
-            for (int u = 0; u < MAXG; u++)
-                if (tid + u * nt < n4) {
-                    const double v0 = (double) xa[u].x - mean, v1 = (double) xa[u].y - mean;
-                    const double v2 = (double) xa[u].z - mean, v3 = (double) xa[u].w - mean;
-                    xa[u].x = (float) v0; xa[u].y = (float) v1; xa[u].z = (float) v2; xa[u].w = (float) v3;
-                    s2 += v0 * v0; s2 += v1 * v1; s2 += v2 * v2; s2 += v3 * v3;
+            for (int u = 0; u < MAXH; u++)
+                if (tid + u * nt < nh) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const double v0 = (double) xa[u][v].x - mean, v1 = (double) xa[u][v].y - mean;
+                        const double v2 = (double) xa[u][v].z - mean, v3 = (double) xa[u][v].w - mean;
+                        xa[u][v].x = (float) v0; xa[u][v].y = (float) v1; xa[u][v].z = (float) v2; xa[u][v].w = (float) v3;
+                        s2 += v0 * v0; s2 += v1 * v1; s2 += v2 * v2; s2 += v3 * v3;
+                    }
                 }
             const double sum2 = block_sum_d(s2, red, 1);
             const float scale = (float) (1.0 / sqrt(sum2 / (double) K + (double) 1e-5f));
 #pragma unroll
-            for (int u = 0; u < MAXG; u++)
-                if (tid + u * nt < n4) {
-                    xa[u].x = xb[u].x * (xa[u].x * scale); xa[u].y = xb[u].y * (xa[u].y * scale);
-                    xa[u].z = xb[u].z * (xa[u].z * scale); xa[u].w = xb[u].w * (xa[u].w * scale);
+            for (int u = 0; u < MAXH; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    xa[u][v].x = xb[u][v].x * (xa[u][v].x * scale); xa[u][v].y = xb[u][v].y * (xa[u][v].y * scale);
+                    xa[u][v].z = xb[u][v].z * (xa[u][v].z * scale); xa[u][v].w = xb[u][v].w * (xa[u][v].w * scale);
                 }
         }
+        // quantize_row_q4_0, AVX2 branch (ggml.c:456-523), two lanes per block
+        const int nbp = nchunks * 8;
 #pragma unroll
-        for (int u = 0; u < MAXG; u++) {
-            const int gi = tid + u * nt;
-            if (gi < n4) { float *o = ybuf + pidx(4 * gi); o[0] = xa[u].x; o[1] = xa[u].y; o[2] = xa[u].z; o[3] = xa[u].w; }
+        for (int u = 0; u < MAXH; u++) {
+            const int hi = tid + u * nt;                       // half-block index; block = hi >> 1, half = hi & 1
+            const bool live = hi < nh;
+            float amax = 0.0f;
+            if (live) {
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    amax = fmaxf(fmaxf(fmaxf(amax, fabsf(xa[u][v].x)), fabsf(xa[u][v].y)), fmaxf(fabsf(xa[u][v].z), fabsf(xa[u][v].w)));
+            }
+            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax));    // partner half (lane ^ 1); both dead or both live
+            const float dd = amax / 7.0f;
+            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+            // this half's 8 element pairs: pair p = elements (2p, 2p+1) of the half -> one 16-bit field
+            uint32_t pr[8];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const uint32_t n0 = (uint32_t) ((int) __builtin_rintf(xa[u][v].x * id)) & 0xF, n1 = (uint32_t) ((int) __builtin_rintf(xa[u][v].y * id)) & 0xF;
+                const uint32_t n2 = (uint32_t) ((int) __builtin_rintf(xa[u][v].z * id)) & 0xF, n3 = (uint32_t) ((int) __builtin_rintf(xa[u][v].w * id)) & 0xF;
+                pr[2 * v] = n0 | (n1 << 8);
+                pr[2 * v + 1] = n2 | (n3 << 8);
+            }
+            // chain k of the block = pair k of half 0 (low 16 bits) | pair k of half 1 (high 16 bits)
+            const int half = hi & 1, b = hi >> 1, c = b >> 3, j = b & 7;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t other = (uint32_t) __builtin_amdgcn_mov_dpp((int) pr[k], DPP_QUAD_XOR1, 0xF, 0xF, true);
+                const uint32_t dw = (half ? (other | (pr[k] << 16)) : (pr[k] | (other << 16))) << (4 * (j & 1));
+                // half 0 stores chains 0..3, half 1 chains 4..7
+                if (live && (k >> 2) == half) ldsA[(c * 8 + k) * 8 + j] = dw;
+            }
+            if (live && half == 0) ldsD[b] = dd;
         }
-        __syncthreads();
-        quantize_y(ybuf, K, nchunks * 256, ldsA, ldsD, nullptr);
+        // zero the padded blocks (K not a multiple of 256)
+        for (int b = K / 32 + tid; b < nbp; b += nt) {
+            const int c = b >> 3, j = b & 7;
+#pragma unroll
+            for (int k = 0; k < 8; k++) ldsA[(c * 8 + k) * 8 + j] = 0;
+            ldsD[b] = 0.0f;
+        }
         __syncthreads();
     } else {
         float *ybuf = (float *) (red + 32);
@@ -570,22 +644,34 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
 
     const int k = lane & 7;
     float acc = 0.0f;
-#define LH_CONSUME(SLOT, CH)                                                                       \
+    // LDS operands (activation nibbles + scales of one chunk) are fetched one chunk ahead into the
+    // other half of a two-entry register buffer, so their ~100-cycle latency is off the FMA chain
+    static_assert(D % 2 == 0, "the two-entry LDS operand buffer alternates by slot parity: ring depth must be even");
+    u32x4 la0[2], la1[2];
+    f32x4 ld0[2], ld1[2];
+#define LH_LDSLOAD(BUF, CH)                                                                        \
     {                                                                                              \
         const int cl_ = min((CH), last);                                                           \
+        const u32x4 *pa = (const u32x4 *) (ldsA + (cl_ * 8 + k) * 8);                              \
+        la0[BUF] = pa[0]; la1[BUF] = pa[1];                                                        \
+        const f32x4 *pd = (const f32x4 *) (ldsD + cl_ * 8);                                        \
+        ld0[BUF] = pd[0]; ld1[BUF] = pd[1];                                                        \
+    }
+#define LH_CONSUME(SLOT, CH)                                                                       \
+    {                                                                                              \
         const u32x4 w = wq[SLOT];                                                                  \
         const f32x2 sw = ws[SLOT];                                                                 \
-        const u32x4 *pa = (const u32x4 *) (ldsA + (cl_ * 8 + k) * 8);                              \
-        const u32x4 a0 = pa[0], a1 = pa[1];                                                        \
-        const f32x4 *pd = (const f32x4 *) (ldsD + cl_ * 8);                                        \
-        const f32x4 d0 = pd[0], d1 = pd[1];                                                        \
-        const uint32_t w0 = w.x ^ 0x88888888u, w1 = w.y ^ 0x88888888u;                             \
-        const uint32_t w2 = w.z ^ 0x88888888u, w3 = w.w ^ 0x88888888u;                             \
+        const u32x4 a0 = la0[(SLOT) & 1], a1 = la1[(SLOT) & 1];                                    \
+        const f32x4 d0 = ld0[(SLOT) & 1], d1 = ld1[(SLOT) & 1];                                    \
+        LH_LDSLOAD(((SLOT) + 1) & 1, (CH) + 1)                                                     \
+        const uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;                                     \
         LH_STEP(0, w0, a0.x, d0.x) LH_STEP(1, w0, a0.y, d0.y)                                      \
         LH_STEP(2, w1, a0.z, d0.z) LH_STEP(3, w1, a0.w, d0.w)                                      \
         LH_STEP(4, w2, a1.x, d1.x) LH_STEP(5, w2, a1.y, d1.y)                                      \
         LH_STEP(6, w3, a1.z, d1.z) LH_STEP(7, w3, a1.w, d1.w)                                      \
     }
+    LH_STAMP(2);
+    LH_LDSLOAD(0, 0)
     int c0 = 0;
     if (RING) {
         do {
@@ -603,9 +689,11 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         LH_CONSUME(i, c0 + i)
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef LH_LDSLOAD
 #undef LH_CONSUME
 #undef LH_LOADW
 
+    LH_STAMP(3);
     acc = fold8(acc);
     int lg = g;
     if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
@@ -638,6 +726,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         if (EPI == EPI_RESID) acc = acc + resid[m];
         y[m] = acc;
     }
+    LH_STAMP(4);
 }
 
 // Multi-column (prompt) variant: NC activation rows share every weight tile.  QA is read straight
@@ -667,8 +756,7 @@ k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int g
             w_next = __builtin_nontemporal_load((const u32x4 *) (wbase + (size_t) (c + 1) * TILE_BYTES + lane * 16));
             s_next = __builtin_nontemporal_load((const f32x2 *) (wbase + (size_t) (c + 1) * TILE_BYTES + soff));
         }
-        const uint32_t w0 = w.x ^ 0x88888888u, w1 = w.y ^ 0x88888888u;
-        const uint32_t w2 = w.z ^ 0x88888888u, w3 = w.w ^ 0x88888888u;
+        const uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
         const float s0 = quad_bcast<0>(sw.x), s1 = quad_bcast<1>(sw.x), s2 = quad_bcast<2>(sw.x), s3 = quad_bcast<3>(sw.x);
         const float s4 = quad_bcast<0>(sw.y), s5 = quad_bcast<1>(sw.y), s6 = quad_bcast<2>(sw.y), s7 = quad_bcast<3>(sw.y);
 #pragma unroll
@@ -678,7 +766,7 @@ k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int g
             const f32x4 *pd = (const f32x4 *) (qa_d + n * strideD + c * 8);
             const f32x4 d0 = pd[0], d1 = pd[1];
             float acc = accs[n];
-#define LH_STEPN(SW, WD, AD, DA) { const float sc_ = (SW) * (DA); const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, false); acc = fmaf(sc_, (float) p_, acc); }
+#define LH_STEPN(SW, WD, AD, DA) { const float sc_ = (SW) * (DA); const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, true); acc = fmaf(sc_, (float) p_, acc); }
             LH_STEPN(s0, w0, a0.x, d0.x) LH_STEPN(s1, w0, a0.y, d0.y)
             LH_STEPN(s2, w1, a0.z, d0.z) LH_STEPN(s3, w1, a0.w, d0.w)
             LH_STEPN(s4, w2, a1.x, d1.x) LH_STEPN(s5, w2, a1.y, d1.y)
@@ -1014,16 +1102,20 @@ __global__ void k_add(const float *__restrict__ a, const float *__restrict__ b, 
 // ================================================================================================
 #define LH_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
+hipError_t set_phase_probe(unsigned long long *dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_probe), &dev_buf, sizeof(dev_buf));
+}
+
 hipError_t init_kernel_attrs() {
     // fused prologues of wide models (K = 22016) need more than the default 64 KB of dynamic LDS
     const int cap = 160 * 1024;
 #define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
     LH_ATTR(k_prep_qa<PREP_PLAIN>); LH_ATTR(k_prep_qa<PREP_NORM>); LH_ATTR(k_prep_qa<PREP_SILU_MUL>); LH_ATTR(k_prep_qa<PREP_SUM>);
-#define LH_ATTR_G1(PRE, EPI, PG) LH_ATTR((k_gemv<PRE, EPI, 16, false, PG>)); LH_ATTR((k_gemv<PRE, EPI, 16, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 13, true, PG>)); \
-    LH_ATTR((k_gemv<PRE, EPI, 11, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 10, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 8, true, PG>))
-#define LH_ATTR_G(PRE, EPI) LH_ATTR_G1(PRE, EPI, 4); LH_ATTR_G1(PRE, EPI, 12)
-    LH_ATTR_G(PRE_QA, EPI_STORE); LH_ATTR_G(PRE_QA, EPI_RESID); LH_ATTR_G(PREP_NORM, EPI_STORE);
-    LH_ATTR_G(PREP_PLAIN, EPI_RESID); LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 2);
+#define LH_ATTR_G1(PRE, EPI, PG) LH_ATTR((k_gemv<PRE, EPI, 16, false, PG>)); LH_ATTR((k_gemv<PRE, EPI, 16, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 22, true, PG>)); \
+    LH_ATTR((k_gemv<PRE, EPI, 18, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 14, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 10, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 8, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 4, true, PG>))
+    LH_ATTR_G1(PRE_QA, EPI_STORE, 4); LH_ATTR_G1(PRE_QA, EPI_STORE, 12); LH_ATTR_G1(PRE_QA, EPI_RESID, 4); LH_ATTR_G1(PRE_QA, EPI_RESID, 12);
+    LH_ATTR_G1(PREP_NORM, EPI_STORE, 1); LH_ATTR_G1(PREP_NORM, EPI_STORE, 2); LH_ATTR_G1(PREP_PLAIN, EPI_RESID, 1); LH_ATTR_G1(PREP_PLAIN, EPI_RESID, 2);
+    LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
     LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk);
@@ -1079,13 +1171,18 @@ static int pick_waves(int ngroups) {
     return 1;
 }
 
-// ring depth for a row of `nchunks` chunks: whole row in flight when it fits 16 slots, else the
-// depth in {8..16} that wastes the fewest padded (zero-tile) chunks
-static int pick_depth(int nchunks) {
-    if (nchunks <= 16) return 16;
-    static const int cand[] = { 16, 13, 11, 10, 8 };
-    int best = 16, best_waste = 1 << 30;
-    for (int d : cand) {
+// Ring depth for a row of `nchunks` chunks (always even, see k_gemv).  Launches with >= 4 waves per
+// CU keep the ring shallow (8 or 10 slots: 128 VGPRs, 4 waves per SIMD); small launches (2 waves per
+// CU) need the depth for bytes in flight.  Among the candidates the one padding the fewest zero-tile
+// chunks wins, ties go to the deeper ring.
+static int pick_depth(int nchunks, int ngroups) {
+    static const int very_shallow[] = { 4 }, shallow[] = { 10, 8 }, deep[] = { 22, 18, 16, 14, 10, 8 };
+    // >= 8 waves per CU: a 4-deep ring (24 VGPRs) still keeps > 40 KB per CU in flight
+    const int *cand = ngroups >= 2048 ? very_shallow : ngroups >= 1024 ? shallow : deep;
+    const int n = ngroups >= 2048 ? 1 : ngroups >= 1024 ? 2 : 6;
+    int best = cand[0], best_waste = 1 << 30;
+    for (int i = 0; i < n; i++) {
+        const int d = cand[i];
         const int waste = (nchunks + d - 1) / d * d - nchunks;
         if (waste < best_waste) { best_waste = waste; best = d; }
     }
@@ -1099,21 +1196,21 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
                                  uint32_t *out_A, float *out_d, hipStream_t st) {
     const int grid = (w.ngroups + nw - 1) / nw;
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
-    if (PRE != PRE_QA) lds += prep_lds_bytes(w.K);
+    if (PRE == PREP_SILU_MUL || PRE == PREP_SUM) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
 #define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, nsum, sum_stride, out_A, out_d)
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
     if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) {
         LH_GO(16, false);
-    } else if (w.nchunks <= 16) {
-        LH_GO(8, true);
     } else {
-        switch (pick_depth(w.nchunks)) {
+        switch (pick_depth(w.nchunks, w.ngroups)) {
+            case 4:  LH_GO(4, true); break;
             case 8:  LH_GO(8, true); break;
             case 10: LH_GO(10, true); break;
-            case 11: LH_GO(11, true); break;
-            case 13: LH_GO(13, true); break;
+            case 14: LH_GO(14, true); break;
+            case 18: LH_GO(18, true); break;
+            case 22: LH_GO(22, true); break;
             default: LH_GO(16, true); break;
         }
     }
@@ -1134,20 +1231,27 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
     if constexpr (EPI == EPI_SILU_QA) {
         // 8 waves = 4 gate row-groups + the 4 matching up row-groups (interleaved layout)
         const int nw = 8;
-        if (!w.gmapF8 || w.ngroups % 8 != 0 || w.K / 4 > 2 * 512) return hipErrorInvalidValue;
-        return launch_gemv_pg<PRE, EPI, 2>(LH_PGARGS);
+        if (!w.gmapF8 || w.ngroups % 8 != 0 || w.K / 16 > 1 * 512) return hipErrorInvalidValue;
+        return launch_gemv_pg<PRE, EPI, 1>(LH_PGARGS);
     } else if constexpr (PRE == PREP_SILU_MUL || PRE == PREP_SUM) {
         const int nw = pick_waves(w.ngroups);
         return launch_gemv_pg<PRE, EPI, 1>(LH_PGARGS);
     } else {
         int nw = pick_waves(w.ngroups);
-        const int need = (PRE == PRE_QA) ? w.nchunks * 16 : w.K / 4;
-        // prefer the small budget; grow the workgroup (up to 4 waves) before growing the budget
-        while (nw < 4 && need > 4 * nw * 64) nw *= 2;
-        if (need <= 4 * nw * 64) return launch_gemv_pg<PRE, EPI, 4>(LH_PGARGS);
-        nw = pick_waves(w.ngroups);
-        while (nw < 4 && need > 12 * nw * 64) nw *= 2;
-        if (need <= 12 * nw * 64) return launch_gemv_pg<PRE, EPI, 12>(LH_PGARGS);
+        if constexpr (PRE == PRE_QA) {
+            const int need = w.nchunks * 16;
+            // prefer the small budget; grow the workgroup (up to 4 waves) before growing the budget
+            while (nw < 4 && need > 4 * nw * 64) nw *= 2;
+            if (need <= 4 * nw * 64) return launch_gemv_pg<PRE, EPI, 4>(LH_PGARGS);
+            nw = pick_waves(w.ngroups);
+            while (nw < 4 && need > 12 * nw * 64) nw *= 2;
+            if (need <= 12 * nw * 64) return launch_gemv_pg<PRE, EPI, 12>(LH_PGARGS);
+        } else {
+            const int need = w.K / 16;            // half-block granules (32 VGPRs each with the norm weight)
+            while (nw < 4 && need > 1 * nw * 64) nw *= 2;
+            if (need <= 1 * nw * 64) return launch_gemv_pg<PRE, EPI, 1>(LH_PGARGS);
+            if (need <= 2 * nw * 64) return launch_gemv_pg<PRE, EPI, 2>(LH_PGARGS);
+        }
         return hipErrorInvalidValue;          // caller falls back to the unfused path
     }
 #undef LH_PGARGS

@@ -732,6 +732,40 @@ int64_t llamahip_tensor_bytes(llamahip_model *m, const char *name, void *out, in
     return n;
 }
 
+// Phase-timing probe: arms the in-kernel s_memtime probe of k_gemv, runs `n_steps` greedy decode steps
+// (graph replay, i.e. the real decode loop) and returns one record of 8 uint64 per GEMV launch:
+// {entry, loads issued, prologue done, weights consumed, exit, ngroups, nchunks, PRE*16+EPI}.
+// Returns the number of records written (<= cap).  Measurement tooling only.
+int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t first_token, int32_t n_steps,
+                                     uint64_t *records, int64_t cap, char *err, size_t err_cap) {
+    if (!m || m->host_only || cap < 1) { set_err(err, err_cap, "bad arguments"); return -1; }
+    if (hipSetDevice(m->device) != hipSuccess) return -1;
+    unsigned long long *d_buf = nullptr;
+    const size_t bytes = (size_t) (cap + 1) * 8 * sizeof(unsigned long long);
+    if (hipMalloc((void **) &d_buf, bytes) != hipSuccess) return -1;
+    (void) hipMemset(d_buf, 0, bytes);
+    const unsigned long long hdr[2] = { 0, (unsigned long long) cap };
+    (void) hipMemcpy(d_buf, hdr, sizeof(hdr), hipMemcpyHostToDevice);
+    // warm the graph / caches first, unprobed
+    std::vector<int32_t> toks(n_steps);
+    int rc = llamahip_decode_greedy(m, 8, n_past, first_token, n_steps, toks.data(), nullptr, err, err_cap);
+    if (rc == 0) {
+        (void) set_phase_probe(d_buf);
+        rc = llamahip_decode_greedy(m, 8, n_past, first_token, n_steps, toks.data(), nullptr, err, err_cap);
+        (void) set_phase_probe(nullptr);
+    }
+    int64_t n = -1;
+    if (rc == 0) {
+        std::vector<unsigned long long> h((size_t) (cap + 1) * 8);
+        if (hipMemcpy(h.data(), d_buf, bytes, hipMemcpyDeviceToHost) == hipSuccess) {
+            n = (int64_t) std::min<unsigned long long>(h[0], (unsigned long long) cap);
+            for (int64_t i = 0; i < n * 8; i++) records[i] = h[8 + i];
+        }
+    }
+    (void) hipFree(d_buf);
+    return n;
+}
+
 int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out) {
     if (!m || !out) return LLAMAHIP_ERR_UNKNOWN;
     out->struct_size = (int32_t) sizeof(*out);

@@ -24,6 +24,7 @@ struct QMat {
 };
 
 hipError_t init_kernel_attrs();
+hipError_t set_phase_probe(unsigned long long *dev_buf);
 
 hipError_t launch_add(const float *a, const float *b, float *c, long n, hipStream_t st);
 hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int gmap, int goff, hipStream_t st);
