@@ -171,7 +171,14 @@ def main():
     F = n_ff(cfg)
     d = cfg["n_embd"]
     dom = max(r["shapes"], key=lambda s: s["algo_bytes"] * (1 if s["name"] == "output" else cfg["n_layer"]))
-    achieved = r["gemv_bytes_per_token"] / (r["gemv_us_per_token"] * 1e-6) / 1e9
+    all_gemv = r["gemv_bytes_per_token"] / (r["gemv_us_per_token"] * 1e-6) / 1e9
+    achieved = dom["GBps"]
+    traffic = None
+    try:        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), committed under profiles/
+        tj = json.load(open(os.path.join(ROOT, "profiles", "gemv_traffic.json")))
+        traffic = tj["per_launch"][dom["name"]]["traffic_bytes"] if args.model == "7B" else None
+    except Exception:
+        pass
     result = {
         "metric": "decode tokens/sec LLaMA-7B Q4_0 @1 GPU; % HBM-roofline on Q4_0 GEMV",
         "value": tps, "unit": "tokens/s", "n_gpus": 1, "steps": r["steps"], "warmup": args.warmup,
@@ -183,13 +190,18 @@ def main():
                    "n_threads_semantics": args.threads, "parallelism": "1 GPU"},
         "value_pcie": r["value_pcie"],
         "load_s": r["t_load"],
-        "roofline": {"bound": "hbm", "kernel": "lh::k_gemv (Q4_0 x Q4_0 decode GEMV, all 5 matrix kinds, one model pass)",
+        "roofline": {"bound": "hbm",
+                     "kernel": f"lh::k_gemv, the Q4_0 x Q4_0 decode GEMV, on its dominant shape {dom['name']} "
+                               f"(M={dom['M']}, K={dom['K']}: {dom['algo_bytes'] * cfg['n_layer'] / r['gemv_bytes_per_token'] * 100:.0f}% of the GEMV bytes of a token)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": dom["algo_bytes"], "us_per_launch": dom["us_per_launch"],
+                     "all_gemv_launches_of_a_token": {"achieved": all_gemv, "frac": all_gemv / HBM_PEAK_GBPS,
+                                                      "bytes": r["gemv_bytes_per_token"], "us": r["gemv_us_per_token"]},
                      "per_shape": [{k: s[k] for k in ("name", "M", "K", "us_per_launch", "GBps")} for s in r["shapes"]],
-                     "dominant_shape": {k: dom[k] for k in ("name", "M", "K", "us_per_launch", "GBps")},
-                     "note": "algorithmic bytes per launch = M*(K/32)*20 + (K/32)*20 + 4*M (SURVEY.md 8d); durations are HIP-event "
-                             "averages on the launch stream over back-to-back launches cycling through all layers"},
+                     "note": "algorithmic bytes per launch = M*(K/32)*20 + (K/32)*20 + 4*M (SURVEY.md 8d); duration = HIP-event "
+                             "average on the launch stream over back-to-back launches cycling through all 32 layers (cold weights; "
+                             "includes the inter-launch dispatch gap that rocprofv3's kernel duration excludes); traffic = HBM "
+                             "bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_c_gemv_pmc.txt)"},
     }
     if not args.no_cpu_baseline and args.cpu_seconds > 0:
         try:

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "llamahip_internal.h"
 
@@ -985,6 +987,138 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
     }
 }
 
+// Fused decode attention: one workgroup per (head, 32-column block), 1024 threads.  Every workgroup
+// of a head recomputes the head's RoPE'd q, the new K row and ALL scores (the four workgroups of a
+// head land on the same XCD -- linear id = h + H*cb, H a multiple of 8 -- so the repeated K reads are
+// L2 hits), then soft_max, its 32 columns of the nth-chunked V*P, the ordered combine and the Q4_0
+// quantization of one activation block.  One launch instead of two saves a kernel boundary and a
+// round trip of the scores through memory; arithmetic is identical to k_dec_scores + k_dec_pv_blk.
+// dynamic LDS: [32 doubles][dh q][dh k_new][n_ctx p][nth*32 partials]
+__global__ void __launch_bounds__(1024)
+k_dec_attn(const float *__restrict__ qkv, int d, int dh, const double *__restrict__ sincos_tab,
+           float *__restrict__ Kc, float *__restrict__ Vc, int n_ctx, int nth, float kq_scale,
+           float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
+           const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st) {
+    extern __shared__ double smem_d[];
+    double *red = smem_d;
+    float *qs = (float *) (smem_d + 32);
+    float *kn = qs + dh;
+    float *p = kn + dh;
+    float *part = p + n_ctx;
+    const int h = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int n_past = st[0];
+    const int T = n_past + 1;
+    // ---- RoPE of q and of the new key (ggml.c:7076-7131); the cb == 0 workgroup appends K and V (.mm:586-611)
+    {
+        const double *tab = sincos_tab + (size_t) n_past * dh;
+        const float *q = qkv + h * dh, *kk = qkv + d + h * dh, *vv = qkv + 2 * d + h * dh;
+        if (tid < dh / 2) {
+            const int e = 2 * tid;
+            const double cs = tab[e], sn = tab[e + 1];
+            const double x0 = (double) q[e], x1 = (double) q[e + 1];
+            qs[e] = (float) (x0 * cs - x1 * sn);
+            qs[e + 1] = (float) (x0 * sn + x1 * cs);
+            const double k0 = (double) kk[e], k1 = (double) kk[e + 1];
+            const float r0 = (float) (k0 * cs - k1 * sn), r1 = (float) (k0 * sn + k1 * cs);
+            kn[e] = r0; kn[e + 1] = r1;
+            if (cb == 0) {
+                Kc[(size_t) n_past * d + h * dh + e] = r0;
+                Kc[(size_t) n_past * d + h * dh + e + 1] = r1;
+            }
+        } else if (cb == 0 && tid >= 64 && tid < 64 + dh) {
+            Vc[(size_t) n_past * d + h * dh + (tid - 64)] = vv[tid - 64];
+        }
+    }
+    __syncthreads();
+    // ---- scores: one half-wave per key, 4 keys in flight per half-wave (ggml.c:1223-1258, 872-887)
+    {
+        const int hw = tid >> 5, l = tid & 31, nhw = nt >> 5;
+        for (int tb = hw * 4; tb < T; tb += nhw * 4) {
+            float kv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float *kr = Kc + (size_t) min(tb + u, n_past) * d + h * dh;
+#pragma unroll
+                for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = tb + u;
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i * 32 < dh) {
+                        const float kval = (t == n_past) ? kn[i * 32 + l] : kv[u][i];   // the row just appended is not visible through global memory yet
+                        s = fmaf(kval, qs[i * 32 + l], s);
+                    }
+                }
+                s += __shfl_xor(s, 8);
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                if (l == 0 && t <= n_past) p[t] = s * kq_scale;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- soft_max (ggml.c:6982-7050)
+    float mx = -INFINITY;
+    for (int t = tid; t < T; t += nt) mx = fmaxf(mx, p[t]);
+    mx = block_max_f(mx, red, 0);
+    double sum = 0.0;
+    for (int t = tid; t < T; t += nt) {
+        const float e = h2f_bits(T_exp[f2h_bits(p[t] - mx)]);
+        p[t] = e;
+        sum += (double) e;
+    }
+    sum = block_sum_d(sum, red, 1);
+    const float inv = (float) (1.0 / sum);
+    for (int t = tid; t < T; t += nt) p[t] *= inv;
+    __syncthreads();
+    // ---- V*P for this workgroup's 32 columns, nth chunks (ggml.c:5619-5665); the new V row comes from qkv
+    const int c = tid & 31, sub = tid >> 5, nsub = nt >> 5;
+    const int dc = (T + nth - 1) / nth;
+    const int col = h * dh + cb * 32 + c;
+    const float *vcol = Vc + col;
+    const float vnew = qkv[2 * d + col];
+    for (int th = sub; th < nth; th += nsub) {
+        const int t0 = dc * th, t1 = min(t0 + dc, T);
+        float acc = 0.0f;
+        for (int tb = t0; tb < t1; tb += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = vcol[(size_t) min(tb + u, max(n_past - 1, 0)) * d];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int t = tb + u;
+                const float pe = (t < t1) ? p[min(t, T - 1)] : 0.0f;              // fma(v, 0, acc) == acc
+                acc = fmaf(t == n_past ? vnew : v[u], pe, acc);
+            }
+        }
+        part[th * 32 + c] = acc;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = part[tid];
+        for (int th = 1; th < nth; th++) s += part[th * 32 + tid];          // thread order (ggml.c:5553-5577)
+        if (merged) merged[col] = s;
+        float amax = fabsf(s);
+        amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));  amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        const float dd = amax / 7.0f;
+        const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+        const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
+        const int kk = tid & 7;
+        const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+        const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+        const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
+        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+        if (tid == 0) qa_d[b] = dd;
+    }
+}
+
 // One workgroup per (head, 32-column block of the head): soft_max of the head's score row
 // (recomputed by each of the head's dh/32 workgroups -- exact in any order), the nth partial V*P sums
 // for its 32 columns (one sequential FMA chain per (chunk, column), all nth*32 chains in parallel),
@@ -1118,7 +1252,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
-    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk);
+    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk); LH_ATTR(k_dec_attn);
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -1176,14 +1310,26 @@ static int pick_waves(int ngroups) {
 // CU) need the depth for bytes in flight.  Among the candidates the one padding the fewest zero-tile
 // chunks wins, ties go to the deeper ring.
 static int pick_depth(int nchunks, int ngroups) {
-    static const int very_shallow[] = { 4 }, shallow[] = { 10, 8 }, deep[] = { 22, 18, 16, 14, 10, 8 };
-    // >= 8 waves per CU: a 4-deep ring (24 VGPRs) still keeps > 40 KB per CU in flight
+    // tuning override (measurement only): LLAMAHIP_DEPTH="small,mid,big" ring depths by launch size
+    static int ovr[3] = { -1, -1, -1 };
+    if (ovr[0] == -1) {
+        ovr[0] = ovr[1] = ovr[2] = 0;
+        if (const char *e = getenv("LLAMAHIP_DEPTH")) sscanf(e, "%d,%d,%d", &ovr[0], &ovr[1], &ovr[2]);
+    }
+    const int o = ovr[ngroups >= 2048 ? 2 : ngroups >= 1024 ? 1 : 0];
+    if (o == 4 || o == 8 || o == 10 || o == 14 || o == 16 || o == 18 || o == 22) return o;
+    static const int very_shallow[] = { 4 }, shallow[] = { 10, 8 }, deep[] = { 10, 14, 16, 18, 22, 8 };
+    // >= 8 waves per CU: a 4-deep ring (24 VGPRs) still keeps > 40 KB per CU in flight.
+    // Small launches: measured on MI355X (w2, 43 chunks) the 10-deep ring beats 14..22 although it
+    // pads 7 zero-tile chunks -- smaller code and fewer live registers win; take the first candidate
+    // that wastes <= 20 %, else the least wasteful.
     const int *cand = ngroups >= 2048 ? very_shallow : ngroups >= 1024 ? shallow : deep;
     const int n = ngroups >= 2048 ? 1 : ngroups >= 1024 ? 2 : 6;
     int best = cand[0], best_waste = 1 << 30;
     for (int i = 0; i < n; i++) {
         const int d = cand[i];
         const int waste = (nchunks + d - 1) / d * d - nchunks;
+        if (waste * 5 <= nchunks) return d;
         if (waste < best_waste) { best_waste = waste; best = d; }
     }
     return best;
@@ -1201,7 +1347,8 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
 #define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, nsum, sum_stride, out_A, out_d)
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
-    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) {
+    static const bool no_full = getenv("LLAMAHIP_NO_FULL") != nullptr;      // tuning override (measurement only)
+    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024) && !(no_full && w.nchunks == 16)) {
         LH_GO(16, false);
     } else {
         switch (pick_depth(w.nchunks, w.ngroups)) {
@@ -1332,6 +1479,17 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st) {
     const int dh = d / H;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
+    (void) part;
+    // The single-launch variant (k_dec_attn) measured SLOWER on MI355X (13.3 us vs 4.9 + 5.7 us per layer at
+    // 7B, n_ctx 512: its 16-wave workgroups serialise four phases that the split version spreads over
+    // 8x more workgroups); it stays selectable for comparison only.
+    static const bool fused = getenv("LLAMAHIP_FUSED_ATTN") != nullptr;
+    if (fused) {
+        const size_t lds = 32 * sizeof(double) + ((size_t) 2 * dh + n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
+        hipLaunchKernelGGL(k_dec_attn, dim3(H, dh / 32), dim3(1024), lds, st, qkv, d, dh, tab, Kc, Vc, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state);
+        LH_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     const int nsl = (n_ctx + DEC_TS - 1) / DEC_TS;
     hipLaunchKernelGGL(k_dec_scores, dim3(H, nsl), dim3(256), 2 * dh * sizeof(float), st, qkv, d, dh, tab, Kc, Vc, sc, n_ctx, kq_scale, state);
     LH_LAUNCH_CHECK();
