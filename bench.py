@@ -158,7 +158,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cfg = MODELS[args.model]
 
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or os.environ.get("LLAMAHIP_FORCE_PIPELINE"):      # FORCE: exercise the N > 1 code path on one GPU
         from llama_swift_amd import pipeline
         return pipeline.bench_main(args, cfg, model_path, log)
 

@@ -11,7 +11,11 @@ stage 0.
 A single greedy stream is strictly sequential through the stages, so throughput comes from keeping
 ``n_seq`` independent sequences in flight (each stage holds one KV cache per sequence).  All sends
 are non-blocking (``isend``): with blocking sends the token feedback edge closes a cycle of
-rendezvous and the pipeline deadlocks once every stage holds an item.
+rendezvous and the pipeline deadlocks once every stage holds an item.  On NCCL/RCCL, non-blocking is
+not enough: all point-to-point operations of one communicator execute in issue order on one internal
+stream, so stage 0's S-th hand-off (queued before its first token receive) would wait for the last
+stage, whose token send waits for exactly that receive.  The token feedback therefore travels on its
+OWN process group (own communicator, own stream); the forward edges alone form a DAG.
 
 The schedule is independent of what a *stage* is: anything with ``run(seq, n_past, tokens, hidden)``.
 The product stage is :class:`HipStage` (C ABI ``llamahip_eval_stage``); the CPU tests plug in an
@@ -76,7 +80,7 @@ class HipStage:
 
 
 def pipeline_rounds(stage: Stage, rank: int, world: int, dist, torch, tokens_per_seq: Sequence[np.ndarray],
-                    n_past: Sequence[int], rounds: int):
+                    n_past: Sequence[int], rounds: int, token_group=None):
     """Runs `rounds` pipeline rounds.  Round 0 feeds tokens_per_seq[s] (a prompt chunk or one token) for
     every sequence s; every later round feeds the token the last stage picked in the previous round.
     Returns (tokens [n_seq][rounds] on every rank, final n_past list)."""
@@ -99,7 +103,7 @@ def pipeline_rounds(stage: Stage, rank: int, world: int, dist, torch, tokens_per
             if stage.is_first:
                 if k > 0 and world > 1:          # token picked by the last stage for (k-1, s)
                     t = torch.zeros(1, dtype=torch.int32, device=dev)
-                    dist.recv(t, src=world - 1)
+                    dist.recv(t, src=world - 1, group=token_group)
                     cur[s] = t.cpu().numpy().astype(np.int32)
                     picked[s, k - 1] = int(cur[s][0])
                 hidden = None
@@ -115,7 +119,7 @@ def pipeline_rounds(stage: Stage, rank: int, world: int, dist, torch, tokens_per
                 picked[s, k] = tok
                 if world > 1:
                     t = torch.tensor([tok], dtype=torch.int32, device=dev)
-                    pending.append((dist.isend(t, dst=0), t))
+                    pending.append((dist.isend(t, dst=0, group=token_group), t))
                 else:
                     cur[s] = np.array([tok], np.int32)
             else:
@@ -125,7 +129,7 @@ def pipeline_rounds(stage: Stage, rank: int, world: int, dist, torch, tokens_per
     if stage.is_first and world > 1:
         for s in range(S):
             t = torch.zeros(1, dtype=torch.int32, device=dev)
-            dist.recv(t, src=world - 1)
+            dist.recv(t, src=world - 1, group=token_group)
             picked[s, rounds - 1] = int(t.cpu()[0])
     reap(0)
     if world > 1:                                # every rank reports the same token matrix
@@ -148,6 +152,7 @@ def bench_main(args, cfg, model_path_fn, log):
                          f"use: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
     if rank == 0:
         path = model_path_fn(args.model, cfg, args.seed)
     dist.barrier()
@@ -159,11 +164,11 @@ def bench_main(args, cfg, model_path_fn, log):
     prompts = [np.concatenate([[1], rng.integers(3, cfg["n_vocab"], 7)]).astype(np.int32) for _ in range(S)]
     steps = min(args.steps, args.n_ctx - 8 - args.warmup - 1)
     # prompt round (8 tokens per sequence) + warm-up rounds, untimed
-    toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + args.warmup)
+    toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + args.warmup, token_group)
     last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps)
+    toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group)
     dist.barrier(); torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)

@@ -155,6 +155,31 @@ def test_runner_event_stream_matches_the_reference_driver(L, oracle, tmp_path):
     assert out[len(ids):] == want
 
 
+@pytest.mark.parametrize("name,kw,parts", [
+    ("13B-shaped", dict(n_vocab=32000, n_embd=5120, n_mult=256, n_head=40, n_layer=2), 2),      # K = 5120 / 13824, two part files
+    ("30B-shaped", dict(n_vocab=4000, n_embd=6656, n_mult=256, n_head=52, n_layer=1), 4),       # K = 6656 / 17920, four part files
+    ("65B-shaped", dict(n_vocab=4000, n_embd=8192, n_mult=256, n_head=64, n_layer=1), 8),       # K = 8192 / 22016, eight part files
+])
+def test_wider_models_vs_oracle(L, oracle, tmp_path, name, kw, parts):
+    """The other widths of the family (LLAMA_N_PARTS, .mm:33-38): different chunk counts exercise other
+    ring depths / prologue budgets of the GEMV, and the part counts the loader derives from n_embd."""
+    path = synth_tool(tmp_path / "m.bin", seed=5, parts=parts, **kw)
+    om = oracle.load(path, 48)
+    with L.Model(path, n_ctx=48) as gm:
+        assert gm.n_parts == parts == om.n_parts
+        prompt = synth.synth_prompt(9, kw["n_vocab"], seed=3)
+        a, b = gm.eval_debug(prompt, 0, 8, dump_layer=kw["n_layer"] - 1), om.eval(prompt, 0, 8, all_logits=True, dump_layer=kw["n_layer"] - 1)
+        for k in b:
+            assert same(a[k], b[k]), f"{name} {k}: " + describe(a[k], b[k])
+        tok, want = int(np.argmax(b["logits"])), []
+        t = tok
+        for i in range(5):
+            lo = om.eval(np.array([t], np.int32), 9 + i, 8)["logits"]
+            t = int(np.argmax(lo)); want.append(t)
+        got, last = gm.decode_greedy(tok, 9, 5, 8, want_logits=True)
+        assert got.tolist() == want and same(last, lo), name
+
+
 # ------------------------------------------------------------------------------------------------ full LLaMA-7B size
 @pytest.fixture(scope="module")
 def model7b(tmp_path_factory):

@@ -53,11 +53,12 @@ def _worker(rank, world, path, n_layer, init_file, rounds, out_file):
     import torch.distributed as dist
     from llama_swift_amd.pipeline import pipeline_rounds
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    token_group = dist.new_group(list(range(world)))
     S = world + 1                                  # more sequences than stages also has to work
     stage = OracleStage(path, 64, rank, world, S, n_layer)
     prompts = [synth.synth_prompt(5 + s, 96, seed=10 + s) for s in range(S)]
-    toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, rounds)
-    toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, [np.array([toks[s, -1]], np.int32) for s in range(S)], n_past, 3)
+    toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, rounds, token_group)
+    toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, [np.array([toks[s, -1]], np.int32) for s in range(S)], n_past, 3, token_group)
     if rank == 0:
         np.savez(out_file, toks=np.concatenate([toks, toks2], axis=1), n_past=np.array(n_past))
     dist.barrier()
@@ -88,6 +89,30 @@ def test_pipeline_schedule_gloo(built, tmp_path, world):
             lg = m.eval(np.array([t], np.int32), n_past, 8)["logits"]; n_past += 1
         assert got["toks"][s].tolist() == want, f"sequence {s}"
         assert int(got["n_past"][s]) == len(prompt) + rounds - 1 + 3
+
+
+@pytest.mark.gpu
+def test_hip_stage_in_the_pipeline_schedule_single_rank(L, tmp_path):
+    """world_size 1 on the real device: HipStage (llamahip_eval_stage, KV sequence slots) driven by
+    the same schedule the multi-GPU bench uses, against the device-resident greedy loop."""
+    import torch
+
+    from llama_swift_amd.pipeline import HipStage, pipeline_rounds
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=3)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=17))
+    S = 3
+    stage = HipStage(path, 64, 0, 1, S, hp.n_layer, 0)
+    prompts = [synth.synth_prompt(4 + s, hp.n_vocab, seed=40 + s) for s in range(S)]
+    toks, n_past = pipeline_rounds(stage, 0, 1, None, torch, prompts, [0] * S, 6)
+    assert n_past == [len(p) + 5 for p in prompts]
+    with L.Model(path, n_ctx=64) as whole:
+        for s in range(S):
+            lg = whole.eval(prompts[s], 0, 8)
+            first = int(np.argmax(lg))
+            rest = whole.decode_greedy(first, len(prompts[s]), 5, 8)
+            assert toks[s].tolist() == [first] + rest.tolist(), f"sequence {s}"
+    stage.model.close()
 
 
 @pytest.mark.gpu
