@@ -538,6 +538,14 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             }
         }
     }
+    // the residual operand of the epilogue is fetched here too, not at the end of the kernel where it
+    // would add a memory round trip to every wave's critical path
+    float resid_v = 0.0f;
+    if (EPI == EPI_RESID) {
+        int lg0 = g;
+        if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+        resid_v = resid[min(lg0 * 8 + (lane >> 3), M - 1)];
+    }
     if (PRE == PRE_QA) {
         const int nqa = (nchunks * 16 + nt - 1) / nt, nqd = (nchunks * 2 + nt - 1) / nt;
 #pragma unroll
@@ -725,7 +733,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             if (y && lane < 32) y[b * 32 + i] = act;
         }
     } else if (valid && k == 0 && m < M) {
-        if (EPI == EPI_RESID) acc = acc + resid[m];
+        if (EPI == EPI_RESID) acc = acc + resid_v;
         y[m] = acc;
     }
     LH_STAMP(4);
