@@ -798,6 +798,106 @@ k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int g
     }
 }
 
+// Prompt path, LDS-staged: the activation operands of NC columns for one chunk (NC x 288 B) are
+// staged once per workgroup in LDS (double-buffered, one barrier per chunk) and shared by its 4
+// waves, instead of every lane re-reading them through the texture path (k_gemm_nc: 64 vector loads
+// per chunk per wave, which bound that kernel at ~1/6 of its VALU limit).  Same arithmetic.
+//   ncols <= NC: columns past ncols are clamped duplicates whose results are not stored.
+template <int NC, int EPI>
+__global__ void __launch_bounds__(256)
+k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
+           const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols,
+           float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    __shared__ u32x4 sA[2][NC * 16];          // [buf][col][chain k][2 x u32x4]  = [col][64 dwords]
+    __shared__ f32x4 sD[2][NC * 2];           // [buf][col][8 floats]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+    const int g = min((int) (blockIdx.x * nw + wave), ngroups - 1);
+    const bool valid = (int) (blockIdx.x * nw + wave) < ngroups;
+    const uint8_t *wbase = wt + (size_t) g * (nchunks + 1) * TILE_BYTES;
+    const int k = lane & 7;
+    const long strideA = (long) nchunks * 16, strideD = (long) nchunks * 2;      // in 16-byte granules
+    const int soff = 1024 + ((lane >> 3) * 8 + (lane & 3) * 2) * 4;
+    constexpr int GA = (NC * 16 + 255) / 256, GD = 1;                             // granules per thread per chunk
+    float accs[NC];
+#pragma unroll
+    for (int n = 0; n < NC; n++) accs[n] = 0.0f;
+
+    constexpr int RD = 4;                     // weight ring depth
+    u32x4 wq[RD];
+    f32x2 ws[RD];
+#pragma unroll
+    for (int i = 0; i < RD; i++) {
+        const uint8_t *tp = wbase + (size_t) min(i, nchunks) * TILE_BYTES;
+        wq[i] = __builtin_nontemporal_load((const u32x4 *) (tp + lane * 16));
+        ws[i] = __builtin_nontemporal_load((const f32x2 *) (tp + soff));
+    }
+    // QA granule (col n, piece p) of chunk c lives at qa_A4[n * strideA + c * 16 + p]
+    u32x4 ga[GA];
+    f32x4 gd[GD];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < GA; u++) {
+            const int gi = min(tid + u * nt, NC * 16 - 1), n = min(gi >> 4, ncols - 1), pce = gi & 15;
+            ga[u] = ((const u32x4 *) qa_A)[n * strideA + (long) c * 16 + pce];
+        }
+        const int gj = min(tid, NC * 2 - 1), n = min(gj >> 1, ncols - 1);
+        gd[0] = ((const f32x4 *) qa_d)[n * strideD + (long) c * 2 + (gj & 1)];
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < GA; u++) { const int gi = tid + u * nt; if (gi < NC * 16) sA[buf][gi] = ga[u]; }
+        if (tid < NC * 2) sD[buf][tid] = gd[0];
+    };
+    fetch(0);
+    stash(0);
+    for (int c0 = 0; c0 < nchunks; c0 += RD) {
+#pragma unroll
+        for (int i = 0; i < RD; i++) {
+            const int c = c0 + i;                        // chunks past the row end read the zero tile: no effect
+            __syncthreads();
+            const int buf = c & 1;
+            if (c + 1 < nchunks) fetch(c + 1);
+            const u32x4 w = wq[i];
+            const f32x2 sw = ws[i];
+            {
+                const uint8_t *tp = wbase + (size_t) min(c + RD, nchunks) * TILE_BYTES;
+                wq[i] = __builtin_nontemporal_load((const u32x4 *) (tp + lane * 16));
+                ws[i] = __builtin_nontemporal_load((const f32x2 *) (tp + soff));
+            }
+            if (c < nchunks) {
+                const uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
+                const float s0 = quad_bcast<0>(sw.x), s1 = quad_bcast<1>(sw.x), s2 = quad_bcast<2>(sw.x), s3 = quad_bcast<3>(sw.x);
+                const float s4 = quad_bcast<0>(sw.y), s5 = quad_bcast<1>(sw.y), s6 = quad_bcast<2>(sw.y), s7 = quad_bcast<3>(sw.y);
+#pragma unroll
+                for (int n = 0; n < NC; n++) {
+                    const u32x4 a0 = sA[buf][n * 16 + k * 2], a1 = sA[buf][n * 16 + k * 2 + 1];
+                    const f32x4 d0 = sD[buf][n * 2], d1 = sD[buf][n * 2 + 1];
+                    float acc = accs[n];
+#define LH_STEPN(SW, WD, AD, DA) { const float sc_ = (SW) * (DA); const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, true); acc = fmaf(sc_, (float) p_, acc); }
+                    LH_STEPN(s0, w0, a0.x, d0.x) LH_STEPN(s1, w0, a0.y, d0.y)
+                    LH_STEPN(s2, w1, a0.z, d0.z) LH_STEPN(s3, w1, a0.w, d0.w)
+                    LH_STEPN(s4, w2, a1.x, d1.x) LH_STEPN(s5, w2, a1.y, d1.y)
+                    LH_STEPN(s6, w3, a1.z, d1.z) LH_STEPN(s7, w3, a1.w, d1.w)
+#undef LH_STEPN
+                    accs[n] = acc;
+                }
+            }
+            if (c + 1 < nchunks) stash((c + 1) & 1);
+        }
+    }
+    int lg = g;
+    if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+    const int m = lg * 8 + (lane >> 3);
+#pragma unroll
+    for (int n = 0; n < NC; n++) {
+        float acc = fold8(accs[n]);
+        if (valid && k == 0 && m < M && n < ncols) {
+            if (EPI == EPI_RESID) acc = acc + resid[(size_t) n * resid_stride + m];
+            y[(size_t) n * y_stride + m] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // RoPE + KV append (ggml.c:7076-7131, .mm:586-611).  The reference copies K un-rotated into the
 // cache and rotates it there (mode 1); writing the rotated value directly is the same arithmetic.
@@ -1441,10 +1541,25 @@ static hipError_t launch_gemm_nc_t(const QMat &w, int epi, const uint32_t *qa_A,
     return hipSuccess;
 }
 
-// N activation rows (QA precomputed, row stride = Kp bytes / Kp/32 floats): tiles of 16/8/4/2/1 columns
+template <int NC>
+static hipError_t launch_gemm_lds_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols,
+                                    float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const int nw = 4;
+    const int grid = (w.ngroups + nw - 1) / nw;
+    if (epi == EPI_RESID)
+        hipLaunchKernelGGL((k_gemm_lds<NC, EPI_RESID>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, y, y_stride, resid, resid_stride);
+    else
+        hipLaunchKernelGGL((k_gemm_lds<NC, EPI_STORE>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, y, y_stride, resid, resid_stride);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// N activation rows (QA precomputed, row stride = Kp bytes / Kp/32 floats): column tiles of 16 (the last
+// one clamped), small remainders as 8 / 4 columns, a single row through the decode GEMV
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
+    static const bool old_path = getenv("LLAMAHIP_GEMM_NC") != nullptr;     // measurement: the non-LDS variant
     int n0 = 0;
     while (n0 < N) {
         const int rem = N - n0;
@@ -1454,11 +1569,16 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         const float *rr = resid ? resid + (size_t) n0 * resid_stride : nullptr;
         hipError_t e;
         int step;
-        if (rem >= 16)     { step = 16; e = launch_gemm_nc_t<16>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-        else if (rem >= 8) { step = 8;  e = launch_gemm_nc_t<8>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-        else if (rem >= 4) { step = 4;  e = launch_gemm_nc_t<4>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-        else if (rem >= 2) { step = 2;  e = launch_gemm_nc_t<2>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-        else               { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, 0, 0, nullptr, nullptr, st); }
+        if (old_path) {
+            if (rem >= 16)     { step = 16; e = launch_gemm_nc_t<16>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
+            else if (rem >= 8) { step = 8;  e = launch_gemm_nc_t<8>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
+            else if (rem >= 4) { step = 4;  e = launch_gemm_nc_t<4>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
+            else if (rem >= 2) { step = 2;  e = launch_gemm_nc_t<2>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
+            else               { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, 0, 0, nullptr, nullptr, st); }
+        } else if (rem == 1)   { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, 0, 0, nullptr, nullptr, st); }
+        else if (rem > 8)      { step = rem < 16 ? rem : 16; e = launch_gemm_lds_t<16>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
+        else if (rem > 4)      { step = rem;                 e = launch_gemm_lds_t<8>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
+        else                   { step = rem;                 e = launch_gemm_lds_t<4>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
         if (e != hipSuccess) return e;
         n0 += step;
     }

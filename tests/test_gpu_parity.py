@@ -111,6 +111,28 @@ def test_model_vs_oracle_with_multipart_files(L, oracle, tmp_path, parts, nth):
             assert same(gk, ok) and same(gv, ov), f"KV cache layer {il}"
 
 
+def test_long_prompt_in_one_eval(L, oracle, tmp_path):
+    """n_ctx is a load parameter here (the reference hard-codes 512, .mm:790): a 1100-token prompt in a
+    single eval (column tiles of 16/8/4/2/1 through k_gemm_nc, k_attn over up to 1100 keys), then
+    decode at the far end of a 1280-token context."""
+    hp = synth.HParams(n_vocab=256, n_embd=256, n_mult=64, n_head=2, n_layer=2)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=77))
+    om = oracle.load(path, 1280)
+    with L.Model(path, n_ctx=1280) as gm:
+        prompt = synth.synth_prompt(1100, hp.n_vocab, seed=8)
+        a = gm.eval_debug(prompt, 0, 8, all_logits=True)
+        b = om.eval(prompt, 0, 8, all_logits=True)
+        assert same(a["logits_all"], b["logits_all"]), describe(a["logits_all"], b["logits_all"])
+        tok = int(np.argmax(b["logits"]))
+        want, t = [], tok
+        for i in range(40):
+            lo = om.eval(np.array([t], np.int32), 1100 + i, 8)["logits"]
+            t = int(np.argmax(lo)); want.append(t)
+        got, last = gm.decode_greedy(tok, 1100, 40, 8, want_logits=True)
+        assert got.tolist() == want and same(last, lo)
+
+
 def test_context_overflow_and_bad_tokens_are_errors(L, tmp_path):
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=64, n_head=2, n_layer=1)
     path = str(tmp_path / "m.bin")
