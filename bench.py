@@ -159,6 +159,9 @@ def main():
     cfg = MODELS[args.model]
 
     if world > 1 or args.gpus > 1 or os.environ.get("LLAMAHIP_FORCE_PIPELINE"):      # FORCE: exercise the N > 1 code path on one GPU
+        # every stream of a rank (compute, one per RCCL communicator) gets its own hardware queue, so
+        # a point-to-point kernel waiting for its peer can never sit in front of unrelated work
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         from llama_swift_amd import pipeline
         return pipeline.bench_main(args, cfg, model_path, log)
 

@@ -130,6 +130,31 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
                         const void *hidden_in, void *hidden_out, float *logits_out,
                         char *err, size_t err_cap);
 
+/* Asynchronous, stream-ordered single-token stage steps: the decode loop of the layer pipeline
+ *  with no host round trip per token.
+ *
+ * llamahip_stage_bind fixes, for sequence slot `seq`, the context position of the next token and the
+ * caller-owned DEVICE buffers the step reads and writes:
+ *   token_in   int32[1]        the token to evaluate            (first stage; NULL elsewhere)
+ *   hidden_in  fp32[n_embd]    residual stream from the previous stage (NULL on the first stage)
+ *   hidden_out fp32[n_embd]    residual stream for the next stage      (NULL on the last stage)
+ *   token_out  int32[1]        greedy pick (argmax, lowest index on ties) of the last stage; may be
+ *                              NULL, and may alias token_in on a whole-model handle
+ * llamahip_stage_step enqueues one token step for that slot on `stream` (a hipStream_t; NULL = the
+ * handle's own stream) and returns without waiting: the caller orders its receives before and its
+ * sends after the step on the same stream.  The position advances on the device after every step
+ * (the KV cache must already hold positions [0, n_past): llamahip_eval_stage with the same slot
+ * selected fills it).  Stepping past n_ctx is refused.
+ * llamahip_stage_trace waits for the device, returns the number of steps taken since the bind,
+ * stores the current position in *n_past and (last stage) the picked tokens in tokens[0..min(cap,n)). */
+int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
+                        void *token_in, const void *hidden_in, void *hidden_out, void *token_out,
+                        char *err, size_t err_cap);
+int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void *stream,
+                        char *err, size_t err_cap);
+int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_t *tokens, int32_t cap,
+                         char *err, size_t err_cap);
+
 /* Select which of the handle's n_seq KV caches subsequent evals read and write (default 0). */
 int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap);
 

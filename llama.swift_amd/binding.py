@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
     L.llamahip_decode_greedy.argtypes = [vp, i32, i32, i32, i32, vp, vp, cp, sz]
     L.llamahip_eval_debug.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, C.c_int64, vp, cp, sz]
     L.llamahip_eval_stage.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, cp, sz]
+    L.llamahip_stage_bind.argtypes = [vp, i32, i32, vp, vp, vp, vp, cp, sz]
+    L.llamahip_stage_step.argtypes = [vp, i32, i32, vp, cp, sz]
+    L.llamahip_stage_trace.argtypes = [vp, i32, vp, vp, i32, cp, sz]
     L.llamahip_kv_read.argtypes = [vp, i32, i32, vp, vp, cp, sz]
     L.llamahip_set_seq.argtypes = [vp, i32, cp, sz]
     L.llamahip_tensor_bytes.argtypes = [vp, cp, vp, C.c_int64]
@@ -232,6 +235,26 @@ class Model:
                                        _ptr(logits), err, len(err))
         _check(rc, err)
         return logits
+
+    def stage_bind(self, seq: int, n_past: int, token_in: int = 0, hidden_in: int = 0, hidden_out: int = 0, token_out: int = 0):
+        """Fix slot `seq`'s next position and its DEVICE i/o buffers (addresses) for stage_step."""
+        err = C.create_string_buffer(1024)
+        _check(lib().llamahip_stage_bind(self._h, seq, n_past, C.c_void_p(token_in), C.c_void_p(hidden_in), C.c_void_p(hidden_out),
+                                         C.c_void_p(token_out), err, len(err)), err)
+
+    def stage_step(self, seq: int, n_threads: int = 8, stream: int = 0):
+        """Enqueue one token step of this stage on `stream` (hipStream_t address, 0 = own stream); asynchronous."""
+        err = C.create_string_buffer(256)
+        _check(lib().llamahip_stage_step(self._h, seq, n_threads, C.c_void_p(stream), err, len(err)), err)
+
+    def stage_trace(self, seq: int, cap: int = 0):
+        """Waits for the device.  Returns (steps taken since bind, current position, tokens picked [last stage])."""
+        toks = np.zeros(max(cap, 1), np.int32)
+        pos = C.c_int32(0)
+        err = C.create_string_buffer(1024)
+        n = lib().llamahip_stage_trace(self._h, seq, C.byref(pos), _ptr(toks), cap, err, len(err))
+        _check(min(n, 0), err)
+        return n, pos.value, toks[:min(n, cap)]
 
     def decode_greedy(self, first_token: int, n_past: int, n_steps: int, n_threads: int = 8, want_logits: bool = False):
         out = np.empty(n_steps, np.int32)

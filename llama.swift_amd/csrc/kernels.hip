@@ -1332,6 +1332,11 @@ __global__ void k_argmax(const float *__restrict__ logits, int V, int32_t *__res
     }
 }
 
+// a pipeline stage that does not pick the token still has to advance its device-resident position
+__global__ void k_advance(int32_t *__restrict__ st) {
+    if (threadIdx.x == 0) { st[0] += 1; st[1] += 1; }
+}
+
 // elementwise add (ggml_add, ggml.c:4425-4476) -- only the debug/dump path uses it; the production
 // path fuses the residual add into the GEMV epilogue (same single fp32 add)
 __global__ void k_add(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ c, long n) {
@@ -1630,6 +1635,12 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
 
 hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st) {
     hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, V, out, out_idx, next_token, state);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_advance(int32_t *state, hipStream_t st) {
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, state);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -157,6 +157,17 @@ struct llamahip_model {
     bool w13_interleaved = false;
     int n_seq = 1, cur_seq = 0;          // KV caches: [seq][layer][n_ctx][d]
     std::map<int, hipGraphExec_t> decode_graphs;   // keyed by nth * 4096 + seq
+    // asynchronous pipeline-stage steps (llamahip_stage_bind / llamahip_stage_step)
+    struct StageSlot {
+        int32_t *token_in = nullptr, *token_out = nullptr;     // caller-owned device buffers
+        const float *hidden_in = nullptr; float *hidden_out = nullptr;
+        bool bound = false;
+        int next_pos = 0;                                       // host mirror of the device position (bounds check)
+        std::map<int, hipGraphExec_t> graphs;                   // keyed by nth
+    };
+    std::vector<StageSlot> slots;        // one per sequence slot
+    int32_t *d_slot_state = nullptr;     // [n_seq][2]: {position, step index}, advanced on the device
+    int32_t *d_slot_trace = nullptr;     // [n_seq][n_ctx]: tokens picked by the last stage
 
     // stats
     int64_t weight_bytes = 0, kv_bytes = 0, n_evals = 0;
@@ -181,6 +192,8 @@ llamahip_model::~llamahip_model() {
     free_dev(d_out_tokens);
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
+    for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
+    free_dev(d_slot_state); free_dev(d_slot_trace);
     if (stream) (void) hipStreamDestroy(stream);
 }
 
@@ -270,8 +283,17 @@ struct DumpSink {
 // The forward pass for N tokens at n_past on this handle's layers (.mm:510-735).
 //   hidden_in  : device fp32 [N][d] residual stream from the previous stage (nullptr on the first stage)
 //   want_all   : compute logits for every token (debug) instead of only the last (.mm:724-725)
+//   io         : (fused single-token path only) device-side endpoints of a captured step: token slot,
+//                position state, and the residual-stream buffers read by the first / written by the
+//                last layer of this stage in place of m->x (no staging copies)
+struct StepIO {
+    const int32_t *token = nullptr;
+    int32_t *state = nullptr;
+    const float *x_first = nullptr;
+    float *x_last = nullptr;
+};
 int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool state_on_device,
-            bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap) {
+            bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap, const StepIO *io = nullptr) {
     const HParams &hp = m->hp;
     const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx;
     const int nth = std::max(1, std::min(n_threads, 64));
@@ -284,9 +306,12 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         HIP_TRY(hipMemcpyAsync(m->d_state, hs, sizeof(hs), hipMemcpyHostToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
 
+    int32_t *state = (io && io->state) ? io->state : m->d_state;
+    const float *x_first = (io && fused && m->l1 > m->l0) ? io->x_first : nullptr;
+    float *x_last = (io && fused && m->l1 > m->l0) ? io->x_last : nullptr;
     if (m->first_stage) {
-        HIP_TRY(launch_embed(m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
-    } else {
+        HIP_TRY(launch_embed((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
+    } else if (!x_first) {
         HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
 
@@ -299,15 +324,17 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         if (fused) {
             // ---- decode: activation preparation lives in GEMV prologues / producer epilogues;
             // the context position is read from m->d_state by the attention kernels
-            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, L.attention_norm, m->qkv, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, m->d_state, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, m->x, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            const float *xa = (il == m->l0 && x_first) ? x_first : m->x;      // residual stream into this layer
+            float *xo = (il == m->l1 - 1 && x_last) ? x_last : m->x;           // ... and out of it
+            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             if (m->w13_interleaved) {
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, 0, 0, m->qa2_A, m->qa2_d, st), LLAMAHIP_ERR_PREDICT);
-                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, m->x, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             } else {
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
-                HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, m->x, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, xo, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             }
             continue;
         }
@@ -703,6 +730,122 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
     m->n_evals += n_steps;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
+}
+
+// ---- asynchronous pipeline-stage steps ---------------------------------------------------------
+int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
+                        void *token_in, const void *hidden_in, void *hidden_out, void *token_out,
+                        char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    if (m->host_only) { set_err(err, err_cap, "model was loaded with LLAMAHIP_FLAG_HOST_ONLY: no device state, cannot evaluate"); return LLAMAHIP_ERR_PREDICT; }
+    if (seq < 0 || seq >= m->n_seq) { set_err(err, err_cap, "sequence slot %d out of range [0, %d)", seq, m->n_seq); return LLAMAHIP_ERR_PREDICT; }
+    if (n_past < 0 || n_past >= m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (1) > n_ctx (%d)", n_past, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
+    if (m->flags & LLAMAHIP_FLAG_UNFUSED) { set_err(err, err_cap, "llamahip_stage_step needs the fused decode schedule (handle was loaded with LLAMAHIP_FLAG_UNFUSED)"); return LLAMAHIP_ERR_PREDICT; }
+    if (m->first_stage && !token_in) { set_err(err, err_cap, "stage [%d,%d) is the first stage: token_in is required", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
+    if (!m->first_stage && !hidden_in) { set_err(err, err_cap, "stage [%d,%d) needs hidden_in", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
+    if (!m->last_stage && !hidden_out) { set_err(err, err_cap, "stage [%d,%d) needs hidden_out", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    int rc = ensure_workspace(m, 1, err, err_cap);
+    if (rc) return rc;
+    if (!m->d_slot_state) {
+        HIP_TRY(hipMalloc((void **) &m->d_slot_state, (size_t) m->n_seq * 2 * sizeof(int32_t)), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMalloc((void **) &m->d_slot_trace, (size_t) m->n_seq * m->hp.n_ctx * sizeof(int32_t)), LLAMAHIP_ERR_PREDICT);
+        m->slots.resize(m->n_seq);
+    }
+    auto &sl = m->slots[seq];
+    const bool same = sl.bound && sl.token_in == token_in && sl.token_out == token_out && sl.hidden_in == hidden_in && sl.hidden_out == hidden_out;
+    if (!same) {                 // captured graphs hold the old pointers
+        HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+        for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
+        sl.graphs.clear();
+    }
+    sl.token_in = (int32_t *) token_in; sl.token_out = (int32_t *) token_out;
+    sl.hidden_in = (const float *) hidden_in; sl.hidden_out = (float *) hidden_out;
+    sl.bound = true;
+    sl.next_pos = n_past;
+    const int32_t hs[2] = { n_past, 0 };
+    HIP_TRY(hipMemcpy(m->d_slot_state + 2 * seq, hs, sizeof(hs), hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
+    return LLAMAHIP_OK;
+}
+
+namespace {
+// the launches of one stage step, issued on m->stream (directly or under capture)
+int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, size_t err_cap) {
+    auto &sl = m->slots[seq];
+    int32_t *state = m->d_slot_state + 2 * seq;
+    StepIO io;
+    io.token = sl.token_in; io.state = state;
+    io.x_first = m->first_stage ? nullptr : sl.hidden_in;
+    io.x_last = m->last_stage ? nullptr : sl.hidden_out;
+    const int save_seq = m->cur_seq;
+    m->cur_seq = seq;
+    int rc = forward(m, nth, 0, 1, sl.hidden_in, true, false, -1, nullptr, err, err_cap, &io);
+    m->cur_seq = save_seq;
+    if (rc) return rc;
+    const size_t d = m->hp.n_embd;
+    if (!m->last_stage && m->l1 == m->l0)           // a stage without layers only forwards the stream
+        HIP_TRY(hipMemcpyAsync(sl.hidden_out, m->x, d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    if (m->last_stage) {
+        // greedy pick on the device: trace[step] = token; token_out (if any) = token; position advances
+        HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_slot_trace + (size_t) seq * m->hp.n_ctx, 0, sl.token_out, state, m->stream), LLAMAHIP_ERR_PREDICT);
+    } else {
+        HIP_TRY(launch_advance(state, m->stream), LLAMAHIP_ERR_PREDICT);
+    }
+    return 0;
+}
+}  // namespace
+
+int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void *stream, char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    if (seq < 0 || seq >= (int32_t) m->slots.size() || !m->slots[seq].bound) { set_err(err, err_cap, "sequence slot %d is not bound (llamahip_stage_bind)", seq); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    const int nth = std::max(1, std::min(n_threads, 64));
+    hipStream_t run_on = stream ? (hipStream_t) stream : m->stream;
+    auto &sl = m->slots[seq];
+    if (sl.next_pos >= m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (1) > n_ctx (%d)", sl.next_pos, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
+    if (m->flags & LLAMAHIP_FLAG_NO_GRAPH) {
+        hipStream_t own = m->stream;
+        m->stream = run_on;
+        int rc = stage_step_launches(m, seq, nth, err, err_cap);
+        m->stream = own;
+        if (rc) return rc;
+    } else {
+        auto it = sl.graphs.find(nth);
+        if (it == sl.graphs.end()) {
+            // One step of this stage (embed | stream in -> layers -> stream out | lm head + argmax)
+            // captured once per (slot, n_threads); the position lives in device memory and the last
+            // node advances it, so the same executable graph is replayed for every token.
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal), LLAMAHIP_ERR_PREDICT);
+            int rc = stage_step_launches(m, seq, nth, err, err_cap);
+            hipError_t e2 = hipStreamEndCapture(m->stream, &graph);
+            if (rc) { if (graph) (void) hipGraphDestroy(graph); return rc; }
+            HIP_TRY(e2, LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), LLAMAHIP_ERR_PREDICT);
+            (void) hipGraphDestroy(graph);
+            it = sl.graphs.emplace(nth, exec).first;
+        }
+        HIP_TRY(hipGraphLaunch(it->second, run_on), LLAMAHIP_ERR_PREDICT);
+    }
+    sl.next_pos++;
+    m->n_evals++;
+    return LLAMAHIP_OK;
+}
+
+int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_t *tokens, int32_t cap, char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    if (seq < 0 || seq >= (int32_t) m->slots.size() || !m->slots[seq].bound) { set_err(err, err_cap, "sequence slot %d is not bound (llamahip_stage_bind)", seq); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    int32_t hs[2] = { 0, 0 };
+    HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);       // steps may be in flight on any caller stream
+    HIP_TRY(hipMemcpy(hs, m->d_slot_state + 2 * seq, sizeof(hs), hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    if (n_past) *n_past = hs[0];
+    const int n = std::min(std::min(hs[1], cap), m->hp.n_ctx);
+    if (tokens && m->last_stage && n > 0)
+        HIP_TRY(hipMemcpy(tokens, m->d_slot_trace + (size_t) seq * m->hp.n_ctx, (size_t) n * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    return hs[1];
 }
 
 int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap) {

@@ -17,9 +17,19 @@ stream, so stage 0's S-th hand-off (queued before its first token receive) would
 stage, whose token send waits for exactly that receive.  The token feedback therefore travels on its
 OWN process group (own communicator, own stream); the forward edges alone form a DAG.
 
-The schedule is independent of what a *stage* is: anything with ``run(seq, n_past, tokens, hidden)``.
-The product stage is :class:`HipStage` (C ABI ``llamahip_eval_stage``); the CPU tests plug in an
-oracle-backed stage to check the schedule itself.
+Two schedules share these rules:
+
+* :func:`pipeline_rounds` -- host-synchronous, any number of tokens per item (prompt chunks).  Every
+  hand-off returns to the host (``llamahip_eval_stage``).
+* :func:`pipeline_decode` -- the steady-state decode loop, fully stream-ordered: receive -> stage step
+  (one hipGraph launch, ``llamahip_stage_step``) -> send are enqueued on the device and the host never
+  waits; the last stage picks the token on the device and the position advances on the device.  The
+  forward edges alternate between two process groups by parity of the sending rank, so a rank's
+  receive (from r-1) and its send (to r+1) never share a communicator stream and the next item's
+  receive can be posted while the previous send is still in flight.
+
+The schedules are independent of what a *stage* is.  The product stage is :class:`HipStage` (C ABI);
+the CPU tests plug in an oracle-backed stage to check the schedules themselves under ``gloo``.
 """
 from __future__ import annotations
 
@@ -41,6 +51,25 @@ class Stage(Protocol):
     def run(self, seq: int, n_past: int, tokens: Optional[np.ndarray], hidden):
         """first stage: tokens -> hidden ; middle: hidden -> hidden ; last: ... -> logits (np.ndarray).
         hidden is a torch tensor [N * n_embd] fp32 on ``device``."""
+        ...
+
+    # --- stream-ordered single-token steps (pipeline_decode) ---
+    tok_in: list      # per sequence: int32[1] tensor on ``device`` (first stage reads it)
+    tok_out: list     # per sequence: int32[1] tensor (last stage writes the greedy pick)
+    hid_in: list      # per sequence: fp32[n_embd] tensor (None on the first stage)
+    hid_out: list     # per sequence: fp32[n_embd] tensor (None on the last stage)
+
+    def bind(self, seq: int, n_past: int, first_token: int) -> None:
+        """Position of the next token of `seq` and (first stage) the token itself; allocates the i/o tensors."""
+        ...
+
+    def step(self, seq: int) -> None:
+        """One token through this stage's layers: tok_in|hid_in -> hid_out|tok_out, asynchronous on
+        the device's current stream; the position advances by one."""
+        ...
+
+    def trace(self, seq: int, cap: int):
+        """Waits for the device; (steps since bind, position, tokens picked [last stage only])."""
         ...
 
 
@@ -77,6 +106,30 @@ class HipStage:
             hidden_in=0 if self.is_first else hidden.data_ptr(), hidden_out=0 if self.is_last else out.data_ptr(),
             want_logits=self.is_last, n_threads=self.n_threads)
         return logits if self.is_last else out
+
+    # --- stream-ordered steps ---
+    def bind(self, seq, n_past, first_token):
+        torch = self._torch
+        if not hasattr(self, "tok_in"):
+            S, dev = self.model.n_seq, self.device
+            self.tok_in = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(S)]
+            # a whole-model stage feeds its own pick back: same buffer
+            self.tok_out = self.tok_in if (self.is_first and self.is_last) else [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(S)]
+            self.hid_in = [None if self.is_first else torch.zeros(self.n_embd, dtype=torch.float32, device=dev) for _ in range(S)]
+            self.hid_out = [None if self.is_last else torch.zeros(self.n_embd, dtype=torch.float32, device=dev) for _ in range(S)]
+        self.tok_in[seq].fill_(int(first_token))
+        torch.cuda.current_stream().synchronize()
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        self.model.stage_bind(seq, n_past,
+                              token_in=ptr(self.tok_in[seq]) if self.is_first else 0,
+                              hidden_in=ptr(self.hid_in[seq]), hidden_out=ptr(self.hid_out[seq]),
+                              token_out=ptr(self.tok_out[seq]) if self.is_last else 0)
+
+    def step(self, seq):
+        self.model.stage_step(seq, self.n_threads, self._torch.cuda.current_stream().cuda_stream)
+
+    def trace(self, seq, cap):
+        return self.model.stage_trace(seq, cap)
 
 
 def pipeline_rounds(stage: Stage, rank: int, world: int, dist, torch, tokens_per_seq: Sequence[np.ndarray],
@@ -139,6 +192,56 @@ def pipeline_rounds(stage: Stage, rank: int, world: int, dist, torch, tokens_per
     return picked, n_past
 
 
+def pipeline_decode(stage: Stage, rank: int, world: int, dist, n_seq: int, rounds: int,
+                    fwd_groups=None, token_group=None):
+    """`rounds` greedy tokens for each of `n_seq` bound sequences (stage.bind), one token per sequence
+    per round, with no host synchronisation: every receive, stage step and send is enqueued in program
+    order and ordered on the device.  Round 0 evaluates the token already in ``stage.tok_in`` (from
+    bind or from the previous call); the call ends with stage 0 receiving (stream-ordered) the last
+    round's picks into ``tok_in``, so calls can be chained and no send is left unmatched.
+    Returns nothing: read the picks with ``stage.trace`` on the last stage."""
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    grp = (lambda sender: fwd_groups[sender % 2]) if fwd_groups else (lambda sender: None)
+    pending = []
+
+    def reap(limit):
+        while len(pending) > limit:
+            pending.pop(0).wait()
+
+    for k in range(rounds):
+        for s in range(n_seq):
+            if stage.is_first:
+                if world > 1 and k > 0:
+                    dist.recv(stage.tok_in[s], src=world - 1, group=token_group)     # pick of the previous round
+            else:
+                dist.recv(stage.hid_in[s], src=prv, group=grp(prv))
+            stage.step(s)
+            if not stage.is_last:
+                pending.append(dist.isend(stage.hid_out[s], dst=nxt, group=grp(rank)))
+            elif world > 1:
+                pending.append(dist.isend(stage.tok_out[s], dst=0, group=token_group))
+            reap(2 * n_seq)
+    if stage.is_first and world > 1 and rounds > 0:
+        for s in range(n_seq):
+            dist.recv(stage.tok_in[s], src=world - 1, group=token_group)
+    reap(0)
+
+
+def gather_traces(stage: Stage, rank: int, world: int, dist, torch, n_seq: int, cap: int):
+    """Tokens picked since bind, [n_seq][cap] on every rank (the last stage owns them)."""
+    out = np.zeros((n_seq, cap), np.int32)
+    pos = [0] * n_seq
+    for s in range(n_seq):
+        n, pos[s], toks = stage.trace(s, cap)
+        if stage.is_last:
+            out[s, :len(toks)] = toks
+    if world > 1:
+        buf = torch.from_numpy(out).to(stage.device)
+        dist.broadcast(buf, src=world - 1)
+        out = buf.cpu().numpy()
+    return out, pos
+
+
 def bench_main(args, cfg, model_path_fn, log):
     """`bench.py --gpus N` for N > 1 (launched by torch.distributed.run, one rank per GPU)."""
     import torch
@@ -153,6 +256,8 @@ def bench_main(args, cfg, model_path_fn, log):
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
+    fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]   # forward edges by sender parity
+    sync_schedule = os.environ.get("LLAMAHIP_PIPELINE_SYNC", "0") == "1"
     if rank == 0:
         path = model_path_fn(args.model, cfg, args.seed)
     dist.barrier()
@@ -163,13 +268,23 @@ def bench_main(args, cfg, model_path_fn, log):
     rng = np.random.default_rng(1234)
     prompts = [np.concatenate([[1], rng.integers(3, cfg["n_vocab"], 7)]).astype(np.int32) for _ in range(S)]
     steps = min(args.steps, args.n_ctx - 8 - args.warmup - 1)
-    # prompt round (8 tokens per sequence) + warm-up rounds, untimed
-    toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + args.warmup, token_group)
-    last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
-    dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group)
-    dist.barrier(); torch.cuda.synchronize()
+    # prompt round (8 tokens per sequence): host-synchronous schedule, untimed
+    if sync_schedule:
+        toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + args.warmup, token_group)
+        last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group)
+        dist.barrier(); torch.cuda.synchronize()
+    else:
+        toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group)
+        for s in range(S):
+            stage.bind(s, n_past[s], int(toks[s, -1]))
+        pipeline_decode(stage, rank, world, dist, S, args.warmup, fwd_groups, token_group)      # untimed; captures the graphs
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipeline_decode(stage, rank, world, dist, S, steps, fwd_groups, token_group)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
@@ -187,5 +302,6 @@ def bench_main(args, cfg, model_path_fn, log):
                        "parallelism": f"pp{world} (RCCL p2p hand-off of the fp32 residual stream)",
                        "sequences": S, "tokens_timed": total},
             "single_stream_tokens_per_s_estimate": steps / dt,
+            "schedule": "host-synchronous" if sync_schedule else "stream-ordered (hipGraph stage steps, device-side greedy pick)",
         }), flush=True)
     dist.destroy_process_group()

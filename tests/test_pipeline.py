@@ -46,21 +46,58 @@ class OracleStage:
         hout, logits = self.models[seq].eval_range(self.lo, self.hi, n_past, tokens=tokens if self.is_first else None, hidden_in=hin, n_threads=8)
         return logits if self.is_last else torch.from_numpy(hout)
 
+    # single-token steps on bound sequences (pipeline_decode); synchronous on the CPU
+    def bind(self, seq, n_past, first_token):
+        import torch
+        if not hasattr(self, "tok_in"):
+            S = len(self.models)
+            self.tok_in = [torch.zeros(1, dtype=torch.int32) for _ in range(S)]
+            self.tok_out = self.tok_in if (self.is_first and self.is_last) else [torch.zeros(1, dtype=torch.int32) for _ in range(S)]
+            self.hid_in = [None if self.is_first else torch.zeros(self.n_embd) for _ in range(S)]
+            self.hid_out = [None if self.is_last else torch.zeros(self.n_embd) for _ in range(S)]
+            self.pos, self.picked = [0] * S, [[] for _ in range(S)]
+        self.tok_in[seq].fill_(int(first_token))
+        self.pos[seq], self.picked[seq] = n_past, []
+
+    def step(self, seq):
+        import torch
+        tk = self.tok_in[seq].numpy().copy() if self.is_first else None
+        hin = None if self.is_first else self.hid_in[seq].numpy()
+        hout, logits = self.models[seq].eval_range(self.lo, self.hi, self.pos[seq], tokens=tk, hidden_in=hin, n_threads=8)
+        self.pos[seq] += 1
+        if self.is_last:
+            t = int(np.argmax(logits))
+            self.picked[seq].append(t)
+            self.tok_out[seq].fill_(t)
+        else:
+            self.hid_out[seq].copy_(torch.from_numpy(hout).reshape(-1))
+
+    def trace(self, seq, cap):
+        return len(self.picked[seq]), self.pos[seq], np.array(self.picked[seq][:cap], np.int32)
+
 
 def _worker(rank, world, path, n_layer, init_file, rounds, out_file):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     import torch
     import torch.distributed as dist
-    from llama_swift_amd.pipeline import pipeline_rounds
+    from llama_swift_amd.pipeline import gather_traces, pipeline_decode, pipeline_rounds
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     token_group = dist.new_group(list(range(world)))
+    fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]
     S = world + 1                                  # more sequences than stages also has to work
     stage = OracleStage(path, 64, rank, world, S, n_layer)
     prompts = [synth.synth_prompt(5 + s, 96, seed=10 + s) for s in range(S)]
     toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, rounds, token_group)
     toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, [np.array([toks[s, -1]], np.int32) for s in range(S)], n_past, 3, token_group)
+    # ... and the stream-ordered decode schedule continues every sequence: 2 + 3 chained rounds
+    for s in range(S):
+        stage.bind(s, n_past[s], int(toks2[s, -1]))
+    pipeline_decode(stage, rank, world, dist, S, 2, fwd_groups, token_group)
+    pipeline_decode(stage, rank, world, dist, S, 3, fwd_groups, token_group)
+    toks3, pos = gather_traces(stage, rank, world, dist, torch, S, 5)
+    assert pos == [n + 5 for n in n_past], (rank, pos, n_past)
     if rank == 0:
-        np.savez(out_file, toks=np.concatenate([toks, toks2], axis=1), n_past=np.array(n_past))
+        np.savez(out_file, toks=np.concatenate([toks, toks2, toks3], axis=1), n_past=np.array(pos))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,11 +121,11 @@ def test_pipeline_schedule_gloo(built, tmp_path, world):
         prompt = synth.synth_prompt(5 + s, 96, seed=10 + s)
         lg = m.eval(prompt, 0, 8)["logits"]
         n_past, want = len(prompt), []
-        for _ in range(rounds + 3):
+        for _ in range(rounds + 3 + 5):
             t = int(np.argmax(lg)); want.append(t)
             lg = m.eval(np.array([t], np.int32), n_past, 8)["logits"]; n_past += 1
         assert got["toks"][s].tolist() == want, f"sequence {s}"
-        assert int(got["n_past"][s]) == len(prompt) + rounds - 1 + 3
+        assert int(got["n_past"][s]) == len(prompt) + rounds - 1 + 3 + 5
 
 
 @pytest.mark.gpu
@@ -145,5 +182,89 @@ def test_two_stages_on_one_gpu_equal_the_whole_model(L, tmp_path):
         a.set_seq(2)
     with pytest.raises(L.LlamaHipError):
         b.eval([1], 0)                                                        # a stage handle is not a whole model
+    for m in (whole, a, b):
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 1])          # hipGraph replay / eager launches on the caller's stream
+def test_stream_ordered_stage_steps_single_rank(L, tmp_path, flags):
+    """pipeline_decode on one rank: llamahip_stage_bind/step/trace (device-side position and greedy
+    pick, caller's stream) must continue a sequence exactly like the device-resident greedy loop."""
+    import torch
+
+    from llama_swift_amd.pipeline import HipStage, gather_traces, pipeline_decode, pipeline_rounds
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=3)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=17))
+    S = 3
+    stage = HipStage(path, 64, 0, 1, S, hp.n_layer, 0)
+    stage.model.close()
+    stage.model = L.Model(path, n_ctx=64, device=0, n_seq=S, flags=flags)
+    prompts = [synth.synth_prompt(4 + s, hp.n_vocab, seed=40 + s) for s in range(S)]
+    toks, n_past = pipeline_rounds(stage, 0, 1, None, torch, prompts, [0] * S, 1)
+    for s in range(S):
+        stage.bind(s, n_past[s], int(toks[s, -1]))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                  # not the default stream: the step must follow the caller's
+        pipeline_decode(stage, 0, 1, None, S, 4)
+        pipeline_decode(stage, 0, 1, None, S, 3)
+    got, pos = gather_traces(stage, 0, 1, None, torch, S, 7)
+    assert pos == [len(p) + 7 for p in prompts]
+    with L.Model(path, n_ctx=64) as whole:
+        for s in range(S):
+            first = int(np.argmax(whole.eval(prompts[s], 0, 8)))
+            assert first == int(toks[s, -1])
+            rest = whole.decode_greedy(first, len(prompts[s]), 7, 8)
+            assert got[s].tolist() == rest.tolist(), f"sequence {s}"
+    # stepping past the context is refused on the host
+    stage.bind(0, 63, 1)
+    stage.step(0)
+    with pytest.raises(L.LlamaHipError, match="context overflow"):
+        stage.step(0)
+    with pytest.raises(L.LlamaHipError, match="not bound"):
+        stage.model.stage_step(S + 5)
+    stage.model.close()
+
+
+@pytest.mark.gpu
+def test_stream_ordered_two_stages_on_one_gpu(L, tmp_path):
+    """Two stage handles chained on one stream through shared device buffers (what the RCCL
+    send/recv pair does between GPUs): embed+layer 0 -> layers 1..3 + lm head + pick -> token slot."""
+    import torch
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=4)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=9))
+    a = L.Model(path, n_ctx=64, layer_begin=0, layer_end=1, n_seq=2)
+    b = L.Model(path, n_ctx=64, layer_begin=1, layer_end=4, n_seq=2)
+    whole = L.Model(path, n_ctx=64)
+    prompts = [synth.synth_prompt(9, hp.n_vocab, seed=1), synth.synth_prompt(6, hp.n_vocab, seed=2)]
+    tok = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(2)]
+    hid = [torch.zeros(hp.n_embd, dtype=torch.float32, device="cuda") for _ in range(2)]
+    firsts = []
+    for s in range(2):                              # prompts through the host-synchronous entry point
+        h = torch.empty(len(prompts[s]) * hp.n_embd, dtype=torch.float32, device="cuda")
+        a.set_seq(s); b.set_seq(s)
+        a.eval_stage(0, tokens=prompts[s], hidden_out=h.data_ptr())
+        lg = b.eval_stage(0, n_tokens=len(prompts[s]), hidden_in=h.data_ptr(), want_logits=True)
+        firsts.append(int(np.argmax(lg)))
+        tok[s].fill_(firsts[s])
+        torch.cuda.synchronize()
+        a.stage_bind(s, len(prompts[s]), token_in=tok[s].data_ptr(), hidden_out=hid[s].data_ptr())
+        b.stage_bind(s, len(prompts[s]), hidden_in=hid[s].data_ptr(), token_out=tok[s].data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(6):
+        for s in (1, 0):
+            a.stage_step(s, 8, st)
+            b.stage_step(s, 8, st)
+    for s in range(2):
+        n, pos, got = b.stage_trace(s, 6)
+        assert (n, pos) == (6, len(prompts[s]) + 6)
+        assert a.stage_trace(s, 0)[:2] == (6, len(prompts[s]) + 6)
+        assert int(np.argmax(whole.eval(prompts[s], 0, 8))) == firsts[s]
+        want = whole.decode_greedy(firsts[s], len(prompts[s]), 6, 8)
+        assert got.tolist() == want.tolist(), f"sequence {s}"
+    with pytest.raises(L.LlamaHipError, match="hidden_in"):
+        b.stage_bind(0, 0, token_in=tok[0].data_ptr())
     for m in (whole, a, b):
         m.close()
