@@ -55,8 +55,7 @@ def model_path(name: str, cfg: dict, seed: int) -> str:
         tool = os.path.join(ROOT, "llama.swift_amd", "csrc", "tools", "make_synth_model")
         t0 = time.time()
         args = [tool, "--out", path, "--seed", str(seed)] + [x for k, v in cfg.items() for x in (f"--{k}", str(v))]
-        if name in ("13B", "65B"):
-            args += ["--parts", "1"]          # single-part synthetic file (multi-part merge is covered by tests)
+        # the generator writes the reference's part count for the width (.mm:33-38): 13B = 2 files, 65B = 8
         subprocess.run(args, check=True)
         open(path + ".done", "w").close()
         log(f"[bench] wrote synthetic {name} model in {time.time() - t0:.1f}s: {path}")

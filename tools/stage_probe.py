@@ -10,7 +10,7 @@ import torch
 from llama_swift_amd import binding as L
 from llama_swift_amd.pipeline import layer_range
 
-path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/llamahip_bench_7B_s20230312.bin"
+path = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "-" else os.path.join(os.environ.get("LLAMAHIP_MODEL_DIR", "/tmp/llamahip_models"), "7B-seed20230312", "ggml-model-q4_0.bin")
 n_layer = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 worlds = [int(a) for a in sys.argv[3:]] or [1, 2, 4, 8]
 for world in worlds:
