@@ -899,6 +899,159 @@ k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Prompt path, row-per-lane: second resident copy of a matrix in ROW-LANE tiles.
+//   tile (row-block R of 64 rows, chunk c) = 10240 B; a row-block is nchunks + 1 tiles, the last all-zero:
+//     vector k = 0..7 : [64 lanes x 16 B]  lane = row: chain k of the row's 8 blocks (same 4 dwords a
+//                       decode tile holds for lane (r, k))
+//     vector 8, 9     : [64 lanes x 16 B]  the row's block scales s0..s3 | s4..s7
+// A wave owns 64 rows x NC activation columns; every lane runs all 8 chains of ITS row, so the
+// activation operand (column n, chunk c: 64 dwords + 8 scales) is the same for the whole wave: it is
+// fetched with scalar loads and fed to v_dot8_i32_i4 / v_mul_f32 as an SGPR operand -- no LDS, no
+// barriers, no cross-lane traffic, and the d_w*d_a product is shared by the 8 chains of a block
+// (25 VALU instructions per row x block x column instead of 32).  Same arithmetic, same order.
+// ------------------------------------------------------------------------------------------------
+constexpr int ROWTILE_BYTES = 10240;
+
+// decode tiles -> row-lane tiles (load time).  One thread per (row-block, chunk, vector, lane).
+__global__ void k_tiles_to_rows(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ rows,
+                                int ngroups, int nchunks, int nrb, int gmapF8) {
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long) nrb * (nchunks + 1) * 10 * 64;
+    if (gid >= total) return;
+    const int lane = (int) (gid & 63);
+    const long t = gid >> 6;
+    const int v = (int) (t % 10);
+    const int c = (int) ((t / 10) % (nchunks + 1));      // c == nchunks: the all-zero tile closing the row-block
+    const int rb = (int) (t / 10 / (nchunks + 1));
+    const int m = rb * 64 + lane, lg = m >> 3, r = m & 7;
+    u32x4 out = { 0u, 0u, 0u, 0u };
+    if (lg < ngroups && c < nchunks) {
+        int tg = lg;
+        if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
+        const uint8_t *tp = tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
+        if (v < 8) {
+            out = *(const u32x4 *) (tp + (r * 8 + v) * 16);
+        } else {
+            const uint32_t *sp = (const uint32_t *) (tp + 1024 + r * 32);     // stored [s0,s4,s1,s5,s2,s6,s3,s7]
+            const int o = (v - 8);
+            out = u32x4{ sp[0 + o], sp[2 + o], sp[4 + o], sp[6 + o] };
+        }
+    }
+    *(u32x4 *) (rows + ((size_t) rb * (nchunks + 1) + c) * ROWTILE_BYTES + v * 1024 + lane * 16) = out;
+}
+
+//   DB  : double-buffer the weight chunk in registers (next chunk in flight during the arithmetic);
+//         without it the wave stalls on every chunk and the other waves of the SIMD cover -- fewer
+//         registers, more waves
+//   WPE : occupancy target (waves per SIMD) the register allocator must honour
+template <int NC, int EPI, bool DB, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE)))
+k_gemm_rows(const uint8_t *__restrict__ wr, int nrb, int nchunks, int M,
+            const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
+            float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    // XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD its own
+    // row-blocks (rb % 8) and walk the column groups of one row-block back to back, so the weight
+    // tiles a column group streams are still in that XCD's L2 for the next one
+    // (one wave per workgroup: grouping 4 row-blocks of the same columns into a workgroup, to share the
+    // scalar-cache lines of the operand, measured 3 % slower)
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    const int cg = q % ncg, rb = (q / ncg) * 8 + xcd;
+    if (rb >= nrb) return;
+    const int lane = threadIdx.x;
+    const int n0 = cg * NC;
+    const uint8_t *wbase = wr + (size_t) rb * (nchunks + 1) * ROWTILE_BYTES + lane * 16;
+    const long strideA = (long) nchunks * 64, strideD = (long) nchunks * 8;      // per column, in dwords / floats
+    float acc[NC][8];
+#pragma unroll
+    for (int n = 0; n < NC; n++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[n][k] = 0.0f;
+
+// one chunk (registers WQ[8], scales SA/SB) against the NC columns at activation chunk CA
+#define LH_ROWS_CONSUME(WQ, SA, SB, CA)                                                                        \
+    {                                                                                                          \
+        const float sw_[8] = { (SA).x, (SA).y, (SA).z, (SA).w, (SB).x, (SB).y, (SB).z, (SB).w };               \
+        _Pragma("unroll") for (int n = 0; n < NC; n++) {                                                       \
+            const int col_ = min(n0 + n, ncols - 1);           /* wave-uniform: scalar loads below */          \
+            const uint32_t *Ap_ = qa_A + col_ * strideA + (long) (CA) * 64;                                    \
+            const float *Dp_ = qa_d + col_ * strideD + (long) (CA) * 8;                                        \
+            _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                    \
+                const float sc_ = sw_[j] * Dp_[j];                                                             \
+                _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                \
+                    const uint32_t wd_ = (j >> 1) == 0 ? (WQ)[k].x : (j >> 1) == 1 ? (WQ)[k].y : (j >> 1) == 2 ? (WQ)[k].z : (WQ)[k].w; \
+                    /* int -> float without v_cvt: accumulate onto the bit pattern of 1.5 * 2^23 (ulp 1), so the  */ \
+                    /* result IS the float 12582912 + isum; subtracting the constant is exact and pairs up as   */ \
+                    /* v_pk_add_f32 (|isum| <= 8 * 7 * 8 * 8 never leaves the binade)                           */ \
+                    const int p_ = __builtin_amdgcn_sdot8((int) wd_, (int) Ap_[k * 8 + j], 0x4B400000, true);  \
+                    acc[n][k] = fmaf(sc_, __builtin_bit_cast(float, p_) - 12582912.0f, acc[n][k]);             \
+                }                                                                                              \
+                if (NC == 1 && (j & 1)) __builtin_amdgcn_sched_barrier(0);   /* ring variant: bound the live temporaries */ \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+#define LH_ROWS_LOAD(WQ, SA, SB, CH)                                                                           \
+    {                                                                                                          \
+        const uint8_t *tp_ = wbase + (size_t) (CH) * ROWTILE_BYTES;                                            \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) (WQ)[k] = __builtin_nontemporal_load((const u32x4 *) (tp_ + k * 1024)); \
+        (SA) = __builtin_nontemporal_load((const f32x4 *) (tp_ + 8192));                                       \
+        (SB) = __builtin_nontemporal_load((const f32x4 *) (tp_ + 9216));                                       \
+    }
+    if constexpr (NC >= 2 && DB) {
+        // column groups: accumulators take the registers (8 * NC) and one chunk of arithmetic
+        // (>= 1000 VALU instructions) covers the next chunk's load latency: double buffer
+        u32x4 w[8], wn[8];
+        f32x4 s0, s1, s0n, s1n;
+        LH_ROWS_LOAD(wn, s0n, s1n, 0)
+        for (int c = 0; c < nchunks; c++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = wn[k];
+            s0 = s0n; s1 = s1n;
+            LH_ROWS_LOAD(wn, s0n, s1n, min(c + 1, nchunks - 1))
+            LH_ROWS_CONSUME(w, s0, s1, c)
+        }
+    } else if constexpr (NC >= 2) {
+        u32x4 w[8];
+        f32x4 s0, s1;
+        for (int c = 0; c < nchunks; c++) {
+            LH_ROWS_LOAD(w, s0, s1, c)
+            LH_ROWS_CONSUME(w, s0, s1, c)
+        }
+    } else {
+        // single columns (short prompts on small matrices): little arithmetic per chunk, so a ring of RD chunks
+        // with RD - 1 in flight.  Straight-line body (no branch around loads, see k_gemv): chunks past
+        // the row end are the zero tile closing the row-block, whose scale 0 makes fma(0 * da, p, acc) == acc.
+        constexpr int RD = 4;
+        u32x4 w[RD][8];
+        f32x4 s0[RD], s1[RD];
+#pragma unroll
+        for (int i = 0; i < RD; i++) LH_ROWS_LOAD(w[i], s0[i], s1[i], min(i, nchunks))
+        __builtin_amdgcn_sched_barrier(0);
+        for (int c0 = 0; c0 < nchunks; c0 += RD) {
+#pragma unroll
+            for (int i = 0; i < RD; i++) {
+                const int c = c0 + i;
+                LH_ROWS_CONSUME(w[i], s0[i], s1[i], min(c, nchunks - 1))
+                __builtin_amdgcn_sched_barrier(0);
+                LH_ROWS_LOAD(w[i], s0[i], s1[i], min(c + RD, nchunks))
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#undef LH_ROWS_CONSUME
+#undef LH_ROWS_LOAD
+    const int m = rb * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < NC; n++) {
+        // the reference's lane fold: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7))  (ggml.c:872-887 tree)
+        float r = ((acc[n][0] + acc[n][4]) + (acc[n][2] + acc[n][6])) + ((acc[n][1] + acc[n][5]) + (acc[n][3] + acc[n][7]));
+        if (m < M && n0 + n < ncols) {
+            if (EPI == EPI_RESID) r = r + resid[(size_t) (n0 + n) * resid_stride + m];
+            y[(size_t) (n0 + n) * y_stride + m] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // RoPE + KV append (ggml.c:7076-7131, .mm:586-611).  The reference copies K un-rotated into the
 // cache and rotates it there (mode 1); writing the rotated value directly is the same arithmetic.
 // cos/sin come from a host table built with the host libm exactly as the reference computes them
@@ -1013,6 +1166,134 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
         for (int th = 1; th < nth; th++) s += part[th * dh + tid];
         merged[(size_t) n * d + h * dh + tid] = s;
         if (dbg_kqv) dbg_kqv[((size_t) h * N + n) * dh + tid] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prompt attention for many query rows (N >= 32, head size 128): lane = QUERY ROW.
+// k_attn above gives every (head, query) its own workgroup and re-reads the head's whole K and V for
+// each query: 2048 rows stream 69 GB per layer through L2.  Here a wave owns 64 consecutive queries
+// of one head and walks the keys; the key row (scores) / value row (V*P) is the same for all 64 lanes,
+// so it is fetched with SCALAR loads and used as an SGPR operand of v_fma_f32 -- no LDS, no
+// cross-lane reduction (each lane runs the reference's 32 FMA chains and its reduction tree itself),
+// and K / V are read once per 64 queries.  Scores are materialised like the reference's KQ tensor
+// (.mm:614), in a [head][key][query] workspace so that lanes read and write it coalesced; queries
+// are processed in batches of NB rows to bound it.
+//   k_attnq_scores   grid (NB/64, H, KS): KQ * scale for its key slice, running max      -> S, pmax
+//   k_attnq_softmax  grid (NB/64, H) x (64 queries x 4 key phases): exp LUT, double sum   -> S = e, inv
+//   k_attnq_pv       grid (NB/64, H, 4 column groups): p = e * inv; the reference's nth-way key split
+//                    with FMA chains per chunk and the ordered add of the partials      -> merged
+// Arithmetic is identical to k_attn.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
+k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
+               int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
+    const int lane = threadIdx.x, h = blockIdx.y, ks = blockIdx.z;
+    const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
+    const bool valid = n < N;
+    const int nq = valid ? n : N - 1;
+    const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
+    const int Tb = n_past + nb_end;                       // keys any query of this block can see
+    const int per = (Tb + KS - 1) / KS, t0 = ks * per, t1 = min(Tb, t0 + per);
+    const int tq = n_past + nq;                           // last key this lane's query sees
+    float q[128];
+    {
+        const f32x4 *qp = (const f32x4 *) (qr + (size_t) nq * d + h * 128);
+#pragma unroll
+        for (int i = 0; i < 32; i++) { const f32x4 v = qp[i]; q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w; }
+    }
+    float mx = -INFINITY;
+    for (int t = t0; t < t1; t++) {
+        const float *kr = Kc + (size_t) t * d + h * 128;                  // wave-uniform: scalar loads
+        // ggml_vec_dot_f32 (ggml.c:1223-1258): chain l (0..31) = elements l, l+32, l+64, l+96 by FMA from 0;
+        // reduction tree (ggml.c:872-887) = lanes xor 8, 16, 4, 1, 2.  Chains 0..15 first, then 16..31.
+        float r1[2][8];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            float c[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) c[e] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) c[e] = fmaf(kr[32 * j + 16 * half + e], q[32 * j + 16 * half + e], c[e]);
+#pragma unroll
+            for (int l = 0; l < 8; l++) r1[half][l] = c[l] + c[l + 8];
+        }
+        float u[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) u[l] = r1[0][l] + r1[1][l];
+        const float v0 = u[0] + u[4], v1 = u[1] + u[5], v2 = u[2] + u[6], v3 = u[3] + u[7];
+        const float sc = ((v0 + v1) + (v2 + v3)) * kq_scale;
+        if (t <= tq) mx = fmaxf(mx, sc);
+        S[((size_t) h * T + t) * NB + nl] = sc;
+    }
+    pmax[((size_t) h * KS + ks) * NB + nl] = mx;
+}
+
+__global__ void __launch_bounds__(256)
+k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__restrict__ inv,
+                int n_past, int N, int nb0, int NB, int T, int KS, const uint16_t *__restrict__ T_exp) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6, h = blockIdx.y;
+    const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
+    const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
+    const int Tb = n_past + nb_end;
+    const int tq = n_past + (n < N ? n : N - 1);
+    float mx = -INFINITY;
+    for (int k = 0; k < KS; k++) mx = fmaxf(mx, pmax[((size_t) h * KS + k) * NB + nl]);
+    double sum = 0.0;
+    for (int t = ph; t < Tb; t += 4) {
+        float *sp = S + ((size_t) h * T + t) * NB + nl;
+        float e = 0.0f;                                   // masked keys (-inf in the reference) contribute 0
+        if (t <= tq) { e = h2f_bits(T_exp[f2h_bits(*sp - mx)]); sum += (double) e; }
+        *sp = e;
+    }
+    part[ph][lane] = sum;
+    __syncthreads();
+    if (ph == 0) {
+        // every term is a multiple of 2^-24 and <= 1: the double sum is exact in any order
+        const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        inv[(size_t) h * NB + nl] = (float) (1.0 / tot);
+    }
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+k_attnq_pv(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ merged,
+           int n_past, int N, int nb0, int NB, int d, int T, int nth) {
+    const int lane = threadIdx.x, h = blockIdx.y, c0 = blockIdx.z * 32;
+    const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
+    const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
+    const int Tb = n_past + nb_end;
+    const float iv = inv[(size_t) h * NB + nl];
+    const int dc = (T + nth - 1) / nth;
+    float s[32], acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) s[c] = 0.0f;
+    for (int th = 0; th < nth; th++) {
+        const int t0 = dc * th;
+        const int t1 = min(min(t0 + dc, T), Tb);          // beyond Tb every P of this block is 0: fma(v, 0, acc) == acc
+#pragma unroll
+        for (int c = 0; c < 32; c++) acc[c] = 0.0f;
+        const float *sp = S + ((size_t) h * T + t0) * NB + nl;
+        for (int t = t0; t < t1; t++, sp += NB) {
+            const float p = *sp * iv;                      // soft_max's final scale (ggml.c:7036-7041)
+            const float *vr = Vc + (size_t) t * d + h * 128 + c0;          // wave-uniform: scalar loads
+#pragma unroll
+            for (int c = 0; c < 32; c++) acc[c] = fmaf(vr[c], p, acc[c]);
+        }
+        if (th == 0) {
+#pragma unroll
+            for (int c = 0; c < 32; c++) s[c] = acc[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 32; c++) s[c] += acc[c];
+        }
+    }
+    if (n < N) {
+        f32x4 *o = (f32x4 *) (merged + (size_t) n * d + h * 128 + c0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = f32x4{ s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3] };
     }
 }
 
@@ -1559,12 +1840,55 @@ static hipError_t launch_gemm_lds_t(const QMat &w, int epi, const uint32_t *qa_A
     return hipSuccess;
 }
 
-// N activation rows (QA precomputed, row stride = Kp bytes / Kp/32 floats): column tiles of 16 (the last
-// one clamped), small remainders as 8 / 4 columns, a single row through the decode GEMV
+template <int NC, bool DB, int WPE>
+static hipError_t launch_gemm_rows_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols,
+                                     float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const int ncg = (ncols + NC - 1) / NC;
+    const int grid = ((w.nrb + 7) / 8) * ncg * 8;
+    if (epi == EPI_RESID)
+        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_RESID, DB, WPE>), dim3(grid), dim3(64), 0, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+    else
+        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_STORE, DB, WPE>), dim3(grid), dim3(64), 0, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
+    const long total = (long) w.nrb * (w.nchunks + 1) * 10 * 64;
+    hipLaunchKernelGGL(k_tiles_to_rows, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, w.tiles, w.rows, w.ngroups, w.nchunks, w.nrb, w.gmapF8);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// N activation rows (QA precomputed, row stride = Kp bytes / Kp/32 floats).
+//   matrix has a row-lane copy: one k_gemm_rows launch (column-group width: see below)
+//   else: LDS-staged column tiles of 16 (the last one clamped), small remainders as 8 / 4 columns
+//   a single row always goes through the decode GEMV
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
     static const bool old_path = getenv("LLAMAHIP_GEMM_NC") != nullptr;     // measurement: the non-LDS variant
+    static const bool no_rows = getenv("LLAMAHIP_GEMM_LDS") != nullptr;     // measurement: skip the row-lane kernel
+    static const int force_nc = getenv("LLAMAHIP_GEMM_ROWS_NC") ? atoi(getenv("LLAMAHIP_GEMM_ROWS_NC")) : 0;
+    if (w.rows && N >= 2 && !old_path && !no_rows) {
+        // widest column group that still gives the chip >= 2 waves per SIMD.  Wider groups (8, 16
+        // columns: 191 / 249 VGPRs, 2 waves per SIMD) measured 10-16 % slower than 4 columns at 3 waves
+        // per SIMD on a 512-token prompt: the kernel runs at ~85 % of its VALU issue limit and the third
+        // wave is what hides the scalar-load latency of the operand.
+        int nc = 1;
+        for (int cand : { 4, 2 })
+            if ((long) w.nrb * ((N + cand - 1) / cand) >= 2048) { nc = cand; break; }
+        if (force_nc) nc = force_nc;
+#define LH_ROWS_ARGS w, epi, qa_A, qa_d, N, y, y_stride, resid, resid_stride, st
+        switch (nc) {
+        case 16: return launch_gemm_rows_t<16, true, 2>(LH_ROWS_ARGS);
+        case 8:  return launch_gemm_rows_t<8, true, 2>(LH_ROWS_ARGS);
+        case 4:  return launch_gemm_rows_t<4, true, 3>(LH_ROWS_ARGS);
+        case 2:  return launch_gemm_rows_t<2, true, 3>(LH_ROWS_ARGS);
+        default: return launch_gemm_rows_t<1, true, 2>(LH_ROWS_ARGS);
+        }
+#undef LH_ROWS_ARGS
+    }
     int n0 = 0;
     while (n0 < N) {
         const int rem = N - n0;
@@ -1598,9 +1922,24 @@ hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, cons
 }
 
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
-                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, hipStream_t st) {
+                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st) {
     const int dh = d / H, T = n_past + N;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
+    static const bool old_only = getenv("LLAMAHIP_ATTN_ROWWISE") != nullptr;     // measurement: per-row kernel for every N
+    if (ws && ws->S && dh == 128 && N >= 32 && !dbg_p && !dbg_kqv && T <= ws->T_cap && !old_only) {
+        for (int nb0 = 0; nb0 < N; nb0 += ws->NB) {
+            const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
+            int KS = (2048 + qb * H - 1) / (qb * H);
+            KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
+            hipLaunchKernelGGL(k_attnq_scores, dim3(qb, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
+            LH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(256), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
+            LH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_attnq_pv, dim3(qb, H, 4), dim3(64), 0, st, ws->S, ws->inv, Vc, merged, n_past, N, nb0, ws->NB, d, T, nth);
+            LH_LAUNCH_CHECK();
+        }
+        return hipSuccess;
+    }
     const size_t lds = 32 * sizeof(double) + ((size_t) T + (size_t) nth * dh + dh + 16) * sizeof(float);
     hipLaunchKernelGGL(k_attn, dim3(H, N), dim3(256), lds, st, qr, Kc, Vc, merged, dbg_p, dbg_kqv, n_past, N, d, dh, nth, kq_scale, T_exp);
     LH_LAUNCH_CHECK();

@@ -156,6 +156,7 @@ struct llamahip_model {
     float *qa1_d = nullptr, *qa2_d = nullptr;
     bool w13_interleaved = false;
     int n_seq = 1, cur_seq = 0;          // KV caches: [seq][layer][n_ctx][d]
+    AttnWs attn_ws;                      // many-row prompt attention workspace (allocated with the first eval of >= 32 tokens)
     std::map<int, hipGraphExec_t> decode_graphs;   // keyed by nth * 4096 + seq
     // asynchronous pipeline-stage steps (llamahip_stage_bind / llamahip_stage_step)
     struct StageSlot {
@@ -185,6 +186,7 @@ llamahip_model::~llamahip_model() {
     for (auto &l : layers) {
         free_dev(l.attention_norm); free_dev(l.ffn_norm);
         free_dev(l.qkv.tiles); free_dev(l.wo.tiles); free_dev(l.w13.tiles); free_dev(l.w2.tiles);
+        free_dev(l.qkv.rows); free_dev(l.wo.rows); free_dev(l.w13.rows); free_dev(l.w2.rows);
     }
     free_dev(Kc); free_dev(Vc); free_dev(T_silu); free_dev(T_exp); free_dev(sincos);
     free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
@@ -194,6 +196,7 @@ llamahip_model::~llamahip_model() {
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
     for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
     free_dev(d_slot_state); free_dev(d_slot_trace);
+    free_dev(attn_ws.S); free_dev(attn_ws.pmax); free_dev(attn_ws.inv);
     if (stream) (void) hipStreamDestroy(stream);
 }
 
@@ -219,6 +222,17 @@ int alloc_qmat(QMat &q, int M, int K, llamahip_model *m, char *err, size_t err_c
     q.nchunks = (K + 255) / 256;
     HIP_TRY(hipMalloc((void **) &q.tiles, q.bytes()), LLAMAHIP_ERR_LOAD);
     m->weight_bytes += (int64_t) q.bytes();
+    return 0;
+}
+
+// second resident copy in row-lane tiles for the prompt-path GEMM (k_gemm_rows); built from the
+// finished decode tiles, skipped with LLAMAHIP_FLAG_NO_PREFILL_COPY (the LDS-staged GEMM then runs)
+int make_rows(QMat &q, llamahip_model *m, char *err, size_t err_cap) {
+    if (m->flags & LLAMAHIP_FLAG_NO_PREFILL_COPY) return 0;
+    q.nrb = (q.M + 63) / 64;
+    HIP_TRY(hipMalloc((void **) &q.rows, q.rows_bytes()), LLAMAHIP_ERR_LOAD);
+    m->weight_bytes += (int64_t) q.rows_bytes();
+    HIP_TRY(launch_tiles_to_rows(q, m->stream), LLAMAHIP_ERR_LOAD);
     return 0;
 }
 
@@ -261,6 +275,19 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     HIP_TRY(hipMalloc((void **) &m->dbg_p, H * n * C * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->dbg_kqv, n * d * 4), LLAMAHIP_ERR_PREDICT);
     m->ws_cap = N;
+    return 0;
+}
+
+// the score workspace of the many-row prompt attention: [n_head][n_ctx][NB] fp32, NB = 512 query rows
+// per batch (7B, n_ctx 2560: 168 MB)
+int ensure_attn_ws(llamahip_model *m, int N, char *err, size_t err_cap) {
+    if (N < 32 || m->attn_ws.S) return 0;
+    const size_t H = m->hp.n_head, C = m->hp.n_ctx;
+    AttnWs &w = m->attn_ws;
+    w.NB = 512; w.T_cap = (int) C; w.KS_cap = 16;
+    HIP_TRY(hipMalloc((void **) &w.S, H * C * w.NB * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &w.pmax, H * w.KS_cap * w.NB * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &w.inv, H * w.NB * 4), LLAMAHIP_ERR_PREDICT);
     return 0;
 }
 
@@ -352,7 +379,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         }
         HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);        // .mm:586-611
         if (dmp && !sink->put(5, m->qr, (int64_t) N * d)) goto dump_fail;
-        HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, dmp ? m->dbg_p : nullptr, dmp ? m->dbg_kqv : nullptr, n_past, N, d, H, nth, m->T_exp, st), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
+        HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, dmp ? m->dbg_p : nullptr, dmp ? m->dbg_kqv : nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
         if (dmp) {
             if (!sink->put(6, m->dbg_p, (int64_t) H * N * (n_past + N))) goto dump_fail;
             if (!sink->put(7, m->dbg_kqv, (int64_t) N * d)) goto dump_fail;
@@ -547,8 +574,10 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
         LOAD_TRY(upload_q4(m.get(), p + "attention.wq.weight", L.qkv, 0, d_stage, h_stage, err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "attention.wk.weight", L.qkv, d, d_stage, h_stage, err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "attention.wv.weight", L.qkv, 2 * d, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(make_rows(L.qkv, m.get(), err, err_cap));
         LOAD_TRY(alloc_qmat(L.wo, d, d, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "attention.wo.weight", L.wo, 0, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(make_rows(L.wo, m.get(), err, err_cap));
         LOAD_TRY(alloc_qmat(L.w13, 2 * F, d, m.get(), err, err_cap));
         if (m->w13_interleaved) {
             // every 8 tile groups = 32 rows of w1 followed by the same 32 rows of w3 (k_repack_q4)
@@ -559,8 +588,10 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
             LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w1.weight", L.w13, 0, d_stage, h_stage, err, err_cap));
             LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w3.weight", L.w13, F, d_stage, h_stage, err, err_cap));
         }
+        LOAD_TRY(make_rows(L.w13, m.get(), err, err_cap));
         LOAD_TRY(alloc_qmat(L.w2, d, F, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w2.weight", L.w2, 0, d_stage, h_stage, err, err_cap));
+        LOAD_TRY(make_rows(L.w2, m.get(), err, err_cap));
     }
 #undef LOAD_TRY
     (void) hipFree(d_stage);
@@ -625,6 +656,8 @@ int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     rc = ensure_workspace(m, N, err, err_cap);
     if (rc) return rc;
+    rc = ensure_attn_ws(m, N, err, err_cap);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     DumpSink sink;
     if (dump_layer >= 0 && dump && dump_sizes) {
@@ -657,6 +690,8 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
     const double t0 = now_ms();
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     rc = ensure_workspace(m, N, err, err_cap);
+    if (rc) return rc;
+    rc = ensure_attn_ws(m, N, err, err_cap);
     if (rc) return rc;
     if (m->first_stage) HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     rc = forward(m, n_threads, n_past, N, (const float *) hidden_in, false, false, -1, nullptr, err, err_cap);
@@ -954,6 +989,11 @@ int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const flo
         if (hipMemcpyAsync(d_w, w_q4_0, wbytes, hipMemcpyHostToDevice, st) != hipSuccess) break;
         if (hipMemcpyAsync(d_x, x, (size_t) N * K * 4, hipMemcpyHostToDevice, st) != hipSuccess) break;
         if (launch_repack(d_w, q.tiles, M, K, 0, 0, st) != hipSuccess) break;
+        if (N >= 2 && !getenv("LLAMAHIP_GEMM_LDS")) {          // the model path's prompt GEMM: row-lane copy
+            q.nrb = (M + 63) / 64;
+            if (hipMalloc((void **) &q.rows, q.rows_bytes()) != hipSuccess) break;
+            if (launch_tiles_to_rows(q, st) != hipSuccess) break;
+        }
         if (launch_prep(PREP_PLAIN, d_x, nullptr, K, 0, K, N, d_qA, d_qd, nullptr, nullptr, nullptr, 0, 0, st) != hipSuccess) break;
         if (launch_gemm(q, EPI_STORE, d_qA, d_qd, N, d_y, M, nullptr, 0, st) != hipSuccess) break;
         if (hipMemcpyAsync(y, d_y, (size_t) N * M * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
@@ -962,7 +1002,7 @@ int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const flo
     } while (0);
     if (rc != LLAMAHIP_OK) set_err(err, err_cap, "HIP error in llamahip_op_mul_mat_q4_0: %s", hipGetErrorString(hipGetLastError()));
     if (st) (void) hipStreamDestroy(st);
-    free_dev(d_w); free_dev(q.tiles); free_dev(d_x); free_dev(d_y); free_dev(d_qA); free_dev(d_qd);
+    free_dev(d_w); free_dev(q.tiles); free_dev(q.rows); free_dev(d_x); free_dev(d_y); free_dev(d_qA); free_dev(d_qd);
     return rc;
 }
 

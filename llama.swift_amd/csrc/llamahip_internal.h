@@ -19,6 +19,11 @@ struct QMat {
     int ngroups = 0;            // ceil(M / 8)
     int nchunks = 0;            // ceil(K / 256)
     int gmapF8 = 0;             // F/8 for the interleaved w1|w3 matrix, else 0 (see k_repack_q4)
+    // optional second copy for the prompt path: row-lane tiles, nrb * (nchunks + 1) * 10240 B (see k_gemm_rows);
+    // rows are in LOGICAL order here (no w1|w3 interleave)
+    uint8_t *rows = nullptr;
+    int nrb = 0;                // ceil(M / 64)
+    size_t rows_bytes() const { return (size_t) nrb * (nchunks + 1) * 10240; }
     size_t bytes() const { return (size_t) ngroups * (nchunks + 1) * TILE_BYTES; }
     int Kp() const { return nchunks * 256; }
 };
@@ -28,6 +33,7 @@ hipError_t set_phase_probe(unsigned long long *dev_buf);
 
 hipError_t launch_add(const float *a, const float *b, float *c, long n, hipStream_t st);
 hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int gmap, int goff, hipStream_t st);
+hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st);   // w.rows / w.nrb set by the caller
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st);
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
@@ -40,8 +46,15 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st);
 hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, const double *tab,
                           float *qr, float *Kc, float *Vc, int n_past, int N, hipStream_t st);
+// workspace of the many-row prompt attention (k_attnq_*): scores [H][T_cap][NB] fp32 + per-query max / 1/sum
+struct AttnWs {
+    float *S = nullptr, *pmax = nullptr, *inv = nullptr;
+    int NB = 0;        // query rows per batch (multiple of 64)
+    int T_cap = 0;     // keys the workspace can hold
+    int KS_cap = 16;   // key slices of the score pass
+};
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
-                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, hipStream_t st);
+                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st);
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st);
