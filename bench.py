@@ -134,9 +134,24 @@ def run_single(args, cfg, path):
         per_token = 1 if which == 4 else cfg["n_layer"]
         tot_bytes += r["algo_bytes"] * per_token
         tot_us += r["us_per_launch"] * per_token
+    # prompt evaluation (not the headline metric): one eval of n_ctx - 8 tokens from an empty context,
+    # and the same prompt in the reference's 9-token chunks (.mm:848-861, n_batch 8)
+    rng = np.random.default_rng(7)
+    ptoks = rng.integers(3, cfg["n_vocab"], args.n_ctx - 8).astype(np.int32)
+    ptoks[0] = 1
+    m.eval(ptoks, 0, args.threads)
+    t2 = time.perf_counter(); m.eval(ptoks, 0, args.threads); dt_pre = time.perf_counter() - t2
+    t2 = time.perf_counter()
+    for c0 in range(0, len(ptoks) - 8, 9):
+        m.eval(ptoks[c0:c0 + 9], c0, args.threads)
+    n9 = ((len(ptoks) - 8 + 8) // 9) * 9
+    dt_9 = time.perf_counter() - t2
+    prefill = {"one_eval": {"tokens": int(len(ptoks)), "tokens_per_s": len(ptoks) / dt_pre},
+               "reference_9_token_chunks": {"tokens": int(n9), "tokens_per_s": n9 / dt_9},
+               "note": "exact path (bit-identical to the reference); host logits copy included"}
     m.close()
     return dict(steps=steps, dt=dt, tokens=out, t_load=t_load, value_pcie=n_pcie / dt_pcie, shapes=shapes,
-                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, same=same)
+                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, same=same, prefill=prefill)
 
 
 def main():
@@ -192,6 +207,7 @@ def main():
                    "n_threads_semantics": args.threads, "parallelism": "1 GPU"},
         "value_pcie": r["value_pcie"],
         "load_s": r["t_load"],
+        "prefill": r["prefill"],
         "roofline": {"bound": "hbm",
                      "kernel": f"lh::k_gemv, the Q4_0 x Q4_0 decode GEMV, on its dominant shape {dom['name']} "
                                f"(M={dom['M']}, K={dom['K']}: {dom['algo_bytes'] * cfg['n_layer'] / r['gemv_bytes_per_token'] * 100:.0f}% of the GEMV bytes of a token)",

@@ -1181,8 +1181,9 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 // are processed in batches of NB rows to bound it.
 //   k_attnq_scores   grid (NB/64, H, KS): KQ * scale for its key slice, running max      -> S, pmax
 //   k_attnq_softmax  grid (NB/64, H) x (64 queries x 4 key phases): exp LUT, double sum   -> S = e, inv
-//   k_attnq_pv       grid (NB/64, H, 4 column groups): p = e * inv; the reference's nth-way key split
-//                    with FMA chains per chunk and the ordered add of the partials      -> merged
+//   k_attnq_pv       grid (NB/64, H, 4 column groups x nth): p = e * inv; one FMA chain per chunk of the
+//                    reference's nth-way key split                                       -> part
+//   k_attnq_merge    the ordered add of the nth partials                                 -> merged
 // Arithmetic is identical to k_attn.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
@@ -1259,42 +1260,43 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
 }
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
-k_attnq_pv(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ merged,
+k_attnq_pv(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ part,
            int n_past, int N, int nb0, int NB, int d, int T, int nth) {
-    const int lane = threadIdx.x, h = blockIdx.y, c0 = blockIdx.z * 32;
-    const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
+    // one wave = 64 queries x 32 columns x ONE chunk of the reference's nth-way key split; the chunks'
+    // partial sums are added in thread order by k_attnq_merge (ggml.c:5553-5577)
+    const int lane = threadIdx.x, h = blockIdx.y, cg = blockIdx.z & 3, th = blockIdx.z >> 2, c0 = cg * 32;
+    const int nl = blockIdx.x * 64 + lane;
     const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
     const int Tb = n_past + nb_end;
     const float iv = inv[(size_t) h * NB + nl];
     const int dc = (T + nth - 1) / nth;
-    float s[32], acc[32];
+    const int t0 = dc * th;
+    const int t1 = min(min(t0 + dc, T), Tb);              // beyond Tb every P of this block is 0: fma(v, 0, acc) == acc
+    float acc[32];
 #pragma unroll
-    for (int c = 0; c < 32; c++) s[c] = 0.0f;
-    for (int th = 0; th < nth; th++) {
-        const int t0 = dc * th;
-        const int t1 = min(min(t0 + dc, T), Tb);          // beyond Tb every P of this block is 0: fma(v, 0, acc) == acc
+    for (int c = 0; c < 32; c++) acc[c] = 0.0f;
+    const float *sp = S + ((size_t) h * T + t0) * NB + nl;
+    for (int t = t0; t < t1; t++, sp += NB) {
+        const float p = *sp * iv;                          // soft_max's final scale (ggml.c:7036-7041)
+        const float *vr = Vc + (size_t) t * d + h * 128 + c0;              // wave-uniform: scalar loads
 #pragma unroll
-        for (int c = 0; c < 32; c++) acc[c] = 0.0f;
-        const float *sp = S + ((size_t) h * T + t0) * NB + nl;
-        for (int t = t0; t < t1; t++, sp += NB) {
-            const float p = *sp * iv;                      // soft_max's final scale (ggml.c:7036-7041)
-            const float *vr = Vc + (size_t) t * d + h * 128 + c0;          // wave-uniform: scalar loads
-#pragma unroll
-            for (int c = 0; c < 32; c++) acc[c] = fmaf(vr[c], p, acc[c]);
-        }
-        if (th == 0) {
-#pragma unroll
-            for (int c = 0; c < 32; c++) s[c] = acc[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 32; c++) s[c] += acc[c];
-        }
+        for (int c = 0; c < 32; c++) acc[c] = fmaf(vr[c], p, acc[c]);
     }
-    if (n < N) {
-        f32x4 *o = (f32x4 *) (merged + (size_t) n * d + h * 128 + c0);
+    // part[th][h][nl][128]
+    f32x4 *o = (f32x4 *) (part + (((size_t) th * gridDim.y + h) * NB + nl) * 128 + c0);
 #pragma unroll
-        for (int i = 0; i < 8; i++) o[i] = f32x4{ s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3] };
-    }
+    for (int i = 0; i < 8; i++) o[i] = f32x4{ acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3] };
+}
+
+// merged[n][h*128 + c] = part[0] + part[1] + ... in thread order.  grid (NB/2, H), 256 threads = 2 queries x 128 columns
+__global__ void __launch_bounds__(256)
+k_attnq_merge(const float *__restrict__ part, float *__restrict__ merged, int N, int nb0, int NB, int d, int nth) {
+    const int c = threadIdx.x & 127, nl = blockIdx.x * 2 + (threadIdx.x >> 7), h = blockIdx.y, H = gridDim.y;
+    const int n = nb0 + nl;
+    if (n >= N) return;
+    float s = part[(((size_t) 0 * H + h) * NB + nl) * 128 + c];
+    for (int th = 1; th < nth; th++) s += part[(((size_t) th * H + h) * NB + nl) * 128 + c];
+    merged[(size_t) n * d + h * 128 + c] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1926,16 +1928,18 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
     const int dh = d / H, T = n_past + N;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const bool old_only = getenv("LLAMAHIP_ATTN_ROWWISE") != nullptr;     // measurement: per-row kernel for every N
-    if (ws && ws->S && dh == 128 && N >= 32 && !dbg_p && !dbg_kqv && T <= ws->T_cap && !old_only) {
+    if (ws && ws->S && dh == 128 && N >= 32 && !dbg_p && !dbg_kqv && T <= ws->T_cap && nth <= ws->nth_cap && !old_only) {
         for (int nb0 = 0; nb0 < N; nb0 += ws->NB) {
             const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
-            int KS = (2048 + qb * H - 1) / (qb * H);
+            int KS = (6144 + qb * H - 1) / (qb * H);      // ~2 rounds of 3 waves per SIMD: the waves are latency-bound
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
             hipLaunchKernelGGL(k_attnq_scores, dim3(qb, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(256), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_attnq_pv, dim3(qb, H, 4), dim3(64), 0, st, ws->S, ws->inv, Vc, merged, n_past, N, nb0, ws->NB, d, T, nth);
+            hipLaunchKernelGGL(k_attnq_pv, dim3(qb, H, 4 * nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
+            LH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_attnq_merge, dim3((nb + 1) / 2, H), dim3(256), 0, st, ws->part, merged, N, nb0, ws->NB, d, nth);
             LH_LAUNCH_CHECK();
         }
         return hipSuccess;

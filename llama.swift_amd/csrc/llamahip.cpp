@@ -196,7 +196,7 @@ llamahip_model::~llamahip_model() {
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
     for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
     free_dev(d_slot_state); free_dev(d_slot_trace);
-    free_dev(attn_ws.S); free_dev(attn_ws.pmax); free_dev(attn_ws.inv);
+    free_dev(attn_ws.S); free_dev(attn_ws.pmax); free_dev(attn_ws.inv); free_dev(attn_ws.part);
     if (stream) (void) hipStreamDestroy(stream);
 }
 
@@ -284,10 +284,11 @@ int ensure_attn_ws(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N < 32 || m->attn_ws.S) return 0;
     const size_t H = m->hp.n_head, C = m->hp.n_ctx;
     AttnWs &w = m->attn_ws;
-    w.NB = 512; w.T_cap = (int) C; w.KS_cap = 16;
+    w.NB = 512; w.T_cap = (int) C; w.KS_cap = 32; w.nth_cap = 8;
     HIP_TRY(hipMalloc((void **) &w.S, H * C * w.NB * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &w.pmax, H * w.KS_cap * w.NB * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &w.inv, H * w.NB * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &w.part, (size_t) w.nth_cap * H * w.NB * 128 * 4), LLAMAHIP_ERR_PREDICT);
     return 0;
 }
 

@@ -48,10 +48,11 @@ hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, cons
                           float *qr, float *Kc, float *Vc, int n_past, int N, hipStream_t st);
 // workspace of the many-row prompt attention (k_attnq_*): scores [H][T_cap][NB] fp32 + per-query max / 1/sum
 struct AttnWs {
-    float *S = nullptr, *pmax = nullptr, *inv = nullptr;
+    float *S = nullptr, *pmax = nullptr, *inv = nullptr, *part = nullptr;   // part: [nth_cap][H][NB][128]
     int NB = 0;        // query rows per batch (multiple of 64)
     int T_cap = 0;     // keys the workspace can hold
-    int KS_cap = 16;   // key slices of the score pass
+    int KS_cap = 32;   // key slices of the score pass
+    int nth_cap = 8;   // chunks of the V*P key split the workspace can hold (larger n_threads: per-row kernel)
 };
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st);
