@@ -142,9 +142,10 @@ def run_single(args, cfg, path):
     m.eval(ptoks, 0, args.threads)
     t2 = time.perf_counter(); m.eval(ptoks, 0, args.threads); dt_pre = time.perf_counter() - t2
     t2 = time.perf_counter()
+    n9 = 0
     for c0 in range(0, len(ptoks) - 8, 9):
         m.eval(ptoks[c0:c0 + 9], c0, args.threads)
-    n9 = ((len(ptoks) - 8 + 8) // 9) * 9
+        n9 += len(ptoks[c0:c0 + 9])
     dt_9 = time.perf_counter() - t2
     prefill = {"one_eval": {"tokens": int(len(ptoks)), "tokens_per_s": len(ptoks) / dt_pre},
                "reference_9_token_chunks": {"tokens": int(n9), "tokens_per_s": n9 / dt_9},

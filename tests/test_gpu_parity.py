@@ -133,6 +133,40 @@ def test_long_prompt_in_one_eval(L, oracle, tmp_path):
         assert got.tolist() == want and same(last, lo)
 
 
+@pytest.mark.parametrize("nth", [8, 3, 5])
+def test_prompt_continuation_and_ragged_batches(L, oracle, tmp_path, nth):
+    """The many-row prompt kernels (row-per-lane GEMM, lane = query attention) away from the easy case:
+    evals that start at n_past > 0, row counts that are not multiples of the 64-query blocks or of the
+    GEMM column groups, a row count just under / over the per-row-kernel threshold (32), thread counts
+    whose V*P key split is uneven, then decode on top of that cache.  Also the handle without the
+    second weight copy (LLAMAHIP_FLAG_NO_PREFILL_COPY = 8: LDS-staged GEMM) must agree bit for bit."""
+    hp = synth.HParams(n_vocab=128, n_embd=256, n_mult=64, n_head=2, n_layer=2)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=123))
+    om = oracle.load(path, 400)
+    prompt = synth.synth_prompt(330, hp.n_vocab, seed=3)
+    with L.Model(path, n_ctx=400) as gm, L.Model(path, n_ctx=400, flags=8) as gl:
+        n_past = 0
+        for n in (31, 33, 100, 2, 64, 97):                  # 327 tokens in ragged pieces
+            chunk = prompt[n_past:n_past + n]
+            a = gm.eval_debug(chunk, n_past, nth, all_logits=True)
+            b = om.eval(chunk, n_past, nth, all_logits=True)
+            c = gl.eval_debug(chunk, n_past, nth, all_logits=True)
+            assert same(a["logits_all"], b["logits_all"]), (n_past, n, describe(a["logits_all"], b["logits_all"]))
+            assert same(c["logits_all"], b["logits_all"]), (n_past, n, "no prefill copy")
+            n_past += n
+        for il in range(hp.n_layer):
+            gk, gv = gm.kv(il, n_past)
+            ok, ov = om.kv(il, n_past)
+            assert same(gk, ok) and same(gv, ov), f"kv cache layer {il}"
+        tok, want = int(np.argmax(b["logits"])), []
+        t = tok
+        for i in range(12):
+            lo = om.eval(np.array([t], np.int32), n_past + i, nth)["logits"]
+            t = int(np.argmax(lo)); want.append(t)
+        assert gm.decode_greedy(tok, n_past, 12, nth).tolist() == want
+
+
 def test_context_overflow_and_bad_tokens_are_errors(L, tmp_path):
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=64, n_head=2, n_layer=1)
     path = str(tmp_path / "m.bin")
