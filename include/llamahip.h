@@ -145,7 +145,7 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
  *   token_out  int32[1]        greedy pick (argmax, lowest index on ties) of the last stage; may be
  *                              NULL, and may alias token_in on a whole-model handle
  * llamahip_stage_step enqueues one token step for that slot on `stream` (a hipStream_t; NULL = the
- * handle's own stream) and returns without waiting: the caller orders its receives before and its
+ * null stream) and returns without waiting: the caller orders its receives before and its
  * sends after the step on the same stream.  The position advances on the device after every step
  * (the KV cache must already hold positions [0, n_past): llamahip_eval_stage with the same slot
  * selected fills it).  Stepping past n_ctx is refused.

@@ -243,7 +243,7 @@ class Model:
                                          C.c_void_p(token_out), err, len(err)), err)
 
     def stage_step(self, seq: int, n_threads: int = 8, stream: int = 0):
-        """Enqueue one token step of this stage on `stream` (hipStream_t address, 0 = own stream); asynchronous."""
+        """Enqueue one token step of this stage on `stream` (hipStream_t address, 0 = the null stream); asynchronous."""
         err = C.create_string_buffer(256)
         _check(lib().llamahip_stage_step(self._h, seq, n_threads, C.c_void_p(stream), err, len(err)), err)
 

@@ -836,7 +836,7 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
     if (seq < 0 || seq >= (int32_t) m->slots.size() || !m->slots[seq].bound) { set_err(err, err_cap, "sequence slot %d is not bound (llamahip_stage_bind)", seq); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     const int nth = std::max(1, std::min(n_threads, 64));
-    hipStream_t run_on = stream ? (hipStream_t) stream : m->stream;
+    hipStream_t run_on = (hipStream_t) stream;          // NULL = the null stream, as everywhere in HIP
     auto &sl = m->slots[seq];
     if (sl.next_pos >= m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (1) > n_ctx (%d)", sl.next_pos, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
     if (m->flags & LLAMAHIP_FLAG_NO_GRAPH) {

@@ -253,6 +253,12 @@ def bench_main(args, cfg, model_path_fn, log):
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with {args.gpus} ranks (WORLD_SIZE={world}); "
                          f"use: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    # RCCL prints a version banner on STDOUT when it creates a communicator; the bench contract is ONE
+    # JSON line on stdout, so everything before that line goes to stderr at the file-descriptor level
+    import sys
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
@@ -280,14 +286,20 @@ def bench_main(args, cfg, model_path_fn, log):
         toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group)
         for s in range(S):
             stage.bind(s, n_past[s], int(toks[s, -1]))
-        pipeline_decode(stage, rank, world, dist, S, args.warmup, fwd_groups, token_group)      # untimed; captures the graphs
+        lane = torch.cuda.Stream()               # the decode loop's own stream: receives, stage steps and sends are ordered on it
+        with torch.cuda.stream(lane):
+            pipeline_decode(stage, rank, world, dist, S, args.warmup, fwd_groups, token_group)      # untimed; captures the graphs
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pipeline_decode(stage, rank, world, dist, S, steps, fwd_groups, token_group)
+        with torch.cuda.stream(lane):
+            pipeline_decode(stage, rank, world, dist, S, steps, fwd_groups, token_group)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
         total = S * steps
         print(json.dumps({
@@ -304,4 +316,5 @@ def bench_main(args, cfg, model_path_fn, log):
             "single_stream_tokens_per_s_estimate": steps / dt,
             "schedule": "host-synchronous" if sync_schedule else "stream-ordered (hipGraph stage steps, device-side greedy pick)",
         }), flush=True)
+    os.dup2(2, 1)                                # communicator teardown may print as well
     dist.destroy_process_group()
