@@ -42,6 +42,9 @@ typedef struct llama_runner_config {
     int32_t n_ctx;                /* extension: 0 = 512 */
     int32_t greedy;               /* extension: 1 = argmax instead of top-k/top-p sampling */
     int32_t seed;                 /* gpt_params.seed, default -1 (utils.h:16) */
+    int32_t keepModel;            /* extension: 1 = the bridge keeps the loaded model between
+                                     runs instead of the reference's load + free per run (.mm:790, :900); the
+                                     loading events are still posted.  The model is freed with the bridge. */
 } llama_runner_config;
 
 /* text = token bytes for OUTPUT_TOKEN, the NSLocalizedDescription message for FAILED, else NULL;
@@ -53,9 +56,12 @@ typedef struct llama_runner_bridge llama_runner_bridge;
 llama_runner_bridge *llama_runner_bridge_new(const char *model_path);          /* -initWithModelPath: */
 void llama_runner_bridge_free(llama_runner_bridge *b);
 const char *llama_runner_bridge_model_path(const llama_runner_bridge *b);      /* @property modelPath */
+int64_t llama_runner_bridge_loads(const llama_runner_bridge *b);              /* model loads performed so far (keepModel tests) */
 
 /* -runWithPrompt:config:eventHandler:eventHandlerQueue:  -- one load + one generation per call,
- * exactly like one LlamaPredictOperation.  Returns 0 if `completed` was emitted, else the error code. */
+ * exactly like one LlamaPredictOperation (unless config->keepModel).  Runs on one bridge are
+ * serialised (the reference's operation queue runs one operation at a time, LlamaRunnerBridge.mm:18-26).
+ * Returns 0 if `completed` was emitted, else the error code. */
 int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt, const llama_runner_config *config,
                                 llama_event_handler handler, void *user);
 

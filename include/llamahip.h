@@ -170,6 +170,14 @@ int llamahip_kv_read(llamahip_model *m, int32_t il, int32_t n_pos, float *out_k,
  * loader / multi-part merge parity.  Returns the byte count, or -1 for an unknown name. */
 int64_t llamahip_tensor_bytes(llamahip_model *m, const char *name, void *out, int64_t cap);
 
+/* ---- the step before the path: f32 / f16 model file -> Q4_0 model file ------------------------
+ * Replaces llama_model_quantize (Sources/cpp/quantize.cpp:32-286): same
+ * container handling (every 2-D tensor named "*weight" is quantized, everything else is copied, the
+ * header's f16 field becomes `itype`), the reference's offline quantizer (utils.cpp:431-485) run on the
+ * device.  itype 2 = Q4_0; 3 (Q4_1) is refused.  Byte-identical output. */
+int llamahip_quantize_file(const char *fname_inp, const char *fname_out, int32_t itype,
+                           char *err, size_t err_cap);
+
 /* ---- single-op entry points (parity tests and kernel benchmarks; host buffers in/out) ---------- */
 /* y[n][m] = W . quantize_q4_0(x[n])  with W = M rows of K/32 Q4_0 blocks in file layout
  * (replaces ggml_compute_forward_mul_mat_q4_0_f32, ggml.c:5987-6285). */

@@ -24,6 +24,7 @@ from .binding import (  # noqa: F401
     lib,
     op_mul_mat_q4_0,
     op_quantize_row_q4_0,
+    quantize_file,
     version,
 )
 from .runner import Config, LlamaRunner, RunState  # noqa: F401

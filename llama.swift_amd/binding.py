@@ -102,6 +102,7 @@ def lib() -> C.CDLL:
     L.llamahip_stage_bind.argtypes = [vp, i32, i32, vp, vp, vp, vp, cp, sz]
     L.llamahip_stage_step.argtypes = [vp, i32, i32, vp, cp, sz]
     L.llamahip_stage_trace.argtypes = [vp, i32, vp, vp, i32, cp, sz]
+    L.llamahip_quantize_file.argtypes = [cp, cp, i32, cp, sz]
     L.llamahip_kv_read.argtypes = [vp, i32, i32, vp, vp, cp, sz]
     L.llamahip_set_seq.argtypes = [vp, i32, cp, sz]
     L.llamahip_tensor_bytes.argtypes = [vp, cp, vp, C.c_int64]
@@ -142,6 +143,12 @@ def _ptr(a: np.ndarray | None):
 def _check(rc: int, err) -> None:
     if rc != 0:
         raise LlamaHipError(rc, err.value.decode(errors="replace"))
+
+
+def quantize_file(fname_inp: str, fname_out: str, itype: int = 2) -> None:
+    """f32 / f16 model file -> Q4_0 model file (replaces llama_model_quantize, quantize.cpp:32-286)."""
+    err = C.create_string_buffer(1024)
+    _check(lib().llamahip_quantize_file(fname_inp.encode(), fname_out.encode(), itype, err, len(err)), err)
 
 
 class Model:

@@ -189,6 +189,40 @@ __global__ void k_repack_q4(const uint8_t *__restrict__ src, uint8_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// offline quantizer: ggml_quantize_q4_0 (utils.cpp:431-485) -- one thread per 32-element block.
+// NOT the runtime activation quantizer: d = amax / 7, id = d ? 1 / d : 0, round half away from zero.
+// src: fp32 (f16 = 0) or IEEE half (f16 = 1, widened exactly as ggml_fp16_to_fp32 does).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_quantize_offline(const void *__restrict__ src, int f16, uint8_t *__restrict__ dst, long nblocks) {
+    const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    float x[32];
+    if (f16) {
+        const uint16_t *p = (const uint16_t *) src + b * 32;
+#pragma unroll
+        for (int i = 0; i < 32; i++) x[i] = h2f_bits(p[i]);
+    } else {
+        const float *p = (const float *) src + b * 32;
+#pragma unroll
+        for (int i = 0; i < 32; i++) x[i] = p[i];
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) amax = fmaxf(amax, fabsf(x[i]));
+    const float d = amax / 7.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint8_t *o = dst + b * 20;
+    const uint32_t db = __builtin_bit_cast(uint32_t, d);
+    o[0] = db & 0xFF; o[1] = (db >> 8) & 0xFF; o[2] = (db >> 16) & 0xFF; o[3] = db >> 24;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float v0 = x[2 * j] * id, v1 = x[2 * j + 1] * id;
+        const int q0 = (int) (int8_t) roundf(v0) + 8, q1 = (int) (int8_t) roundf(v1) + 8;     // C round(): half away from zero
+        o[4 + j] = (uint8_t) (q0 | (q1 << 4));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // embedding gather: ggml_get_rows on a Q4_0 matrix (ggml.c:6760-6785 -> dequantize_row_q4_0 :651-684)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb,
@@ -1978,6 +2012,12 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
 
 hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st) {
     hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, V, out, out_idx, next_token, state);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_quantize_offline, dim3((unsigned) ((nblocks + 127) / 128)), dim3(128), 0, st, src, f16, dst, nblocks);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

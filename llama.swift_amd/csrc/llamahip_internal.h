@@ -59,6 +59,7 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st);
+hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st);
 hipError_t launch_advance(int32_t *state, hipStream_t st);
 hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st);
 

@@ -17,6 +17,7 @@
 #include <random>
 #include <string>
 #include <utility>
+#include <mutex>
 #include <vector>
 
 struct llamahip_sampler {
@@ -26,6 +27,10 @@ struct llamahip_sampler {
 
 struct llama_runner_bridge {
     std::string model_path;
+    std::mutex run_lock;                 // one generation at a time per bridge
+    llamahip_model *kept = nullptr;      // config.keepModel: the model of the previous run ...
+    int32_t kept_n_ctx = 0;              // ... and the context size it was loaded with
+    int64_t loads = 0;                   // model loads performed by this bridge (tests)
 };
 
 extern "C" {
@@ -133,6 +138,7 @@ void llama_runner_config_default(llama_runner_config *c) {
     c->n_ctx = 0;
     c->greedy = 0;
     c->seed = -1;                 // utils.h:16
+    c->keepModel = 0;             // the reference reloads the model on every run
 }
 
 llama_runner_bridge *llama_runner_bridge_new(const char *model_path) {
@@ -140,11 +146,18 @@ llama_runner_bridge *llama_runner_bridge_new(const char *model_path) {
     b->model_path = model_path ? model_path : "";
     return b;
 }
-void llama_runner_bridge_free(llama_runner_bridge *b) { delete b; }
+void llama_runner_bridge_free(llama_runner_bridge *b) {
+    if (!b) return;
+    if (b->kept) llamahip_model_free(b->kept);
+    delete b;
+}
+int64_t llama_runner_bridge_loads(const llama_runner_bridge *b) { return b ? b->loads : 0; }
 const char *llama_runner_bridge_model_path(const llama_runner_bridge *b) { return b ? b->model_path.c_str() : nullptr; }
 
 int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, const llama_runner_config *config,
                                 llama_event_handler handler, void *user) {
+    if (!b) return LLAMAHIP_ERR_LOAD;
+    std::lock_guard<std::mutex> guard(b->run_lock);
     llama_runner_config cfg;
     llama_runner_config_default(&cfg);
     if (config) cfg = *config;
@@ -161,11 +174,22 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     char err[512] = { 0 };
     post(LLAMA_EVENT_STARTED_LOADING_MODEL, nullptr, 0, 0);                         // .mm:785
     llamahip_model *model = nullptr;
-    int rc = llamahip_model_load(b->model_path.c_str(), n_ctx, nullptr, &model, err, sizeof(err));
-    if (rc != 0) {                                                                  // .mm:790-793
-        post(LLAMA_EVENT_FAILED, err, (uint32_t) strlen(err), LLAMAHIP_ERR_LOAD);
-        return LLAMAHIP_ERR_LOAD;
+    if (b->kept && (!cfg.keepModel || b->kept_n_ctx != n_ctx)) {                    // a kept model that no longer fits the request
+        llamahip_model_free(b->kept);
+        b->kept = nullptr;
     }
+    if (b->kept) {
+        model = b->kept;                                                            // every position the run reads is rewritten first
+    } else {
+        int rc = llamahip_model_load(b->model_path.c_str(), n_ctx, nullptr, &model, err, sizeof(err));
+        if (rc != 0) {                                                              // .mm:790-793
+            post(LLAMA_EVENT_FAILED, err, (uint32_t) strlen(err), LLAMAHIP_ERR_LOAD);
+            return LLAMAHIP_ERR_LOAD;
+        }
+        b->loads++;
+        if (cfg.keepModel) { b->kept = model; b->kept_n_ctx = n_ctx; }
+    }
+    auto release = [&](void) { if (model != b->kept) llamahip_model_free(model); };
     post(LLAMA_EVENT_FINISHED_LOADING_MODEL, nullptr, 0, 0);                        // .mm:797
     post(LLAMA_EVENT_STARTED_GENERATING_OUTPUT, nullptr, 0, 0);                     // .mm:800
 
@@ -182,7 +206,7 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     std::vector<float> logits(n_vocab);
     auto fail = [&](void) {
         post(LLAMA_EVENT_FAILED, err, (uint32_t) strlen(err), LLAMAHIP_ERR_PREDICT);
-        llamahip_model_free(model);
+        release();
         return (int32_t) LLAMAHIP_ERR_PREDICT;
     };
     {   // warm-up eval that sizes the reference's scratch buffer (.mm:820-825); kept because it
@@ -230,7 +254,7 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     }
     llamahip_sampler_free(sampler);
     post(LLAMA_EVENT_COMPLETED, nullptr, 0, 0);                                     // .mm:898
-    llamahip_model_free(model);                                                     // .mm:900
+    release();                                                                      // .mm:900
     return 0;
 }
 

@@ -22,6 +22,7 @@ class Config:
     n_ctx: int = 0
     greedy: bool = False
     seed: int = -1
+    keepModel: bool = False      # keep the model loaded between runs of one LlamaRunner
 
 
 Config.default = Config()  # type: ignore[attr-defined]
@@ -38,7 +39,7 @@ class RunState(enum.Enum):
 
 class _CConfig(C.Structure):
     _fields_ = [("numberOfThreads", C.c_uint32), ("numberOfTokens", C.c_uint32), ("reversePrompt", C.c_char_p),
-                ("n_ctx", C.c_int32), ("greedy", C.c_int32), ("seed", C.c_int32)]
+                ("n_ctx", C.c_int32), ("greedy", C.c_int32), ("seed", C.c_int32), ("keepModel", C.c_int32)]
 
 
 _HANDLER = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int32)
@@ -47,17 +48,44 @@ _HANDLER = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_in
 class LlamaRunner:
     def __init__(self, modelURL: str):
         self.modelURL = modelURL
+        self._bridge = None          # created with the first run; owns the kept model (Config.keepModel)
+
+    def _get_bridge(self):
+        L = binding.lib()
+        L.llama_runner_bridge_new.restype = C.c_void_p
+        L.llama_runner_bridge_new.argtypes = [C.c_char_p]
+        L.llama_runner_bridge_free.argtypes = [C.c_void_p]
+        L.llama_runner_bridge_loads.argtypes = [C.c_void_p]
+        L.llama_runner_bridge_loads.restype = C.c_int64
+        L.llama_runner_bridge_run.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_CConfig), _HANDLER, C.c_void_p]
+        L.llama_runner_bridge_run.restype = C.c_int32
+        if self._bridge is None:
+            self._bridge = C.c_void_p(L.llama_runner_bridge_new(self.modelURL.encode()))
+        return L, self._bridge
+
+    @property
+    def loads(self) -> int:
+        """Model loads performed so far by this runner's bridge."""
+        if self._bridge is None:
+            return 0
+        return int(binding.lib().llama_runner_bridge_loads(self._bridge))
+
+    def close(self) -> None:
+        if self._bridge is not None:
+            binding.lib().llama_runner_bridge_free(self._bridge)
+            self._bridge = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def run(self, prompt: str, config: Config = Config.default,  # type: ignore[attr-defined]
             tokenHandler: Optional[Callable[[bytes], None]] = None,
             stateChangeHandler: Optional[Callable[[RunState, Optional[Exception]], None]] = None) -> list[bytes]:
         """Closure-based run (LlamaRunner.swift:90-123).  Returns the emitted tokens as well."""
-        L = binding.lib()
-        L.llama_runner_bridge_new.restype = C.c_void_p
-        L.llama_runner_bridge_new.argtypes = [C.c_char_p]
-        L.llama_runner_bridge_free.argtypes = [C.c_void_p]
-        L.llama_runner_bridge_run.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_CConfig), _HANDLER, C.c_void_p]
-        L.llama_runner_bridge_run.restype = C.c_int32
+        L, bridge = self._get_bridge()
 
         tokens: list[bytes] = []
         failure: list[Exception] = []
@@ -87,12 +115,8 @@ class LlamaRunner:
         cb = _HANDLER(on_event)
         cfg = _CConfig(config.numThreads, config.numTokens,
                        config.reversePrompt.encode() if config.reversePrompt is not None else None,
-                       config.n_ctx, int(config.greedy), config.seed)
-        bridge = C.c_void_p(L.llama_runner_bridge_new(self.modelURL.encode()))
-        try:
-            L.llama_runner_bridge_run(bridge, prompt.encode(), C.byref(cfg), cb, None)
-        finally:
-            L.llama_runner_bridge_free(bridge)
+                       config.n_ctx, int(config.greedy), config.seed, int(config.keepModel))
+        L.llama_runner_bridge_run(bridge, prompt.encode(), C.byref(cfg), cb, None)
         if failure:
             raise failure[0]
         return tokens

@@ -132,6 +132,34 @@ def random_tensors(hp: HParams, seed: int = 20230312, sigma: float = 0.02) -> di
     return out
 
 
+def write_model_unquantized(path: str, hp: HParams, tensors: dict[str, np.ndarray], ftype: int = 1,
+                            vocab: list[bytes] | None = None) -> None:
+    """Single-part f16 (ftype 1) or f32 (ftype 0) model file as tools/convert-pth-to-ggml.py:92-169
+    writes it: 1-D tensors always f32, 2-D tensors in `ftype`; header f16 field = ftype.  This is the
+    INPUT of the quantize tool (quantize.cpp)."""
+    vocab = vocab if vocab is not None else make_vocab(hp.n_vocab)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", MAGIC))
+        f.write(struct.pack("<7i", hp.n_vocab, hp.n_embd, hp.n_mult, hp.n_head, hp.n_layer, hp.n_rot, ftype))
+        for w in vocab:
+            f.write(struct.pack("<I", len(w)))
+            f.write(w)
+        for name, _shape in tensor_specs(hp):
+            t = tensors[name]
+            nb = name.encode()
+            if t.ndim == 1:
+                f.write(struct.pack("<3i", 1, len(nb), 0))
+                f.write(struct.pack("<i", t.shape[0]))
+                f.write(nb)
+                f.write(np.ascontiguousarray(t, dtype=np.float32).tobytes())
+            else:
+                rows, cols = t.shape
+                f.write(struct.pack("<3i", 2, len(nb), ftype))
+                f.write(struct.pack("<2i", cols, rows))
+                f.write(nb)
+                f.write(np.ascontiguousarray(t, dtype=np.float16 if ftype == 1 else np.float32).tobytes())
+
+
 def write_model(path: str, hp: HParams, tensors: dict[str, np.ndarray], n_parts: int = 1,
                 vocab: list[bytes] | None = None) -> None:
     """Write ``path`` (+ ``path.1`` ... for n_parts > 1) in the reference's container format.

@@ -211,6 +211,60 @@ def test_runner_event_stream_matches_the_reference_driver(L, oracle, tmp_path):
     assert out[len(ids):] == want
 
 
+@pytest.mark.parametrize("tag", ["f16", "f32"])
+def test_quantize_file_matches_the_reference_tool(L, oracle, tmp_path, tag):
+    """llamahip_quantize_file against the file the reference's own quantize tool wrote
+    for the same input (tests/golden/quantize_file.npz): byte-identical, crafted .5 ties / zero blocks /
+    outliers included; the result loads and evaluates like any other Q4_0 model; bad requests fail."""
+    import subprocess
+    g = np.load(os.path.join(G, "quantize_file.npz"))
+    src, dst = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    g[f"in_{tag}"].tofile(src)
+    L.quantize_file(src, dst, 2)
+    got = np.fromfile(dst, np.uint8)
+    assert got.size == g[f"out_{tag}"].size and np.array_equal(got, g[f"out_{tag}"])
+    toks = np.array([1, 5, 9, 30, 2], np.int32)
+    with L.Model(dst, n_ctx=16) as gm:
+        assert same(gm.eval(toks, 0, 8), oracle.load(dst, 16).eval(toks, 0, 8)["logits"])
+    tool = os.path.join(os.path.dirname(G), os.pardir, "llama.swift_amd", "csrc", "tools", "quantize")
+    dst2 = str(tmp_path / "out2.bin")
+    assert subprocess.run([tool, src, dst2, "2"], capture_output=True).returncode == 0
+    assert np.array_equal(np.fromfile(dst2, np.uint8), g[f"out_{tag}"])
+    with pytest.raises(L.LlamaHipError, match="Q4_1"):
+        L.quantize_file(src, dst2, 3)
+    with pytest.raises(L.LlamaHipError, match="unsupported ftype"):
+        L.quantize_file(dst, dst2, 2)                                  # already quantized
+    with pytest.raises(L.LlamaHipError, match="failed to open"):
+        L.quantize_file(str(tmp_path / "missing.bin"), dst2, 2)
+    open(str(tmp_path / "junk.bin"), "wb").write(b"not a model file at all")
+    with pytest.raises(L.LlamaHipError, match="bad magic"):
+        L.quantize_file(str(tmp_path / "junk.bin"), dst2, 2)
+
+
+def test_runner_keeps_the_model_between_runs_when_asked(L, tmp_path):
+    """the reference reloads the model on every run (.mm:790, :900).  With
+    Config.keepModel the bridge reuses the loaded handle; a second run on the stale KV cache must give
+    exactly the tokens of a freshly loaded model, sampled path included (mt19937 seeded per run)."""
+    hp = synth.HParams(n_vocab=96, n_embd=256, n_mult=64, n_head=2, n_layer=2)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=21))
+    prompts = ["hello world abc tok00050 zz", "tok00007 a much longer second prompt tok00011 tok00012 xyz", "b"]
+    for greedy in (True, False):
+        fresh = [L.LlamaRunner(path).run(p, L.Config(numTokens=10, greedy=greedy, n_ctx=64, seed=5)) for p in prompts]
+        kept = L.LlamaRunner(path)
+        states = []
+        got = [kept.run(p, L.Config(numTokens=10, greedy=greedy, n_ctx=64, seed=5, keepModel=True), None,
+                        lambda s, e: states.append(s)) for p in prompts]
+        assert got == fresh
+        assert kept.loads == 1
+        assert states.count(L.RunState.initializing) == 3 and states.count(L.RunState.completed) == 3
+        kept.run(prompts[0], L.Config(numTokens=4, greedy=greedy, n_ctx=32, seed=5, keepModel=True))     # other n_ctx: reload
+        assert kept.loads == 2
+        kept.run(prompts[0], L.Config(numTokens=4, greedy=greedy, n_ctx=32, seed=5))                      # reference behaviour again
+        assert kept.loads == 3
+        kept.close()
+
+
 @pytest.mark.parametrize("name,kw,parts", [
     ("13B-shaped", dict(n_vocab=32000, n_embd=5120, n_mult=256, n_head=40, n_layer=2), 2),      # K = 5120 / 13824, two part files
     ("30B-shaped", dict(n_vocab=4000, n_embd=6656, n_mult=256, n_head=52, n_layer=1), 4),       # K = 6656 / 17920, four part files

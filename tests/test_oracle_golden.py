@@ -89,3 +89,41 @@ def test_tiny_model_forward(oracle, tmp_path, nth):
 def test_thread_count_is_part_of_the_numerics():
     g = load("tiny_model.npz")
     assert not np.array_equal(g["nth1_prompt_logits_all"], g["nth8_prompt_logits_all"])
+
+
+def test_quantize_tool_golden_is_consistent_with_the_offline_quantizer(oracle):
+    """tests/golden/quantize_file.npz was written by the reference's quantize tool (oracle/_ref/quantize).
+    Walk both containers: headers and 1-D tensors are copied, the f16 field becomes 2, and every 2-D
+    tensor's bytes equal the restated offline quantizer (utils.cpp:431-485) on the widened input."""
+    import struct
+    g = load("quantize_file.npz")
+
+    def walk(buf):
+        b = buf.tobytes()
+        magic, = struct.unpack_from("<I", b, 0)
+        hp = struct.unpack_from("<7i", b, 4)
+        off = 32
+        for _ in range(hp[0]):
+            n, = struct.unpack_from("<I", b, off); off += 4 + n
+        tensors = []
+        while off < len(b):
+            n_dims, length, ftype = struct.unpack_from("<3i", b, off); off += 12
+            ne = struct.unpack_from(f"<{n_dims}i", b, off); off += 4 * n_dims
+            name = b[off:off + length].decode(); off += length
+            nel = int(np.prod(ne))
+            size = {0: nel * 4, 1: nel * 2, 2: nel // 32 * 20}[ftype]
+            tensors.append((name, ne, ftype, b[off:off + size])); off += size
+        return magic, hp, off, tensors
+
+    for tag in ("f16", "f32"):
+        mi, hi, endi, ti = walk(g[f"in_{tag}"])
+        mo, ho, endo, to = walk(g[f"out_{tag}"])
+        assert mi == mo == 0x67676d6c and hi[:6] == ho[:6] and ho[6] == 2
+        assert endo == g[f"out_{tag}"].size and [t[0] for t in ti] == [t[0] for t in to]
+        for (name, ne, ft, data), (_, ne2, ft2, data2) in zip(ti, to):
+            assert ne == ne2
+            if len(ne) == 1:
+                assert ft2 == 0 and data == data2
+                continue
+            x = np.frombuffer(data, np.float16 if ft == 1 else np.float32).astype(np.float32).reshape(ne[1], ne[0])
+            assert ft2 == 2 and oracle.quantize_offline(x).tobytes() == data2, name
