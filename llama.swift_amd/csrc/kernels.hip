@@ -49,12 +49,6 @@ __device__ __forceinline__ float quad_bcast(float v) {           // lane Q of ev
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q | (Q << 2) | (Q << 4) | (Q << 6), 0xF, 0xF, true));
 }
 
-template <int J>
-__device__ __forceinline__ float bcast8(float v) {               // lane J of every aligned group of 8 lanes
-    // ds_swizzle bit-mask mode: src = ((lane & and_mask) | or_mask) ^ xor_mask, and=0x18, or=J, xor=0
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (J << 5)));
-}
-
 __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_xor(lo, m);
@@ -276,7 +270,6 @@ __device__ __forceinline__ int pidx(int i) { return i + (i >> 5); }
 //   PREP_PLAIN    y = in0
 //   PREP_NORM     y = w * ((float)(x - mean) * scale)          ggml_norm + ggml_mul, ggml.c:5327-5385, :4555
 //   PREP_SILU_MUL y = silu_lut(in0) * in1                      ggml.c:1956-1963 + ggml_mul (.mm:678-680)
-//   PREP_SUM      y = in0[0] + in0[1] + ... (in order)         attention partial buffers, ggml.c:5553-5577
 // Global loads are issued in batches of LB float4 per thread before anything consumes them (indices
 // clamped, never branched around), so a prologue costs a couple of L2 round trips instead of one per
 // element: these prologues run inside the GEMV kernels, in front of the weight stream.
@@ -297,7 +290,7 @@ __device__ unsigned long long *g_phase_probe = nullptr;
 
 template <int MODE, int LB = LB_DEFAULT>
 __device__ void make_y(float *ybuf, double *red, const float *__restrict__ in0, const float *__restrict__ in1,
-                       int K, const uint16_t *__restrict__ T_silu, int nsum, long sum_stride) {
+                       int K, const uint16_t *__restrict__ T_silu) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n4 = K >> 2;                                   // K is a multiple of 32
     const f32x4 *a4 = (const f32x4 *) in0;
@@ -332,25 +325,6 @@ __device__ void make_y(float *ybuf, double *red, const float *__restrict__ in0, 
                     o[0] = h2f_bits(lut[u][0]) * up[u].x; o[1] = h2f_bits(lut[u][1]) * up[u].y;
                     o[2] = h2f_bits(lut[u][2]) * up[u].z; o[3] = h2f_bits(lut[u][3]) * up[u].w;
                 }
-            }
-        }
-    } else if (MODE == PREP_SUM) {
-        for (int base = tid; base < n4; base += nt * LB) {
-            f32x4 acc[LB];
-#pragma unroll
-            for (int u = 0; u < LB; u++) acc[u] = a4[min(base + u * nt, n4 - 1)];
-            for (int j = 1; j < nsum; j++) {
-                const f32x4 *p4 = (const f32x4 *) (in0 + (size_t) j * sum_stride);
-                f32x4 v[LB];
-#pragma unroll
-                for (int u = 0; u < LB; u++) v[u] = p4[min(base + u * nt, n4 - 1)];
-#pragma unroll
-                for (int u = 0; u < LB; u++) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
-            }
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int g = base + u * nt;
-                if (g < n4) { float *o = ybuf + pidx(4 * g); o[0] = acc[u].x; o[1] = acc[u].y; o[2] = acc[u].z; o[3] = acc[u].w; }
             }
         }
     } else {  // PREP_NORM
@@ -454,13 +428,13 @@ template <int MODE>
 __global__ void k_prep_qa(const float *__restrict__ in0, const float *__restrict__ in1, long in_stride, long in1_stride,
                           int K, int Kp, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
                           float *__restrict__ y_out, uint8_t *__restrict__ raw_out,
-                          const uint16_t *__restrict__ T_silu, int nsum, long sum_stride) {
+                          const uint16_t *__restrict__ T_silu) {
     extern __shared__ double smem_d[];
     double *red = smem_d;
     float *ybuf = (float *) (smem_d + 32);
     const int n = blockIdx.x;
     make_y<MODE>(ybuf, red, in0 + (size_t) n * in_stride, in1 ? in1 + (size_t) n * in1_stride : nullptr,
-                 K, T_silu, nsum, sum_stride);
+                 K, T_silu);
     if (y_out)
         for (int i = threadIdx.x; i < K; i += blockDim.x) y_out[(size_t) n * K + i] = ybuf[pidx(i)];
     quantize_y(ybuf, K, Kp, qa_A + (size_t) n * Kp / 4, qa_d + (size_t) n * (Kp / 32),
@@ -513,7 +487,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
        const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d,
        const float *__restrict__ in0, const float *__restrict__ in1, int K,
        float *__restrict__ y, const float *__restrict__ resid,
-       const uint16_t *__restrict__ T_silu, int nsum, long sum_stride,
+       const uint16_t *__restrict__ T_silu,
        uint32_t *__restrict__ out_A, float *__restrict__ out_d) {
     extern __shared__ double smem_d[];
     uint32_t *ldsA = (uint32_t *) smem_d;
@@ -681,7 +655,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         __syncthreads();
     } else {
         float *ybuf = (float *) (red + 32);
-        make_y<PRE>(ybuf, red, in0, in1, K, T_silu, nsum, sum_stride);
+        make_y<PRE>(ybuf, red, in0, in1, K, T_silu);
         quantize_y(ybuf, K, nchunks * 256, ldsA, ldsD, nullptr);
         __syncthreads();
     }
@@ -773,69 +747,10 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     LH_STAMP(4);
 }
 
-// Multi-column (prompt) variant: NC activation rows share every weight tile.  QA is read straight
-// from global memory (L1/L2 resident: NC * 288 B per chunk), no LDS, no barriers.
-template <int NC, int EPI>
-__global__ void __launch_bounds__(256)
-k_gemm_nc(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
-          const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d,
-          float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    const int g = blockIdx.x * nw + wave;
-    if (g >= ngroups) return;
-    const uint8_t *wbase = wt + (size_t) g * (nchunks + 1) * TILE_BYTES;
-    const int k = lane & 7;
-    const long strideA = (long) nchunks * 64, strideD = (long) nchunks * 8;
-    float accs[NC];
-#pragma unroll
-    for (int n = 0; n < NC; n++) accs[n] = 0.0f;
-
-    const int soff = 1024 + ((lane >> 3) * 8 + (lane & 3) * 2) * 4;
-    u32x4 w_next = __builtin_nontemporal_load((const u32x4 *) (wbase + lane * 16));
-    f32x2 s_next = __builtin_nontemporal_load((const f32x2 *) (wbase + soff));
-    for (int c = 0; c < nchunks; c++) {
-        const u32x4 w = w_next;
-        const f32x2 sw = s_next;
-        if (c + 1 < nchunks) {
-            w_next = __builtin_nontemporal_load((const u32x4 *) (wbase + (size_t) (c + 1) * TILE_BYTES + lane * 16));
-            s_next = __builtin_nontemporal_load((const f32x2 *) (wbase + (size_t) (c + 1) * TILE_BYTES + soff));
-        }
-        const uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
-        const float s0 = quad_bcast<0>(sw.x), s1 = quad_bcast<1>(sw.x), s2 = quad_bcast<2>(sw.x), s3 = quad_bcast<3>(sw.x);
-        const float s4 = quad_bcast<0>(sw.y), s5 = quad_bcast<1>(sw.y), s6 = quad_bcast<2>(sw.y), s7 = quad_bcast<3>(sw.y);
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            const u32x4 *pa = (const u32x4 *) (qa_A + n * strideA + (c * 8 + k) * 8);
-            const u32x4 a0 = pa[0], a1 = pa[1];
-            const f32x4 *pd = (const f32x4 *) (qa_d + n * strideD + c * 8);
-            const f32x4 d0 = pd[0], d1 = pd[1];
-            float acc = accs[n];
-#define LH_STEPN(SW, WD, AD, DA) { const float sc_ = (SW) * (DA); const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, true); acc = fmaf(sc_, (float) p_, acc); }
-            LH_STEPN(s0, w0, a0.x, d0.x) LH_STEPN(s1, w0, a0.y, d0.y)
-            LH_STEPN(s2, w1, a0.z, d0.z) LH_STEPN(s3, w1, a0.w, d0.w)
-            LH_STEPN(s4, w2, a1.x, d1.x) LH_STEPN(s5, w2, a1.y, d1.y)
-            LH_STEPN(s6, w3, a1.z, d1.z) LH_STEPN(s7, w3, a1.w, d1.w)
-#undef LH_STEPN
-            accs[n] = acc;
-        }
-    }
-    int lg = g;
-    if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
-    const int m = lg * 8 + (lane >> 3);
-#pragma unroll
-    for (int n = 0; n < NC; n++) {
-        float acc = fold8(accs[n]);
-        if (k == 0 && m < M) {
-            if (EPI == EPI_RESID) acc = acc + resid[(size_t) n * resid_stride + m];
-            y[(size_t) n * y_stride + m] = acc;
-        }
-    }
-}
-
-// Prompt path, LDS-staged: the activation operands of NC columns for one chunk (NC x 288 B) are
-// staged once per workgroup in LDS (double-buffered, one barrier per chunk) and shared by its 4
-// waves, instead of every lane re-reading them through the texture path (k_gemm_nc: 64 vector loads
-// per chunk per wave, which bound that kernel at ~1/6 of its VALU limit).  Same arithmetic.
+// Prompt path on the decode tiles (runs when the handle has no row-lane copy): NC activation rows
+// share every weight tile; their operands for one chunk (NC x 288 B) are staged once per workgroup in
+// LDS (double-buffered, one barrier per chunk) and shared by its 4 waves.  (Round 1's first variant
+// read them through the texture path instead: 64 vector loads per chunk per wave, 1.8x slower.)
 //   ncols <= NC: columns past ncols are clamped duplicates whose results are not stored.
 template <int NC, int EPI>
 __global__ void __launch_bounds__(256)
@@ -1674,7 +1589,7 @@ hipError_t init_kernel_attrs() {
     // fused prologues of wide models (K = 22016) need more than the default 64 KB of dynamic LDS
     const int cap = 160 * 1024;
 #define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
-    LH_ATTR(k_prep_qa<PREP_PLAIN>); LH_ATTR(k_prep_qa<PREP_NORM>); LH_ATTR(k_prep_qa<PREP_SILU_MUL>); LH_ATTR(k_prep_qa<PREP_SUM>);
+    LH_ATTR(k_prep_qa<PREP_PLAIN>); LH_ATTR(k_prep_qa<PREP_NORM>); LH_ATTR(k_prep_qa<PREP_SILU_MUL>);
 #define LH_ATTR_G1(PRE, EPI, PG) LH_ATTR((k_gemv<PRE, EPI, 16, false, PG>)); LH_ATTR((k_gemv<PRE, EPI, 16, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 22, true, PG>)); \
     LH_ATTR((k_gemv<PRE, EPI, 18, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 14, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 10, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 8, true, PG>)); LH_ATTR((k_gemv<PRE, EPI, 4, true, PG>))
     LH_ATTR_G1(PRE_QA, EPI_STORE, 4); LH_ATTR_G1(PRE_QA, EPI_STORE, 12); LH_ATTR_G1(PRE_QA, EPI_RESID, 4); LH_ATTR_G1(PRE_QA, EPI_RESID, 12);
@@ -1712,15 +1627,14 @@ size_t prep_lds_bytes(int K) { return 32 * sizeof(double) + ((size_t) K + K / 32
 
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
-                       int nsum, long sum_stride, hipStream_t st) {
+                       hipStream_t st) {
     const int Kp = (K + 255) / 256 * 256;
     const size_t lds = prep_lds_bytes(K);
-#define LH_PREP(MODE) hipLaunchKernelGGL(k_prep_qa<MODE>, dim3(N), dim3(256), lds, st, in0, in1, in_stride, in1_stride, K, Kp, qa_A, qa_d, y_out, raw_out, T_silu, nsum, sum_stride)
+#define LH_PREP(MODE) hipLaunchKernelGGL(k_prep_qa<MODE>, dim3(N), dim3(256), lds, st, in0, in1, in_stride, in1_stride, K, Kp, qa_A, qa_d, y_out, raw_out, T_silu)
     switch (mode) {
         case PREP_PLAIN:    LH_PREP(PREP_PLAIN); break;
         case PREP_NORM:     LH_PREP(PREP_NORM); break;
         case PREP_SILU_MUL: LH_PREP(PREP_SILU_MUL); break;
-        case PREP_SUM:      LH_PREP(PREP_SUM); break;
         default: return hipErrorInvalidValue;
     }
 #undef LH_PREP
@@ -1768,13 +1682,13 @@ static int pick_depth(int nchunks, int ngroups) {
 template <int PRE, int EPI, int PG>
 static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, const float *qa_d,
                                  const float *in0, const float *in1, float *y, const float *resid,
-                                 const uint16_t *T_silu, int nsum, long sum_stride,
+                                 const uint16_t *T_silu,
                                  uint32_t *out_A, float *out_d, hipStream_t st) {
     const int grid = (w.ngroups + nw - 1) / nw;
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
-    if (PRE == PREP_SILU_MUL || PRE == PREP_SUM) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
+    if (PRE == PREP_SILU_MUL) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
-#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, nsum, sum_stride, out_A, out_d)
+#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d)
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
     static const bool no_full = getenv("LLAMAHIP_NO_FULL") != nullptr;      // tuning override (measurement only)
@@ -1802,15 +1716,15 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
 template <int PRE, int EPI>
 static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float *qa_d,
                                 const float *in0, const float *in1, float *y, const float *resid,
-                                const uint16_t *T_silu, int nsum, long sum_stride,
+                                const uint16_t *T_silu,
                                 uint32_t *out_A, float *out_d, hipStream_t st) {
-#define LH_PGARGS w, nw, qa_A, qa_d, in0, in1, y, resid, T_silu, nsum, sum_stride, out_A, out_d, st
+#define LH_PGARGS w, nw, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, st
     if constexpr (EPI == EPI_SILU_QA) {
         // 8 waves = 4 gate row-groups + the 4 matching up row-groups (interleaved layout)
         const int nw = 8;
         if (!w.gmapF8 || w.ngroups % 8 != 0 || w.K / 16 > 1 * 512) return hipErrorInvalidValue;
         return launch_gemv_pg<PRE, EPI, 1>(LH_PGARGS);
-    } else if constexpr (PRE == PREP_SILU_MUL || PRE == PREP_SUM) {
+    } else if constexpr (PRE == PREP_SILU_MUL) {
         const int nw = pick_waves(w.ngroups);
         return launch_gemv_pg<PRE, EPI, 1>(LH_PGARGS);
     } else {
@@ -1836,9 +1750,9 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
 
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
-                       const uint16_t *T_silu, int nsum, long sum_stride,
+                       const uint16_t *T_silu,
                        uint32_t *out_A, float *out_d, hipStream_t st) {
-#define LH_ARGS w, qa_A, qa_d, in0, in1, y, resid, T_silu, nsum, sum_stride, out_A, out_d, st
+#define LH_ARGS w, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, st
     // only the (prologue, epilogue) pairs the forward pass uses are instantiated
     if (pre == PRE_QA && epi == EPI_STORE)        return launch_gemv_t<PRE_QA, EPI_STORE>(LH_ARGS);
     if (pre == PRE_QA && epi == EPI_RESID)        return launch_gemv_t<PRE_QA, EPI_RESID>(LH_ARGS);
@@ -1848,19 +1762,6 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
     if (pre == PREP_SILU_MUL && epi == EPI_RESID) return launch_gemv_t<PREP_SILU_MUL, EPI_RESID>(LH_ARGS);
 #undef LH_ARGS
     return hipErrorInvalidValue;
-}
-
-template <int NC>
-static hipError_t launch_gemm_nc_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d,
-                                   float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
-    const int nw = pick_waves(w.ngroups);
-    const int grid = (w.ngroups + nw - 1) / nw;
-    if (epi == EPI_RESID)
-        hipLaunchKernelGGL((k_gemm_nc<NC, EPI_RESID>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, y, y_stride, resid, resid_stride);
-    else
-        hipLaunchKernelGGL((k_gemm_nc<NC, EPI_STORE>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, y, y_stride, resid, resid_stride);
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
 }
 
 template <int NC>
@@ -1903,10 +1804,9 @@ hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
-    static const bool old_path = getenv("LLAMAHIP_GEMM_NC") != nullptr;     // measurement: the non-LDS variant
     static const bool no_rows = getenv("LLAMAHIP_GEMM_LDS") != nullptr;     // measurement: skip the row-lane kernel
     static const int force_nc = getenv("LLAMAHIP_GEMM_ROWS_NC") ? atoi(getenv("LLAMAHIP_GEMM_ROWS_NC")) : 0;
-    if (w.rows && N >= 2 && !old_path && !no_rows) {
+    if (w.rows && N >= 2 && !no_rows) {
         // widest column group that still gives the chip >= 2 waves per SIMD.  Wider groups (8, 16
         // columns: 191 / 249 VGPRs, 2 waves per SIMD) measured 10-16 % slower than 4 columns at 3 waves
         // per SIMD on a 512-token prompt: the kernel runs at ~85 % of its VALU issue limit and the third
@@ -1934,13 +1834,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         const float *rr = resid ? resid + (size_t) n0 * resid_stride : nullptr;
         hipError_t e;
         int step;
-        if (old_path) {
-            if (rem >= 16)     { step = 16; e = launch_gemm_nc_t<16>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-            else if (rem >= 8) { step = 8;  e = launch_gemm_nc_t<8>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-            else if (rem >= 4) { step = 4;  e = launch_gemm_nc_t<4>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-            else if (rem >= 2) { step = 2;  e = launch_gemm_nc_t<2>(w, epi, A, D, yy, y_stride, rr, resid_stride, st); }
-            else               { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, 0, 0, nullptr, nullptr, st); }
-        } else if (rem == 1)   { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, 0, 0, nullptr, nullptr, st); }
+        if (rem == 1)   { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, nullptr, nullptr, st); }
         else if (rem > 8)      { step = rem < 16 ? rem : 16; e = launch_gemm_lds_t<16>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
         else if (rem > 4)      { step = rem;                 e = launch_gemm_lds_t<8>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
         else                   { step = rem;                 e = launch_gemm_lds_t<4>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }

@@ -354,22 +354,22 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             // the context position is read from m->d_state by the attention kernels
             const float *xa = (il == m->l0 && x_first) ? x_first : m->x;      // residual stream into this layer
             float *xo = (il == m->l1 - 1 && x_last) ? x_last : m->x;           // ... and out of it
-            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             if (m->w13_interleaved) {
-                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, 0, 0, m->qa2_A, m->qa2_d, st), LLAMAHIP_ERR_PREDICT);
-                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             } else {
-                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
-                HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, xo, m->x1, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, xo, m->x1, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             }
             continue;
         }
 
         // ---- general path (prompt chunks, debug dumps): prepare -> GEMM per mat-mul
         if (dmp && !sink->put(0, m->x, (int64_t) N * d)) goto dump_fail;
-        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
+        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
         if (dmp && !sink->put(1, m->dbg_y, (int64_t) N * d)) goto dump_fail;
         HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
         if (dmp) {
@@ -386,7 +386,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             if (!sink->put(7, m->dbg_kqv, (int64_t) N * d)) goto dump_fail;
             if (!sink->put(8, m->merged, (int64_t) N * d)) goto dump_fail;
         }
-        HIP_TRY(launch_prep(PREP_PLAIN, m->merged, nullptr, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(launch_prep(PREP_PLAIN, m->merged, nullptr, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
         if (dmp) {
             HIP_TRY(launch_gemm(L.wo, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);      // .mm:649-651
             if (!sink->put(9, m->tmp, (int64_t) N * d)) goto dump_fail;
@@ -395,7 +395,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         } else {
             HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, N, m->x1, d, m->x, d, st), LLAMAHIP_ERR_PREDICT);
         }
-        HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
+        HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (dmp && !sink->put(11, m->dbg_y, (int64_t) N * d)) goto dump_fail;
         HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, N, m->gu, 2L * F, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);     // .mm:668-675
         if (dmp) {
@@ -404,7 +404,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) F * 4, m->gu, (size_t) 2 * F * 4, (size_t) F * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
             if (!sink->put(13, m->tmp, (int64_t) N * F)) goto dump_fail;       // w1 output
         }
-        HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
+        HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
         if (dmp && !sink->put(14, m->dbg_y, (int64_t) N * F)) goto dump_fail;
         if (dmp) {
             HIP_TRY(launch_gemm(L.w2, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);      // .mm:682-684
@@ -421,12 +421,12 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         // last (.mm:724-725); only the last row is computed here unless every row is requested.
         const int V = hp.n_vocab;
         if (fused) {
-            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, 0, 0, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
         } else if (want_all) {
-            HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, N, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
         } else {
-            HIP_TRY(launch_prep(PREP_NORM, m->x + (size_t) (N - 1) * d, m->norm_w, d, 0, d, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_prep(PREP_NORM, m->x + (size_t) (N - 1) * d, m->norm_w, d, 0, d, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, 1, m->logits + (size_t) (N - 1) * V, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
         }
     }
@@ -995,7 +995,7 @@ int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const flo
             if (hipMalloc((void **) &q.rows, q.rows_bytes()) != hipSuccess) break;
             if (launch_tiles_to_rows(q, st) != hipSuccess) break;
         }
-        if (launch_prep(PREP_PLAIN, d_x, nullptr, K, 0, K, N, d_qA, d_qd, nullptr, nullptr, nullptr, 0, 0, st) != hipSuccess) break;
+        if (launch_prep(PREP_PLAIN, d_x, nullptr, K, 0, K, N, d_qA, d_qd, nullptr, nullptr, nullptr, st) != hipSuccess) break;
         if (launch_gemm(q, EPI_STORE, d_qA, d_qd, N, d_y, M, nullptr, 0, st) != hipSuccess) break;
         if (hipMemcpyAsync(y, d_y, (size_t) N * M * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
@@ -1020,7 +1020,7 @@ int llamahip_op_quantize_row_q4_0(const float *x, int32_t k, void *y, char *err,
         if (hipMalloc((void **) &d_qd, (Kp / 32) * 4) != hipSuccess) break;
         if (hipMalloc((void **) &d_raw, (size_t) (k / 32) * 20) != hipSuccess) break;
         if (hipMemcpy(d_x, x, (size_t) k * 4, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (launch_prep(PREP_PLAIN, d_x, nullptr, k, 0, k, 1, d_qA, d_qd, nullptr, d_raw, nullptr, 0, 0, nullptr) != hipSuccess) break;
+        if (launch_prep(PREP_PLAIN, d_x, nullptr, k, 0, k, 1, d_qA, d_qd, nullptr, d_raw, nullptr, nullptr) != hipSuccess) break;
         if (hipMemcpy(y, d_raw, (size_t) (k / 32) * 20, hipMemcpyDeviceToHost) != hipSuccess) break;
         rc = LLAMAHIP_OK;
     } while (0);
@@ -1052,10 +1052,10 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
     std::vector<float> hx(q->K);
     for (int i = 0; i < q->K; i++) hx[i] = (float) ((i * 2654435761u) >> 8 & 0xFFFF) / 32768.0f - 1.0f;
     HIP_TRY(hipMemcpyAsync(m->tmp, hx.data(), (size_t) q->K * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(launch_prep(PREP_PLAIN, m->tmp, nullptr, q->K, 0, q->K, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, 0, 0, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(launch_prep(PREP_PLAIN, m->tmp, nullptr, q->K, 0, q->K, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
     float *yout = which == 4 ? m->logits : m->gu;     // gu (2F floats) is large enough for every layer matrix
-    auto run = [&](const QMat *w) { return launch_gemv(*w, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, 0, 0, nullptr, nullptr, m->stream); };
+    auto run = [&](const QMat *w) { return launch_gemv(*w, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, nullptr, nullptr, m->stream); };
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipEventCreate(&e1), LLAMAHIP_ERR_PREDICT);
@@ -1067,7 +1067,7 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
         for (int it = 0; it < warmup + iters; it++) {
             size_t flushed = 0;
             for (const Layer &L : m->layers) {
-                HIP_TRY(launch_gemv(L.w13, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, m->gu, nullptr, m->T_silu, 0, 0, nullptr, nullptr, m->stream), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w13, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, m->gu, nullptr, m->T_silu, nullptr, nullptr, m->stream), LLAMAHIP_ERR_PREDICT);
                 flushed += L.w13.bytes();
                 if (flushed > (size_t) 400 << 20) break;
             }

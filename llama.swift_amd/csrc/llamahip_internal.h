@@ -9,7 +9,7 @@ namespace lh {
 constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 64 fp32 scales
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
-enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_SUM = 4 };
+enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2 };
 
 // a Q4_0 weight matrix resident in HBM in chain-major tile layout
@@ -37,11 +37,10 @@ hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st);   // w.rows / w.
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st);
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
-                       int nsum, long sum_stride, hipStream_t st);
+                       hipStream_t st);
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
-                       const uint16_t *T_silu, int nsum, long sum_stride,
-                       uint32_t *out_A, float *out_d, hipStream_t st);
+                       const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st);
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st);
 hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, const double *tab,

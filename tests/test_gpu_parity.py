@@ -113,7 +113,7 @@ def test_model_vs_oracle_with_multipart_files(L, oracle, tmp_path, parts, nth):
 
 def test_long_prompt_in_one_eval(L, oracle, tmp_path):
     """n_ctx is a load parameter here (the reference hard-codes 512, .mm:790): a 1100-token prompt in a
-    single eval (column tiles of 16/8/4/2/1 through k_gemm_nc, k_attn over up to 1100 keys), then
+    single eval (k_gemm_rows column groups, three 512-row batches of k_attnq_* over up to 1100 keys), then
     decode at the far end of a 1280-token context."""
     hp = synth.HParams(n_vocab=256, n_embd=256, n_mult=64, n_head=2, n_layer=2)
     path = str(tmp_path / "m.bin")
