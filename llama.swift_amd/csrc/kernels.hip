@@ -1497,15 +1497,28 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     const float *vcol = Vc + col;
     for (int th = sub; th < nth; th += nsub) {
         const int t0 = dc * th, t1 = min(t0 + dc, T);
+        // The chain is sequential but its loads are not: two register batches of 16 rows, the next one
+        // in flight while the current one is consumed (a chain walks T/nth rows 16 KB apart; at a
+        // 2 000-token context the single-batch loop spent one memory round trip per 16 rows).
+        // Rows past the chunk end are clamped re-reads weighted by 0: fma(v, 0, acc) == acc.
         float acc = 0.0f;
-        for (int tb = t0; tb < t1; tb += 16) {
-            float v[16];
+        float va[16], vb[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = vcol[(size_t) min(tb + u, t1 - 1) * d];
+        for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(t0 + u, t1 - 1) * d];
+        for (int tb = t0; tb < t1; tb += 32) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(tb + 16 + u, t1 - 1) * d];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
-                const float pe = (tb + u < t1) ? p[min(tb + u, T - 1)] : 0.0f;      // fma(v, 0, acc) == acc
-                acc = fmaf(v[u], pe, acc);
+                const float pe = (tb + u < t1) ? p[min(tb + u, T - 1)] : 0.0f;
+                acc = fmaf(va[u], pe, acc);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(tb + 32 + u, t1 - 1) * d];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float pe = (tb + 16 + u < t1) ? p[min(tb + 16 + u, T - 1)] : 0.0f;
+                acc = fmaf(vb[u], pe, acc);
             }
         }
         part[th * 32 + c] = acc;
