@@ -1129,7 +1129,7 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 // (.mm:614), in a [head][key][query] workspace so that lanes read and write it coalesced; queries
 // are processed in batches of NB rows to bound it.
 //   k_attnq_scores   grid (NB/64, H, KS): KQ * scale for its key slice, running max      -> S, pmax
-//   k_attnq_softmax  grid (NB/64, H) x (64 queries x 4 key phases): exp LUT, double sum   -> S = e, inv
+//   k_attnq_softmax  grid (NB/64, H) x (64 queries x 16 key phases): exp LUT, double sum  -> S = e, inv
 //   k_attnq_pv       grid (NB/64, H, 4 column groups x nth): p = e * inv; one FMA chain per chunk of the
 //                    reference's nth-way key split                                       -> part
 //   k_attnq_merge    the ordered add of the nth partials                                 -> merged
@@ -1181,10 +1181,11 @@ k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float
     pmax[((size_t) h * KS + ks) * NB + nl] = mx;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__restrict__ inv,
                 int n_past, int N, int nb0, int NB, int T, int KS, const uint16_t *__restrict__ T_exp) {
-    __shared__ double part[4][64];
+    constexpr int PH = 16;                                // key phases: a thread takes every 16th key of its query
+    __shared__ double part[PH][64];
     const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6, h = blockIdx.y;
     const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
     const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
@@ -1193,7 +1194,7 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
     float mx = -INFINITY;
     for (int k = 0; k < KS; k++) mx = fmaxf(mx, pmax[((size_t) h * KS + k) * NB + nl]);
     double sum = 0.0;
-    for (int t = ph; t < Tb; t += 4) {
+    for (int t = ph; t < Tb; t += PH) {
         float *sp = S + ((size_t) h * T + t) * NB + nl;
         float e = 0.0f;                                   // masked keys (-inf in the reference) contribute 0
         if (t <= tq) { e = h2f_bits(T_exp[f2h_bits(*sp - mx)]); sum += (double) e; }
@@ -1203,7 +1204,9 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
     __syncthreads();
     if (ph == 0) {
         // every term is a multiple of 2^-24 and <= 1: the double sum is exact in any order
-        const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < PH; k++) tot += part[k][lane];
         inv[(size_t) h * NB + nl] = (float) (1.0 / tot);
     }
 }
@@ -1869,14 +1872,15 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
     const int dh = d / H, T = n_past + N;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const bool old_only = getenv("LLAMAHIP_ATTN_ROWWISE") != nullptr;     // measurement: per-row kernel for every N
-    if (ws && ws->S && dh == 128 && N >= 32 && !dbg_p && !dbg_kqv && T <= ws->T_cap && nth <= ws->nth_cap && !old_only) {
+    static const int attnq_min = getenv("LLAMAHIP_ATTNQ_MIN") ? atoi(getenv("LLAMAHIP_ATTNQ_MIN")) : 2;
+    if (ws && ws->S && dh == 128 && N >= attnq_min && !dbg_p && !dbg_kqv && T <= ws->T_cap && nth <= ws->nth_cap && !old_only) {
         for (int nb0 = 0; nb0 < N; nb0 += ws->NB) {
             const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
             int KS = (6144 + qb * H - 1) / (qb * H);      // ~2 rounds of 3 waves per SIMD: the waves are latency-bound
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
             hipLaunchKernelGGL(k_attnq_scores, dim3(qb, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(256), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
+            hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_pv, dim3(qb, H, 4 * nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
             LH_LAUNCH_CHECK();

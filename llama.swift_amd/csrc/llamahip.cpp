@@ -248,9 +248,14 @@ int upload_f32(llamahip_model *m, const std::string &name, float **dst, char *er
 
 int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N <= m->ws_cap) return 0;
-    // captured decode graphs hold the old workspace pointers
+    // captured graphs hold the old workspace pointers
+    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
     for (auto &kv : m->decode_graphs) (void) hipGraphExecDestroy(kv.second);
     m->decode_graphs.clear();
+    for (auto &sl : m->slots) {
+        for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
+        sl.graphs.clear();
+    }
     const HParams &hp = m->hp;
     const size_t d = hp.n_embd, F = hp.n_ff, V = hp.n_vocab, C = hp.n_ctx, H = hp.n_head;
     const size_t KpMax = ((std::max(d, F) + 255) / 256) * 256;
@@ -278,10 +283,10 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     return 0;
 }
 
-// the score workspace of the many-row prompt attention: [n_head][n_ctx][NB] fp32, NB = 512 query rows
-// per batch (7B, n_ctx 2560: 168 MB)
+// the score workspace of the multi-row prompt attention: [n_head][n_ctx][NB] fp32, NB = 512 query rows
+// per batch (7B, n_ctx 2560: 168 MB), allocated with the first multi-token eval
 int ensure_attn_ws(llamahip_model *m, int N, char *err, size_t err_cap) {
-    if (N < 32 || m->attn_ws.S) return 0;
+    if (N < 2 || m->attn_ws.S) return 0;
     const size_t H = m->hp.n_head, C = m->hp.n_ctx;
     AttnWs &w = m->attn_ws;
     w.NB = 512; w.T_cap = (int) C; w.KS_cap = 32; w.nth_cap = 8;
