@@ -1559,9 +1559,15 @@ __global__ void k_argmax(const float *__restrict__ logits, int V, int32_t *__res
     __shared__ int bi[1024];
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        const float v = logits[i];
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    for (int i0 = threadIdx.x; i0 < V; i0 += 8 * blockDim.x) {        // 8 loads in flight per thread, compared in index order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * blockDim.x; v[u] = i < V ? logits[i] : -INFINITY; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * blockDim.x;
+            if (i < V && (v[u] > best || (v[u] == best && i < idx))) { best = v[u]; idx = i; }
+        }
     }
     bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
     __syncthreads();
