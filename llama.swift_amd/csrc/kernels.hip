@@ -452,8 +452,11 @@ __global__ void k_prep_qa(const float *__restrict__ in0, const float *__restrict
 #define LH_STEP(J, WD, AD, DA)                                                                     \
     {                                                                                              \
         const float sc_ = quad_bcast<((J) & 3)>((J) < 4 ? sw.x : sw.y) * (DA);                     \
-        const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, true);  /* clamp: one VOP3P op, |isum| <= 512 never saturates */ \
-        acc = fmaf(sc_, (float) p_, acc);                                                          \
+        /* int -> float without v_cvt: the dot accumulates onto the bit pattern of 1.5 * 2^23 (ulp 1), so  */ \
+        /* its result IS the float 12582912 + isum; the exact subtraction pairs up as v_pk_add_f32.        */ \
+        /* clamp: VOP3P form, |isum| <= 512 never saturates                                                 */ \
+        const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0x4B400000, true);           \
+        acc = fmaf(sc_, __builtin_bit_cast(float, p_) - 12582912.0f, acc);                         \
     }
 
 __device__ __forceinline__ float fold8(float acc) {
@@ -682,11 +685,31 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         const u32x4 a0 = la0[(SLOT) & 1], a1 = la1[(SLOT) & 1];                                    \
         const f32x4 d0 = ld0[(SLOT) & 1], d1 = ld1[(SLOT) & 1];                                    \
         LH_LDSLOAD(((SLOT) + 1) & 1, (CH) + 1)                                                     \
-        const uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;                                     \
-        LH_STEP(0, w0, a0.x, d0.x) LH_STEP(1, w0, a0.y, d0.y)                                      \
-        LH_STEP(2, w1, a0.z, d0.z) LH_STEP(3, w1, a0.w, d0.w)                                      \
-        LH_STEP(4, w2, a1.x, d1.x) LH_STEP(5, w2, a1.y, d1.y)                                      \
-        LH_STEP(6, w3, a1.z, d1.z) LH_STEP(7, w3, a1.w, d1.w)                                      \
+        /* 8 blocks: integer dots first, accumulated onto the bit pattern of 1.5 * 2^23 (ulp 1) so each  */ \
+        /* result IS the float 12582912 + isum (|isum| <= 512; clamp selects the VOP3P form and never    */ \
+        /* saturates); the exact subtraction is done two at a time (v_pk_add_f32) instead of 8 v_cvt;    */ \
+        /* then the block-ordered FMA chain with the DPP-broadcast scales.                                */ \
+        const int i0_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.x, 0x4B400000, true);           \
+        const int i1_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.y, 0x4B400000, true);           \
+        const int i2_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.z, 0x4B400000, true);           \
+        const int i3_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.w, 0x4B400000, true);           \
+        const int i4_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.x, 0x4B400000, true);           \
+        const int i5_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.y, 0x4B400000, true);           \
+        const int i6_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.z, 0x4B400000, true);           \
+        const int i7_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.w, 0x4B400000, true);           \
+        const f32x2 mg_ = { 12582912.0f, 12582912.0f };                                            \
+        const f32x2 q01_ = f32x2{ __builtin_bit_cast(float, i0_), __builtin_bit_cast(float, i1_) } - mg_; \
+        const f32x2 q23_ = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
+        const f32x2 q45_ = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
+        const f32x2 q67_ = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
+        acc = fmaf(quad_bcast<0>(sw.x) * d0.x, q01_.x, acc);                                       \
+        acc = fmaf(quad_bcast<1>(sw.x) * d0.y, q01_.y, acc);                                       \
+        acc = fmaf(quad_bcast<2>(sw.x) * d0.z, q23_.x, acc);                                       \
+        acc = fmaf(quad_bcast<3>(sw.x) * d0.w, q23_.y, acc);                                       \
+        acc = fmaf(quad_bcast<0>(sw.y) * d1.x, q45_.x, acc);                                       \
+        acc = fmaf(quad_bcast<1>(sw.y) * d1.y, q45_.y, acc);                                       \
+        acc = fmaf(quad_bcast<2>(sw.y) * d1.z, q67_.x, acc);                                       \
+        acc = fmaf(quad_bcast<3>(sw.y) * d1.w, q67_.y, acc);                                       \
     }
     LH_STAMP(2);
     LH_LDSLOAD(0, 0)
@@ -1665,6 +1688,8 @@ hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_str
 }
 
 static int pick_waves(int ngroups) {
+    static const int ovr = getenv("LLAMAHIP_WAVES") ? atoi(getenv("LLAMAHIP_WAVES")) : 0;      // tuning override (measurement only)
+    if (ovr == 1 || ovr == 2 || ovr == 4) return ovr;
     // aim for >= 2 workgroups per CU (256 CUs) before growing the workgroup
     if (ngroups >= 4 * 512) return 4;
     if (ngroups >= 2 * 512) return 2;

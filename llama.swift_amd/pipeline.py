@@ -269,7 +269,9 @@ def bench_main(args, cfg, model_path_fn, log):
     dist.barrier()
     path = model_path_fn(args.model, cfg, args.seed)
 
-    S = world                                    # one sequence in flight per stage (weak scaling)
+    # sequences in flight: two per stage (weak scaling).  With exactly one per stage every stage waits out
+    # the hand-off latency of its predecessor on every step; a second one keeps a ready item queued.
+    S = world * max(1, int(os.environ.get("LLAMAHIP_PIPE_SEQS_PER_STAGE", "2"))) if world > 1 else 1
     stage = HipStage(path, args.n_ctx, rank, world, S, cfg["n_layer"], local, args.threads)
     rng = np.random.default_rng(1234)
     prompts = [np.concatenate([[1], rng.integers(3, cfg["n_vocab"], 7)]).astype(np.int32) for _ in range(S)]
