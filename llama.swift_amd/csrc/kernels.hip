@@ -1024,6 +1024,226 @@ k_gemm_rows(const uint8_t *__restrict__ wr, int nrb, int nchunks, int M,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Prompt path on the matrix cores, still bit-exact.
+// The reference needs, per output and Q4_0 block, EIGHT separate 4-element integer sums (one per
+// lane of its AVX accumulator), each scaled and FMA-accumulated on its own chain -- an MFMA sums
+// over its whole K.  So the activation operand is MASKED: v_mfma_i32_32x32x32_i8 (K = 32 = one
+// block) is issued once per chain with every byte of B zeroed except that chain's 4 elements; the
+// product is that chain's exact integer sum for a 32 x 32 tile of outputs.  7/8 of the MACs multiply
+// zeros, which the matrix pipe has to spare, and the VALU is left with what cannot be avoided: the
+// conversion and the scaled FMA, both packed (v_pk_add_f32 / v_pk_fma_f32), 16 outputs per lane.
+//   * A = weights as int8 = signed nibble << 4 (two VALU per 8 nibbles); the x16 is undone for free
+//     by accumulating onto the bit pattern of 1.5 * 2^19 (ulp 1/16): D IS the float 786432 + isum.
+//   * d_w * d_a: 16 products per lane and block, shared by the 8 chains.
+// Third resident copy of a matrix ("mtiles"): tile (row-block of 32, quad of 4 blocks) = 2560 B:
+//   [j 0..3][lane 0..63][8 B]  lane = m + 32 * kg (kg = K-half: elements 16kg..16kg+15 of block 4q+j);
+//                              dword 0 = signed nibbles of (k = 0..3, p = 0,1), dword 1 = k = 4..7,
+//                              nibble index 2 * (k & 3) + p  <->  element 2k + p + 16kg
+//   [j][32 rows] fp32 scales
+// Activation operand "QB" (k_qa_to_qb): per column [block][kg][16 int8] in the matching K order:
+//   dword t = (k >> 2) * 2 + p, byte k & 3.
+// Workgroup = 4 waves = 64 rows x 64 columns, operands of one quad staged in LDS (double-buffered).
+// ------------------------------------------------------------------------------------------------
+constexpr int MTILE_BYTES = 2560;
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x16v __attribute__((ext_vector_type(16)));
+
+// decode tiles -> mtiles (load time).  One thread per (row-block, quad, j, lane) for the nibbles,
+// plus the scales.
+__global__ void k_tiles_to_mtiles(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ mt,
+                                  int ngroups, int nchunks, int nrb32, int gmapF8) {
+    const int nq = nchunks * 2;
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long) nrb32 * nq * 4 * 64;
+    if (gid >= total) return;
+    const int lane = (int) (gid & 63), j = (int) ((gid >> 6) & 3);
+    const long t = gid >> 8;
+    const int q = (int) (t % nq), rb = (int) (t / nq);
+    const int m = lane & 31, kg = lane >> 5;
+    const int row = rb * 32 + m, lg = row >> 3, r = row & 7;
+    const int b = q * 4 + j, c = b >> 3, jj = b & 7, i = jj >> 1, half = jj & 1;
+    uint32_t x0 = 0, x1 = 0;
+    float d = 0.0f;
+    if (lg < ngroups) {
+        int tg = lg;
+        if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
+        const uint8_t *tp = tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t dw = ((const uint32_t *) (tp + (r * 8 + k) * 16))[i];       // chain k, blocks (2i, 2i+1)
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {
+                const uint32_t nib = (dw >> (8 * (2 * kg + pp) + 4 * half)) & 0xF;        // element 2k + pp + 16kg, already signed
+                if (k < 4) x0 |= nib << (4 * (2 * k + pp)); else x1 |= nib << (4 * (2 * (k - 4) + pp));
+            }
+        }
+        // scales of a row are stored [s0,s4,s1,s5,s2,s6,s3,s7]
+        d = ((const float *) (tp + 1024 + r * 32))[(jj & 3) * 2 + (jj >> 2)];
+    }
+    uint8_t *o = mt + ((size_t) rb * nq + q) * MTILE_BYTES;
+    ((uint32_t *) (o + j * 512 + lane * 8))[0] = x0;
+    ((uint32_t *) (o + j * 512 + lane * 8))[1] = x1;
+    if (kg == 0) ((float *) (o + 2048))[j * 32 + m] = d;
+}
+
+// QA (chain-major signed nibbles) -> QB (int8, MFMA K order).  One thread per (column, block, kg).
+__global__ void k_qa_to_qb(const uint32_t *__restrict__ qa_A, uint8_t *__restrict__ qb, int nchunks, int N) {
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int nbp = nchunks * 8;                           // blocks per column incl. padding
+    const long total = (long) N * nbp * 2;
+    if (gid >= total) return;
+    const int kg = (int) (gid & 1);
+    const long t = gid >> 1;
+    const int b = (int) (t % nbp), n = (int) (t / nbp);
+    const int c = b >> 3, jj = b & 7;
+    const uint32_t *src = qa_A + (size_t) n * nchunks * 64 + c * 64 + jj;
+    uint32_t out[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t dw = src[k * 8];
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+            const int nib = (int) ((dw >> (8 * (2 * kg + pp) + 4 * (jj & 1))) & 0xF);
+            const uint32_t v = (uint32_t) ((nib ^ 8) - 8) & 0xFF;                           // sign-extend 4 -> 8 bits
+            out[(k >> 2) * 2 + pp] |= v << (8 * (k & 3));
+        }
+    }
+    *(u32x4 *) (qb + ((size_t) n * nbp + b) * 32 + kg * 16) = u32x4{ out[0], out[1], out[2], out[3] };
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
+            const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
+            float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    constexpr int BSTRIDE = 144;                            // 128 B of a column's quad + 16 B pad: conflict-free b128 reads
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][2][MTILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t sB[2][64 * BSTRIDE];
+    __shared__ __attribute__((aligned(16))) float sDa[2][64 * 4];
+    // XCD-aware: a row-pair's column tiles run back to back on one XCD (its weights stay in that L2)
+    const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
+    const int ct = qq % nct, rp = (qq / nct) * 8 + xcd;
+    if (rp * 2 >= nrb32) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave & 1, wc = wave >> 1;
+    const int n0 = ct * 64;
+    const int nbp = nq * 4;
+    const long strideD = (long) nq * 4;                    // floats per column in qa_d
+
+    // ---- global -> registers -> LDS staging of one quad
+    u32x4 gw[2], gb[2];
+    f32x4 gd;
+    auto fetch = [&](int q) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int g = tid + u * 256;                   // 320 granules of weights (2 tiles x 160)
+            const int tile = min(g / 160, 1), off = (g % 160) * 16;
+            const int rb = min(rp * 2 + tile, nrb32 - 1);
+            gw[u] = *(const u32x4 *) (mt + ((size_t) rb * nq + q) * MTILE_BYTES + off);
+            const int col = min(n0 + (g >> 3), ncols - 1), part = g & 7;     // 512 granules of activations
+            gb[u] = *(const u32x4 *) (qb + ((size_t) col * nbp + q * 4) * 32 + part * 16);
+        }
+        gd = *(const f32x4 *) (qa_d + (size_t) min(n0 + (tid & 63), ncols - 1) * strideD + q * 4);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int g = tid + u * 256;
+            if (g < 320) *(u32x4 *) (&sW[buf][g / 160][(g % 160) * 16]) = gw[u];
+            *(u32x4 *) (&sB[buf][(g >> 3) * BSTRIDE + (g & 7) * 16]) = gb[u];
+        }
+        if (tid < 64) *(f32x4 *) (&sDa[buf][tid * 4]) = gd;
+    };
+
+    f32x2 acc[8][8];                                        // [chain][pair of adjacent C/D registers]
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[k][r] = f32x2{ 0.0f, 0.0f };
+    i32x16v cm;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cm[r] = 0x49400000;       // 1.5 * 2^19: ulp 1/16
+
+    const bool second_tile_real = rp * 2 + 1 < nrb32;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int q = 0; q < nq; q++) {
+        const int buf = q & 1;
+        if (q + 1 < nq) fetch(q + 1);
+        const uint8_t *wt_ = sW[buf][wr];
+        const uint8_t *bt_ = &sB[buf][(wc * 32 + (lane & 31)) * BSTRIDE + (lane >> 5) * 16];
+        const f32x4 da4 = *(const f32x4 *) (&sDa[buf][(wc * 32 + (lane & 31)) * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x0 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[0];
+            const uint32_t x1 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[1];
+            const i32x4v A = { (int) ((x0 << 4) & 0xF0F0F0F0u), (int) (x0 & 0xF0F0F0F0u), (int) ((x1 << 4) & 0xF0F0F0F0u), (int) (x1 & 0xF0F0F0F0u) };
+            const u32x4 B = *(const u32x4 *) (bt_ + j * 32);
+            const float da = j == 0 ? da4.x : j == 1 ? da4.y : j == 2 ? da4.z : da4.w;
+            f32x2 sc[8];
+            const f32x2 da2 = { da, da };
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 dw = *(const f32x4 *) (wt_ + 2048 + (j * 32 + 8 * g + 4 * (lane >> 5)) * 4);
+                sc[2 * g + 0] = f32x2{ dw.x, dw.y } * da2;
+                sc[2 * g + 1] = f32x2{ dw.z, dw.w } * da2;
+            }
+            // chain k: B with every byte but that chain's 4 elements zeroed.  Two MFMAs stay in flight
+            // ahead of the packed conversion + FMA of a chain.  Left alone, the scheduler issues all 32
+            // MFMAs of a quad first and spills their 512 result registers, so the order is pinned with
+            // empty volatile asms (they keep their program order): "use" all 16 accumulators of chain k,
+            // then "define" the operand of chain k + 2.
+            i32x16v D[2];
+#define LH_MFMA(K, PIN)                                                                            \
+            {                                                                                      \
+                const uint32_t mask_ = 0xFFu << (8 * ((K) & 3));                                   \
+                i32x4v Bk_ = { 0, 0, 0, 0 };                                                       \
+                if ((K) < 4) { Bk_.x = (int) (B.x & mask_); Bk_.y = (int) (B.y & mask_); }         \
+                else         { Bk_.z = (int) (B.z & mask_); Bk_.w = (int) (B.w & mask_); }         \
+                if (PIN) { if ((K) < 4) asm volatile("" : "+v"(Bk_.x)); else asm volatile("" : "+v"(Bk_.z)); } \
+                D[(K) % 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bk_, cm, 0, 0, 0);           \
+            }
+            LH_MFMA(0, true)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k + 1 < 8) LH_MFMA(k + 1, true)             // in flight behind the consumption of chain k
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    // (scalar copies: __builtin_bit_cast on a vector ELEMENT reads element 0)
+                    const int d0 = D[k % 2][2 * r], d1 = D[k % 2][2 * r + 1];
+                    const f32x2 qv = f32x2{ __builtin_bit_cast(float, d0), __builtin_bit_cast(float, d1) } - f32x2{ 786432.0f, 786432.0f };
+                    // in-place packed FMA (tied operand): left to the register allocator, the 128 accumulators
+                    // come out of the loop body in other registers than they went in (~100 copies per block)
+                    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r]) : "v"(sc[r]), "v"(qv));
+                }
+                asm volatile("" :: "v"(acc[k][0]), "v"(acc[k][1]), "v"(acc[k][2]), "v"(acc[k][3]),
+                             "v"(acc[k][4]), "v"(acc[k][5]), "v"(acc[k][6]), "v"(acc[k][7]));
+            }
+#undef LH_MFMA
+        }
+        if (q + 1 < nq) stash(buf ^ 1);
+        __syncthreads();
+    }
+    (void) second_tile_real;
+    // ---- fold the 8 chains (ggml.c:872-887 tree) and store: lane = column, 16 rows (C/D layout)
+    const int n = n0 + wc * 32 + (lane & 31);
+    const int mb = (rp * 2 + wr) * 32 + 4 * (lane >> 5);
+    if (n < ncols && rp * 2 + wr < nrb32) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+#define LH_A(K) ((r & 1) ? acc[K][r >> 1].y : acc[K][r >> 1].x)
+            float v = ((LH_A(0) + LH_A(4)) + (LH_A(2) + LH_A(6))) + ((LH_A(1) + LH_A(5)) + (LH_A(3) + LH_A(7)));
+#undef LH_A
+            if (m < M) {
+                if (EPI == EPI_RESID) v = v + resid[(size_t) n * resid_stride + m];
+                y[(size_t) n * y_stride + m] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // RoPE + KV append (ggml.c:7076-7131, .mm:586-611).  The reference copies K un-rotated into the
 // cache and rotates it there (mode 1); writing the rotated value directly is the same arithmetic.
 // cos/sin come from a host table built with the host libm exactly as the reference computes them
@@ -1837,6 +2057,33 @@ static hipError_t launch_gemm_rows_t(const QMat &w, int epi, const uint32_t *qa_
     return hipSuccess;
 }
 
+hipError_t launch_tiles_to_mtiles(const QMat &w, hipStream_t st) {
+    const long total = (long) w.nrb32 * w.nchunks * 2 * 4 * 64;
+    hipLaunchKernelGGL(k_tiles_to_mtiles, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_qa_to_qb(const uint32_t *qa_A, uint8_t *qb, int nchunks, int N, hipStream_t st) {
+    const long total = (long) N * nchunks * 8 * 2;
+    hipLaunchKernelGGL(k_qa_to_qb, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, qa_A, qb, nchunks, N);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+static hipError_t launch_gemm_mfma(const QMat &w, int epi, const uint8_t *qb, const float *qa_d, int ncols,
+                                   float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const int nct = (ncols + 63) / 64, nq = w.nchunks * 2;
+    const int nrp = (w.nrb32 + 1) / 2;
+    const int grid = ((nrp + 7) / 8) * nct * 8;
+    if (epi == EPI_RESID)
+        hipLaunchKernelGGL((k_gemm_mfma<EPI_RESID>), dim3(grid), dim3(256), 0, st, w.mt, w.nrb32, nq, w.M, qb, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+    else
+        hipLaunchKernelGGL((k_gemm_mfma<EPI_STORE>), dim3(grid), dim3(256), 0, st, w.mt, w.nrb32, nq, w.M, qb, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
     const long total = (long) w.nrb * (w.nchunks + 1) * 10 * 64;
     hipLaunchKernelGGL(k_tiles_to_rows, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, w.tiles, w.rows, w.ngroups, w.nchunks, w.nrb, w.gmapF8);
@@ -1849,7 +2096,17 @@ hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
 //   else: LDS-staged column tiles of 16 (the last one clamped), small remainders as 8 / 4 columns
 //   a single row always goes through the decode GEMV
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
-                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws) {
+    // Matrix-core path when its 64 x 64-output workgroups fill the chip twice over (measured crossover
+    // against the row-per-lane kernel on MI355X: N ~ 256 for the 7B matrices; 1.25x faster at N = 1024).
+    static const int mfma_min = getenv("LLAMAHIP_MFMA_MIN") ? atoi(getenv("LLAMAHIP_MFMA_MIN")) : 0;     // measurement override
+    const long mfma_wgs = (long) ((w.nrb32 + 1) / 2) * ((N + 63) / 64);
+    if (w.mt && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
+        // matrix-core path: needs the int8 operand (QB) of these N activation rows
+        hipError_t e = launch_qa_to_qb(qa_A, qb_ws, w.nchunks, N, st);
+        if (e != hipSuccess) return e;
+        return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
+    }
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
     static const bool no_rows = getenv("LLAMAHIP_GEMM_LDS") != nullptr;     // measurement: skip the row-lane kernel
     static const int force_nc = getenv("LLAMAHIP_GEMM_ROWS_NC") ? atoi(getenv("LLAMAHIP_GEMM_ROWS_NC")) : 0;

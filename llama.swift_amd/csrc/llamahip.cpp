@@ -144,6 +144,7 @@ struct llamahip_model {
     float *logits = nullptr;             // [ws_cap][V] (all rows only in debug evals)
     uint32_t *qa_A = nullptr;
     float *qa_d = nullptr;
+    uint8_t *qb_ws = nullptr;            // [ws_cap][KpMax] int8 operand of the matrix-core prompt GEMM
     float *dbg_y = nullptr, *dbg_p = nullptr, *dbg_kqv = nullptr;
     int32_t *d_out_tokens = nullptr;     // greedy decode results
     int out_tokens_cap = 0;
@@ -187,10 +188,11 @@ llamahip_model::~llamahip_model() {
         free_dev(l.attention_norm); free_dev(l.ffn_norm);
         free_dev(l.qkv.tiles); free_dev(l.wo.tiles); free_dev(l.w13.tiles); free_dev(l.w2.tiles);
         free_dev(l.qkv.rows); free_dev(l.wo.rows); free_dev(l.w13.rows); free_dev(l.w2.rows);
+        free_dev(l.qkv.mt); free_dev(l.wo.mt); free_dev(l.w13.mt); free_dev(l.w2.mt);
     }
     free_dev(Kc); free_dev(Vc); free_dev(T_silu); free_dev(T_exp); free_dev(sincos);
     free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
-    free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
+    free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(d_out_tokens);
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
@@ -233,6 +235,11 @@ int make_rows(QMat &q, llamahip_model *m, char *err, size_t err_cap) {
     HIP_TRY(hipMalloc((void **) &q.rows, q.rows_bytes()), LLAMAHIP_ERR_LOAD);
     m->weight_bytes += (int64_t) q.rows_bytes();
     HIP_TRY(launch_tiles_to_rows(q, m->stream), LLAMAHIP_ERR_LOAD);
+    // ... and the matrix-core tiles for long prompts (k_gemm_mfma)
+    q.nrb32 = (q.M + 31) / 32;
+    HIP_TRY(hipMalloc((void **) &q.mt, q.mt_bytes()), LLAMAHIP_ERR_LOAD);
+    m->weight_bytes += (int64_t) q.mt_bytes();
+    HIP_TRY(launch_tiles_to_mtiles(q, m->stream), LLAMAHIP_ERR_LOAD);
     return 0;
 }
 
@@ -262,6 +269,7 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     float **bufs[] = { &m->x, &m->x1, &m->qkv, &m->qr, &m->merged, &m->gu, &m->tmp, &m->logits, &m->qa_d, &m->dbg_y, &m->dbg_p, &m->dbg_kqv };
     for (auto b : bufs) { free_dev(*b); *b = nullptr; }
     free_dev(m->qa_A); m->qa_A = nullptr;
+    free_dev(m->qb_ws); m->qb_ws = nullptr;
     free_dev(m->d_tokens); m->d_tokens = nullptr;
     m->ws_cap = 0;
     const size_t n = (size_t) N;
@@ -276,6 +284,7 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     HIP_TRY(hipMalloc((void **) &m->logits, n * V * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->qa_A, n * KpMax), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->qa_d, n * (KpMax / 32) * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc((void **) &m->qb_ws, n * KpMax), LLAMAHIP_ERR_PREDICT);      // int8 operand of the matrix-core GEMM
     HIP_TRY(hipMalloc((void **) &m->dbg_y, n * std::max(d, F) * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->dbg_p, H * n * C * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->dbg_kqv, n * d * 4), LLAMAHIP_ERR_PREDICT);
@@ -376,7 +385,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         if (dmp && !sink->put(0, m->x, (int64_t) N * d)) goto dump_fail;
         HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
         if (dmp && !sink->put(1, m->dbg_y, (int64_t) N * d)) goto dump_fail;
-        HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
+        HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
         if (dmp) {
             for (int which = 0; which < 3; which++) {           // q, k, v are column slices of qkv[N][3d]
                 HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) d * 4, m->qkv + (size_t) which * d, (size_t) 3 * d * 4, (size_t) d * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
@@ -393,16 +402,16 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         }
         HIP_TRY(launch_prep(PREP_PLAIN, m->merged, nullptr, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
         if (dmp) {
-            HIP_TRY(launch_gemm(L.wo, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);      // .mm:649-651
+            HIP_TRY(launch_gemm(L.wo, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);      // .mm:649-651
             if (!sink->put(9, m->tmp, (int64_t) N * d)) goto dump_fail;
             HIP_TRY(launch_add(m->tmp, m->x, m->x1, (long) N * d, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:654
             if (!sink->put(10, m->x1, (int64_t) N * d)) goto dump_fail;
         } else {
-            HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, N, m->x1, d, m->x, d, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, N, m->x1, d, m->x, d, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);
         }
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (dmp && !sink->put(11, m->dbg_y, (int64_t) N * d)) goto dump_fail;
-        HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, N, m->gu, 2L * F, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);     // .mm:668-675
+        HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, N, m->gu, 2L * F, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);     // .mm:668-675
         if (dmp) {
             HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) F * 4, m->gu + F, (size_t) 2 * F * 4, (size_t) F * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
             if (!sink->put(12, m->tmp, (int64_t) N * F)) goto dump_fail;       // w3 output ("tmp" in the reference)
@@ -412,12 +421,12 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
         if (dmp && !sink->put(14, m->dbg_y, (int64_t) N * F)) goto dump_fail;
         if (dmp) {
-            HIP_TRY(launch_gemm(L.w2, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);      // .mm:682-684
+            HIP_TRY(launch_gemm(L.w2, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);      // .mm:682-684
             if (!sink->put(15, m->tmp, (int64_t) N * d)) goto dump_fail;
             HIP_TRY(launch_add(m->tmp, m->x1, m->x, (long) N * d, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:687
             if (!sink->put(16, m->x, (int64_t) N * d)) goto dump_fail;
         } else {
-            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qa_A, m->qa_d, N, m->x, d, m->x1, d, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qa_A, m->qa_d, N, m->x, d, m->x1, d, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);
         }
     }
 

@@ -23,6 +23,10 @@ struct QMat {
     // rows are in LOGICAL order here (no w1|w3 interleave)
     uint8_t *rows = nullptr;
     int nrb = 0;                // ceil(M / 64)
+    // optional third copy for long prompts: MFMA tiles, nrb32 * (2 * nchunks) * 2560 B (see k_gemm_mfma)
+    uint8_t *mt = nullptr;
+    int nrb32 = 0;              // ceil(M / 32)
+    size_t mt_bytes() const { return (size_t) nrb32 * nchunks * 2 * 2560; }
     size_t rows_bytes() const { return (size_t) nrb * (nchunks + 1) * 10240; }
     size_t bytes() const { return (size_t) ngroups * (nchunks + 1) * TILE_BYTES; }
     int Kp() const { return nchunks * 256; }
@@ -34,6 +38,7 @@ hipError_t set_phase_probe(unsigned long long *dev_buf);
 hipError_t launch_add(const float *a, const float *b, float *c, long n, hipStream_t st);
 hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int gmap, int goff, hipStream_t st);
 hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st);   // w.rows / w.nrb set by the caller
+hipError_t launch_tiles_to_mtiles(const QMat &w, hipStream_t st); // w.mt / w.nrb32 set by the caller
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st);
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
@@ -41,8 +46,10 @@ hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_str
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st);
+// qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
-                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st);
+                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st,
+                       uint8_t *qb_ws = nullptr);
 hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, const double *tab,
                           float *qr, float *Kc, float *Vc, int n_past, int N, hipStream_t st);
 // workspace of the many-row prompt attention (k_attnq_*): scores [H][T_cap][NB] fp32 + per-query max / 1/sum

@@ -167,6 +167,19 @@ def test_prompt_continuation_and_ragged_batches(L, oracle, tmp_path, nth):
         assert gm.decode_greedy(tok, n_past, 12, nth).tolist() == want
 
 
+def test_matrix_core_prompt_gemm_forced_on_small_models():
+    """k_gemm_mfma (masked int8 MFMA per chain, bit-exact) is only selected when its workgroups fill the chip,
+    which the small test models never do: re-run the prompt tests with LLAMAHIP_MFMA_MIN=32 (read once per
+    process, hence the subprocess) so that every eval of >= 32 rows goes through the matrix cores."""
+    import subprocess
+    import sys
+    env = dict(os.environ, LLAMAHIP_MFMA_MIN="32")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "prompt_continuation or long_prompt or multipart or wider_models"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_context_overflow_and_bad_tokens_are_errors(L, tmp_path):
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=64, n_head=2, n_layer=1)
     path = str(tmp_path / "m.bin")
