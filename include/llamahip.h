@@ -59,9 +59,10 @@ typedef struct llamahip_opts {
 #define LLAMAHIP_FLAG_HOST_ONLY  4   /* parse + validate the file and vocab only (no device work): the
                                         handle serves tokenize / token_text / tensor_bytes / sampler;
                                         every compute call on it fails with LLAMAHIP_ERR_PREDICT */
-#define LLAMAHIP_FLAG_NO_PREFILL_COPY 8 /* do not keep the second (row-lane) copy of the layer matrices
-                                        that the multi-token prompt GEMM reads: halves weight memory,
-                                        prompt evaluation falls back to the slower LDS-staged GEMM.
+#define LLAMAHIP_FLAG_NO_PREFILL_COPY 8 /* do not keep the two extra copies of the layer matrices (row-lane
+                                        tiles, MFMA tiles) that the multi-token prompt GEMMs read: a third
+                                        of the weight memory, prompt evaluation falls back to the slower
+                                        LDS-staged GEMM.
                                         Results are bit-identical either way. */
 
 /* ---- the drop-in boundary ------------------------------------------------------------------ */
