@@ -968,7 +968,6 @@ k_gemm_rows(const uint8_t *__restrict__ wr, int nrb, int nchunks, int M,
                     const int p_ = __builtin_amdgcn_sdot8((int) wd_, (int) Ap_[k * 8 + j], 0x4B400000, true);  \
                     acc[n][k] = fmaf(sc_, __builtin_bit_cast(float, p_) - 12582912.0f, acc[n][k]);             \
                 }                                                                                              \
-                if (NC == 1 && (j & 1)) __builtin_amdgcn_sched_barrier(0);   /* ring variant: bound the live temporaries */ \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -1000,20 +999,55 @@ k_gemm_rows(const uint8_t *__restrict__ wr, int nrb, int nchunks, int M,
             LH_ROWS_CONSUME(w, s0, s1, c)
         }
     } else {
-        // single columns (short prompts on small matrices): little arithmetic per chunk, so a ring of RD chunks
-        // with RD - 1 in flight.  Straight-line body (no branch around loads, see k_gemv): chunks past
-        // the row end are the zero tile closing the row-block, whose scale 0 makes fma(0 * da, p, acc) == acc.
-        constexpr int RD = 4;
+        // single columns (short prompts: the reference feeds 9 tokens at a time): the wave is alone on
+        // its SIMD and walks K serially, so nothing may sit on its critical path but the arithmetic:
+        //   * weights: a ring of RD chunks with RD - 1 in flight.  Straight-line body (no branch around loads,
+        //     see k_gemv): chunks past the row end are the zero tile closing the row-block (scale 0);
+        //   * the column's whole operand (K + K/8 bytes) is copied to LDS once and read back with broadcast
+        //     ds_reads one block pair ahead -- scalar loads per chunk cannot be prefetched (a chunk's operand
+        //     is 72 of the ~100 SGPRs) and cost this kernel a scalar-cache round trip per chunk.
+        extern __shared__ __attribute__((aligned(16))) uint32_t lds_op[];   // [nchunks * 64] A dwords | [nchunks * 8] da
+        {
+            const int col = min(n0, ncols - 1);
+            const u32x4 *ga = (const u32x4 *) (qa_A + col * strideA);
+            const f32x4 *gd = (const f32x4 *) (qa_d + col * strideD);
+            for (int i = lane; i < nchunks * 16; i += 64) ((u32x4 *) lds_op)[i] = ga[i];
+            for (int i = lane; i < nchunks * 2; i += 64) ((f32x4 *) (lds_op + nchunks * 64))[i] = gd[i];
+        }
+        constexpr int RD = 3;                                     // 3 x 40 VGPRs; a 4th slot spills
         u32x4 w[RD][8];
         f32x4 s0[RD], s1[RD];
 #pragma unroll
         for (int i = 0; i < RD; i++) LH_ROWS_LOAD(w[i], s0[i], s1[i], min(i, nchunks))
+        __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
+        const float *lds_d = (const float *) (lds_op + nchunks * 64);
         for (int c0 = 0; c0 < nchunks; c0 += RD) {
 #pragma unroll
             for (int i = 0; i < RD; i++) {
-                const int c = c0 + i;
-                LH_ROWS_CONSUME(w[i], s0[i], s1[i], min(c, nchunks - 1))
+                const int c = c0 + i, ca = min(c, nchunks - 1);
+                const float sw[8] = { s0[i].x, s0[i].y, s0[i].z, s0[i].w, s1[i].x, s1[i].y, s1[i].z, s1[i].w };
+                const f32x4 d0 = *(const f32x4 *) (lds_d + ca * 8), d1 = *(const f32x4 *) (lds_d + ca * 8 + 4);
+                const float da[8] = { d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w };
+#pragma unroll
+                for (int h = 0; h < 2; h++) {                     // blocks 4h .. 4h + 3 of every chain: 8 ds_read_b128
+                    u32x4 a[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a[k] = *(const u32x4 *) (lds_op + ca * 64 + k * 8 + 4 * h);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const int j = 4 * h + jj;
+                        const float sc = sw[j] * da[j];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t wd = (j >> 1) == 0 ? w[i][k].x : (j >> 1) == 1 ? w[i][k].y : (j >> 1) == 2 ? w[i][k].z : w[i][k].w;
+                            const uint32_t ad = jj == 0 ? a[k].x : jj == 1 ? a[k].y : jj == 2 ? a[k].z : a[k].w;
+                            const int p = __builtin_amdgcn_sdot8((int) wd, (int) ad, 0x4B400000, true);
+                            acc[0][k] = fmaf(sc, __builtin_bit_cast(float, p) - 12582912.0f, acc[0][k]);
+                        }
+                        if (jj & 1) __builtin_amdgcn_sched_barrier(0);      // bound the live temporaries
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 LH_ROWS_LOAD(w[i], s0[i], s1[i], min(c + RD, nchunks))
                 __builtin_amdgcn_sched_barrier(0);
@@ -2060,10 +2094,11 @@ static hipError_t launch_gemm_rows_t(const QMat &w, int epi, const uint32_t *qa_
                                      float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     const int ncg = (ncols + NC - 1) / NC;
     const int grid = ((w.nrb + 7) / 8) * ncg * 8;
+    const size_t lds = NC == 1 ? (size_t) w.nchunks * 288 : 0;       // the single-column variant keeps its operand in LDS
     if (epi == EPI_RESID)
-        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_RESID, DB, WPE>), dim3(grid), dim3(64), 0, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_RESID, DB, WPE>), dim3(grid), dim3(64), lds, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
     else
-        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_STORE, DB, WPE>), dim3(grid), dim3(64), 0, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_STORE, DB, WPE>), dim3(grid), dim3(64), lds, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
