@@ -1426,6 +1426,8 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
                int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
+    // (one wave per workgroup: grouping four query blocks of a head into a workgroup so that they share
+    // the K rows in the scalar cache measured 7x SLOWER)
     const int lane = threadIdx.x, h = blockIdx.y, ks = blockIdx.z;
     const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
     const bool valid = n < N;
@@ -1441,22 +1443,33 @@ k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float
         for (int i = 0; i < 32; i++) { const f32x4 v = qp[i]; q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w; }
     }
     float mx = -INFINITY;
+    // ggml_vec_dot_f32 (ggml.c:1223-1258): chain l (0..31) = elements l, l+32, l+64, l+96 by FMA from 0;
+    // reduction tree (ggml.c:872-887) = lanes xor 8, 16, 4, 1, 2.  Chains 0..15 first, then 16..31.
+    // The key row reaches the FMAs as SGPR operands, 16 floats (one s_load_dwordx16) per PIECE; a key is
+    // 8 pieces, consumed in the order (half, j): piece pi covers elements 32 * (pi & 3) + 16 * (pi >> 2) + e.
+    // A whole row (128 SGPRs) cannot be resident, so the pieces of consecutive keys form one stream that is
+    // software-pipelined three pieces ahead through four 16-SGPR buffers (the scalar-cache round trip
+    // per piece was this kernel's critical path).
+    float kb[4][16];
+#define LH_LOADP(BUF, TT, PI)                                                                      \
+    {                                                                                              \
+        const float *p_ = Kc + (size_t) min((TT), t1 - 1) * d + h * 128 + 32 * ((PI) & 3) + 16 * ((PI) >> 2);   /* wave-uniform */ \
+        _Pragma("unroll") for (int e = 0; e < 16; e++) kb[BUF][e] = p_[e];                         \
+    }
+    if (t0 < t1) { LH_LOADP(0, t0, 0) LH_LOADP(1, t0, 1) LH_LOADP(2, t0, 2) }
     for (int t = t0; t < t1; t++) {
-        const float *kr = Kc + (size_t) t * d + h * 128;                  // wave-uniform: scalar loads
-        // ggml_vec_dot_f32 (ggml.c:1223-1258): chain l (0..31) = elements l, l+32, l+64, l+96 by FMA from 0;
-        // reduction tree (ggml.c:872-887) = lanes xor 8, 16, 4, 1, 2.  Chains 0..15 first, then 16..31.
         float r1[2][8];
+        float c[16];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            float c[16];
+        for (int pi = 0; pi < 8; pi++) {
+            LH_LOADP((pi + 3) & 3, t + ((pi + 3) >> 3), (pi + 3) & 7)
+            const int base = 32 * (pi & 3) + 16 * (pi >> 2);
 #pragma unroll
-            for (int e = 0; e < 16; e++) c[e] = 0.0f;
+            for (int e = 0; e < 16; e++) c[e] = fmaf(kb[pi & 3][e], q[base + e], (pi & 3) == 0 ? 0.0f : c[e]);
+            if ((pi & 3) == 3) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) c[e] = fmaf(kr[32 * j + 16 * half + e], q[32 * j + 16 * half + e], c[e]);
-#pragma unroll
-            for (int l = 0; l < 8; l++) r1[half][l] = c[l] + c[l + 8];
+                for (int l = 0; l < 8; l++) r1[pi >> 2][l] = c[l] + c[l + 8];
+            }
         }
         float u[8];
 #pragma unroll
@@ -1466,6 +1479,7 @@ k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float
         if (t <= tq) mx = fmaxf(mx, sc);
         S[((size_t) h * T + t) * NB + nl] = sc;
     }
+#undef LH_LOADP
     pmax[((size_t) h * KS + ks) * NB + nl] = mx;
 }
 
