@@ -56,6 +56,8 @@ struct Layer {
     QMat wo;     // d x d
     QMat w13;    // rows [w1; w3]      (2F x d)
     QMat w2;     // d x F
+    // f16 / f32 model files (hp.f16 = 1 / 0): the same matrices, row-major as in the file
+    DMat dqkv, dwo, dw13, dw2;
 };
 
 // fp16 lookup tables, built on the host with the host libm exactly as ggml_init does
@@ -124,9 +126,11 @@ struct llamahip_model {
     hipStream_t stream = nullptr;
 
     // weights
-    uint8_t *tok_emb = nullptr;          // file-layout Q4_0 rows (gathered, never streamed)
+    uint8_t *tok_emb = nullptr;          // file-layout rows (gathered, never streamed)
     float *norm_w = nullptr;
     QMat output;
+    bool dense = false;                  // f16 / f32 model file: DMat weights, un-fused schedule (dense.hip)
+    DMat doutput;
     std::vector<Layer> layers;           // index il - l0
 
     // KV cache: fp32 [layer][n_ctx][d] each (.mm:290-304)
@@ -183,12 +187,13 @@ static void free_dev(void *p) { if (p) (void) hipFree(p); }
 llamahip_model::~llamahip_model() {
     if (host_only) return;
     (void) hipSetDevice(device);
-    free_dev(tok_emb); free_dev(norm_w); free_dev(output.tiles);
+    free_dev(tok_emb); free_dev(norm_w); free_dev(output.tiles); free_dev(doutput.w);
     for (auto &l : layers) {
         free_dev(l.attention_norm); free_dev(l.ffn_norm);
         free_dev(l.qkv.tiles); free_dev(l.wo.tiles); free_dev(l.w13.tiles); free_dev(l.w2.tiles);
         free_dev(l.qkv.rows); free_dev(l.wo.rows); free_dev(l.w13.rows); free_dev(l.w2.rows);
         free_dev(l.qkv.mt); free_dev(l.wo.mt); free_dev(l.w13.mt); free_dev(l.w2.mt);
+        free_dev(l.dqkv.w); free_dev(l.dwo.w); free_dev(l.dw13.w); free_dev(l.dw2.w);
     }
     free_dev(Kc); free_dev(Vc); free_dev(T_silu); free_dev(T_exp); free_dev(sincos);
     free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
@@ -215,6 +220,23 @@ int upload_q4(llamahip_model *m, const std::string &name, QMat &dst, int row0, u
     uint8_t *out = dst.tiles + (size_t) (row0 / 8) * (dst.nchunks + 1) * TILE_BYTES;
     HIP_TRY(launch_repack(d_stage, out, (int) t.ne1, (int) t.ne0, gmap, goff, m->stream), LLAMAHIP_ERR_LOAD);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_LOAD);      // h_stage / d_stage are reused
+    return 0;
+}
+
+// f16 / f32 model files: one tensor, merged, copied as it is into rows [row0, row0 + ne1) of `dst`
+int upload_dense(llamahip_model *m, const std::string &name, DMat &dst, int row0, std::vector<uint8_t> &h_stage, char *err, size_t err_cap) {
+    const TensorInfo &t = m->file.tensors.at(name);
+    h_stage.resize((size_t) t.nbytes());
+    std::string e;
+    if (!m->file.read_tensor(name, h_stage.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
+    HIP_TRY(hipMemcpy((uint8_t *) dst.w + (size_t) row0 * t.row_bytes(), h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+    return 0;
+}
+
+int alloc_dmat(DMat &q, int M, int K, llamahip_model *m, char *err, size_t err_cap) {
+    q.M = M; q.K = K; q.wtype = m->hp.f16;
+    HIP_TRY(hipMalloc(&q.w, q.bytes()), LLAMAHIP_ERR_LOAD);
+    m->weight_bytes += (int64_t) q.bytes();
     return 0;
 }
 
@@ -322,6 +344,46 @@ struct DumpSink {
     }
 };
 
+// f16 / f32 model files: the same graph with dense mat-muls (dense.hip).  Un-fused:
+// norm -> fp32 activations -> dense mat-mul; RoPE, KV cache and attention are the Q4_0 path's kernels.
+int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool want_all,
+                  char *err, size_t err_cap) {
+    const HParams &hp = m->hp;
+    const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx, V = hp.n_vocab;
+    const int nth = std::max(1, std::min(n_threads, 64));
+    hipStream_t st = m->stream;
+    if (m->first_stage) {
+        HIP_TRY(launch_embed_dense(m->d_tokens, m->tok_emb, hp.f16, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);     // .mm:558-561
+    } else {
+        HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
+    }
+    float *y = m->dbg_y;                                  // fp32 activations of the next mat-mul: [N][max(d, F)]
+    for (int il = m->l0; il < m->l1; il++) {
+        const Layer &L = m->layers[il - m->l0];
+        const size_t kv_at = ((size_t) m->cur_seq * (m->l1 - m->l0) + (il - m->l0)) * C * d;
+        float *Kl = m->Kc + kv_at, *Vl = m->Vc + kv_at;
+        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);          // .mm:570-575
+        HIP_TRY(launch_dense_mm(L.dqkv, EPI_STORE, y, d, N, m->qkv, 3L * d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:580-582
+        HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);                                 // .mm:586-611
+        HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT);     // .mm:614-646
+        HIP_TRY(launch_dense_mm(L.dwo, EPI_RESID, m->merged, d, N, m->x1, d, m->x, d, st), LLAMAHIP_ERR_PREDICT);                                     // .mm:649-654
+        HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);              // .mm:660-665
+        HIP_TRY(launch_dense_mm(L.dw13, EPI_STORE, y, d, N, m->gu, 2L * F, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);                                    // .mm:668-675
+        HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
+        HIP_TRY(launch_dense_mm(L.dw2, EPI_RESID, y, F, N, m->x, d, m->x1, d, st), LLAMAHIP_ERR_PREDICT);                                             // .mm:682-687
+    }
+    if (m->last_stage) {
+        if (want_all) {
+            HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, N, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
+        } else {
+            HIP_TRY(launch_prep(PREP_NORM, m->x + (size_t) (N - 1) * d, m->norm_w, d, 0, d, 1, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, 1, m->logits + (size_t) (N - 1) * V, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
+        }
+    }
+    return 0;
+}
+
 // The forward pass for N tokens at n_past on this handle's layers (.mm:510-735).
 //   hidden_in  : device fp32 [N][d] residual stream from the previous stage (nullptr on the first stage)
 //   want_all   : compute logits for every token (debug) instead of only the last (.mm:724-725)
@@ -341,6 +403,10 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     const int nth = std::max(1, std::min(n_threads, 64));
     hipStream_t st = m->stream;
     const bool debug = dump_layer >= 0 && sink;
+    if (m->dense) {
+        if (debug) { set_err(err, err_cap, "per-layer dumps are available for Q4_0 models only"); return LLAMAHIP_ERR_PREDICT; }
+        return forward_dense(m, n_threads, n_past, N, hidden_in, want_all, err, err_cap);
+    }
     const bool fused = (N == 1) && !debug && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
     if (fused && !state_on_device) {
         // host-driven single-token eval: publish the position to the device-resident state
@@ -560,7 +626,7 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
     size_t max_bytes = 0;
     for (const auto &kv : m->file.tensors) if (kv.second.q4) max_bytes = std::max(max_bytes, (size_t) kv.second.nbytes());
     uint8_t *d_stage = nullptr;
-    HIP_TRY(hipMalloc((void **) &d_stage, max_bytes), LLAMAHIP_ERR_LOAD);
+    HIP_TRY(hipMalloc((void **) &d_stage, std::max<size_t>(max_bytes, 256)), LLAMAHIP_ERR_LOAD);
     std::vector<uint8_t> h_stage;
     int rc = 0;
 #define LOAD_TRY(x) do { rc = (x); if (rc != 0) { (void) hipFree(d_stage); return rc; } } while (0)
@@ -573,12 +639,38 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
         HIP_TRY(hipMemcpy(m->tok_emb, h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
         m->weight_bytes += (int64_t) h_stage.size();
     }
+    m->dense = (hp.f16 != 2);
+    if (m->dense && (d % 32 != 0 || F % 32 != 0)) { (void) hipFree(d_stage); set_err(err, err_cap, "f16 / f32 model: n_embd and n_ff must be multiples of 32"); return LLAMAHIP_ERR_LOAD; }
+    m->layers.resize(m->l1 - m->l0);
+    if (m->dense) {
+        if (m->last_stage) {
+            LOAD_TRY(upload_f32(m.get(), "norm.weight", &m->norm_w, err, err_cap));
+            LOAD_TRY(alloc_dmat(m->doutput, V, d, m.get(), err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), "output.weight", m->doutput, 0, h_stage, err, err_cap));
+        }
+        for (int il = m->l0; il < m->l1; il++) {
+            Layer &L = m->layers[il - m->l0];
+            const std::string p = "layers." + std::to_string(il) + ".";
+            LOAD_TRY(upload_f32(m.get(), p + "attention_norm.weight", &L.attention_norm, err, err_cap));
+            LOAD_TRY(upload_f32(m.get(), p + "ffn_norm.weight", &L.ffn_norm, err, err_cap));
+            LOAD_TRY(alloc_dmat(L.dqkv, 3 * d, d, m.get(), err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), p + "attention.wq.weight", L.dqkv, 0, h_stage, err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), p + "attention.wk.weight", L.dqkv, d, h_stage, err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), p + "attention.wv.weight", L.dqkv, 2 * d, h_stage, err, err_cap));
+            LOAD_TRY(alloc_dmat(L.dwo, d, d, m.get(), err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), p + "attention.wo.weight", L.dwo, 0, h_stage, err, err_cap));
+            LOAD_TRY(alloc_dmat(L.dw13, 2 * F, d, m.get(), err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), p + "feed_forward.w1.weight", L.dw13, 0, h_stage, err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), p + "feed_forward.w3.weight", L.dw13, F, h_stage, err, err_cap));
+            LOAD_TRY(alloc_dmat(L.dw2, d, F, m.get(), err, err_cap));
+            LOAD_TRY(upload_dense(m.get(), p + "feed_forward.w2.weight", L.dw2, 0, h_stage, err, err_cap));
+        }
+    } else {
     if (m->last_stage) {
         LOAD_TRY(upload_f32(m.get(), "norm.weight", &m->norm_w, err, err_cap));
         LOAD_TRY(alloc_qmat(m->output, V, d, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), "output.weight", m->output, 0, d_stage, h_stage, err, err_cap));
     }
-    m->layers.resize(m->l1 - m->l0);
     m->w13_interleaved = (F % 32 == 0);
     for (int il = m->l0; il < m->l1; il++) {
         Layer &L = m->layers[il - m->l0];
@@ -607,6 +699,7 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
         LOAD_TRY(alloc_qmat(L.w2, d, F, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w2.weight", L.w2, 0, d_stage, h_stage, err, err_cap));
         LOAD_TRY(make_rows(L.w2, m.get(), err, err_cap));
+    }
     }
 #undef LOAD_TRY
     (void) hipFree(d_stage);
@@ -743,7 +836,7 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         HIP_TRY(hipMemcpyAsync(m->d_state, hs, sizeof(hs), hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     }
     const int nth = std::max(1, std::min(n_threads, 64));
-    const bool fusable = !(m->flags & LLAMAHIP_FLAG_UNFUSED);
+    const bool fusable = !(m->flags & LLAMAHIP_FLAG_UNFUSED) && !m->dense;
     if (fusable && !(m->flags & LLAMAHIP_FLAG_NO_GRAPH)) {
         // One decode step (embed -> layers -> lm head -> argmax) captured once per n_threads value.
         // Nothing in it depends on the step: position and token slots live in device memory and
@@ -790,7 +883,7 @@ int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
     if (m->host_only) { set_err(err, err_cap, "model was loaded with LLAMAHIP_FLAG_HOST_ONLY: no device state, cannot evaluate"); return LLAMAHIP_ERR_PREDICT; }
     if (seq < 0 || seq >= m->n_seq) { set_err(err, err_cap, "sequence slot %d out of range [0, %d)", seq, m->n_seq); return LLAMAHIP_ERR_PREDICT; }
     if (n_past < 0 || n_past >= m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (1) > n_ctx (%d)", n_past, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
-    if (m->flags & LLAMAHIP_FLAG_UNFUSED) { set_err(err, err_cap, "llamahip_stage_step needs the fused decode schedule (handle was loaded with LLAMAHIP_FLAG_UNFUSED)"); return LLAMAHIP_ERR_PREDICT; }
+    if ((m->flags & LLAMAHIP_FLAG_UNFUSED) || m->dense) { set_err(err, err_cap, "llamahip_stage_step needs the fused Q4_0 decode schedule (LLAMAHIP_FLAG_UNFUSED handle or f16 / f32 model): use llamahip_eval_stage"); return LLAMAHIP_ERR_PREDICT; }
     if (m->first_stage && !token_in) { set_err(err, err_cap, "stage [%d,%d) is the first stage: token_in is required", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
     if (!m->first_stage && !hidden_in) { set_err(err, err_cap, "stage [%d,%d) needs hidden_in", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
     if (!m->last_stage && !hidden_out) { set_err(err, err_cap, "stage [%d,%d) needs hidden_out", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }

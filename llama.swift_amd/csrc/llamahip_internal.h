@@ -32,6 +32,17 @@ struct QMat {
     int Kp() const { return nchunks * 256; }
 };
 
+// an f16 / f32 weight matrix (file layout: row-major [M][K]) of a dense model file (dense.hip)
+struct DMat {
+    void *w = nullptr;
+    int M = 0, K = 0;
+    int wtype = 0;              // 0 fp32, 1 fp16
+    size_t bytes() const { return (size_t) M * K * (wtype == 1 ? 2 : 4); }
+};
+hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
+                           const float *resid, long resid_stride, hipStream_t st);
+hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st);
+
 hipError_t init_kernel_attrs();
 hipError_t set_phase_probe(unsigned long long *dev_buf);
 

@@ -55,9 +55,9 @@ int split_type_of(const std::string &name) {       // .mm:358-388
     return 0;
 }
 
-void expect(std::map<std::string, TensorInfo> &m, const std::string &name, int n_dims, int64_t ne0, int64_t ne1, bool q4, int n_parts) {
+void expect(std::map<std::string, TensorInfo> &m, const std::string &name, int n_dims, int64_t ne0, int64_t ne1, int wtype, int n_parts) {
     TensorInfo t;
-    t.name = name; t.n_dims = n_dims; t.ne0 = ne0; t.ne1 = ne1; t.q4 = q4;
+    t.name = name; t.n_dims = n_dims; t.ne0 = ne0; t.ne1 = ne1; t.wtype = wtype; t.q4 = wtype == 2;
     t.split = split_type_of(name);
     t.shards.resize(n_parts);
     m[name] = t;
@@ -102,9 +102,9 @@ bool ModelFile::open(const std::string &path, int32_t n_ctx, int32_t force_parts
     }
 
     switch (hp.f16) {                                                   // .mm:168-180
-        case 2: break;
-        case 0: case 1: case 3:
-            err = fmt("invalid model file '%s' (f16 value %d: only Q4_0 files, f16 = 2, run on the HIP path)", path.c_str(), hp.f16);
+        case 0: case 1: case 2: break;                                   // fp32, fp16, Q4_0 weights
+        case 3:
+            err = fmt("invalid model file '%s' (f16 value 3: Q4_1 files do not run on the HIP path)", path.c_str());
             return false;
         default:
             err = fmt("invalid model file '%s' (bad f16 value %d)", path.c_str(), hp.f16);
@@ -113,20 +113,21 @@ bool ModelFile::open(const std::string &path, int32_t n_ctx, int32_t force_parts
 
     const int64_t d = hp.n_embd, F = hp.n_ff, V = hp.n_vocab;
     const int np = hp.n_parts;
-    expect(tensors, "tok_embeddings.weight", 2, d, V, true, np);        // .mm:246-286
-    expect(tensors, "norm.weight", 1, d, 1, false, np);
-    expect(tensors, "output.weight", 2, d, V, true, np);
+    const int wt = hp.f16;                                              // wtype of every 2-D tensor (.mm:168-180)
+    expect(tensors, "tok_embeddings.weight", 2, d, V, wt, np);          // .mm:246-286
+    expect(tensors, "norm.weight", 1, d, 1, 0, np);
+    expect(tensors, "output.weight", 2, d, V, wt, np);
     for (int i = 0; i < hp.n_layer; i++) {
         const std::string p = "layers." + std::to_string(i) + ".";
-        expect(tensors, p + "attention_norm.weight", 1, d, 1, false, np);
-        expect(tensors, p + "attention.wq.weight", 2, d, d, true, np);
-        expect(tensors, p + "attention.wk.weight", 2, d, d, true, np);
-        expect(tensors, p + "attention.wv.weight", 2, d, d, true, np);
-        expect(tensors, p + "attention.wo.weight", 2, d, d, true, np);
-        expect(tensors, p + "ffn_norm.weight", 1, d, 1, false, np);
-        expect(tensors, p + "feed_forward.w1.weight", 2, d, F, true, np);
-        expect(tensors, p + "feed_forward.w2.weight", 2, F, d, true, np);
-        expect(tensors, p + "feed_forward.w3.weight", 2, d, F, true, np);
+        expect(tensors, p + "attention_norm.weight", 1, d, 1, 0, np);
+        expect(tensors, p + "attention.wq.weight", 2, d, d, wt, np);
+        expect(tensors, p + "attention.wk.weight", 2, d, d, wt, np);
+        expect(tensors, p + "attention.wv.weight", 2, d, d, wt, np);
+        expect(tensors, p + "attention.wo.weight", 2, d, d, wt, np);
+        expect(tensors, p + "ffn_norm.weight", 1, d, 1, 0, np);
+        expect(tensors, p + "feed_forward.w1.weight", 2, d, F, wt, np);
+        expect(tensors, p + "feed_forward.w2.weight", 2, F, d, wt, np);
+        expect(tensors, p + "feed_forward.w3.weight", 2, d, F, wt, np);
     }
 
     const int64_t tensors_at = fin.tell();                              // .mm:306 (same offset in every part, :322)
@@ -223,7 +224,7 @@ bool ModelFile::read_tensor(const std::string &name, uint8_t *dst, std::string &
         } else if (t.split == 0) {
             // column shard: each row receives a contiguous slice of row_bytes/np (.mm:467-477)
             const int64_t slice = row_bytes / np;
-            const int64_t at = ((int64_t) part * t.shards[part].ne0 / 32) * 20;
+            const int64_t at = (int64_t) part * slice;                  // shards are equal slices of a row
             std::vector<uint8_t> buf((size_t) slice * t.ne1);
             ok = fp.read(buf.data(), buf.size());
             if (ok) for (int64_t r = 0; r < t.ne1; r++) memcpy(dst + r * row_bytes + at, buf.data() + r * slice, (size_t) slice);

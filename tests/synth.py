@@ -133,26 +133,37 @@ def random_tensors(hp: HParams, seed: int = 20230312, sigma: float = 0.02) -> di
 
 
 def write_model_unquantized(path: str, hp: HParams, tensors: dict[str, np.ndarray], ftype: int = 1,
-                            vocab: list[bytes] | None = None) -> None:
-    """Single-part f16 (ftype 1) or f32 (ftype 0) model file as tools/convert-pth-to-ggml.py:92-169
-    writes it: 1-D tensors always f32, 2-D tensors in `ftype`; header f16 field = ftype.  This is the
-    INPUT of the quantize tool (quantize.cpp)."""
+                            vocab: list[bytes] | None = None, n_parts: int = 1) -> None:
+    """f16 (ftype 1) or f32 (ftype 0) model file(s) as tools/convert-pth-to-ggml.py:92-169 writes them:
+    1-D tensors always f32, 2-D tensors in `ftype`; header f16 field = ftype; one file per part with the
+    same column / row shards as the quantized files.  This is the INPUT of the quantize tool
+    (quantize.cpp) and what an f16 / f32 model run loads."""
     vocab = vocab if vocab is not None else make_vocab(hp.n_vocab)
-    with open(path, "wb") as f:
-        f.write(struct.pack("<I", MAGIC))
-        f.write(struct.pack("<7i", hp.n_vocab, hp.n_embd, hp.n_mult, hp.n_head, hp.n_layer, hp.n_rot, ftype))
-        for w in vocab:
-            f.write(struct.pack("<I", len(w)))
-            f.write(w)
-        for name, _shape in tensor_specs(hp):
-            t = tensors[name]
-            nb = name.encode()
-            if t.ndim == 1:
-                f.write(struct.pack("<3i", 1, len(nb), 0))
-                f.write(struct.pack("<i", t.shape[0]))
-                f.write(nb)
-                f.write(np.ascontiguousarray(t, dtype=np.float32).tobytes())
-            else:
+    for part in range(n_parts):
+        fname = path if part == 0 else f"{path}.{part}"
+        with open(fname, "wb") as f:
+            f.write(struct.pack("<I", MAGIC))
+            f.write(struct.pack("<7i", hp.n_vocab, hp.n_embd, hp.n_mult, hp.n_head, hp.n_layer, hp.n_rot, ftype))
+            for w in vocab:
+                f.write(struct.pack("<I", len(w)))
+                f.write(w)
+            for name, _shape in tensor_specs(hp):
+                t = tensors[name]
+                nb = name.encode()
+                if t.ndim == 1:
+                    f.write(struct.pack("<3i", 1, len(nb), 0))
+                    f.write(struct.pack("<i", t.shape[0]))
+                    f.write(nb)
+                    f.write(np.ascontiguousarray(t, dtype=np.float32).tobytes())
+                    continue
+                if n_parts > 1:
+                    rows, cols = t.shape
+                    if split_type(name) == 0:
+                        w = cols // n_parts
+                        t = t[:, part * w:(part + 1) * w]
+                    else:
+                        h = rows // n_parts
+                        t = t[part * h:(part + 1) * h, :]
                 rows, cols = t.shape
                 f.write(struct.pack("<3i", 2, len(nb), ftype))
                 f.write(struct.pack("<2i", cols, rows))

@@ -254,6 +254,55 @@ def test_quantize_file_matches_the_reference_tool(L, oracle, tmp_path, tag):
         L.quantize_file(str(tmp_path / "junk.bin"), dst2, 2)
 
 
+@pytest.mark.parametrize("tag,ftype", [("f16", 1), ("f32", 0)])
+def test_dense_model_files_golden(L, tmp_path, tag, ftype):
+    """f16 / f32 model files (dense.hip) against vectors the reference itself produced
+    (tests/golden/make_dense_golden.py): all-row prompt logits from an empty and from a non-empty context,
+    13 greedy tokens, the last logits and one layer's KV rows -- bit for bit, for two thread counts."""
+    g = np.load(os.path.join(G, "dense_model.npz"))
+    v, e, mult, h, nl = (int(x) for x in g["hp"])
+    hp = synth.HParams(n_vocab=v, n_embd=e, n_mult=mult, n_head=h, n_layer=nl)
+    path = str(tmp_path / "m.bin")
+    synth.write_model_unquantized(path, hp, synth.random_tensors(hp, seed=int(g["seed"][0])), ftype)
+    prompt = g["prompt"]
+    for nth in (8, 3):
+        with L.Model(path, n_ctx=64) as m:
+            a = m.eval_debug(prompt[:28], 0, nth, all_logits=True)["logits_all"]
+            b = m.eval_debug(prompt[28:], 28, nth, all_logits=True)
+            assert same(a, g[f"{tag}_nth{nth}_logits_a"]) and same(b["logits_all"], g[f"{tag}_nth{nth}_logits_b"])
+            want = g[f"{tag}_nth{nth}_tokens"]
+            assert int(np.argmax(b["logits"])) == want[0]
+            got, last = m.decode_greedy(int(want[0]), len(prompt), 12, nth, want_logits=True)
+            assert got.tolist() == want[1:].tolist() and same(last, g[f"{tag}_nth{nth}_logits_last"])
+            k, vv = m.kv(1, len(prompt) + 12)
+            assert same(k, g[f"{tag}_nth{nth}_k1"]) and same(vv, g[f"{tag}_nth{nth}_v1"])
+
+
+def test_dense_multipart_files_vs_reference(L, ref, tmp_path):
+    """An f16 model in two part files (column / row shards merged at load, .mm:358-388, 467-487) against
+    the reference library on the same files; refusals: per-layer dumps, the fused stage step, Q4_1 files."""
+    hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=128, n_head=2, n_layer=1)
+    path = str(tmp_path / "m.bin")
+    t = synth.random_tensors(hp, seed=77)
+    synth.write_model_unquantized(path, hp, t, 1, n_parts=2)
+    prompt = synth.synth_prompt(35, hp.n_vocab, seed=2)
+    rm = ref.load(path, 48, 2)
+    with L.Model(path, n_ctx=48, n_parts=2) as m:
+        assert same(m.eval_debug(prompt, 0, 8, all_logits=True)["logits_all"], rm.eval(prompt, 0, 8, all_logits=True)["logits_all"])
+        for name in ("layers.0.attention.wo.weight", "layers.0.feed_forward.w1.weight", "tok_embeddings.weight"):
+            assert m.tensor_bytes(name).tobytes() == np.ascontiguousarray(t[name], np.float16).tobytes(), name
+        with pytest.raises(L.LlamaHipError, match="Q4_0 models only"):
+            m.eval_debug(prompt[:4], 0, 8, dump_layer=0)
+        with pytest.raises(L.LlamaHipError, match="llamahip_eval_stage"):
+            m.stage_bind(0, 0, token_in=1)
+    hp3 = synth.HParams(n_vocab=64, n_embd=256, n_mult=128, n_head=2, n_layer=1)
+    synth.write_model_unquantized(str(tmp_path / "q41.bin"), hp3, t, 1)
+    raw = bytearray(open(str(tmp_path / "q41.bin"), "rb").read()); raw[28:32] = (3).to_bytes(4, "little")
+    open(str(tmp_path / "q41.bin"), "wb").write(raw)
+    with pytest.raises(L.LlamaHipError, match="Q4_1"):
+        L.Model(str(tmp_path / "q41.bin"), n_ctx=16)
+
+
 def test_runner_keeps_the_model_between_runs_when_asked(L, tmp_path):
     """the reference reloads the model on every run (.mm:790, :900).  With
     Config.keepModel the bridge reuses the loaded handle; a second run on the stale KV cache must give

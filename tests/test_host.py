@@ -148,3 +148,24 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(L):
     with pytest.raises(L.LlamaHipError) as e:
         L.op_quantize_row_q4_0(np.zeros(32, np.float32))
     assert "no CPU fallback" in e.value.message
+
+
+def test_dense_model_files_parse_on_the_host(L, tmp_path):
+    """f16 / f32 model files (f16 = 1 / 0) are accepted by the reader; a HOST_ONLY handle serves their
+    merged tensors byte for byte (two part files: column and row shards), Q4_1 files are refused."""
+    import synth
+    hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=128, n_head=2, n_layer=1)
+    t = synth.random_tensors(hp, seed=5)
+    for ftype, dt in ((1, np.float16), (0, np.float32)):
+        path = str(tmp_path / f"m{ftype}.bin")
+        synth.write_model_unquantized(path, hp, t, ftype, n_parts=2)
+        with L.Model(path, n_ctx=16, n_parts=2, flags=4) as m:
+            for name in ("tok_embeddings.weight", "output.weight", "layers.0.attention.wq.weight", "layers.0.attention.wo.weight",
+                         "layers.0.feed_forward.w2.weight", "layers.0.feed_forward.w3.weight"):
+                assert m.tensor_bytes(name).tobytes() == np.ascontiguousarray(t[name], dt).tobytes(), (ftype, name)
+            assert m.tensor_bytes("norm.weight").tobytes() == np.ascontiguousarray(t["norm.weight"], np.float32).tobytes()
+    raw = bytearray(open(str(tmp_path / "m1.bin"), "rb").read())
+    raw[28:32] = (3).to_bytes(4, "little")
+    open(str(tmp_path / "q41.bin"), "wb").write(raw)
+    with pytest.raises(L.LlamaHipError, match="Q4_1"):
+        L.Model(str(tmp_path / "q41.bin"), n_ctx=16, flags=4)
