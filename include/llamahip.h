@@ -175,7 +175,7 @@ int64_t llamahip_tensor_bytes(llamahip_model *m, const char *name, void *out, in
  * Replaces llama_model_quantize (Sources/cpp/quantize.cpp:32-286): same
  * container handling (every 2-D tensor named "*weight" is quantized, everything else is copied, the
  * header's f16 field becomes `itype`), the reference's offline quantizer (utils.cpp:431-485) run on the
- * device.  itype 2 = Q4_0; 3 (Q4_1) is refused.  Byte-identical output. */
+ * device.  itype 2 = Q4_0, 3 = Q4_1.  Byte-identical output. */
 int llamahip_quantize_file(const char *fname_inp, const char *fname_out, int32_t itype,
                            char *err, size_t err_cap);
 

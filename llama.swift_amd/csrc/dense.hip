@@ -1,4 +1,4 @@
-// dense.hip -- f16 / f32 model files (ggml-model-f16.bin, f16 = 1; f32 = 0): SURVEY.md section 8f N3.
+// dense.hip -- the other model file types: f16 / f32 (f16 = 1 / 0) and Q4_1 (f16 = 3; N2).
 //
 // Only the weight mat-muls and the embedding gather differ from a Q4_0 model; norm, RoPE, KV cache and
 // attention are the same kernels (kernels.hip).  Reference semantics (x86 AVX2+F16C build):
@@ -14,6 +14,7 @@
 // bandwidth-lean for decode (weights read once), not tuned.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "llamahip_internal.h"
 
@@ -112,8 +113,159 @@ hipError_t go(const DMat &w, int epi, const float *x, long x_stride, int N, floa
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Q4_1 model files.  The reference's Q4_1 path is scalar C end to end (no SIMD branch exists):
+//   row layout    [nb floats min][nb floats d][nb * 16 nibble bytes]   (struct of arrays PER ROW, ggml.c:606-615)
+//   activations   quantize_row_q4_1 (ggml.c:606-648): min / max of 32, d = (max - min) / 15, id = d ? 1/d : 0,
+//                 code = (uint8) round((x - min) * id)
+//   dot product   ggml_vec_dot_q4_1 (ggml.c:1584-1626): ONE float accumulator per output, walked over all
+//                 blocks and byte pairs in order:  sumf += (d0*q0 + m0) * (d1*p0 + m1) + (d0*q1 + m0) * (d1*p1 + m1)
+//                 with every product and sum rounded separately (-std=c11: no contraction).
+// There is no parallelism inside an output, so a lane owns a whole weight row; the activation side
+// (d1*p + m1, the same for every row) is expanded once per mat-mul by k_q41_act and reaches the lanes
+// as SGPR operands.  Weights are regrouped at load into [row-block of 64][block][lane] so that a wave's
+// loads are coalesced.  Correct first, not fast: K/2 dependent additions per output.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t du32x4 __attribute__((ext_vector_type(4)));
+typedef float df32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// raw rows -> MD[rb][block][lane] = {min, d}, NB[rb][block][lane] = 16 nibble bytes
+__global__ void k_q41_repack(const uint8_t *__restrict__ raw, df32x2 *__restrict__ md, du32x4 *__restrict__ nbv, int M, int nb) {
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int nrb = (M + 63) / 64;
+    if (gid >= (long) nrb * nb * 64) return;
+    const int lane = (int) (gid & 63), i = (int) ((gid >> 6) % nb), rb = (int) ((gid >> 6) / nb);
+    const int row = rb * 64 + lane;
+    df32x2 o = { 0.0f, 0.0f };
+    du32x4 q = { 0u, 0u, 0u, 0u };
+    if (row < M) {
+        const uint8_t *base = raw + (size_t) row * nb * 24;
+        uint32_t b0, b1;
+        memcpy(&b0, base + 4 * i, 4);
+        memcpy(&b1, base + 4 * (nb + i), 4);
+        o = df32x2{ __builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1) };
+        uint32_t t[4];
+        memcpy(t, base + 8 * nb + 16 * i, 16);
+        q = du32x4{ t[0], t[1], t[2], t[3] };
+    }
+    md[gid] = o;
+    nbv[gid] = q;
+}
+
+// one activation row: quantize to Q4_1 and expand again (the operand ggml_vec_dot_q4_1 builds from src1)
+__global__ void k_q41_act(const float *__restrict__ x, long x_stride, int K, float *__restrict__ a) {
+    const int n = blockIdx.x;
+    const float *xr = x + (size_t) n * x_stride;
+    for (int i = threadIdx.x; i < K / 32; i += blockDim.x) {
+        float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+        float v[32];
+#pragma unroll
+        for (int l = 0; l < 32; l++) { v[l] = xr[i * 32 + l]; if (v[l] < mn) mn = v[l]; if (v[l] > mx) mx = v[l]; }
+        const float d = (mx - mn) / 15.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+#pragma unroll
+        for (int l = 0; l < 32; l++) {
+            const uint32_t q = (uint32_t) (uint8_t) round((double) ((v[l] - mn) * id)) & 0xF;     // pp = vi0 | vi1 << 4: 4 bits survive
+            a[(size_t) n * K + i * 32 + l] = d * (float) q + mn;
+        }
+    }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(64)
+k_q41_mm(const df32x2 *__restrict__ md, const du32x4 *__restrict__ nbv, int M, int nb, const float *__restrict__ a, int K, int N,
+         float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    const int lane = threadIdx.x, rb = blockIdx.x, n = blockIdx.y;
+    const float *ar = a + (size_t) n * K;                  // wave-uniform: scalar loads
+    const size_t base = (size_t) rb * nb * 64 + lane;
+    float sum = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        const df32x2 w = md[base + (size_t) i * 64];
+        const du32x4 q = nbv[base + (size_t) i * 64];
+        const uint32_t qq[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t b = (qq[j >> 2] >> (8 * (j & 3))) & 0xFF;
+            const float f0 = w.y * (float) (b & 0xF) + w.x;
+            const float f1 = w.y * (float) (b >> 4) + w.x;
+            const float t = f0 * ar[i * 32 + 2 * j], u = f1 * ar[i * 32 + 2 * j + 1];
+            sum = sum + (t + u);
+        }
+    }
+    const int m = rb * 64 + lane;
+    if (m < M) {
+        if (EPI == EPI_RESID) sum = sum + resid[(size_t) n * resid_stride + m];
+        y[(size_t) n * y_stride + m] = sum;
+    }
+}
+
+__global__ void k_embed_q41(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb, float *__restrict__ x, int d) {
+    const int n = blockIdx.x, nb = d / 32;
+    const uint8_t *base = emb + (size_t) tokens[n] * nb * 24;             // dequantize_row_q4_1 (ggml.c:686-717)
+    for (int e = threadIdx.x; e < d; e += blockDim.x) {
+        const int i = e >> 5, l = e & 31;
+        uint32_t b0, b1;
+        memcpy(&b0, base + 4 * i, 4);
+        memcpy(&b1, base + 4 * (nb + i), 4);
+        const float mn = __builtin_bit_cast(float, b0), dd = __builtin_bit_cast(float, b1);
+        const uint32_t byte = base[8 * nb + 16 * i + (l >> 1)];
+        const int vi = (l & 1) ? (int) (byte >> 4) : (int) (byte & 0xF);
+        x[(size_t) n * d + e] = (float) vi * dd + mn;
+    }
+}
+
+// ggml_quantize_q4_1 (utils.cpp:487-544), one thread per block.  NOT quantize_row_q4_1: here `max` starts
+// at std::numeric_limits<float>::min() (the smallest POSITIVE float), as the reference has it.
+__global__ void k_quantize_q41_offline(const void *__restrict__ src, int f16, uint8_t *__restrict__ dst, long nrows, int nb) {
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nrows * nb) return;
+    const long row = gid / nb;
+    const int i = (int) (gid % nb);
+    float v[32];
+    if (f16) { const uint16_t *p = (const uint16_t *) src + gid * 32; for (int l = 0; l < 32; l++) v[l] = h2f(p[l]); }
+    else     { const float *p = (const float *) src + gid * 32; for (int l = 0; l < 32; l++) v[l] = p[l]; }
+    float mn = 3.402823466e+38f, mx = 1.175494351e-38f;
+    for (int l = 0; l < 32; l++) { if (v[l] < mn) mn = v[l]; if (v[l] > mx) mx = v[l]; }
+    const float d = (mx - mn) / 15.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint8_t *base = dst + (size_t) row * nb * 24;
+    const uint32_t bm = __builtin_bit_cast(uint32_t, mn), bd = __builtin_bit_cast(uint32_t, d);
+    for (int k = 0; k < 4; k++) { base[4 * i + k] = (uint8_t) (bm >> (8 * k)); base[4 * (nb + i) + k] = (uint8_t) (bd >> (8 * k)); }
+    for (int l = 0; l < 32; l += 2) {
+        const uint8_t q0 = (uint8_t) round((double) ((v[l] - mn) * id)), q1 = (uint8_t) round((double) ((v[l + 1] - mn) * id));
+        base[8 * nb + 16 * i + l / 2] = (uint8_t) (q0 | (q1 << 4));
+    }
+}
+
+}  // namespace
+
+hipError_t launch_q41_repack(const uint8_t *raw, DMat &w, hipStream_t st) {
+    const int nb = w.K / 32;
+    const long total = (long) ((w.M + 63) / 64) * nb * 64;
+    hipLaunchKernelGGL(k_q41_repack, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, raw, (df32x2 *) w.w, (du32x4 *) w.w2, w.M, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_q41_offline(const void *src, int f16, uint8_t *dst, long nrows, int nb, hipStream_t st) {
+    const long total = nrows * nb;
+    hipLaunchKernelGGL(k_quantize_q41_offline, dim3((unsigned) ((total + 127) / 128)), dim3(128), 0, st, src, f16, dst, nrows, nb);
+    return hipGetLastError();
+}
+
 hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
-                           const float *resid, long resid_stride, hipStream_t st) {
+                           const float *resid, long resid_stride, hipStream_t st, float *scratch) {
+    if (w.wtype == 3) {
+        if (w.K % 32 != 0 || !scratch) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_q41_act, dim3(N), dim3(64), 0, st, x, x_stride, w.K, scratch);
+        const dim3 grid((w.M + 63) / 64, N);
+        if (epi == EPI_RESID)
+            hipLaunchKernelGGL((k_q41_mm<EPI_RESID>), grid, dim3(64), 0, st, (const df32x2 *) w.w, (const du32x4 *) w.w2, w.M, w.K / 32, scratch, w.K, N, y, y_stride, resid, resid_stride);
+        else
+            hipLaunchKernelGGL((k_q41_mm<EPI_STORE>), grid, dim3(64), 0, st, (const df32x2 *) w.w, (const du32x4 *) w.w2, w.M, w.K / 32, scratch, w.K, N, y, y_stride, resid, resid_stride);
+        return hipGetLastError();
+    }
     if (w.K % 32 != 0 || (w.wtype != 0 && w.wtype != 1)) return hipErrorInvalidValue;
     if (w.wtype == 1) return N == 1 ? go<1, 1>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st)
                                     : go<1, 8>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st);
@@ -122,7 +274,8 @@ hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride
 }
 
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st) {
-    if (wtype == 1) hipLaunchKernelGGL(k_embed_dense<1>, dim3(N), dim3(256), 0, st, tokens, emb, x, d);
+    if (wtype == 3) hipLaunchKernelGGL(k_embed_q41, dim3(N), dim3(256), 0, st, tokens, (const uint8_t *) emb, x, d);
+    else if (wtype == 1) hipLaunchKernelGGL(k_embed_dense<1>, dim3(N), dim3(256), 0, st, tokens, emb, x, d);
     else            hipLaunchKernelGGL(k_embed_dense<0>, dim3(N), dim3(256), 0, st, tokens, emb, x, d);
     return hipGetLastError();
 }

@@ -187,13 +187,14 @@ static void free_dev(void *p) { if (p) (void) hipFree(p); }
 llamahip_model::~llamahip_model() {
     if (host_only) return;
     (void) hipSetDevice(device);
-    free_dev(tok_emb); free_dev(norm_w); free_dev(output.tiles); free_dev(doutput.w);
+    free_dev(tok_emb); free_dev(norm_w); free_dev(output.tiles); free_dev(doutput.w); free_dev(doutput.w2);
     for (auto &l : layers) {
         free_dev(l.attention_norm); free_dev(l.ffn_norm);
         free_dev(l.qkv.tiles); free_dev(l.wo.tiles); free_dev(l.w13.tiles); free_dev(l.w2.tiles);
         free_dev(l.qkv.rows); free_dev(l.wo.rows); free_dev(l.w13.rows); free_dev(l.w2.rows);
         free_dev(l.qkv.mt); free_dev(l.wo.mt); free_dev(l.w13.mt); free_dev(l.w2.mt);
         free_dev(l.dqkv.w); free_dev(l.dwo.w); free_dev(l.dw13.w); free_dev(l.dw2.w);
+        free_dev(l.dqkv.w2); free_dev(l.dwo.w2); free_dev(l.dw13.w2); free_dev(l.dw2.w2);
     }
     free_dev(Kc); free_dev(Vc); free_dev(T_silu); free_dev(T_exp); free_dev(sincos);
     free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
@@ -229,6 +230,21 @@ int upload_dense(llamahip_model *m, const std::string &name, DMat &dst, int row0
     h_stage.resize((size_t) t.nbytes());
     std::string e;
     if (!m->file.read_tensor(name, h_stage.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
+    if (dst.wtype == 3) {
+        // Q4_1: regroup the rows into [row-block of 64][block][lane] (dense.hip); row0 is a multiple of 64
+        uint8_t *d_raw = nullptr;
+        HIP_TRY(hipMalloc((void **) &d_raw, h_stage.size()), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemcpy(d_raw, h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+        DMat view = dst;
+        const size_t at = (size_t) (row0 / 64) * (dst.K / 32) * 64;
+        view.w = (uint8_t *) dst.w + at * 8; view.w2 = (uint8_t *) dst.w2 + at * 16; view.M = (int) t.ne1;
+        hipError_t e1 = launch_q41_repack(d_raw, view, m->stream);
+        hipError_t e2 = hipStreamSynchronize(m->stream);
+        (void) hipFree(d_raw);
+        HIP_TRY(e1, LLAMAHIP_ERR_LOAD);
+        HIP_TRY(e2, LLAMAHIP_ERR_LOAD);
+        return 0;
+    }
     HIP_TRY(hipMemcpy((uint8_t *) dst.w + (size_t) row0 * t.row_bytes(), h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
     return 0;
 }
@@ -236,7 +252,8 @@ int upload_dense(llamahip_model *m, const std::string &name, DMat &dst, int row0
 int alloc_dmat(DMat &q, int M, int K, llamahip_model *m, char *err, size_t err_cap) {
     q.M = M; q.K = K; q.wtype = m->hp.f16;
     HIP_TRY(hipMalloc(&q.w, q.bytes()), LLAMAHIP_ERR_LOAD);
-    m->weight_bytes += (int64_t) q.bytes();
+    if (q.bytes2()) HIP_TRY(hipMalloc(&q.w2, q.bytes2()), LLAMAHIP_ERR_LOAD);
+    m->weight_bytes += (int64_t) (q.bytes() + q.bytes2());
     return 0;
 }
 
@@ -363,22 +380,22 @@ int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const flo
         const size_t kv_at = ((size_t) m->cur_seq * (m->l1 - m->l0) + (il - m->l0)) * C * d;
         float *Kl = m->Kc + kv_at, *Vl = m->Vc + kv_at;
         HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);          // .mm:570-575
-        HIP_TRY(launch_dense_mm(L.dqkv, EPI_STORE, y, d, N, m->qkv, 3L * d, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:580-582
+        HIP_TRY(launch_dense_mm(L.dqkv, EPI_STORE, y, d, N, m->qkv, 3L * d, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                   // .mm:580-582
         HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);                                 // .mm:586-611
         HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT);     // .mm:614-646
-        HIP_TRY(launch_dense_mm(L.dwo, EPI_RESID, m->merged, d, N, m->x1, d, m->x, d, st), LLAMAHIP_ERR_PREDICT);                                     // .mm:649-654
+        HIP_TRY(launch_dense_mm(L.dwo, EPI_RESID, m->merged, d, N, m->x1, d, m->x, d, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                     // .mm:649-654
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);              // .mm:660-665
-        HIP_TRY(launch_dense_mm(L.dw13, EPI_STORE, y, d, N, m->gu, 2L * F, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);                                    // .mm:668-675
+        HIP_TRY(launch_dense_mm(L.dw13, EPI_STORE, y, d, N, m->gu, 2L * F, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                    // .mm:668-675
         HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
-        HIP_TRY(launch_dense_mm(L.dw2, EPI_RESID, y, F, N, m->x, d, m->x1, d, st), LLAMAHIP_ERR_PREDICT);                                             // .mm:682-687
+        HIP_TRY(launch_dense_mm(L.dw2, EPI_RESID, y, F, N, m->x, d, m->x1, d, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                             // .mm:682-687
     }
     if (m->last_stage) {
         if (want_all) {
             HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, N, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, N, m->logits, V, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);
         } else {
             HIP_TRY(launch_prep(PREP_NORM, m->x + (size_t) (N - 1) * d, m->norm_w, d, 0, d, 1, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, 1, m->logits + (size_t) (N - 1) * V, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, 1, m->logits + (size_t) (N - 1) * V, V, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);
         }
     }
     return 0;
@@ -640,7 +657,7 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
         m->weight_bytes += (int64_t) h_stage.size();
     }
     m->dense = (hp.f16 != 2);
-    if (m->dense && (d % 32 != 0 || F % 32 != 0)) { (void) hipFree(d_stage); set_err(err, err_cap, "f16 / f32 model: n_embd and n_ff must be multiples of 32"); return LLAMAHIP_ERR_LOAD; }
+    if (m->dense && (d % 64 != 0 || F % 64 != 0)) { (void) hipFree(d_stage); set_err(err, err_cap, "f16 / f32 / Q4_1 model: n_embd and n_ff must be multiples of 64"); return LLAMAHIP_ERR_LOAD; }
     m->layers.resize(m->l1 - m->l0);
     if (m->dense) {
         if (m->last_stage) {

@@ -34,13 +34,18 @@ struct QMat {
 
 // an f16 / f32 weight matrix (file layout: row-major [M][K]) of a dense model file (dense.hip)
 struct DMat {
-    void *w = nullptr;
+    void *w = nullptr;          // fp32 / fp16: the rows; Q4_1: {min, d} pairs [row-block of 64][block][lane]
+    void *w2 = nullptr;         // Q4_1: the 16 nibble bytes in the same order
     int M = 0, K = 0;
-    int wtype = 0;              // 0 fp32, 1 fp16
-    size_t bytes() const { return (size_t) M * K * (wtype == 1 ? 2 : 4); }
+    int wtype = 0;              // 0 fp32, 1 fp16, 3 Q4_1
+    size_t bytes() const { return wtype == 3 ? (size_t) ((M + 63) / 64) * 64 * (K / 32) * 8 : (size_t) M * K * (wtype == 1 ? 2 : 4); }
+    size_t bytes2() const { return wtype == 3 ? (size_t) ((M + 63) / 64) * 64 * (K / 32) * 16 : 0; }
 };
+// scratch: Q4_1 only, N * K floats for the expanded activation operand
 hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
-                           const float *resid, long resid_stride, hipStream_t st);
+                           const float *resid, long resid_stride, hipStream_t st, float *scratch = nullptr);
+hipError_t launch_q41_repack(const uint8_t *raw_rows, DMat &w, hipStream_t st);
+hipError_t launch_quantize_q41_offline(const void *src, int f16, uint8_t *dst, long nrows, int nb, hipStream_t st);
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st);
 
 hipError_t init_kernel_attrs();

@@ -102,10 +102,7 @@ bool ModelFile::open(const std::string &path, int32_t n_ctx, int32_t force_parts
     }
 
     switch (hp.f16) {                                                   // .mm:168-180
-        case 0: case 1: case 2: break;                                   // fp32, fp16, Q4_0 weights
-        case 3:
-            err = fmt("invalid model file '%s' (f16 value 3: Q4_1 files do not run on the HIP path)", path.c_str());
-            return false;
+        case 0: case 1: case 2: case 3: break;                           // fp32, fp16, Q4_0, Q4_1 weights
         default:
             err = fmt("invalid model file '%s' (bad f16 value %d)", path.c_str(), hp.f16);
             return false;
@@ -185,7 +182,7 @@ bool ModelFile::open(const std::string &path, int32_t n_ctx, int32_t force_parts
                           name.c_str(), (size_t) (t.nbytes() / tp), (size_t) got);
                 return false;
             }
-            if (t.q4 && (ne[0] % 64) != 0) {                            // assert(ne[0] % 64 == 0), .mm:437
+            if ((t.q4 || t.wtype == 3) && (ne[0] % 64) != 0) {          // assert(ne[0] % 64 == 0), .mm:437
                 err = fmt("tensor '%s' has wrong shape in model file: ne[0] = %d is not a multiple of 64", name.c_str(), ne[0]);
                 return false;
             }

@@ -27,11 +27,11 @@ struct TensorInfo {
     std::string name;
     int n_dims = 0;
     int64_t ne0 = 0, ne1 = 1;        // full (merged) shape; ne0 = input dimension
-    int wtype = 0;                   // storage: 0 fp32, 1 fp16, 2 Q4_0 blocks (20 B / 32 elements) -- the ftype codes of the file
+    int wtype = 0;                   // storage: 0 fp32, 1 fp16, 2 Q4_0 (20 B / 32 elements), 3 Q4_1 (24 B / 32) -- the file's ftype codes
     bool q4 = false;                 // wtype == 2
     int split = 0;                   // 0: shards along ne0 (columns), 1: along ne1 (rows)  (.mm:358-388)
     std::vector<ShardLoc> shards;    // one per part (1-D tensors: only part 0 is used, .mm:446-459)
-    int64_t row_bytes() const { return wtype == 2 ? (ne0 / 32) * 20 : wtype == 1 ? ne0 * 2 : ne0 * 4; }
+    int64_t row_bytes() const { return wtype == 2 ? (ne0 / 32) * 20 : wtype == 3 ? (ne0 / 32) * 24 : wtype == 1 ? ne0 * 2 : ne0 * 4; }
     int64_t nbytes() const { return ne1 * row_bytes(); }
 };
 

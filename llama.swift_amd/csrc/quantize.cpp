@@ -1,8 +1,8 @@
 // quantize.cpp -- llamahip_quantize_file: the step before the hot path.
 // Replaces llama_model_quantize (Sources/cpp/quantize.cpp:32-286): copies the container (magic,
 // hparams with the f16 field set to the target type, vocabulary), quantizes every 2-D tensor whose name
-// matches ".*weight" from f32 / f16 to Q4_0 blocks with the reference's OFFLINE quantizer
-// (utils.cpp:431-485) and copies everything else verbatim.  The arithmetic runs on the device
+// matches ".*weight" from f32 / f16 to Q4_0 or Q4_1 with the reference's OFFLINE quantizers
+// (utils.cpp:431-485, :487-544) and copies everything else verbatim.  The arithmetic runs on the device
 // (k_quantize_offline); the host only moves bytes.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
@@ -40,9 +40,8 @@ bool ends_with_weight(const std::string &name) {          // std::regex_match(na
 extern "C" int llamahip_quantize_file(const char *fname_inp, const char *fname_out, int32_t itype, char *err, size_t err_cap) {
     using namespace lh;
     if (!fname_inp || !fname_out) { set_err(err, err_cap, "null file name"); return LLAMAHIP_ERR_LOAD; }
-    if (itype != 2) {                                      // quantize.cpp:35-39 also accepts 3 (Q4_1)
-        set_err(err, err_cap, itype == 3 ? "quantization type 3 (Q4_1) is not supported: the HIP path evaluates Q4_0 models only"
-                                         : "invalid quantization type %d", itype);
+    if (itype != 2 && itype != 3) {                        // quantize.cpp:35-39: 2 = Q4_0, 3 = Q4_1
+        set_err(err, err_cap, "invalid quantization type %d", itype);
         return LLAMAHIP_ERR_LOAD;
     }
     int ndev = 0;
@@ -115,12 +114,13 @@ extern "C" int llamahip_quantize_file(const char *fname_inp, const char *fname_o
         ok = ok && (length == 0 || wr(name.data(), (size_t) length));
         if (quantize) {
             const long nblocks = (long) (nelements / 32);
-            const size_t out_bytes = (size_t) nblocks * 20;
+            const size_t out_bytes = (size_t) nblocks * (itype == 2 ? 20 : 24);
             if (in_bytes > cap_in) { if (d_in) (void) hipFree(d_in); d_in = nullptr; if (hipMalloc((void **) &d_in, in_bytes) != hipSuccess) { rc = LLAMAHIP_ERR_LOAD; set_err(err, err_cap, "hipMalloc failed"); break; } cap_in = in_bytes; }
             if (out_bytes > cap_out) { if (d_out) (void) hipFree(d_out); d_out = nullptr; if (hipMalloc((void **) &d_out, out_bytes) != hipSuccess) { rc = LLAMAHIP_ERR_LOAD; set_err(err, err_cap, "hipMalloc failed"); break; } cap_out = out_bytes; }
             h_out.resize(out_bytes);
             if (hipMemcpy(d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-                launch_quantize_offline(d_in, ftype_in == 1, d_out, nblocks, nullptr) != hipSuccess ||
+                (itype == 2 ? launch_quantize_offline(d_in, ftype_in == 1, d_out, nblocks, nullptr)
+                            : launch_quantize_q41_offline(d_in, ftype_in == 1, d_out, (long) ne[1], ne[0] / 32, nullptr)) != hipSuccess ||
                 hipMemcpy(h_out.data(), d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) {
                 set_err(err, err_cap, "HIP error while quantizing tensor '%s': %s", name.c_str(), hipGetErrorString(hipGetLastError()));
                 rc = LLAMAHIP_ERR_LOAD;

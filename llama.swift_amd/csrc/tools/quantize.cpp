@@ -11,7 +11,7 @@ int main(int argc, char **argv) {
     if (argc != 4) {                                        // quantize.cpp:292-297
         fprintf(stderr, "usage: %s model-f32.bin model-quant.bin type\n", argv[0]);
         fprintf(stderr, "  type = 2 - q4_0\n");
-        fprintf(stderr, "  type = 3 - q4_1 (not supported by the HIP path)\n");
+        fprintf(stderr, "  type = 3 - q4_1\n");
         return 1;
     }
     char err[512] = { 0 };

@@ -243,8 +243,8 @@ def test_quantize_file_matches_the_reference_tool(L, oracle, tmp_path, tag):
     dst2 = str(tmp_path / "out2.bin")
     assert subprocess.run([tool, src, dst2, "2"], capture_output=True).returncode == 0
     assert np.array_equal(np.fromfile(dst2, np.uint8), g[f"out_{tag}"])
-    with pytest.raises(L.LlamaHipError, match="Q4_1"):
-        L.quantize_file(src, dst2, 3)
+    with pytest.raises(L.LlamaHipError, match="invalid quantization type"):
+        L.quantize_file(src, dst2, 4)
     with pytest.raises(L.LlamaHipError, match="unsupported ftype"):
         L.quantize_file(dst, dst2, 2)                                  # already quantized
     with pytest.raises(L.LlamaHipError, match="failed to open"):
@@ -278,9 +278,34 @@ def test_dense_model_files_golden(L, tmp_path, tag, ftype):
             assert same(k, g[f"{tag}_nth{nth}_k1"]) and same(vv, g[f"{tag}_nth{nth}_v1"])
 
 
+def test_q4_1_model_file_golden(L, tmp_path):
+    """Q4_1 files (f16 = 3): the quantize tool with type 3 reproduces the file the reference's tool wrote from
+    the same f16 input (the offline quantizer's FLT_MIN quirk included), and that file evaluates bit for bit
+    like the reference's scalar Q4_1 path: all-row logits from an empty / non-empty context, 11 greedy tokens,
+    last logits, KV rows, two thread counts."""
+    g = np.load(os.path.join(G, "q41_model.npz"))
+    src, dst = str(tmp_path / "in.bin"), str(tmp_path / "q41.bin")
+    g["in_f16"].tofile(src)
+    L.quantize_file(src, dst, 3)
+    assert np.array_equal(np.fromfile(dst, np.uint8), g["q41_file"])
+    prompt = g["prompt"]
+    for nth in (8, 3):
+        with L.Model(dst, n_ctx=64) as m:
+            a = m.eval_debug(prompt[:20], 0, nth, all_logits=True)["logits_all"]
+            b = m.eval_debug(prompt[20:], 20, nth, all_logits=True)
+            assert same(a, g[f"nth{nth}_logits_a"]), describe(a, g[f"nth{nth}_logits_a"])
+            assert same(b["logits_all"], g[f"nth{nth}_logits_b"])
+            want = g[f"nth{nth}_tokens"]
+            assert int(np.argmax(b["logits"])) == want[0]
+            got, last = m.decode_greedy(int(want[0]), len(prompt), 10, nth, want_logits=True)
+            assert got.tolist() == want[1:].tolist() and same(last, g[f"nth{nth}_logits_last"])
+            k, vv = m.kv(1, len(prompt) + 10)
+            assert same(k, g[f"nth{nth}_k1"]) and same(vv, g[f"nth{nth}_v1"])
+
+
 def test_dense_multipart_files_vs_reference(L, ref, tmp_path):
     """An f16 model in two part files (column / row shards merged at load, .mm:358-388, 467-487) against
-    the reference library on the same files; refusals: per-layer dumps, the fused stage step, Q4_1 files."""
+    the reference library on the same files; refusals: per-layer dumps, the fused stage step."""
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=128, n_head=2, n_layer=1)
     path = str(tmp_path / "m.bin")
     t = synth.random_tensors(hp, seed=77)
@@ -295,12 +320,6 @@ def test_dense_multipart_files_vs_reference(L, ref, tmp_path):
             m.eval_debug(prompt[:4], 0, 8, dump_layer=0)
         with pytest.raises(L.LlamaHipError, match="llamahip_eval_stage"):
             m.stage_bind(0, 0, token_in=1)
-    hp3 = synth.HParams(n_vocab=64, n_embd=256, n_mult=128, n_head=2, n_layer=1)
-    synth.write_model_unquantized(str(tmp_path / "q41.bin"), hp3, t, 1)
-    raw = bytearray(open(str(tmp_path / "q41.bin"), "rb").read()); raw[28:32] = (3).to_bytes(4, "little")
-    open(str(tmp_path / "q41.bin"), "wb").write(raw)
-    with pytest.raises(L.LlamaHipError, match="Q4_1"):
-        L.Model(str(tmp_path / "q41.bin"), n_ctx=16)
 
 
 def test_runner_keeps_the_model_between_runs_when_asked(L, tmp_path):

@@ -152,7 +152,7 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(L):
 
 def test_dense_model_files_parse_on_the_host(L, tmp_path):
     """f16 / f32 model files (f16 = 1 / 0) are accepted by the reader; a HOST_ONLY handle serves their
-    merged tensors byte for byte (two part files: column and row shards), Q4_1 files are refused."""
+    merged tensors byte for byte (two part files: column and row shards); a header / tensor type mismatch is an error."""
     import synth
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=128, n_head=2, n_layer=1)
     t = synth.random_tensors(hp, seed=5)
@@ -165,7 +165,7 @@ def test_dense_model_files_parse_on_the_host(L, tmp_path):
                 assert m.tensor_bytes(name).tobytes() == np.ascontiguousarray(t[name], dt).tobytes(), (ftype, name)
             assert m.tensor_bytes("norm.weight").tobytes() == np.ascontiguousarray(t["norm.weight"], np.float32).tobytes()
     raw = bytearray(open(str(tmp_path / "m1.bin"), "rb").read())
-    raw[28:32] = (3).to_bytes(4, "little")
+    raw[28:32] = (3).to_bytes(4, "little")                  # header says Q4_1, tensors are f16: sizes cannot match
     open(str(tmp_path / "q41.bin"), "wb").write(raw)
-    with pytest.raises(L.LlamaHipError, match="Q4_1"):
-        L.Model(str(tmp_path / "q41.bin"), n_ctx=16, flags=4)
+    with pytest.raises(L.LlamaHipError, match="wrong size"):
+        L.Model(str(tmp_path / "q41.bin"), n_ctx=16, n_parts=1, flags=4)
