@@ -10,8 +10,8 @@
 //                same 32 chains without any rounding of the inputs.
 //   embedding    ggml_compute_forward_get_rows_f16 / _f32 (ggml.c:6787-6850): widen / copy.
 // One half-wave (32 lanes = the 32 chains) owns RG weight rows x NC activation rows; the fold is the
-// xor butterfly 8, 16, 4, 1, 2 (the reference's tree; float add commutes).  First version: correct and
-// bandwidth-lean for decode (weights read once), not tuned.
+// xor butterfly 8, 16, 4, 1, 2 (the reference's tree; float add commutes).  Weights and activations are kept
+// in a chain-major order (perm_index) so that a lane's loads are 16 / 32 bytes wide.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -31,10 +31,38 @@ template <> struct WElem<1> { typedef uint16_t T; static __device__ __forceinlin
 
 constexpr int RG = 4;      // weight rows per half-wave
 
-// y[n][m] (+ resid[n][m]) = dot(W[m][:], act(x[n][:])).  grid (ceil(M / (8 * RG)), ceil(N / NC)), 256 threads.
+// Chain-major order inside groups of 256 elements (8 steps of the 32 chains): element g*256 + 32*s + l is stored
+// at g*256 + l*st + s (st = steps in the group: 8, fewer in a tail group), so that lane l -- chain l -- finds
+// its next 8 operands in ONE 16-byte (fp16) or 32-byte (fp32) load and a half-wave reads 512 / 1024 contiguous
+// bytes.  The first version read 2 bytes per lane and step and reached 1.3 TB/s.
+__device__ __forceinline__ long perm_index(long e, int K) {
+    const long g = e >> 8;
+    const int within = (int) (e & 255), l = within & 31, sidx = within >> 5;
+    const int gs = (int) min((long) 256, (long) K - g * 256), st = gs >> 5;
+    return g * 256 + (long) l * st + sidx;
+}
+
+// weights: raw rows -> permuted rows (load time)
+template <int WT>
+__global__ void k_dense_perm_rows(const void *__restrict__ src, void *__restrict__ dst, long M, int K) {
+    typedef typename WElem<WT>::T T;
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= M * K) return;
+    const long m = gid / K, e = gid % K;
+    ((T *) dst)[m * K + perm_index(e, K)] = ((const T *) src)[gid];
+}
+
+// activations: round through fp16 where the weights are fp16 (ggml.c:5681-5985 INIT phase) and permute
+template <int WT>
+__global__ void k_dense_perm_act(const float *__restrict__ x, long x_stride, int K, float *__restrict__ xp) {
+    const int n = blockIdx.x;
+    for (int e = threadIdx.x; e < K; e += blockDim.x) xp[(size_t) n * K + perm_index(e, K)] = WElem<WT>::act(x[(size_t) n * x_stride + e]);
+}
+
+// y[n][m] (+ resid[n][m]) = dot(W[m][:], xp[n][:]) on permuted operands.  grid (ceil(M / (8 * RG)), ceil(N / NC)), 256 threads.
 template <int WT, int NC, int EPI>
 __global__ void __launch_bounds__(256)
-k_dense_mm(const void *__restrict__ wv, int M, int K, const float *__restrict__ x, long x_stride, int N,
+k_dense_mm(const void *__restrict__ wv, int M, int K, const float *__restrict__ xp, int N,
            float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
     typedef typename WElem<WT>::T T;
     const T *w = (const T *) wv;
@@ -42,37 +70,55 @@ k_dense_mm(const void *__restrict__ wv, int M, int K, const float *__restrict__ 
     const int m0 = (blockIdx.x * 8 + hw) * RG, n0 = blockIdx.y * NC;
     const T *wr[RG];
 #pragma unroll
-    for (int r = 0; r < RG; r++) wr[r] = w + (size_t) min(m0 + r, M - 1) * K + l;
+    for (int r = 0; r < RG; r++) wr[r] = w + (size_t) min(m0 + r, M - 1) * K;
     const float *xr[NC];
 #pragma unroll
-    for (int n = 0; n < NC; n++) xr[n] = x + (size_t) min(n0 + n, N - 1) * x_stride + l;
+    for (int n = 0; n < NC; n++) xr[n] = xp + (size_t) min(n0 + n, N - 1) * K;
     float acc[RG][NC];
 #pragma unroll
     for (int r = 0; r < RG; r++)
 #pragma unroll
         for (int n = 0; n < NC; n++) acc[r][n] = 0.0f;
-    constexpr int U = NC == 1 ? 8 : 2;                    // steps of 32 elements in flight
-    for (int j0 = 0; j0 < K; j0 += 32 * U) {
-        T wq[U][RG];
-        float xq[U][NC];
+    const int ng = K >> 8;
+    // full groups: 8 steps per lane and group.  A decode launch is a few hundred waves each streaming its rows
+    // once, so the bytes in flight per lane decide the rate: UG groups (UG x RG vector loads) are issued before
+    // the first is consumed.  Groups past the end are clamped re-reads that are not accumulated.
+    constexpr int UG = NC == 1 ? 4 : 1;
+    for (int g0 = 0; g0 < ng; g0 += UG) {
+        T wq[UG][RG][8];
+        float xq[UG][NC][8];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int j = min(j0 + 32 * u, K - 32);        // K % 32 == 0; past the end: clamped re-read, not accumulated
+        for (int v = 0; v < UG; v++) {
+            const size_t at = (size_t) min(g0 + v, ng - 1) * 256 + l * 8;
 #pragma unroll
-            for (int r = 0; r < RG; r++) wq[u][r] = wr[r][j];
+            for (int r = 0; r < RG; r++)
 #pragma unroll
-            for (int n = 0; n < NC; n++) xq[u][n] = xr[n][j];
+                for (int u = 0; u < 8; u++) wq[v][r][u] = wr[r][at + u];
+#pragma unroll
+            for (int n = 0; n < NC; n++)
+#pragma unroll
+                for (int u = 0; u < 8; u++) xq[v][n][u] = xr[n][at + u];
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (j0 + 32 * u < K) {
+        for (int v = 0; v < UG; v++) {
+            if (g0 + v < ng) {
 #pragma unroll
-                for (int n = 0; n < NC; n++) {
-                    const float xa = WElem<WT>::act(xq[u][n]);
+                for (int u = 0; u < 8; u++)
 #pragma unroll
-                    for (int r = 0; r < RG; r++) acc[r][n] = fmaf(WElem<WT>::widen(wq[u][r]), xa, acc[r][n]);
-                }
+                    for (int n = 0; n < NC; n++)
+#pragma unroll
+                        for (int r = 0; r < RG; r++) acc[r][n] = fmaf(WElem<WT>::widen(wq[v][r][u]), xq[v][n][u], acc[r][n]);
             }
+        }
+    }
+    const int st = (K & 255) >> 5;                         // tail group: st < 8 steps
+    for (int u = 0; u < st; u++) {
+        const size_t at = (size_t) ng * 256 + l * st + u;
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float xa = xr[n][at];
+#pragma unroll
+            for (int r = 0; r < RG; r++) acc[r][n] = fmaf(WElem<WT>::widen(wr[r][at]), xa, acc[r][n]);
         }
     }
 #pragma unroll
@@ -102,12 +148,13 @@ __global__ void k_embed_dense(const int32_t *__restrict__ tokens, const void *__
 
 template <int WT, int NC>
 hipError_t go(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
-              const float *resid, long resid_stride, hipStream_t st) {
+              const float *resid, long resid_stride, hipStream_t st, float *scratch) {
+    hipLaunchKernelGGL(k_dense_perm_act<WT>, dim3(N), dim3(256), 0, st, x, x_stride, w.K, scratch);
     const dim3 grid((w.M + 8 * RG - 1) / (8 * RG), (N + NC - 1) / NC);
     if (epi == EPI_RESID)
-        hipLaunchKernelGGL((k_dense_mm<WT, NC, EPI_RESID>), grid, dim3(256), 0, st, w.w, w.M, w.K, x, x_stride, N, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_dense_mm<WT, NC, EPI_RESID>), grid, dim3(256), 0, st, w.w, w.M, w.K, scratch, N, y, y_stride, resid, resid_stride);
     else
-        hipLaunchKernelGGL((k_dense_mm<WT, NC, EPI_STORE>), grid, dim3(256), 0, st, w.w, w.M, w.K, x, x_stride, N, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_dense_mm<WT, NC, EPI_STORE>), grid, dim3(256), 0, st, w.w, w.M, w.K, scratch, N, y, y_stride, resid, resid_stride);
     return hipGetLastError();
 }
 
@@ -241,6 +288,16 @@ __global__ void k_quantize_q41_offline(const void *__restrict__ src, int f16, ui
 
 }  // namespace
 
+// f16 / f32 rows [row0, row0 + rows) of `w` from raw file-layout rows (load time)
+hipError_t launch_dense_perm_rows(const void *raw, DMat &w, int row0, int rows, hipStream_t st) {
+    const long total = (long) rows * w.K;
+    const size_t esz = w.wtype == 1 ? 2 : 4;
+    void *dst = (uint8_t *) w.w + (size_t) row0 * w.K * esz;
+    if (w.wtype == 1) hipLaunchKernelGGL(k_dense_perm_rows<1>, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, raw, dst, (long) rows, w.K);
+    else              hipLaunchKernelGGL(k_dense_perm_rows<0>, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, raw, dst, (long) rows, w.K);
+    return hipGetLastError();
+}
+
 hipError_t launch_q41_repack(const uint8_t *raw, DMat &w, hipStream_t st) {
     const int nb = w.K / 32;
     const long total = (long) ((w.M + 63) / 64) * nb * 64;
@@ -266,11 +323,11 @@ hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride
             hipLaunchKernelGGL((k_q41_mm<EPI_STORE>), grid, dim3(64), 0, st, (const df32x2 *) w.w, (const du32x4 *) w.w2, w.M, w.K / 32, scratch, w.K, N, y, y_stride, resid, resid_stride);
         return hipGetLastError();
     }
-    if (w.K % 32 != 0 || (w.wtype != 0 && w.wtype != 1)) return hipErrorInvalidValue;
-    if (w.wtype == 1) return N == 1 ? go<1, 1>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st)
-                                    : go<1, 8>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st);
-    return N == 1 ? go<0, 1>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st)
-                  : go<0, 8>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st);
+    if (w.K % 32 != 0 || (w.wtype != 0 && w.wtype != 1) || !scratch) return hipErrorInvalidValue;
+    if (w.wtype == 1) return N == 1 ? go<1, 1>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st, scratch)
+                                    : go<1, 8>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st, scratch);
+    return N == 1 ? go<0, 1>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st, scratch)
+                  : go<0, 8>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st, scratch);
 }
 
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st) {

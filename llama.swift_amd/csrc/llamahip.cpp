@@ -245,7 +245,16 @@ int upload_dense(llamahip_model *m, const std::string &name, DMat &dst, int row0
         HIP_TRY(e2, LLAMAHIP_ERR_LOAD);
         return 0;
     }
-    HIP_TRY(hipMemcpy((uint8_t *) dst.w + (size_t) row0 * t.row_bytes(), h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+    {   // f16 / f32: rows into the chain-major order the dense mat-mul reads (dense.hip perm_index)
+        uint8_t *d_raw = nullptr;
+        HIP_TRY(hipMalloc((void **) &d_raw, h_stage.size()), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemcpy(d_raw, h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+        hipError_t e1 = launch_dense_perm_rows(d_raw, dst, row0, (int) t.ne1, m->stream);
+        hipError_t e2 = hipStreamSynchronize(m->stream);
+        (void) hipFree(d_raw);
+        HIP_TRY(e1, LLAMAHIP_ERR_LOAD);
+        HIP_TRY(e2, LLAMAHIP_ERR_LOAD);
+    }
     return 0;
 }
 

@@ -41,10 +41,11 @@ struct DMat {
     size_t bytes() const { return wtype == 3 ? (size_t) ((M + 63) / 64) * 64 * (K / 32) * 8 : (size_t) M * K * (wtype == 1 ? 2 : 4); }
     size_t bytes2() const { return wtype == 3 ? (size_t) ((M + 63) / 64) * 64 * (K / 32) * 16 : 0; }
 };
-// scratch: Q4_1 only, N * K floats for the expanded activation operand
+// scratch: N * K floats (the permuted / rounded activation operand; Q4_1: the expanded one)
 hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
                            const float *resid, long resid_stride, hipStream_t st, float *scratch = nullptr);
 hipError_t launch_q41_repack(const uint8_t *raw_rows, DMat &w, hipStream_t st);
+hipError_t launch_dense_perm_rows(const void *raw_rows, DMat &w, int row0, int rows, hipStream_t st);
 hipError_t launch_quantize_q41_offline(const void *src, int f16, uint8_t *dst, long nrows, int nb, hipStream_t st);
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st);
 
