@@ -256,9 +256,22 @@ def bench_main(args, cfg, model_path_fn, log):
     # RCCL prints a version banner on STDOUT when it creates a communicator; the bench contract is ONE
     # JSON line on stdout, so everything before that line goes to stderr at the file-descriptor level
     import sys
+    import threading
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    # a multi-rank run that stops making progress (a peer died, a hand-off never matched) must not hang the
+    # caller forever: after `limit` seconds without the JSON line, say so and leave
+    limit = float(os.environ.get("LLAMAHIP_PIPE_WATCHDOG_S", "900"))
+
+    def _abort():
+        os.write(2, f"[bench] rank {rank}/{world}: no result after {limit:.0f} s -- aborting\n".encode())
+        os._exit(3)
+
+    watchdog = threading.Timer(limit, _abort)
+    watchdog.daemon = True
+    watchdog.start()
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
@@ -318,5 +331,6 @@ def bench_main(args, cfg, model_path_fn, log):
             "single_stream_tokens_per_s_estimate": steps / dt,
             "schedule": "host-synchronous" if sync_schedule else "stream-ordered (hipGraph stage steps, device-side greedy pick)",
         }), flush=True)
+    watchdog.cancel()
     os.dup2(2, 1)                                # communicator teardown may print as well
     dist.destroy_process_group()
