@@ -167,6 +167,33 @@ def test_prompt_continuation_and_ragged_batches(L, oracle, tmp_path, nth):
         assert gm.decode_greedy(tok, n_past, 12, nth).tolist() == want
 
 
+@pytest.mark.parametrize("n_embd,n_head", [(128, 4), (128, 2), (256, 1), (512, 2)])       # head sizes 32, 64, 256, 256
+def test_other_head_sizes_vs_oracle(L, oracle, tmp_path, n_embd, n_head):
+    """The loader accepts head sizes 32 / 64 / 128 / 256; only 128 has the lane = query prompt attention, the
+    others take the per-row kernel.  Prompt (all-row logits), decode (graph and eager) and KV rows vs the oracle."""
+    hp = synth.HParams(n_vocab=96, n_embd=n_embd, n_mult=64, n_head=n_head, n_layer=2)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=n_embd + n_head))
+    om = oracle.load(path, 64)
+    prompt = synth.synth_prompt(37, hp.n_vocab, seed=5)
+    b = om.eval(prompt, 0, 8, all_logits=True)
+    tok, want, t = int(np.argmax(b["logits"])), [], None
+    t = tok
+    for i in range(10):
+        lo = om.eval(np.array([t], np.int32), 37 + i, 8)["logits"]
+        t = int(np.argmax(lo)); want.append(t)
+    for flags in (0, 1):
+        with L.Model(path, n_ctx=64, flags=flags) as gm:
+            a = gm.eval_debug(prompt, 0, 8, all_logits=True)
+            assert same(a["logits_all"], b["logits_all"]), describe(a["logits_all"], b["logits_all"])
+            got, last = gm.decode_greedy(tok, 37, 10, 8, want_logits=True)
+            assert got.tolist() == want and same(last, lo)
+            for il in range(hp.n_layer):
+                gk, gv = gm.kv(il, 47)
+                ok, ov = om.kv(il, 47)
+                assert same(gk, ok) and same(gv, ov)
+
+
 def test_matrix_core_prompt_gemm_forced_on_small_models():
     """k_gemm_mfma (masked int8 MFMA per chain, bit-exact) is only selected when its workgroups fill the chip,
     which the small test models never do: re-run the prompt tests with LLAMAHIP_MFMA_MIN=32 (read once per
