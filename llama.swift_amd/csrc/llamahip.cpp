@@ -378,6 +378,12 @@ int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const flo
     const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx, V = hp.n_vocab;
     const int nth = std::max(1, std::min(n_threads, 64));
     hipStream_t st = m->stream;
+    if (N == 1) {
+        // the decode attention kernels read the position from device memory; only st[0] is written here
+        // (st[1], the step counter of the greedy loop, belongs to k_argmax)
+        const int32_t pos = n_past;
+        HIP_TRY(hipMemcpyAsync(m->d_state, &pos, sizeof(pos), hipMemcpyHostToDevice, st), LLAMAHIP_ERR_PREDICT);
+    }
     if (m->first_stage) {
         HIP_TRY(launch_embed_dense(m->d_tokens, m->tok_emb, hp.f16, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);     // .mm:558-561
     } else {
@@ -390,8 +396,13 @@ int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const flo
         float *Kl = m->Kc + kv_at, *Vl = m->Vc + kv_at;
         HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);          // .mm:570-575
         HIP_TRY(launch_dense_mm(L.dqkv, EPI_STORE, y, d, N, m->qkv, 3L * d, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                   // .mm:580-582
-        HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);                                 // .mm:586-611
-        HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT);     // .mm:614-646
+        if (N == 1) {
+            // one row: the decode attention kernels of the Q4_0 path (position from device memory, fp32 output)
+            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, m->merged, m->qa1_A, m->qa1_d, m->T_exp, m->d_state, st), LLAMAHIP_ERR_PREDICT);
+        } else {
+            HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);                             // .mm:586-611
+            HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT); // .mm:614-646
+        }
         HIP_TRY(launch_dense_mm(L.dwo, EPI_RESID, m->merged, d, N, m->x1, d, m->x, d, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                     // .mm:649-654
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);              // .mm:660-665
         HIP_TRY(launch_dense_mm(L.dw13, EPI_STORE, y, d, N, m->gu, 2L * F, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                    // .mm:668-675
