@@ -373,12 +373,12 @@ struct DumpSink {
 // f16 / f32 model files: the same graph with dense mat-muls (dense.hip).  Un-fused:
 // norm -> fp32 activations -> dense mat-mul; RoPE, KV cache and attention are the Q4_0 path's kernels.
 int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool want_all,
-                  char *err, size_t err_cap) {
+                  bool state_on_device, char *err, size_t err_cap) {
     const HParams &hp = m->hp;
     const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx, V = hp.n_vocab;
     const int nth = std::max(1, std::min(n_threads, 64));
     hipStream_t st = m->stream;
-    if (N == 1) {
+    if (N == 1 && !state_on_device) {
         // the decode attention kernels read the position from device memory; only st[0] is written here
         // (st[1], the step counter of the greedy loop, belongs to k_argmax)
         const int32_t pos = n_past;
@@ -442,7 +442,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     const bool debug = dump_layer >= 0 && sink;
     if (m->dense) {
         if (debug) { set_err(err, err_cap, "per-layer dumps are available for Q4_0 models only"); return LLAMAHIP_ERR_PREDICT; }
-        return forward_dense(m, n_threads, n_past, N, hidden_in, want_all, err, err_cap);
+        return forward_dense(m, n_threads, n_past, N, hidden_in, want_all, state_on_device && N == 1, err, err_cap);
     }
     const bool fused = (N == 1) && !debug && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
     if (fused && !state_on_device) {
@@ -873,7 +873,8 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         HIP_TRY(hipMemcpyAsync(m->d_state, hs, sizeof(hs), hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     }
     const int nth = std::max(1, std::min(n_threads, 64));
-    const bool fusable = !(m->flags & LLAMAHIP_FLAG_UNFUSED) && !m->dense;
+    // (f16 / f32 / Q4_1 models: the un-fused single-row schedule is position-free as well, so it is captured too)
+    const bool fusable = !(m->flags & LLAMAHIP_FLAG_UNFUSED) || m->dense;
     if (fusable && !(m->flags & LLAMAHIP_FLAG_NO_GRAPH)) {
         // One decode step (embed -> layers -> lm head -> argmax) captured once per n_threads value.
         // Nothing in it depends on the step: position and token slots live in device memory and
