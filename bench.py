@@ -151,8 +151,19 @@ def run_single(args, cfg, path):
                "reference_9_token_chunks": {"tokens": int(n9), "tokens_per_s": n9 / dt_9},
                "note": "exact path (bit-identical to the reference); host logits copy included"}
     m.close()
+    # a measured ceiling next to the nominal 8 TB/s: device-to-device copy of 1 GiB (read + write)
+    src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record(); torch.cuda.synchronize()
+    copy_gbps = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
     return dict(steps=steps, dt=dt, tokens=out, t_load=t_load, value_pcie=n_pcie / dt_pcie, shapes=shapes,
-                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, same=same, prefill=prefill)
+                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, same=same, prefill=prefill, copy_gbps=copy_gbps)
 
 
 def main():
@@ -214,6 +225,7 @@ def main():
                                f"(M={dom['M']}, K={dom['K']}: {dom['algo_bytes'] * cfg['n_layer'] / r['gemv_bytes_per_token'] * 100:.0f}% of the GEMV bytes of a token)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": dom["algo_bytes"], "us_per_launch": dom["us_per_launch"],
+                     "measured_d2d_copy_GBps": r["copy_gbps"], "frac_of_measured_copy": achieved / r["copy_gbps"],
                      "all_gemv_launches_of_a_token": {"achieved": all_gemv, "frac": all_gemv / HBM_PEAK_GBPS,
                                                       "bytes": r["gemv_bytes_per_token"], "us": r["gemv_us_per_token"]},
                      "per_shape": [{k: s[k] for k in ("name", "M", "K", "us_per_launch", "GBps")} for s in r["shapes"]],
