@@ -452,6 +452,109 @@ __global__ void k_prep_qa(const float *__restrict__ in0, const float *__restrict
                raw_out ? raw_out + (size_t) n * (K / 32) * 20 : nullptr);
 }
 
+// Register-resident variant of k_prep_qa (same arithmetic, the production path whenever no fp32 / raw
+// side output is wanted): one thread owns one HALF-BLOCK (16 contiguous elements), the two halves of a
+// Q4_0 block sit in lanes t and t^1 and exchange through DPP -- no LDS staging of y and no
+// one-thread-per-block serial quantizer.  PLAIN and SILU_MUL have no row-wide reduction, so a row is
+// spread over gridDim.y workgroups (a 9-row chunk of F = 11008 used to run on 9 workgroups);
+// NORM keeps the whole row in one workgroup (blockDim >= K/16, host-checked).
+//   grid (rows, slices); block = multiple of 64
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+k_prep_fast(const float *__restrict__ in0, const float *__restrict__ in1, long in_stride, long in1_stride,
+            int K, int Kp, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d, const uint16_t *__restrict__ T_silu) {
+    __shared__ double red[32];
+    const int n = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int nh = K >> 4, nbp = Kp >> 5;
+    const int hi = blockIdx.y * nt + tid;                    // half-block index; block = hi >> 1, half = hi & 1
+    const bool live = hi < nh;
+    const int hc = min(hi, nh - 1);
+    const f32x4 *a4 = (const f32x4 *) (in0 + (size_t) n * in_stride) + hc * 4;
+    f32x4 xa[4], xb[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) xa[v] = a4[v];
+    if (MODE == PREP_NORM) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) xb[v] = ((const f32x4 *) in1)[hc * 4 + v];
+    } else if (MODE == PREP_SILU_MUL) {
+        const f32x4 *b4 = (const f32x4 *) (in1 + (size_t) n * in1_stride) + hc * 4;
+#pragma unroll
+        for (int v = 0; v < 4; v++) xb[v] = b4[v];
+    }
+    uint32_t *A = qa_A + (size_t) n * (Kp / 4);
+    float *da = qa_d + (size_t) n * nbp;
+    if (MODE == PREP_NORM) {
+        // ggml_norm + ggml_mul (ggml.c:5327-5385, :4555)
+        double s1 = 0.0;
+        if (live) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) { s1 += (double) xa[v].x; s1 += (double) xa[v].y; s1 += (double) xa[v].z; s1 += (double) xa[v].w; }
+        }
+        const double mean = block_sum_d(s1, red, 0) / (double) K;
+        double s2 = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const double v0 = (double) xa[v].x - mean, v1 = (double) xa[v].y - mean;
+            const double v2 = (double) xa[v].z - mean, v3 = (double) xa[v].w - mean;
+            xa[v].x = (float) v0; xa[v].y = (float) v1; xa[v].z = (float) v2; xa[v].w = (float) v3;
+            if (live) { s2 += v0 * v0; s2 += v1 * v1; s2 += v2 * v2; s2 += v3 * v3; }
+        }
+        const double sum2 = block_sum_d(s2, red, 1);
+        const float scale = (float) (1.0 / sqrt(sum2 / (double) K + (double) 1e-5f));
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            xa[v].x = xb[v].x * (xa[v].x * scale); xa[v].y = xb[v].y * (xa[v].y * scale);
+            xa[v].z = xb[v].z * (xa[v].z * scale); xa[v].w = xb[v].w * (xa[v].w * scale);
+        }
+    } else if (MODE == PREP_SILU_MUL) {
+        // silu through the fp16 table (ggml.c:1956-1963), then ggml_mul (.mm:678-680)
+        uint16_t lut[4][4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            lut[v][0] = T_silu[f2h_bits(xa[v].x)]; lut[v][1] = T_silu[f2h_bits(xa[v].y)];
+            lut[v][2] = T_silu[f2h_bits(xa[v].z)]; lut[v][3] = T_silu[f2h_bits(xa[v].w)];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            xa[v].x = h2f_bits(lut[v][0]) * xb[v].x; xa[v].y = h2f_bits(lut[v][1]) * xb[v].y;
+            xa[v].z = h2f_bits(lut[v][2]) * xb[v].z; xa[v].w = h2f_bits(lut[v][3]) * xb[v].w;
+        }
+    }
+    // quantize_row_q4_0, AVX2 branch (ggml.c:456-523), two lanes per block
+    float amax = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(xa[v].x)), fabsf(xa[v].y)), fmaxf(fabsf(xa[v].z), fabsf(xa[v].w)));
+    amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax));          // partner half (lane ^ 1); K/16 is even: both live or both dead
+    const float dd = amax / 7.0f;
+    const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+    uint32_t pr[8];                                          // pair p = elements (2p, 2p+1) of this half -> one 16-bit field
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const uint32_t n0 = (uint32_t) ((int) __builtin_rintf(xa[v].x * id)) & 0xF, n1 = (uint32_t) ((int) __builtin_rintf(xa[v].y * id)) & 0xF;
+        const uint32_t n2 = (uint32_t) ((int) __builtin_rintf(xa[v].z * id)) & 0xF, n3 = (uint32_t) ((int) __builtin_rintf(xa[v].w * id)) & 0xF;
+        pr[2 * v] = n0 | (n1 << 8);
+        pr[2 * v + 1] = n2 | (n3 << 8);
+    }
+    // chain k of the block = pair k of half 0 (low 16 bits) | pair k of half 1 (high 16 bits)
+    const int half = hi & 1, b = hi >> 1, c = b >> 3, j = b & 7;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t other = (uint32_t) __builtin_amdgcn_mov_dpp((int) pr[k], DPP_QUAD_XOR1, 0xF, 0xF, true);
+        const uint32_t dw = (half ? (other | (pr[k] << 16)) : (pr[k] | (other << 16))) << (4 * (j & 1));
+        if (live && (k >> 2) == half) A[(c * 8 + k) * 8 + j] = dw;          // half 0 stores chains 0..3, half 1 chains 4..7
+    }
+    if (live && half == 0) da[b] = dd;
+    // zero the padded blocks (K not a multiple of 256)
+    if (blockIdx.y == 0)
+        for (int pb = K / 32 + tid; pb < nbp; pb += nt) {
+            const int pc = pb >> 3, pj = pb & 7;
+#pragma unroll
+            for (int k = 0; k < 8; k++) A[(pc * 8 + k) * 8 + pj] = 0;
+            da[pb] = 0.0f;
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Q4_0 x Q4_0 mat-vec / mat-mat:  ggml_compute_forward_mul_mat_q4_0_f32 (ggml.c:5987-6285) with
 // ggml_vec_dot_q4_0's AVX2 arithmetic (ggml.c:1415-1466):
@@ -1632,6 +1735,46 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
     }
 }
 
+// Short prompt chunks (2 <= N <= 16 rows, the reference's n_batch = 8 flow): the decode work distribution with
+// one more grid dimension.  Row n (blockIdx.z) is the query at position n_past + n and sees keys
+// 0 .. n_past + n; q is already rotated and K / V already appended by k_rope_kv.  Same 32 FMA chains
+// and reduction tree as k_dec_scores / k_attn.   sc: [row][head][n_ctx]
+__global__ void __launch_bounds__(256)
+k_decn_scores(const float *__restrict__ qr, int d, int dh, const float *__restrict__ Kc, float *__restrict__ sc,
+              int n_ctx, float kq_scale, int n_past) {
+    const int h = blockIdx.x, n = blockIdx.z, H = gridDim.x;
+    const int np = n_past + n;
+    const int t0 = blockIdx.y * DEC_TS;
+    if (t0 > np) return;
+    const int tid = threadIdx.x, hw = tid >> 5, l = tid & 31;
+    constexpr int KPH = DEC_TS / 8;
+    const int tb = t0 + hw * KPH;
+    const float *q = qr + (size_t) n * d + h * dh;
+    float qv[8], kv[KPH][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) qv[i] = (i * 32 < dh) ? q[min(i * 32, dh - 32) + l] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < KPH; u++) {
+        const float *kr = Kc + (size_t) min(tb + u, np) * d + h * dh;
+#pragma unroll
+        for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < KPH; u++) {
+        const int t = tb + u;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i * 32 < dh) s = fmaf(kv[u][i], qv[i], s);
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (l == 0 && t <= np) sc[((size_t) n * H + h) * n_ctx + t] = s * kq_scale;
+    }
+}
+
 // Fused decode attention: one workgroup per (head, 32-column block), 1024 threads.  Every workgroup
 // of a head recomputes the head's RoPE'd q, the new K row and ALL scores (the four workgroups of a
 // head land on the same XCD -- linear id = h + H*cb, H a multiple of 8 -- so the repeated K reads are
@@ -1770,18 +1913,37 @@ k_dec_attn(const float *__restrict__ qkv, int d, int dh, const double *__restric
 // their addition in thread order, and the Q4_0 quantization of exactly one activation block.
 // Splitting a head by columns needs no cross-workgroup hand-off: the ordered combine is per column.
 // block = 32 * min(nth, 32) threads; dynamic LDS: [32 doubles][n_ctx p][nth*32 partials]
+//   MULTI (short prompt chunks): blockIdx.z = row n of the chunk, position n_past0 + n (host value, `st` unused);
+//         sc is [row][head][n_ctx], merged / QA are per row (strides d, qa_strideA dwords, qa_strideD floats) and
+//         the last workgroup of a row zeroes the QA blocks that pad K up to a multiple of 256.
+template <bool MULTI>
 __global__ void __launch_bounds__(1024)
 k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth,
              float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
-             const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st) {
+             const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st,
+             int n_past0, long qa_strideA, long qa_strideD) {
     extern __shared__ double smem_d[];
     double *red = smem_d;
     float *p = (float *) (smem_d + 32);
     float *part = p + n_ctx;
     const int h = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const int n_past = st[0];
+    const int n_past = MULTI ? n_past0 + (int) blockIdx.z : st[0];
     const int T = n_past + 1;
     const float *row = sc + (size_t) h * n_ctx;
+    if (MULTI) {
+        const int n = blockIdx.z;
+        row = sc + ((size_t) n * gridDim.x + h) * n_ctx;
+        if (merged) merged += (size_t) n * d;
+        qa_A += (size_t) n * qa_strideA;
+        qa_d += (size_t) n * qa_strideD;
+        if (h == (int) gridDim.x - 1 && cb == (int) gridDim.y - 1)
+            for (int pb = d / 32 + tid; pb < (int) qa_strideD; pb += nt) {
+                const int pc = pb >> 3, pj = pb & 7;
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) qa_A[(pc * 8 + kk) * 8 + pj] = 0;
+                qa_d[pb] = 0.0f;
+            }
+    }
     float mx = -INFINITY;
     for (int t = tid; t < T; t += nt) { const float v = row[t]; p[t] = v; mx = fmaxf(mx, v); }
     mx = block_max_f(mx, red, 0);
@@ -1794,14 +1956,19 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     sum = block_sum_d(sum, red, 1);
     const float inv = (float) (1.0 / sum);
     for (int t = tid; t < T; t += nt) p[t] *= inv;
+    // a chunk row is as long as the whole chunk's context (ggml.c:5459-5480 splits n_past + N keys over the
+    // threads for every row); the masked tail has weight exp(-inf) = 0 and is walked like the reference does
+    const int Tpv = MULTI ? n_past0 + (int) gridDim.z : T;
+    if (MULTI)
+        for (int t = T + tid; t < Tpv; t += nt) p[t] = 0.0f;
     __syncthreads();
 
     const int c = tid & 31, sub = tid >> 5, nsub = nt >> 5;
-    const int dc = (T + nth - 1) / nth;
+    const int dc = (Tpv + nth - 1) / nth;
     const int col = h * dh + cb * 32 + c;
     const float *vcol = Vc + col;
     for (int th = sub; th < nth; th += nsub) {
-        const int t0 = dc * th, t1 = min(t0 + dc, T);
+        const int t0 = dc * th, t1 = min(t0 + dc, Tpv);
         // The chain is sequential but its loads are not: two register batches of 16 rows, the next one
         // in flight while the current one is consumed (a chain walks T/nth rows 16 KB apart; at a
         // 2 000-token context the single-batch loop spent one memory round trip per 16 rows).
@@ -1815,14 +1982,14 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
             for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(tb + 16 + u, t1 - 1) * d];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
-                const float pe = (tb + u < t1) ? p[min(tb + u, T - 1)] : 0.0f;
+                const float pe = (tb + u < t1) ? p[min(tb + u, Tpv - 1)] : 0.0f;
                 acc = fmaf(va[u], pe, acc);
             }
 #pragma unroll
             for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(tb + 32 + u, t1 - 1) * d];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
-                const float pe = (tb + 16 + u < t1) ? p[min(tb + 16 + u, T - 1)] : 0.0f;
+                const float pe = (tb + 16 + u < t1) ? p[min(tb + 16 + u, Tpv - 1)] : 0.0f;
                 acc = fmaf(vb[u], pe, acc);
             }
         }
@@ -1921,7 +2088,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
-    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk); LH_ATTR(k_dec_attn);
+    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn);
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -1953,6 +2120,23 @@ hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_str
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
                        hipStream_t st) {
     const int Kp = (K + 255) / 256 * 256;
+    static const bool slow_only = getenv("LLAMAHIP_PREP_LDS") != nullptr;      // measurement: the LDS-staged kernel for everything
+    const int nh = K / 16;
+    if (!y_out && !raw_out && !slow_only && (mode != PREP_NORM || nh <= 1024)) {
+        // register-resident kernel: NORM = one workgroup per row, the others sliced 256 half-blocks per workgroup
+        const int nt = mode == PREP_NORM ? (nh + 63) / 64 * 64 : 256;
+        const dim3 grid(N, mode == PREP_NORM ? 1 : (nh + nt - 1) / nt);
+#define LH_PREPF(MODE) hipLaunchKernelGGL(k_prep_fast<MODE>, grid, dim3(nt), 0, st, in0, in1, in_stride, in1_stride, K, Kp, qa_A, qa_d, T_silu)
+        switch (mode) {
+            case PREP_PLAIN:    LH_PREPF(PREP_PLAIN); break;
+            case PREP_NORM:     LH_PREPF(PREP_NORM); break;
+            case PREP_SILU_MUL: LH_PREPF(PREP_SILU_MUL); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef LH_PREPF
+        LH_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     const size_t lds = prep_lds_bytes(K);
 #define LH_PREP(MODE) hipLaunchKernelGGL(k_prep_qa<MODE>, dim3(N), dim3(256), lds, st, in0, in1, in_stride, in1_stride, K, Kp, qa_A, qa_d, y_out, raw_out, T_silu)
     switch (mode) {
@@ -2243,6 +2427,25 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
     return hipSuccess;
 }
 
+// Short prompt chunk (see k_decn_scores): scores -> soft_max + V*P + ordered combine + Q4_0 quantization of the
+// merged rows straight into the QA operand of the wo mat-mul (no separate preparation launch).
+//   sc : scratch of N * H * n_ctx floats
+hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
+                             uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
+                             const uint16_t *T_exp, hipStream_t st) {
+    const int dh = d / H, T = n_past + N;
+    const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
+    const int Kp = (d + 255) / 256 * 256;
+    hipLaunchKernelGGL(k_decn_scores, dim3(H, (T + DEC_TS - 1) / DEC_TS, N), dim3(256), 0, st, qr, d, dh, Kc, sc, n_ctx, kq_scale, n_past);
+    LH_LAUNCH_CHECK();
+    const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;
+    const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
+    hipLaunchKernelGGL(k_dec_pv_blk<true>, dim3(H, dh / 32, N), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp,
+                       (const int32_t *) nullptr, n_past, (long) Kp / 4, (long) Kp / 32);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st) {
@@ -2264,7 +2467,7 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
     LH_LAUNCH_CHECK();
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;      // whole waves: the DPP reductions need every lane live
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_dec_pv_blk, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state);
+    hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -451,6 +451,10 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         HIP_TRY(hipMemcpyAsync(m->d_state, hs, sizeof(hs), hipMemcpyHostToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
 
+    // short prompt chunks (the reference evaluates prompts 8 tokens at a time, .mm / LlamaRunner n_batch) take
+    // the decode-shaped attention; LLAMAHIP_SHORT_MAX = 0 switches it off (measurement)
+    static const int short_max = getenv("LLAMAHIP_SHORT_MAX") ? atoi(getenv("LLAMAHIP_SHORT_MAX")) : 16;
+    const bool short_chunk = N >= 2 && N <= short_max && m->attn_ws.S && N <= m->attn_ws.NB && dh % 32 == 0 && dh <= 256;
     int32_t *state = (io && io->state) ? io->state : m->d_state;
     const float *x_first = (io && fused && m->l1 > m->l0) ? io->x_first : nullptr;
     float *x_last = (io && fused && m->l1 > m->l0) ? io->x_last : nullptr;
@@ -497,6 +501,11 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         }
         HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);        // .mm:586-611
         if (dmp && !sink->put(5, m->qr, (int64_t) N * d)) goto dump_fail;
+        if (short_chunk && !dmp) {
+            // the reference's n_batch = 8 prompt flow: per-row decode-style attention that also quantizes
+            // the merged rows for wo (scores scratch: the many-row path's score matrix)
+            HIP_TRY(launch_attn_short(m->qr, Kl, Vl, m->attn_ws.S, nullptr, m->qa_A, m->qa_d, n_past, N, d, H, C, nth, m->T_exp, st), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
+        } else {
         HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, dmp ? m->dbg_p : nullptr, dmp ? m->dbg_kqv : nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
         if (dmp) {
             if (!sink->put(6, m->dbg_p, (int64_t) H * N * (n_past + N))) goto dump_fail;
@@ -504,6 +513,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             if (!sink->put(8, m->merged, (int64_t) N * d)) goto dump_fail;
         }
         HIP_TRY(launch_prep(PREP_PLAIN, m->merged, nullptr, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
+        }
         if (dmp) {
             HIP_TRY(launch_gemm(L.wo, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);      // .mm:649-651
             if (!sink->put(9, m->tmp, (int64_t) N * d)) goto dump_fail;

@@ -79,6 +79,9 @@ struct AttnWs {
 };
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st);
+hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
+                             uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
+                             const uint16_t *T_exp, hipStream_t st);
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st);
