@@ -984,6 +984,216 @@ k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int 
     }
 }
 
+// Short prompt chunks (2 <= N <= ~32 columns; the reference feeds prompts n_batch = 8 tokens at a time): the
+// decode kernel's work distribution -- lane = (row, chain), weights streamed once per wave through a
+// register ring -- with NC activation columns per wave.  The row-per-lane kernel below needs 64 rows per
+// wave, which leaves a 4096-row matrix with 64 waves per column and makes every column re-read the
+// weights from L2; here a 4096-row matrix is 512 / RG waves per column GROUP and the weights are read once
+// per group.  The QA operands of the workgroup's NC columns are staged whole in LDS before the main loop
+// (no barriers inside it); the weight ring is put in flight before the staging so the two latencies
+// overlap.  Same arithmetic and order as k_gemv.  What bounds this kernel is VALU issue and LDS read
+// bandwidth together (a 16-byte broadcast read still delivers 1 KiB per wave), so:
+//   * a wave owns RG row-groups (lane = row r of each, chain k): every activation read serves RG rows;
+//   * the d_w * d_a products are computed once per quad lane (lane t of a quad holds the weight scales of
+//     blocks t and t + 4 -- the tile's scale layout -- and reads the two matching activation scales with
+//     one 4-byte LDS read each), and the FMA takes them through the DPP quad broadcast of v_fmac_f32_dpp:
+//     8 dots + 4 packed subtractions + 2 products + 8 FMAs = 22 VALU per (lane, chunk, column), not 28.
+//     The DPP form is written as inline assembly (the compiler keeps v_mov_dpp + v_fmac); its one hazard
+//     -- a VALU write of the DPP source needs two wait states before the read -- is padded inside.
+//   grid: XCD-aware, blockIdx -> (row-block of 4 * RG row-groups, column group), column groups of a row-block on one XCD
+//   dynamic LDS: [NC][nchunks * 64] dwords A, then [NC][nchunks * 8] floats d
+#define LH_FMAC8_DPP(ACC, PLO, PHI, Q01, Q23, Q45, Q67)                                            \
+    asm("s_nop 1\n\t"                                                                              \
+        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %1, %5 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %1, %6 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %9 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %10 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"                 \
+        : "+v"(ACC)                                                                                \
+        : "v"(PLO), "v"(PHI), "v"((Q01).x), "v"((Q01).y), "v"((Q23).x), "v"((Q23).y),              \
+          "v"((Q45).x), "v"((Q45).y), "v"((Q67).x), "v"((Q67).y))
+
+// two independent chains interleaved (a dependent v_fmac issues ~1.7x slower than an independent one)
+#define LH_FMAC8_DPP2(ACC0, PLO0, PHI0, A01, A23, A45, A67, ACC1, PLO1, PHI1, B01, B23, B45, B67)  \
+    asm("s_nop 1\n\t"                                                                              \
+        "v_fmac_f32_dpp %0, %2, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %14 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %16 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %17 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %13, %18 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %13, %19 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"            \
+        "v_fmac_f32_dpp %1, %13, %20 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"            \
+        "v_fmac_f32_dpp %1, %13, %21 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"                \
+        : "+v"(ACC0), "+v"(ACC1)                                                                   \
+        : "v"(PLO0), "v"(PHI0), "v"((A01).x), "v"((A01).y), "v"((A23).x), "v"((A23).y),            \
+          "v"((A45).x), "v"((A45).y), "v"((A67).x), "v"((A67).y),                                  \
+          "v"(PLO1), "v"(PHI1), "v"((B01).x), "v"((B01).y), "v"((B23).x), "v"((B23).y),            \
+          "v"((B45).x), "v"((B45).y), "v"((B67).x), "v"((B67).y))
+
+template <int NC, int RG, int EPI>
+__global__ void __launch_bounds__(256)
+k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
+              const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
+              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    extern __shared__ double smem_d[];
+    u32x4 *sA = (u32x4 *) smem_d;                            // [NC][nchunks * 16]
+    f32x4 *sD = (f32x4 *) (sA + (size_t) NC * nchunks * 16); // [NC][nchunks * 2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3, cg = q % ncg, wgi = (q / ncg) * 8 + xcd;
+    const int g0 = (wgi * 4 + wave) * RG;                    // first of this wave's RG consecutive row-groups
+    const int n0 = cg * NC;
+    const int k = lane & 7, t = lane & 3, last = nchunks - 1;
+    const int soff = 1024 + ((lane >> 3) * 8 + t * 2) * 4;
+    const uint8_t *wbase[RG];
+#pragma unroll
+    for (int rg = 0; rg < RG; rg++) wbase[rg] = wt + (size_t) min(g0 + rg, ngroups - 1) * (nchunks + 1) * TILE_BYTES;
+
+    constexpr int D = 4;
+    u32x4 wq[RG][D];
+    f32x2 ws[RG][D];
+#define LH_LOADW(SLOT, CH)                                                                         \
+    _Pragma("unroll")                                                                              \
+    for (int rg = 0; rg < RG; rg++) {                                                              \
+        const uint8_t *tp_ = wbase[rg] + (size_t) min((CH), nchunks) * TILE_BYTES;                 \
+        wq[rg][SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + lane * 16));              \
+        ws[rg][SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + soff));                   \
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) { LH_LOADW(i, i) }
+    __builtin_amdgcn_sched_barrier(0);
+    // stage the NC columns' operands (columns past ncols are clamped duplicates, never stored);
+    // 8 loads per thread in flight per pass: a pass is one L2 round trip
+    {
+        constexpr int LB = 8;
+        const int perA = nchunks * 16, perD = nchunks * 2;     // QA row strides in 16-byte granules
+        const int totA = NC * perA, totD = NC * perD;
+        for (int base = tid; base < totA; base += 256 * LB) {
+            u32x4 v[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int i = min(base + u * 256, totA - 1), n = i / perA, r = i - n * perA;
+                v[u] = ((const u32x4 *) qa_A)[(long) min(n0 + n, ncols - 1) * perA + r];
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) { const int i = base + u * 256; if (i < totA) sA[i] = v[u]; }
+        }
+        for (int base = tid; base < totD; base += 256 * LB) {
+            f32x4 v[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int i = min(base + u * 256, totD - 1), n = i / perD, r = i - n * perD;
+                v[u] = ((const f32x4 *) qa_d)[(long) min(n0 + n, ncols - 1) * perD + r];
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) { const int i = base + u * 256; if (i < totD) sD[i] = v[u]; }
+        }
+    }
+    // The staging loops have run-time trip counts, after which the compiler's waitcnt pass no longer knows
+    // how old the ring loads are and would put a vmcnt(0) at the top of the single-block main loop, i.e. in
+    // EVERY iteration (no prefetch left).  Draining explicitly here makes the loop's entry state exact, and
+    // the waits inside become the counted vmcnt(2 * RG * (D - 1)) of the back edge.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), nothing else
+    __syncthreads();
+
+    const float *sDf = (const float *) sD;
+    float accs[RG][NC];
+#pragma unroll
+    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+        for (int n = 0; n < NC; n++) accs[rg][n] = 0.0f;
+    // LDS operands of step (slot, column) are fetched one step ahead into the other half of a two-entry
+    // register buffer (D * NC steps per loop trip is even, so the parity is a compile-time constant)
+    u32x4 la0[2], la1[2];
+    float ldl[2], ldh[2];
+#define LH_LDSLOAD(BUF, N, CH)                                                                     \
+    {                                                                                              \
+        const int cl_ = min((CH), last);                                                           \
+        const u32x4 *pa_ = sA + ((size_t) (N) * nchunks + cl_) * 16 + k * 2;                       \
+        la0[BUF] = pa_[0]; la1[BUF] = pa_[1];                                                      \
+        const float *pd_ = sDf + ((size_t) (N) * nchunks + cl_) * 8 + t;                           \
+        ldl[BUF] = pd_[0]; ldh[BUF] = pd_[4];                                                      \
+    }
+#define LH_CONSUME(SLOT, CH)                                                                       \
+    {                                                                                              \
+        _Pragma("unroll")                                                                          \
+        for (int n = 0; n < NC; n++) {                                                             \
+            const int pb_ = ((SLOT) * NC + n) & 1;                                                 \
+            const u32x4 a0 = la0[pb_], a1 = la1[pb_];                                              \
+            const float dlo_ = ldl[pb_], dhi_ = ldh[pb_];                                          \
+            if (n + 1 < NC) LH_LDSLOAD(pb_ ^ 1, n + 1, (CH))                                       \
+            else LH_LDSLOAD(pb_ ^ 1, 0, (CH) + 1)                                                  \
+            __builtin_amdgcn_sched_barrier(0);     /* reads for the next step go out before this step's arithmetic */ \
+            float plo_[RG], phi_[RG];                                                              \
+            f32x2 q01_[RG], q23_[RG], q45_[RG], q67_[RG];                                          \
+            _Pragma("unroll")                                                                      \
+            for (int rg = 0; rg < RG; rg++) {                                                      \
+                const u32x4 w = wq[rg][SLOT];                                                      \
+                plo_[rg] = ws[rg][SLOT].x * dlo_; phi_[rg] = ws[rg][SLOT].y * dhi_;                \
+                const int i0_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.x, 0x4B400000, true);   \
+                const int i1_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.y, 0x4B400000, true);   \
+                const int i2_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.z, 0x4B400000, true);   \
+                const int i3_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.w, 0x4B400000, true);   \
+                const int i4_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.x, 0x4B400000, true);   \
+                const int i5_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.y, 0x4B400000, true);   \
+                const int i6_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.z, 0x4B400000, true);   \
+                const int i7_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.w, 0x4B400000, true);   \
+                const f32x2 mg_ = { 12582912.0f, 12582912.0f };                                    \
+                q01_[rg] = f32x2{ __builtin_bit_cast(float, i0_), __builtin_bit_cast(float, i1_) } - mg_; \
+                q23_[rg] = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
+                q45_[rg] = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
+                q67_[rg] = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
+            }                                                                                      \
+            if (RG == 2) {                                                                         \
+                LH_FMAC8_DPP2(accs[0][n], plo_[0], phi_[0], q01_[0], q23_[0], q45_[0], q67_[0],    \
+                              accs[RG - 1][n], plo_[RG - 1], phi_[RG - 1], q01_[RG - 1], q23_[RG - 1], q45_[RG - 1], q67_[RG - 1]); \
+            } else {                                                                               \
+                LH_FMAC8_DPP(accs[0][n], plo_[0], phi_[0], q01_[0], q23_[0], q45_[0], q67_[0]);    \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    }
+    LH_LDSLOAD(0, 0, 0)
+    // straight-line ring body (see k_gemv): chunks past the row end read the zero tile (scale 0)
+    for (int c0 = 0; c0 < nchunks; c0 += D) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            LH_CONSUME(i, c0 + i)
+            LH_LOADW(i, c0 + D + i)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef LH_CONSUME
+#undef LH_LDSLOAD
+#undef LH_LOADW
+
+#pragma unroll
+    for (int rg = 0; rg < RG; rg++) {
+        const int g = g0 + rg;
+        int lg = g;
+        if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+        const int m = lg * 8 + (lane >> 3);
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            float acc = fold8(accs[rg][n]);
+            if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
+                if (EPI == EPI_RESID) acc = acc + resid[(size_t) (n0 + n) * resid_stride + m];
+                y[(size_t) (n0 + n) * y_stride + m] = acc;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Prompt path, row-per-lane: second resident copy of a matrix in ROW-LANE tiles.
 //   tile (row-block R of 64 rows, chunk c) = 10240 B; a row-block is nchunks + 1 tiles, the last all-zero:
@@ -2088,6 +2298,8 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
+#define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
+    LH_ATTR_SK(1); LH_ATTR_SK(2); LH_ATTR_SK(3); LH_ATTR_SK(4);
     LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn);
 #undef LH_ATTR
     return hipSuccess;
@@ -2287,6 +2499,20 @@ static hipError_t launch_gemm_lds_t(const QMat &w, int epi, const uint32_t *qa_A
     return hipSuccess;
 }
 
+template <int NC, int RG>
+static hipError_t launch_gemm_skinny_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg,
+                                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const int nwg = (w.ngroups + 4 * RG - 1) / (4 * RG);
+    const int grid = ((nwg + 7) / 8) * ncg * 8;
+    const size_t lds = (size_t) NC * w.nchunks * 288;
+    if (epi == EPI_RESID)
+        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_RESID>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+    else
+        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_STORE>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 template <int NC, bool DB, int WPE>
 static hipError_t launch_gemm_rows_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols,
                                      float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
@@ -2352,6 +2578,34 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
     }
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
+    // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put
+    // ~1500 waves on the chip (LLAMAHIP_SKINNY_MAX = 0 switches it off, LLAMAHIP_SKINNY_NC forces the width)
+    static const int skinny_max = getenv("LLAMAHIP_SKINNY_MAX") ? atoi(getenv("LLAMAHIP_SKINNY_MAX")) : 32;
+    static const int skinny_nc = getenv("LLAMAHIP_SKINNY_NC") ? atoi(getenv("LLAMAHIP_SKINNY_NC")) : 0;
+    if (N >= 2 && N <= skinny_max) {
+        // widest column group (<= 4) that still leaves ~1500 waves; two row-groups per wave when there
+        // are plenty (halves the LDS operand reads per row)
+        static const int skinny_rg = getenv("LLAMAHIP_SKINNY_RG") ? atoi(getenv("LLAMAHIP_SKINNY_RG")) : 0;
+        int nc = 4;
+        while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
+        if (nc > N) nc = N;
+        if (skinny_nc >= 1 && skinny_nc <= 4) nc = skinny_nc;
+        while (nc > 1 && (size_t) nc * w.nchunks * 288 > 150 * 1024) nc--;
+        const int ncg = (N + nc - 1) / nc;
+        nc = (N + ncg - 1) / ncg;                          // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
+        int rg = 1;                                        // two row-groups per wave measured 3-7 % slower at 9 columns
+        if (skinny_rg == 1 || skinny_rg == 2) rg = skinny_rg;
+#define LH_SK_ARGS w, epi, qa_A, qa_d, N, ncg, y, y_stride, resid, resid_stride, st
+#define LH_SK_CASE(NCV) case NCV: return rg == 2 ? launch_gemm_skinny_t<NCV, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
+        switch (nc) {
+        LH_SK_CASE(4);
+        LH_SK_CASE(3);
+        LH_SK_CASE(2);
+        default: return rg == 2 ? launch_gemm_skinny_t<1, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<1, 1>(LH_SK_ARGS);
+        }
+#undef LH_SK_CASE
+#undef LH_SK_ARGS
+    }
     static const bool no_rows = getenv("LLAMAHIP_GEMM_LDS") != nullptr;     // measurement: skip the row-lane kernel
     static const int force_nc = getenv("LLAMAHIP_GEMM_ROWS_NC") ? atoi(getenv("LLAMAHIP_GEMM_ROWS_NC")) : 0;
     if (w.rows && N >= 2 && !no_rows) {

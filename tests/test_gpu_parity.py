@@ -71,7 +71,8 @@ def test_tiny_model_golden(L, tmp_path, nth, flags):
 
 # ------------------------------------------------------------------------------------------------ oracle, seeded inputs
 @pytest.mark.parametrize("M,K,N", [(8, 64, 1), (40, 256, 1), (64, 704, 2), (256, 4096, 1), (256, 4096, 9), (64, 11008, 1),
-                                   (64, 11008, 5), (24, 5120, 3), (16, 8192, 1), (100, 4096, 17), (8, 13824, 1), (8, 22016, 2)])
+                                   (64, 11008, 5), (24, 5120, 3), (16, 8192, 1), (100, 4096, 17), (8, 13824, 1), (8, 22016, 2),
+                                   (520, 4096, 32), (72, 11008, 13), (40, 22016, 4), (2056, 4096, 8)])
 def test_mul_mat_vs_oracle(L, oracle, M, K, N):
     rng = np.random.default_rng(M + K + N)
     w = synth.quantize_q4_0_offline((0.02 * rng.standard_normal((M, K))).astype(np.float32))
@@ -165,6 +166,32 @@ def test_prompt_continuation_and_ragged_batches(L, oracle, tmp_path, nth):
             lo = om.eval(np.array([t], np.int32), n_past + i, nth)["logits"]
             t = int(np.argmax(lo)); want.append(t)
         assert gm.decode_greedy(tok, n_past, 12, nth).tolist() == want
+
+
+@pytest.mark.parametrize("nth", [1, 4, 8])
+def test_short_chunks_vs_oracle(L, oracle, tmp_path, nth):
+    """The reference feeds a prompt n_batch = 8 tokens at a time, so short evals are THE prompt path of the
+    drop-in: 2..32 rows take the column-grouped decode-shaped GEMM (k_gemm_skinny) and the per-row
+    attention that quantizes its output for wo (k_decn_scores / k_dec_pv_blk<true>); 33 is the first size
+    past both.  n_embd 320 / n_ff 896 leave padded QA blocks (K not a multiple of 256) that these
+    kernels must zero themselves."""
+    hp = synth.HParams(n_vocab=96, n_embd=320, n_mult=64, n_head=5, n_layer=2)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=77))
+    om = oracle.load(path, 192)
+    prompt = synth.synth_prompt(180, hp.n_vocab, seed=5)
+    with L.Model(path, n_ctx=192) as gm:
+        n_past = 0
+        for n in (8, 8, 2, 3, 4, 5, 7, 9, 12, 16, 17, 24, 32, 33):     # 180 tokens
+            chunk = prompt[n_past:n_past + n]
+            a = gm.eval_debug(chunk, n_past, nth, all_logits=True)
+            b = om.eval(chunk, n_past, nth, all_logits=True)
+            assert same(a["logits_all"], b["logits_all"]), (n_past, n, describe(a["logits_all"], b["logits_all"]))
+            n_past += n
+        for il in range(hp.n_layer):
+            gk, gv = gm.kv(il, n_past)
+            ok, ov = om.kv(il, n_past)
+            assert same(gk, ok) and same(gv, ov), f"kv cache layer {il}"
 
 
 @pytest.mark.parametrize("n_embd,n_head", [(128, 4), (128, 2), (256, 1), (512, 2)])       # head sizes 32, 64, 256, 256
