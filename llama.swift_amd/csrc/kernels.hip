@@ -563,6 +563,25 @@ k_prep_fast(const float *__restrict__ in0, const float *__restrict__ in1, long i
 // One wave = one row-group (8 rows x 8 chains).  Weights stream HBM -> VGPR (non-temporal dwordx4,
 // register ring of DEPTH chunks), activations come from LDS (decode) or L1/L2 (multi-column).
 // ------------------------------------------------------------------------------------------------
+// acc = fma(p_j, q_j, acc) for the 8 blocks of a chunk, where lane t of every quad holds p_t (PLO) and
+// p_{t+4} (PHI): v_fmac_f32_dpp reads its first source through the DPP quad broadcast, so the d_w * d_a
+// product is computed twice per lane and chunk instead of eight times.  hipcc keeps v_mov_dpp + v_fmac for
+// the equivalent source, hence inline assembly; the one hazard (a VALU write of the DPP source needs two
+// wait states before the DPP read) is padded inside the statement.
+#define LH_FMAC8_DPP(ACC, PLO, PHI, Q01, Q23, Q45, Q67)                                            \
+    asm("s_nop 1\n\t"                                                                              \
+        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %1, %5 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %1, %6 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %9 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %0, %2, %10 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"                 \
+        : "+v"(ACC)                                                                                \
+        : "v"(PLO), "v"(PHI), "v"((Q01).x), "v"((Q01).y), "v"((Q23).x), "v"((Q23).y),              \
+          "v"((Q45).x), "v"((Q45).y), "v"((Q67).x), "v"((Q67).y))
+
 #define LH_STEP(J, WD, AD, DA)                                                                     \
     {                                                                                              \
         const float sc_ = quad_bcast<((J) & 3)>((J) < 4 ? sw.x : sw.y) * (DA);                     \
@@ -783,21 +802,21 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     // other half of a two-entry register buffer, so their ~100-cycle latency is off the FMA chain
     static_assert(D % 2 == 0, "the two-entry LDS operand buffer alternates by slot parity: ring depth must be even");
     u32x4 la0[2], la1[2];
-    f32x4 ld0[2], ld1[2];
+    float ldl[2], ldh[2];
+    const int tq = lane & 3;                 // this lane's weight scales are those of blocks tq and tq + 4
 #define LH_LDSLOAD(BUF, CH)                                                                        \
     {                                                                                              \
         const int cl_ = min((CH), last);                                                           \
         const u32x4 *pa = (const u32x4 *) (ldsA + (cl_ * 8 + k) * 8);                              \
         la0[BUF] = pa[0]; la1[BUF] = pa[1];                                                        \
-        const f32x4 *pd = (const f32x4 *) (ldsD + cl_ * 8);                                        \
-        ld0[BUF] = pd[0]; ld1[BUF] = pd[1];                                                        \
+        ldl[BUF] = ldsD[cl_ * 8 + tq]; ldh[BUF] = ldsD[cl_ * 8 + 4 + tq];                          \
     }
 #define LH_CONSUME(SLOT, CH)                                                                       \
     {                                                                                              \
         const u32x4 w = wq[SLOT];                                                                  \
         const f32x2 sw = ws[SLOT];                                                                 \
         const u32x4 a0 = la0[(SLOT) & 1], a1 = la1[(SLOT) & 1];                                    \
-        const f32x4 d0 = ld0[(SLOT) & 1], d1 = ld1[(SLOT) & 1];                                    \
+        const float plo_ = sw.x * ldl[(SLOT) & 1], phi_ = sw.y * ldh[(SLOT) & 1];                  \
         LH_LDSLOAD(((SLOT) + 1) & 1, (CH) + 1)                                                     \
         /* 8 blocks: integer dots first, accumulated onto the bit pattern of 1.5 * 2^23 (ulp 1) so each  */ \
         /* result IS the float 12582912 + isum (|isum| <= 512; clamp selects the VOP3P form and never    */ \
@@ -816,14 +835,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         const f32x2 q23_ = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
         const f32x2 q45_ = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
         const f32x2 q67_ = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
-        acc = fmaf(quad_bcast<0>(sw.x) * d0.x, q01_.x, acc);                                       \
-        acc = fmaf(quad_bcast<1>(sw.x) * d0.y, q01_.y, acc);                                       \
-        acc = fmaf(quad_bcast<2>(sw.x) * d0.z, q23_.x, acc);                                       \
-        acc = fmaf(quad_bcast<3>(sw.x) * d0.w, q23_.y, acc);                                       \
-        acc = fmaf(quad_bcast<0>(sw.y) * d1.x, q45_.x, acc);                                       \
-        acc = fmaf(quad_bcast<1>(sw.y) * d1.y, q45_.y, acc);                                       \
-        acc = fmaf(quad_bcast<2>(sw.y) * d1.z, q67_.x, acc);                                       \
-        acc = fmaf(quad_bcast<3>(sw.y) * d1.w, q67_.y, acc);                                       \
+        LH_FMAC8_DPP(acc, plo_, phi_, q01_, q23_, q45_, q67_);                                     \
     }
     LH_STAMP(2);
     LH_LDSLOAD(0, 0)
@@ -1002,20 +1014,6 @@ k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int 
 //     -- a VALU write of the DPP source needs two wait states before the read -- is padded inside.
 //   grid: XCD-aware, blockIdx -> (row-block of 4 * RG row-groups, column group), column groups of a row-block on one XCD
 //   dynamic LDS: [NC][nchunks * 64] dwords A, then [NC][nchunks * 8] floats d
-#define LH_FMAC8_DPP(ACC, PLO, PHI, Q01, Q23, Q45, Q67)                                            \
-    asm("s_nop 1\n\t"                                                                              \
-        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %0, %1, %5 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %0, %1, %6 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %0, %2, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %0, %2, %9 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %0, %2, %10 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"                 \
-        : "+v"(ACC)                                                                                \
-        : "v"(PLO), "v"(PHI), "v"((Q01).x), "v"((Q01).y), "v"((Q23).x), "v"((Q23).y),              \
-          "v"((Q45).x), "v"((Q45).y), "v"((Q67).x), "v"((Q67).y))
-
 // two independent chains interleaved (a dependent v_fmac issues ~1.7x slower than an independent one)
 #define LH_FMAC8_DPP2(ACC0, PLO0, PHI0, A01, A23, A45, A67, ACC1, PLO1, PHI1, B01, B23, B45, B67)  \
     asm("s_nop 1\n\t"                                                                              \
