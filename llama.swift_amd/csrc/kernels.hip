@@ -626,13 +626,22 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
        const uint16_t *__restrict__ T_silu,
        uint32_t *__restrict__ out_A, float *__restrict__ out_d) {
     extern __shared__ double smem_d[];
+    // LDS holds D chunks more than the row has: the ring's tail and its one-chunk-ahead operand fetch run
+    // past the end (against the zero tile), and with zeroed padding those reads need no index clamp -- their
+    // addresses are then `loop base + immediate` instead of three VALU instructions per chunk.
     uint32_t *ldsA = (uint32_t *) smem_d;
-    float *ldsD = (float *) (ldsA + nchunks * 64);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    float *ldsD = (float *) (ldsA + (nchunks + D) * 64);
+    // (the wave index is made provably uniform so that the row-group base lives in SGPRs and every weight
+    //  load is `global_load ... v_off, s[base]` with a constant per-lane offset: no per-chunk address VALU)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int g = blockIdx.x * nw + wave;
     const bool valid = g < ngroups;
     const uint8_t *wbase = wt + (size_t) (valid ? g : 0) * (nchunks + 1) * TILE_BYTES;
-    const int last = nchunks - 1;
+    const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + (lane & 3) * 2) * 4u;
+    // (an empty asm per loop trip keeps the 32 -> 64-bit extension of these lane offsets inside the loop
+    //  block: hoisted out of it they become 64-bit VGPR pairs and the SGPR-base addressing no longer matches)
+    uint32_t vw_ = voff_w, vs_ = voff_s;
+#define LH_OPAQUE_OFFSETS() { vw_ = voff_w; vs_ = voff_s; asm volatile("" : "+v"(vw_), "+v"(vs_)); }
 #if LH_PHASE_PROBE
     unsigned long long *probe_e = nullptr;
     if (g_phase_probe && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
@@ -649,8 +658,8 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     {                                                                                                        \
         const int ch_ = min((CH), nchunks);   /* tile `nchunks` of every row-group is the zero tile */      \
         const uint8_t *tp_ = wbase + (size_t) ch_ * TILE_BYTES;                                              \
-        wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + lane * 16));                            \
-        ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + 1024 + ((lane >> 3) * 8 + (lane & 3) * 2) * 4)); \
+        wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + (size_t) vw_));                         \
+        ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + (size_t) vs_));                         \
     }
     // ---- phase 1: the prologue's own (small, L2-resident) loads go out FIRST.  vmcnt retires in
     // order, so anything issued behind the weight prefetch would have to wait for all of it.
@@ -706,7 +715,11 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
 
     // ---- phase 3: prologue arithmetic while the weights stream in
     LH_STAMP(1);
-    double *red = (double *) (ldsD + nchunks * 8);
+    double *red = (double *) (ldsD + (nchunks + D) * 8);
+    for (int i = tid; i < D * 72; i += nt) {                 // zero the D padding chunks (A: 64 dwords, d: 8 floats each)
+        if (i < D * 64) ldsA[nchunks * 64 + i] = 0u;
+        else ldsD[nchunks * 8 + (i - D * 64)] = 0.0f;
+    }
     if (PRE == PRE_QA) {
 #pragma unroll
         for (int u = 0; u < MAXQA; u++) { const int gi = tid + u * nt; if (gi < nchunks * 16) ((u32x4 *) ldsA)[gi] = qg[u]; }
@@ -806,10 +819,9 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     const int tq = lane & 3;                 // this lane's weight scales are those of blocks tq and tq + 4
 #define LH_LDSLOAD(BUF, CH)                                                                        \
     {                                                                                              \
-        const int cl_ = min((CH), last);                                                           \
-        const u32x4 *pa = (const u32x4 *) (ldsA + (cl_ * 8 + k) * 8);                              \
+        const u32x4 *pa = (const u32x4 *) (ldsA + ((CH) * 8 + k) * 8);                             \
         la0[BUF] = pa[0]; la1[BUF] = pa[1];                                                        \
-        ldl[BUF] = ldsD[cl_ * 8 + tq]; ldh[BUF] = ldsD[cl_ * 8 + 4 + tq];                          \
+        ldl[BUF] = ldsD[(CH) * 8 + tq]; ldh[BUF] = ldsD[(CH) * 8 + 4 + tq];                        \
     }
 #define LH_CONSUME(SLOT, CH)                                                                       \
     {                                                                                              \
@@ -842,6 +854,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     int c0 = 0;
     if (RING) {
         do {
+            LH_OPAQUE_OFFSETS()
 #pragma unroll
             for (int i = 0; i < D; i++) {
                 LH_CONSUME(i, c0 + i)
@@ -859,6 +872,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
 #undef LH_LDSLOAD
 #undef LH_CONSUME
 #undef LH_LOADW
+#undef LH_OPAQUE_OFFSETS
 
     LH_STAMP(3);
     acc = fold8(acc);
@@ -1013,7 +1027,7 @@ k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int 
 //     The DPP form is written as inline assembly (the compiler keeps v_mov_dpp + v_fmac); its one hazard
 //     -- a VALU write of the DPP source needs two wait states before the read -- is padded inside.
 //   grid: XCD-aware, blockIdx -> (row-block of 4 * RG row-groups, column group), column groups of a row-block on one XCD
-//   dynamic LDS: [NC][nchunks * 64] dwords A, then [NC][nchunks * 8] floats d
+//   dynamic LDS: [NC][(nchunks + 4) * 64] dwords A, then [NC][(nchunks + 4) * 8] floats d (4 zeroed padding chunks per column)
 // two independent chains interleaved (a dependent v_fmac issues ~1.7x slower than an independent one)
 #define LH_FMAC8_DPP2(ACC0, PLO0, PHI0, A01, A23, A45, A67, ACC1, PLO1, PHI1, B01, B23, B45, B67)  \
     asm("s_nop 1\n\t"                                                                              \
@@ -1044,28 +1058,33 @@ __global__ void __launch_bounds__(256)
 k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
               const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
               float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    constexpr int D = 4;
     extern __shared__ double smem_d[];
-    u32x4 *sA = (u32x4 *) smem_d;                            // [NC][nchunks * 16]
-    f32x4 *sD = (f32x4 *) (sA + (size_t) NC * nchunks * 16); // [NC][nchunks * 2]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every column's operand is padded with D zeroed chunks: the ring tail and the one-step-ahead operand
+    // fetch run past the row end (against the zero tile) without an index clamp (see k_gemv)
+    const int npad = nchunks + D;
+    u32x4 *sA = (u32x4 *) smem_d;                            // [NC][npad * 16]
+    f32x4 *sD = (f32x4 *) (sA + (size_t) NC * npad * 16);    // [NC][npad * 2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3, cg = q % ncg, wgi = (q / ncg) * 8 + xcd;
     const int g0 = (wgi * 4 + wave) * RG;                    // first of this wave's RG consecutive row-groups
     const int n0 = cg * NC;
-    const int k = lane & 7, t = lane & 3, last = nchunks - 1;
-    const int soff = 1024 + ((lane >> 3) * 8 + t * 2) * 4;
+    const int k = lane & 7, t = lane & 3;
+    const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + t * 2) * 4u;
+    uint32_t vw_ = voff_w, vs_ = voff_s;                     // (see k_gemv: SGPR base + per-lane offset addressing)
+#define LH_OPAQUE_OFFSETS() { vw_ = voff_w; vs_ = voff_s; asm volatile("" : "+v"(vw_), "+v"(vs_)); }
     const uint8_t *wbase[RG];
 #pragma unroll
     for (int rg = 0; rg < RG; rg++) wbase[rg] = wt + (size_t) min(g0 + rg, ngroups - 1) * (nchunks + 1) * TILE_BYTES;
 
-    constexpr int D = 4;
     u32x4 wq[RG][D];
     f32x2 ws[RG][D];
 #define LH_LOADW(SLOT, CH)                                                                         \
     _Pragma("unroll")                                                                              \
     for (int rg = 0; rg < RG; rg++) {                                                              \
         const uint8_t *tp_ = wbase[rg] + (size_t) min((CH), nchunks) * TILE_BYTES;                 \
-        wq[rg][SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + lane * 16));              \
-        ws[rg][SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + soff));                   \
+        wq[rg][SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + (size_t) vw_));           \
+        ws[rg][SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + (size_t) vs_));           \
     }
 #pragma unroll
     for (int i = 0; i < D; i++) { LH_LOADW(i, i) }
@@ -1084,7 +1103,10 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
                 v[u] = ((const u32x4 *) qa_A)[(long) min(n0 + n, ncols - 1) * perA + r];
             }
 #pragma unroll
-            for (int u = 0; u < LB; u++) { const int i = base + u * 256; if (i < totA) sA[i] = v[u]; }
+            for (int u = 0; u < LB; u++) {
+                const int i = base + u * 256, n = i / perA, r = i - n * perA;
+                if (i < totA) sA[n * npad * 16 + r] = v[u];
+            }
         }
         for (int base = tid; base < totD; base += 256 * LB) {
             f32x4 v[LB];
@@ -1094,7 +1116,15 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
                 v[u] = ((const f32x4 *) qa_d)[(long) min(n0 + n, ncols - 1) * perD + r];
             }
 #pragma unroll
-            for (int u = 0; u < LB; u++) { const int i = base + u * 256; if (i < totD) sD[i] = v[u]; }
+            for (int u = 0; u < LB; u++) {
+                const int i = base + u * 256, n = i / perD, r = i - n * perD;
+                if (i < totD) sD[n * npad * 2 + r] = v[u];
+            }
+        }
+        for (int i = tid; i < NC * D * 18; i += 256) {         // zero the padding chunks
+            const int n = i / (D * 18), r = i - n * (D * 18);
+            if (r < D * 16) sA[(n * npad + nchunks) * 16 + r] = u32x4{ 0u, 0u, 0u, 0u };
+            else sD[(n * npad + nchunks) * 2 + (r - D * 16)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
     }
     // The staging loops have run-time trip counts, after which the compiler's waitcnt pass no longer knows
@@ -1116,10 +1146,9 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
     float ldl[2], ldh[2];
 #define LH_LDSLOAD(BUF, N, CH)                                                                     \
     {                                                                                              \
-        const int cl_ = min((CH), last);                                                           \
-        const u32x4 *pa_ = sA + ((size_t) (N) * nchunks + cl_) * 16 + k * 2;                       \
+        const u32x4 *pa_ = sA + ((N) * npad + (CH)) * 16 + k * 2;                                  \
         la0[BUF] = pa_[0]; la1[BUF] = pa_[1];                                                      \
-        const float *pd_ = sDf + ((size_t) (N) * nchunks + cl_) * 8 + t;                           \
+        const float *pd_ = sDf + ((N) * npad + (CH)) * 8 + t;                                      \
         ldl[BUF] = pd_[0]; ldh[BUF] = pd_[4];                                                      \
     }
 #define LH_CONSUME(SLOT, CH)                                                                       \
@@ -1164,6 +1193,7 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
     LH_LDSLOAD(0, 0, 0)
     // straight-line ring body (see k_gemv): chunks past the row end read the zero tile (scale 0)
     for (int c0 = 0; c0 < nchunks; c0 += D) {
+        LH_OPAQUE_OFFSETS()
 #pragma unroll
         for (int i = 0; i < D; i++) {
             LH_CONSUME(i, c0 + i)
@@ -1174,6 +1204,7 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
 #undef LH_CONSUME
 #undef LH_LDSLOAD
 #undef LH_LOADW
+#undef LH_OPAQUE_OFFSETS
 
 #pragma unroll
     for (int rg = 0; rg < RG; rg++) {
@@ -2408,7 +2439,7 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     if (PRE == PREP_SILU_MUL) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
-#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d)
+#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + (D) * 288, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d)
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
     static const bool no_full = getenv("LLAMAHIP_NO_FULL") != nullptr;      // tuning override (measurement only)
@@ -2502,7 +2533,7 @@ static hipError_t launch_gemm_skinny_t(const QMat &w, int epi, const uint32_t *q
                                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     const int nwg = (w.ngroups + 4 * RG - 1) / (4 * RG);
     const int grid = ((nwg + 7) / 8) * ncg * 8;
-    const size_t lds = (size_t) NC * w.nchunks * 288;
+    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
     if (epi == EPI_RESID)
         hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_RESID>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
     else
@@ -2588,7 +2619,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
         if (nc > N) nc = N;
         if (skinny_nc >= 1 && skinny_nc <= 4) nc = skinny_nc;
-        while (nc > 1 && (size_t) nc * w.nchunks * 288 > 150 * 1024) nc--;
+        while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
         const int ncg = (N + nc - 1) / nc;
         nc = (N + ncg - 1) / ncg;                          // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
         int rg = 1;                                        // two row-groups per wave measured 3-7 % slower at 9 columns
