@@ -617,6 +617,17 @@ __device__ __forceinline__ float fold8(float acc) {
 //         the following w2 mat-vec: out_A / out_d.  y, if non-null, receives silu*up as fp32.
 //   PG  : prologue granules (16 B) kept in registers per thread; the host sizes the workgroup so
 //         that PG * blockDim covers the activation row (fp32 modes) or the QA "A" array (PRE_QA)
+// Measured on MI355X, 7B decode in situ (tools/ab_libs.sh): SGPR-base weight addressing (saves the 64-bit
+// per-lane address arithmetic) made the decode kernels 0.1-0.4 us SLOWER per launch, the zero-padded LDS
+// operand tail (clamp-free `base + immediate` reads) helps the ring kernels (wq|wk|wv 9.05 -> 8.58 us) and
+// costs the whole-row-in-flight one 0.3 us -- so: no SGPR base here, padding for RING kernels only.
+// (k_gemm_skinny keeps both: +2 % there.)
+#ifndef LH_GEMV_SADDR
+#define LH_GEMV_SADDR 0
+#endif
+#ifndef LH_GEMV_PAD
+#define LH_GEMV_PAD 1
+#endif
 template <int PRE, int EPI, int D, bool RING, int PG>
 __global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256, EPI == EPI_SILU_QA ? 4 : 1)
 k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
@@ -626,14 +637,15 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
        const uint16_t *__restrict__ T_silu,
        uint32_t *__restrict__ out_A, float *__restrict__ out_d) {
     extern __shared__ double smem_d[];
-    // LDS holds D chunks more than the row has: the ring's tail and its one-chunk-ahead operand fetch run
-    // past the end (against the zero tile), and with zeroed padding those reads need no index clamp -- their
-    // addresses are then `loop base + immediate` instead of three VALU instructions per chunk.
+    // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
+    // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
+    // index clamp -- their addresses are `loop base + immediate` instead of three VALU per chunk.
     uint32_t *ldsA = (uint32_t *) smem_d;
-    float *ldsD = (float *) (ldsA + (nchunks + D) * 64);
-    // (the wave index is made provably uniform so that the row-group base lives in SGPRs and every weight
-    //  load is `global_load ... v_off, s[base]` with a constant per-lane offset: no per-chunk address VALU)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    constexpr int PADC = (LH_GEMV_PAD && RING) ? D : 0;
+    float *ldsD = (float *) (ldsA + (nchunks + PADC) * 64);
+    // (LH_GEMV_SADDR, off: with a provably uniform wave index the row-group base lives in SGPRs and every
+    //  weight load is `global_load ... v_off, s[base]` with a constant per-lane offset -- measured slower here)
+    const int tid = threadIdx.x, lane = tid & 63, wave = LH_GEMV_SADDR ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), nw = blockDim.x >> 6;
     const int g = blockIdx.x * nw + wave;
     const bool valid = g < ngroups;
     const uint8_t *wbase = wt + (size_t) (valid ? g : 0) * (nchunks + 1) * TILE_BYTES;
@@ -658,8 +670,13 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     {                                                                                                        \
         const int ch_ = min((CH), nchunks);   /* tile `nchunks` of every row-group is the zero tile */      \
         const uint8_t *tp_ = wbase + (size_t) ch_ * TILE_BYTES;                                              \
-        wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + (size_t) vw_));                         \
-        ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + (size_t) vs_));                         \
+        if (LH_GEMV_SADDR) {                                                                                 \
+            wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + (size_t) vw_));                     \
+            ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + (size_t) vs_));                     \
+        } else {                                                                                             \
+            wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + lane * 16));                        \
+            ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + 1024 + ((lane >> 3) * 8 + (lane & 3) * 2) * 4)); \
+        }                                                                                                    \
     }
     // ---- phase 1: the prologue's own (small, L2-resident) loads go out FIRST.  vmcnt retires in
     // order, so anything issued behind the weight prefetch would have to wait for all of it.
@@ -715,10 +732,10 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
 
     // ---- phase 3: prologue arithmetic while the weights stream in
     LH_STAMP(1);
-    double *red = (double *) (ldsD + (nchunks + D) * 8);
-    for (int i = tid; i < D * 72; i += nt) {                 // zero the D padding chunks (A: 64 dwords, d: 8 floats each)
-        if (i < D * 64) ldsA[nchunks * 64 + i] = 0u;
-        else ldsD[nchunks * 8 + (i - D * 64)] = 0.0f;
+    double *red = (double *) (ldsD + (nchunks + PADC) * 8);
+    for (int i = tid; i < PADC * 72; i += nt) {              // zero the padding chunks (A: 64 dwords, d: 8 floats each)
+        if (i < PADC * 64) ldsA[nchunks * 64 + i] = 0u;
+        else ldsD[nchunks * 8 + (i - PADC * 64)] = 0.0f;
     }
     if (PRE == PRE_QA) {
 #pragma unroll
@@ -819,9 +836,10 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     const int tq = lane & 3;                 // this lane's weight scales are those of blocks tq and tq + 4
 #define LH_LDSLOAD(BUF, CH)                                                                        \
     {                                                                                              \
-        const u32x4 *pa = (const u32x4 *) (ldsA + ((CH) * 8 + k) * 8);                             \
+        const int cl_ = PADC ? (CH) : min((CH), nchunks - 1);                                      \
+        const u32x4 *pa = (const u32x4 *) (ldsA + (cl_ * 8 + k) * 8);                              \
         la0[BUF] = pa[0]; la1[BUF] = pa[1];                                                        \
-        ldl[BUF] = ldsD[(CH) * 8 + tq]; ldh[BUF] = ldsD[(CH) * 8 + 4 + tq];                        \
+        ldl[BUF] = ldsD[cl_ * 8 + tq]; ldh[BUF] = ldsD[cl_ * 8 + 4 + tq];                          \
     }
 #define LH_CONSUME(SLOT, CH)                                                                       \
     {                                                                                              \
@@ -854,7 +872,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     int c0 = 0;
     if (RING) {
         do {
-            LH_OPAQUE_OFFSETS()
+            if (LH_GEMV_SADDR) LH_OPAQUE_OFFSETS()
 #pragma unroll
             for (int i = 0; i < D; i++) {
                 LH_CONSUME(i, c0 + i)
@@ -2439,7 +2457,7 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     if (PRE == PREP_SILU_MUL) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
-#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + (D) * 288, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d)
+#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d)
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
     static const bool no_full = getenv("LLAMAHIP_NO_FULL") != nullptr;      // tuning override (measurement only)
