@@ -593,10 +593,13 @@ k_prep_fast(const float *__restrict__ in0, const float *__restrict__ in1, long i
     }
 
 __device__ __forceinline__ float fold8(float acc) {
-    // ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) -- float add commutes, so an xor butterfly is exact
-    acc += __shfl_xor(acc, 4);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 1);
+    // ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) in the lane with chain index 0 of every row (the only lane whose
+    // result the callers use).  Float add commutes, so a butterfly of pairwise adds is exact; it is done with
+    // DPP (row_shl:4 -> lane i reads lane i + 4, then the two quad swaps): three VALU instructions instead of
+    // three dependent ds_bpermute round trips at the tail of every launch.
+    acc += dpp_f<0x104>(acc);                 // lanes 0..3 of each 8: a_i + a_{i+4}
+    acc += dpp_f<DPP_QUAD_XOR2>(acc);         // lanes 0, 1: (a0+a4)+(a2+a6), (a1+a5)+(a3+a7)
+    acc += dpp_f<DPP_QUAD_XOR1>(acc);         // lane 0
     return acc;
 }
 
