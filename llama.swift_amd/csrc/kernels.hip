@@ -108,6 +108,18 @@ __device__ __forceinline__ float wave_max_f(float v) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// max over lanes 0..31 of a wave (the result is wave-uniform; lanes 32..63 may be inactive): four DPP
+// steps and two readlanes -- no LDS round trips (the epilogues that quantize one 32-element block sit at
+// the tail of a launch)
+__device__ __forceinline__ float max_lanes_0_31(float v) {
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    const int b = __builtin_bit_cast(int, v);
+    return fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)));
+}
+
 // block-wide sums / max; `red` is LDS scratch of >= 32 doubles.  All threads get the result.
 // Successive calls alternate between the two halves of `red`, so one barrier per call suffices
 // (a slot is rewritten only two calls later, after every wave passed the barrier in between).
@@ -910,9 +922,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             const int i = lane & 31;
             const float act = h2f_bits(T_silu[f2h_bits(gu[i])]) * gu[32 + i];
             float amax = fabsf(act);
-            amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
-            amax = fmaxf(amax, __shfl_xor(amax, 4));  amax = fmaxf(amax, __shfl_xor(amax, 2));
-            amax = fmaxf(amax, __shfl_xor(amax, 1));
+            amax = max_lanes_0_31(amax);
             const float dd = amax / 7.0f;
             const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
             const uint32_t nib = ((uint32_t) ((int) __builtin_rintf(act * id) + 8) - 8) & 0xF;     // signed nibble of (q - 8)
@@ -2152,9 +2162,7 @@ k_dec_attn(const float *__restrict__ qkv, int d, int dh, const double *__restric
         for (int th = 1; th < nth; th++) s += part[th * 32 + tid];          // thread order (ggml.c:5553-5577)
         if (merged) merged[col] = s;
         float amax = fabsf(s);
-        amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
-        amax = fmaxf(amax, __shfl_xor(amax, 4));  amax = fmaxf(amax, __shfl_xor(amax, 2));
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = max_lanes_0_31(amax);
         const float dd = amax / 7.0f;
         const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
         const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
@@ -2262,9 +2270,7 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
         if (merged) merged[col] = s;
         // quantize this 32-element block (ggml.c:456-523), one element per lane
         float amax = fabsf(s);
-        amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
-        amax = fmaxf(amax, __shfl_xor(amax, 4));  amax = fmaxf(amax, __shfl_xor(amax, 2));
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = max_lanes_0_31(amax);
         const float dd = amax / 7.0f;
         const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
         const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
