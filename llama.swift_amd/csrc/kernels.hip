@@ -108,6 +108,18 @@ __device__ __forceinline__ float wave_max_f(float v) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// The reference's reduction of its 32 FMA chains (GGML_F32x8_REDUCE, ggml.c:872-887: xor 8, 16, 4, 1, 2 over
+// 32 lanes), delivered to lane 0 of each 32-lane half only -- which is all the callers use.  Shifts instead
+// of exchanges (lane i reads i + 8 / i + 4: DPP within a 16-lane row) leave one step that crosses rows.
+__device__ __forceinline__ float tree32_to_lane0(float s) {
+    s += dpp_f<0x108>(s);                     // row_shl:8
+    s += __shfl_xor(s, 16);
+    s += dpp_f<0x104>(s);                     // row_shl:4
+    s += dpp_f<DPP_QUAD_XOR1>(s);
+    s += dpp_f<DPP_QUAD_XOR2>(s);
+    return s;
+}
+
 // max over lanes 0..31 of a wave (the result is wave-uniform; lanes 32..63 may be inactive): four DPP
 // steps and two readlanes -- no LDS round trips (the epilogues that quantize one 32-element block sit at
 // the tail of a launch)
@@ -1728,11 +1740,7 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
             const float *kr = Kc + (size_t) t * d + h * dh;
             float s = 0.0f;
             for (int i = 0; i < dh; i += 32) s = fmaf(kr[i + l], qs[i + l], s);
-            s += __shfl_xor(s, 8);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
+            s = tree32_to_lane0(s);
             if (l == 0) sc[t] = s * kq_scale;
         }
     }
@@ -1996,11 +2004,7 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
                 s = fmaf(kval, qs[i * 32 + l], s);
             }
         }
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
+        s = tree32_to_lane0(s);
         if (l == 0 && t <= n_past) sc[(size_t) h * n_ctx + t] = s * kq_scale;
     }
 }
@@ -2036,11 +2040,7 @@ k_decn_scores(const float *__restrict__ qr, int d, int dh, const float *__restri
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if (i * 32 < dh) s = fmaf(kv[u][i], qv[i], s);
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
+        s = tree32_to_lane0(s);
         if (l == 0 && t <= np) sc[((size_t) n * H + h) * n_ctx + t] = s * kq_scale;
     }
 }
@@ -2110,11 +2110,7 @@ k_dec_attn(const float *__restrict__ qkv, int d, int dh, const double *__restric
                         s = fmaf(kval, qs[i * 32 + l], s);
                     }
                 }
-                s += __shfl_xor(s, 8);
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 4);
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
+                s = tree32_to_lane0(s);
                 if (l == 0 && t <= n_past) p[t] = s * kq_scale;
             }
         }
