@@ -259,7 +259,8 @@ __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__res
     const int n = blockIdx.x;
     const int tok = tokens[n];
     const uint8_t *row = emb + (size_t) tok * (d / 32) * 20;
-    for (int i = threadIdx.x; i < d / 2; i += blockDim.x) {       // one byte = two elements
+    // grid.y slices the row (one dependent round trip per workgroup instead of d/512 per thread)
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < d / 2; i += gridDim.y * blockDim.x) {       // one byte = two elements
         const int b = i >> 4, j = i & 15;
         const uint8_t *blk = row + b * 20;
         const uint32_t bits = blk[0] | (blk[1] << 8) | (blk[2] << 16) | ((uint32_t) blk[3] << 24);
@@ -2284,33 +2285,55 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
 // ------------------------------------------------------------------------------------------------
 // st (optional): st[0] = n_past, st[1] = decode step index -- both advanced here so a captured
 // decode graph can be replayed without touching kernel arguments; out[st[1]] receives the token.
-__global__ void k_argmax(const float *__restrict__ logits, int V, int32_t *__restrict__ out, int out_idx,
-                         int32_t *__restrict__ next_token, int32_t *__restrict__ st) {
-    __shared__ float bv[1024];
-    __shared__ int bi[1024];
+// One workgroup of 1024 threads: 32 loads in flight per thread (a 32 000-entry row is one round trip, not
+// four), then the (value, index) pair is reduced inside each wave with DPP exchanges + readlane and across
+// the 16 waves through LDS with a single barrier (a 10-level LDS tree with a barrier per level before).
+__device__ __forceinline__ void argmax_take(float &v, int &i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp(float &v, int &i) {
+    const float ov = dpp_f<CTRL>(v);
+    const int oi = __builtin_amdgcn_mov_dpp(i, CTRL, 0xF, 0xF, true);
+    argmax_take(v, i, ov, oi);
+}
+__global__ void __launch_bounds__(1024)
+k_argmax(const float *__restrict__ logits, int V, int32_t *__restrict__ out, int out_idx,
+         int32_t *__restrict__ next_token, int32_t *__restrict__ st) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i0 = threadIdx.x; i0 < V; i0 += 8 * blockDim.x) {        // 8 loads in flight per thread, compared in index order
-        float v[8];
+    for (int i0 = tid; i0 < V; i0 += 32 * nt) {
+        float v[32];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = i0 + u * blockDim.x; v[u] = i < V ? logits[i] : -INFINITY; }
+        for (int u = 0; u < 32; u++) v[u] = logits[min(i0 + u * nt, V - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + u * blockDim.x;
-            if (i < V && (v[u] > best || (v[u] == best && i < idx))) { best = v[u]; idx = i; }
+        for (int u = 0; u < 32; u++) {
+            const int i = i0 + u * nt;
+            if (i < V) argmax_take(best, idx, v[u], i);       // ascending i: a tie keeps the lower index
         }
     }
-    bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+    argmax_dpp<DPP_QUAD_XOR1>(best, idx);
+    argmax_dpp<DPP_QUAD_XOR2>(best, idx);
+    argmax_dpp<DPP_ROW_HALF_MIRROR>(best, idx);
+    argmax_dpp<DPP_ROW_MIRROR>(best, idx);                    // every lane of a 16-lane row holds the row's pick
+    {
+        const int vb = __builtin_bit_cast(int, best);
+        float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 0));
+        int wi = __builtin_amdgcn_readlane(idx, 0);
+        argmax_take(wv, wi, __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 16)), __builtin_amdgcn_readlane(idx, 16));
+        argmax_take(wv, wi, __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 32)), __builtin_amdgcn_readlane(idx, 32));
+        argmax_take(wv, wi, __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 48)), __builtin_amdgcn_readlane(idx, 48));
+        if ((tid & 63) == 0) { bv[tid >> 6] = wv; bi[tid >> 6] = wi; }
+    }
     __syncthreads();
-    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            const float v = bv[threadIdx.x + s]; const int i = bi[threadIdx.x + s];
-            if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && i < bi[threadIdx.x])) { bv[threadIdx.x] = v; bi[threadIdx.x] = i; }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const int r = bi[0] == 0x7fffffff ? 0 : bi[0];
+    if (tid == 0) {
+        float v = bv[0];
+        int i = bi[0];
+        for (int w = 1; w < (nt >> 6); w++) argmax_take(v, i, bv[w], bi[w]);
+        const int r = i == 0x7fffffff ? 0 : i;
         out[st ? st[1] : out_idx] = r;
         if (next_token) *next_token = r;
         if (st) { st[0] += 1; st[1] += 1; }
@@ -2373,7 +2396,7 @@ hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int
 }
 
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st) {
-    hipLaunchKernelGGL(k_embed, dim3(N), dim3(256), 0, st, tokens, emb, x, d);
+    hipLaunchKernelGGL(k_embed, dim3(N, N <= 64 ? (d / 2 + 255) / 256 : 1), dim3(256), 0, st, tokens, emb, x, d);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
