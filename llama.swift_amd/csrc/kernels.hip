@@ -1097,12 +1097,21 @@ k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int 
           "v"(PLO1), "v"(PHI1), "v"((B01).x), "v"((B01).y), "v"((B23).x), "v"((B23).y),            \
           "v"((B45).x), "v"((B45).y), "v"((B67).x), "v"((B67).y))
 
+//   EPI_SILU_QA (the interleaved w1|w3 matrix only, RG = 1): 8 waves per workgroup = 32 gate rows + the same 32
+//         up rows; wave n of the workgroup then turns column n's 64 outputs into silu_lut(gate) * up
+//         (ggml.c:1956-1963, .mm:678-680) and quantizes them as one Q4_0 activation block (ggml.c:456-523)
+//         of the w2 mat-mul's operand: out_A / out_d, row strides out_strideA dwords / out_strideD floats
+//         (no fp32 round trip, no preparation launch in between)
 template <int NC, int RG, int EPI>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256)
 k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
               const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
-              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride,
+              const uint16_t *__restrict__ T_silu, uint32_t *__restrict__ out_A, float *__restrict__ out_d,
+              long out_strideA, long out_strideD) {
     constexpr int D = 4;
+    constexpr int NW = EPI == EPI_SILU_QA ? 8 : 4, NT = NW * 64;
+    static_assert(EPI != EPI_SILU_QA || RG == 1, "the fused FFN epilogue pairs one gate wave with one up wave");
     extern __shared__ double smem_d[];
     // every column's operand is padded with D zeroed chunks: the ring tail and the one-step-ahead operand
     // fetch run past the row end (against the zero tile) without an index clamp (see k_gemv)
@@ -1111,7 +1120,7 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
     f32x4 *sD = (f32x4 *) (sA + (size_t) NC * npad * 16);    // [NC][npad * 2]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3, cg = q % ncg, wgi = (q / ncg) * 8 + xcd;
-    const int g0 = (wgi * 4 + wave) * RG;                    // first of this wave's RG consecutive row-groups
+    const int g0 = (wgi * NW + wave) * RG;                    // first of this wave's RG consecutive row-groups
     const int n0 = cg * NC;
     const int k = lane & 7, t = lane & 3;
     const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + t * 2) * 4u;
@@ -1139,33 +1148,33 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
         constexpr int LB = 8;
         const int perA = nchunks * 16, perD = nchunks * 2;     // QA row strides in 16-byte granules
         const int totA = NC * perA, totD = NC * perD;
-        for (int base = tid; base < totA; base += 256 * LB) {
+        for (int base = tid; base < totA; base += NT * LB) {
             u32x4 v[LB];
 #pragma unroll
             for (int u = 0; u < LB; u++) {
-                const int i = min(base + u * 256, totA - 1), n = i / perA, r = i - n * perA;
+                const int i = min(base + u * NT, totA - 1), n = i / perA, r = i - n * perA;
                 v[u] = ((const u32x4 *) qa_A)[(long) min(n0 + n, ncols - 1) * perA + r];
             }
 #pragma unroll
             for (int u = 0; u < LB; u++) {
-                const int i = base + u * 256, n = i / perA, r = i - n * perA;
+                const int i = base + u * NT, n = i / perA, r = i - n * perA;
                 if (i < totA) sA[n * npad * 16 + r] = v[u];
             }
         }
-        for (int base = tid; base < totD; base += 256 * LB) {
+        for (int base = tid; base < totD; base += NT * LB) {
             f32x4 v[LB];
 #pragma unroll
             for (int u = 0; u < LB; u++) {
-                const int i = min(base + u * 256, totD - 1), n = i / perD, r = i - n * perD;
+                const int i = min(base + u * NT, totD - 1), n = i / perD, r = i - n * perD;
                 v[u] = ((const f32x4 *) qa_d)[(long) min(n0 + n, ncols - 1) * perD + r];
             }
 #pragma unroll
             for (int u = 0; u < LB; u++) {
-                const int i = base + u * 256, n = i / perD, r = i - n * perD;
+                const int i = base + u * NT, n = i / perD, r = i - n * perD;
                 if (i < totD) sD[n * npad * 2 + r] = v[u];
             }
         }
-        for (int i = tid; i < NC * D * 18; i += 256) {         // zero the padding chunks
+        for (int i = tid; i < NC * D * 18; i += NT) {         // zero the padding chunks
             const int n = i / (D * 18), r = i - n * (D * 18);
             if (r < D * 16) sA[(n * npad + nchunks) * 16 + r] = u32x4{ 0u, 0u, 0u, 0u };
             else sD[(n * npad + nchunks) * 2 + (r - D * 16)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -1250,6 +1259,34 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
 #undef LH_LOADW
 #undef LH_OPAQUE_OFFSETS
 
+    if (EPI == EPI_SILU_QA) {
+        // waves 0-3 hold gate rows wgi*32 .. +31, waves 4-7 the matching up rows
+        float *gu = (float *) smem_d;                          // [NC][64]; the operand staging area is free again
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float acc = fold8(accs[0][n]);
+            if (k == 0) gu[n * 64 + wave * 8 + (lane >> 3)] = acc;
+        }
+        __syncthreads();
+        if (wave < NC && n0 + wave < ncols && wgi * 8 < ngroups) {
+            const int i = lane & 31;
+            const float act = h2f_bits(T_silu[f2h_bits(gu[wave * 64 + i])]) * gu[wave * 64 + 32 + i];
+            const float amax = max_lanes_0_31(fabsf(act));
+            const float dd = amax / 7.0f;
+            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+            const uint32_t nib = (uint32_t) ((int) __builtin_rintf(act * id)) & 0xF;       // signed nibble of (q - 8)
+            const int kk = lane & 7;
+            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+            const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+            const int bb = wgi, c = bb >> 3, j = bb & 7;
+            uint32_t *oA = out_A + (size_t) (n0 + wave) * out_strideA;
+            float *oD = out_d + (size_t) (n0 + wave) * out_strideD;
+            if (lane < 8) oA[(c * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+            if (lane == 0) oD[bb] = dd;
+        }
+        return;
+    }
 #pragma unroll
     for (int rg = 0; rg < RG; rg++) {
         const int g = g0 + rg;
@@ -2375,6 +2412,7 @@ hipError_t init_kernel_attrs() {
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
     LH_ATTR_SK(1); LH_ATTR_SK(2); LH_ATTR_SK(3); LH_ATTR_SK(4);
+    LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
     LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn);
 #undef LH_ATTR
     return hipSuccess;
@@ -2581,11 +2619,58 @@ static hipError_t launch_gemm_skinny_t(const QMat &w, int epi, const uint32_t *q
     const int grid = ((nwg + 7) / 8) * ncg * 8;
     const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
     if (epi == EPI_RESID)
-        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_RESID>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_RESID>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
+                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L);
     else
-        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_STORE>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_STORE>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
+                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L);
     LH_LAUNCH_CHECK();
     return hipSuccess;
+}
+
+template <int NC>
+static hipError_t launch_gemm_skinny_silu_t(const QMat &w, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg,
+                                            const uint16_t *T_silu, uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
+    const int nwg = (w.ngroups + 7) / 8;
+    const int grid = ((nwg + 7) / 8) * ncg * 8;
+    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
+    hipLaunchKernelGGL((k_gemm_skinny<NC, 1, EPI_SILU_QA>), dim3(grid), dim3(512), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg,
+                       (float *) nullptr, 0L, (const float *) nullptr, 0L, T_silu, out_A, out_d, out_strideA, out_strideD);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+static int skinny_max_rows() {
+    static const int v = getenv("LLAMAHIP_SKINNY_MAX") ? atoi(getenv("LLAMAHIP_SKINNY_MAX")) : 32;
+    return v;
+}
+// column-group width of k_gemm_skinny for N rows: the widest (<= 4) that still leaves ~1500 waves, balanced
+static int skinny_pick_nc(const QMat &w, int N) {
+    static const int skinny_nc = getenv("LLAMAHIP_SKINNY_NC") ? atoi(getenv("LLAMAHIP_SKINNY_NC")) : 0;
+    int nc = 4;
+    while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
+    if (nc > N) nc = N;
+    if (skinny_nc >= 1 && skinny_nc <= 4) nc = skinny_nc;
+    while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
+    const int ncg = (N + nc - 1) / nc;
+    return (N + ncg - 1) / ncg;                            // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
+}
+
+// Short evals on the interleaved w1|w3 matrix: mat-mul + SiLU * up + Q4_0 quantization of the result in one
+// launch (k_gemm_skinny<EPI_SILU_QA>).  false = not applicable (row count, layout): use the separate steps.
+bool gemm_silu_qa_applies(const QMat &w13, int N) {
+    static const bool off = getenv("LLAMAHIP_NO_SKINNY_SILU") != nullptr;      // measurement
+    return !off && N >= 2 && N <= skinny_max_rows() && w13.gmapF8 != 0 && w13.ngroups % 8 == 0;
+}
+hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
+                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
+    const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
+    switch (nc) {
+    case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    case 3:  return launch_gemm_skinny_silu_t<3>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    case 2:  return launch_gemm_skinny_silu_t<2>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    default: return launch_gemm_skinny_silu_t<1>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    }
 }
 
 template <int NC, bool DB, int WPE>
@@ -2655,21 +2740,11 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
     // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put
     // ~1500 waves on the chip (LLAMAHIP_SKINNY_MAX = 0 switches it off, LLAMAHIP_SKINNY_NC forces the width)
-    static const int skinny_max = getenv("LLAMAHIP_SKINNY_MAX") ? atoi(getenv("LLAMAHIP_SKINNY_MAX")) : 32;
-    static const int skinny_nc = getenv("LLAMAHIP_SKINNY_NC") ? atoi(getenv("LLAMAHIP_SKINNY_NC")) : 0;
-    if (N >= 2 && N <= skinny_max) {
-        // widest column group (<= 4) that still leaves ~1500 waves; two row-groups per wave when there
-        // are plenty (halves the LDS operand reads per row)
+    if (N >= 2 && N <= skinny_max_rows()) {
+        // two row-groups per wave (halves the LDS operand reads per row) measured 3-7 % slower at 9 columns
         static const int skinny_rg = getenv("LLAMAHIP_SKINNY_RG") ? atoi(getenv("LLAMAHIP_SKINNY_RG")) : 0;
-        int nc = 4;
-        while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
-        if (nc > N) nc = N;
-        if (skinny_nc >= 1 && skinny_nc <= 4) nc = skinny_nc;
-        while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
-        const int ncg = (N + nc - 1) / nc;
-        nc = (N + ncg - 1) / ncg;                          // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
-        int rg = 1;                                        // two row-groups per wave measured 3-7 % slower at 9 columns
-        if (skinny_rg == 1 || skinny_rg == 2) rg = skinny_rg;
+        const int nc = skinny_pick_nc(w, N), ncg = (N + nc - 1) / nc;
+        const int rg = skinny_rg == 2 ? 2 : 1;
 #define LH_SK_ARGS w, epi, qa_A, qa_d, N, ncg, y, y_stride, resid, resid_stride, st
 #define LH_SK_CASE(NCV) case NCV: return rg == 2 ? launch_gemm_skinny_t<NCV, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
         switch (nc) {

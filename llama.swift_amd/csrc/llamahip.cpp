@@ -149,6 +149,8 @@ struct llamahip_model {
     uint32_t *qa_A = nullptr;
     float *qa_d = nullptr;
     uint8_t *qb_ws = nullptr;            // [ws_cap][KpMax] int8 operand of the matrix-core prompt GEMM
+    uint32_t *qaF_A = nullptr;           // short evals: QA operand of w2 written by the fused w1|w3 epilogue, [32][Kp(n_ff)]
+    float *qaF_d = nullptr;              //   (zeroed once: the blocks that pad n_ff to a multiple of 256 are never written)
     float *dbg_y = nullptr, *dbg_p = nullptr, *dbg_kqv = nullptr;
     int32_t *d_out_tokens = nullptr;     // greedy decode results
     int out_tokens_cap = 0;
@@ -199,6 +201,7 @@ llamahip_model::~llamahip_model() {
     free_dev(Kc); free_dev(Vc); free_dev(T_silu); free_dev(T_exp); free_dev(sincos);
     free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
+    free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens);
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
@@ -333,6 +336,13 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     HIP_TRY(hipMalloc((void **) &m->qa_A, n * KpMax), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->qa_d, n * (KpMax / 32) * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->qb_ws, n * KpMax), LLAMAHIP_ERR_PREDICT);      // int8 operand of the matrix-core GEMM
+    if (!m->qaF_A) {
+        const size_t KpF = ((F + 255) / 256) * 256;
+        HIP_TRY(hipMalloc((void **) &m->qaF_A, 32 * KpF), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMalloc((void **) &m->qaF_d, 32 * (KpF / 32) * 4), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(m->qaF_A, 0, 32 * KpF), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(m->qaF_d, 0, 32 * (KpF / 32) * 4), LLAMAHIP_ERR_PREDICT);
+    }
     HIP_TRY(hipMalloc((void **) &m->dbg_y, n * std::max(d, F) * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->dbg_p, H * n * C * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->dbg_kqv, n * d * 4), LLAMAHIP_ERR_PREDICT);
@@ -524,6 +534,13 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         }
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (dmp && !sink->put(11, m->dbg_y, (int64_t) N * d)) goto dump_fail;
+        if (short_chunk && !dmp && m->w13_interleaved && N <= 32 && gemm_silu_qa_applies(L.w13, N)) {
+            // short evals: w1 | w3, SiLU * up and the quantization for w2 in one launch (.mm:668-680)
+            const long KpF = ((long) F + 255) / 256 * 256;
+            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, N, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, N, m->x, d, m->x1, d, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);      // .mm:682-687
+            continue;
+        }
         HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, N, m->gu, 2L * F, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);     // .mm:668-675
         if (dmp) {
             HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) F * 4, m->gu + F, (size_t) 2 * F * 4, (size_t) F * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);

@@ -79,6 +79,9 @@ struct AttnWs {
 };
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st);
+bool gemm_silu_qa_applies(const QMat &w13, int N);
+hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
+                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st);
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
                              const uint16_t *T_exp, hipStream_t st);
