@@ -232,7 +232,7 @@ def main():
                      "note": "algorithmic bytes per launch = M*(K/32)*20 + (K/32)*20 + 4*M (SURVEY.md 8d); duration = HIP-event "
                              "average on the launch stream over back-to-back launches cycling through all 32 layers (cold weights; "
                              "includes the inter-launch dispatch gap that rocprofv3's kernel duration excludes); traffic = HBM "
-                             "bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_c_gemv_pmc.txt)"},
+                             "bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_i_gemv_pmc.txt, tools/pmc_pass.sh)"},
     }
     if not args.no_cpu_baseline and args.cpu_seconds > 0:
         try:
