@@ -318,9 +318,16 @@ constexpr int LB_DEFAULT = 8;
 // layout: [0] = launch counter, [1] = capacity, entry e at 8*(1+e): {5 stamps, ngroups, nchunks, PRE*16+EPI}
 __device__ unsigned long long *g_phase_probe = nullptr;
 #if LH_PHASE_PROBE
+#if LH_PHASE_PROBE == 2      /* prologue detail: entry | ring issued | mean known | scale known | prologue done */
+#define LH_STAMP(IDX) do { if (probe_e && (IDX) < 2) probe_e[IDX] = __builtin_readcyclecounter(); } while (0)
+#define LH_STAMP2(IDX) do { if (probe_e) probe_e[IDX] = __builtin_readcyclecounter(); } while (0)
+#else
 #define LH_STAMP(IDX) do { if (probe_e) probe_e[IDX] = __builtin_readcyclecounter(); } while (0)
+#define LH_STAMP2(IDX) do { } while (0)
+#endif
 #else
 #define LH_STAMP(IDX) do { } while (0)
+#define LH_STAMP2(IDX) do { } while (0)
 #endif
 
 
@@ -782,6 +789,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
                     for (int v = 0; v < 4; v++) { s1 += (double) xa[u][v].x; s1 += (double) xa[u][v].y; s1 += (double) xa[u][v].z; s1 += (double) xa[u][v].w; }
                 }
             const double mean = block_sum_d(s1, red, 0) / (double) K;
+            LH_STAMP2(2);
             double s2 = 0.0;
 #pragma unroll
             for (int u = 0; u < MAXH; u++)
@@ -796,6 +804,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
                 }
             const double sum2 = block_sum_d(s2, red, 1);
             const float scale = (float) (1.0 / sqrt(sum2 / (double) K + (double) 1e-5f));
+            LH_STAMP2(3);
 #pragma unroll
             for (int u = 0; u < MAXH; u++)
 #pragma unroll
@@ -896,6 +905,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         LH_FMAC8_DPP(acc, plo_, phi_, q01_, q23_, q45_, q67_);                                     \
     }
     LH_STAMP(2);
+    LH_STAMP2(4);
     LH_LDSLOAD(0, 0)
     int c0 = 0;
     if (RING) {
