@@ -1107,6 +1107,10 @@ k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int 
           "v"(PLO1), "v"(PHI1), "v"((B01).x), "v"((B01).y), "v"((B23).x), "v"((B23).y),            \
           "v"((B45).x), "v"((B45).y), "v"((B67).x), "v"((B67).y))
 
+//   EPI_ROPE_KV (the wq|wk|wv matrix): the epilogue is k_rope_kv -- outputs 2i, 2i+1 of a row sit in lanes 8
+//         apart of one DPP row, so the pair is rotated in place (double arithmetic, host-built cos/sin table)
+//         and q goes to qr, k and v straight into the cache rows n_past + column: no fp32 qkv round trip,
+//         no RoPE launch
 //   EPI_SILU_QA (the interleaved w1|w3 matrix only, RG = 1): 8 waves per workgroup = 32 gate rows + the same 32
 //         up rows; wave n of the workgroup then turns column n's 64 outputs into silu_lut(gate) * up
 //         (ggml.c:1956-1963, .mm:678-680) and quantizes them as one Q4_0 activation block (ggml.c:456-523)
@@ -1118,7 +1122,7 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
               const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
               float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride,
               const uint16_t *__restrict__ T_silu, uint32_t *__restrict__ out_A, float *__restrict__ out_d,
-              long out_strideA, long out_strideD) {
+              long out_strideA, long out_strideD, RopeKvArgs ra) {
     constexpr int D = 4;
     constexpr int NW = EPI == EPI_SILU_QA ? 8 : 4, NT = NW * 64;
     static_assert(EPI != EPI_SILU_QA || RG == 1, "the fused FFN epilogue pairs one gate wave with one up wave");
@@ -1306,6 +1310,24 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
 #pragma unroll
         for (int n = 0; n < NC; n++) {
             float acc = fold8(accs[rg][n]);
+            if (EPI == EPI_ROPE_KV) {
+                // (ggml.c:7076-7131, .mm:586-611; see k_rope_kv) rows m, m^1 = lanes 8 apart; m is even iff the lane's row is
+                const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
+                if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
+                    const int which = m / ra.d, c = m - which * ra.d, pos = ra.n_past + n0 + n;
+                    if (which == 2) {
+                        ra.Vc[(size_t) pos * ra.d + c] = acc;
+                    } else {
+                        const int pe = (c % ra.dh) & ~1;
+                        const double cs = ra.tab[(size_t) pos * ra.dh + pe], sn = ra.tab[(size_t) pos * ra.dh + pe + 1];
+                        const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
+                        const float val = (c & 1) ? (float) (x0 * sn + x1 * cs) : (float) (x0 * cs - x1 * sn);
+                        if (which == 0) ra.qr[(size_t) (n0 + n) * ra.d + c] = val;
+                        else ra.Kc[(size_t) pos * ra.d + c] = val;
+                    }
+                }
+                continue;
+            }
             if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
                 if (EPI == EPI_RESID) acc = acc + resid[(size_t) (n0 + n) * resid_stride + m];
                 y[(size_t) (n0 + n) * y_stride + m] = acc;
@@ -2422,6 +2444,7 @@ hipError_t init_kernel_attrs() {
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
     LH_ATTR_SK(1); LH_ATTR_SK(2); LH_ATTR_SK(3); LH_ATTR_SK(4);
+    LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
     LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn);
 #undef LH_ATTR
@@ -2630,10 +2653,10 @@ static hipError_t launch_gemm_skinny_t(const QMat &w, int epi, const uint32_t *q
     const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
     if (epi == EPI_RESID)
         hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_RESID>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
-                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L);
+                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, RopeKvArgs{});
     else
         hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_STORE>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
-                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L);
+                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, RopeKvArgs{});
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2645,7 +2668,18 @@ static hipError_t launch_gemm_skinny_silu_t(const QMat &w, const uint32_t *qa_A,
     const int grid = ((nwg + 7) / 8) * ncg * 8;
     const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
     hipLaunchKernelGGL((k_gemm_skinny<NC, 1, EPI_SILU_QA>), dim3(grid), dim3(512), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg,
-                       (float *) nullptr, 0L, (const float *) nullptr, 0L, T_silu, out_A, out_d, out_strideA, out_strideD);
+                       (float *) nullptr, 0L, (const float *) nullptr, 0L, T_silu, out_A, out_d, out_strideA, out_strideD, RopeKvArgs{});
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int NC>
+static hipError_t launch_gemm_skinny_rope_t(const QMat &w, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg, const RopeKvArgs &ra, hipStream_t st) {
+    const int nwg = (w.ngroups + 3) / 4;
+    const int grid = ((nwg + 7) / 8) * ncg * 8;
+    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
+    hipLaunchKernelGGL((k_gemm_skinny<NC, 1, EPI_ROPE_KV>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg,
+                       (float *) nullptr, 0L, (const float *) nullptr, 0L, (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, ra);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2664,6 +2698,21 @@ static int skinny_pick_nc(const QMat &w, int N) {
     while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
     const int ncg = (N + nc - 1) / nc;
     return (N + ncg - 1) / ncg;                            // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
+}
+
+// Short evals, wq|wk|wv: mat-mul + RoPE + KV append in one launch (k_gemm_skinny<EPI_ROPE_KV>)
+bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
+    static const bool off = getenv("LLAMAHIP_NO_SKINNY_ROPE") != nullptr;      // measurement
+    return !off && N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
+}
+hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
+    const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
+    switch (nc) {
+    case 4:  return launch_gemm_skinny_rope_t<4>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    case 3:  return launch_gemm_skinny_rope_t<3>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    case 2:  return launch_gemm_skinny_rope_t<2>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    default: return launch_gemm_skinny_rope_t<1>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    }
 }
 
 // Short evals on the interleaved w1|w3 matrix: mat-mul + SiLU * up + Q4_0 quantization of the result in one

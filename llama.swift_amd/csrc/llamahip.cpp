@@ -502,6 +502,12 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         if (dmp && !sink->put(0, m->x, (int64_t) N * d)) goto dump_fail;
         HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
         if (dmp && !sink->put(1, m->dbg_y, (int64_t) N * d)) goto dump_fail;
+        const bool rope_fused = short_chunk && !dmp && gemm_rope_kv_applies(L.qkv, N, d);
+        if (rope_fused) {
+            // short evals: q / k / v mat-mul, RoPE and the KV append in one launch (.mm:580-611)
+            const RopeKvArgs ra = { m->sincos, m->qr, Kl, Vl, n_past, d, dh };
+            HIP_TRY(launch_gemm_rope_kv(L.qkv, m->qa_A, m->qa_d, N, ra, st), LLAMAHIP_ERR_PREDICT);
+        } else
         HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
         if (dmp) {
             for (int which = 0; which < 3; which++) {           // q, k, v are column slices of qkv[N][3d]
@@ -509,7 +515,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
                 if (!sink->put(2 + which, m->tmp, (int64_t) N * d)) goto dump_fail;
             }
         }
-        HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);        // .mm:586-611
+        if (!rope_fused) HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);        // .mm:586-611
         if (dmp && !sink->put(5, m->qr, (int64_t) N * d)) goto dump_fail;
         if (short_chunk && !dmp) {
             // the reference's n_batch = 8 prompt flow: per-row decode-style attention that also quantizes

@@ -10,7 +10,9 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
 enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3 };
+// operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
+struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; };
 
 // a Q4_0 weight matrix resident in HBM in chain-major tile layout
 struct QMat {
@@ -79,6 +81,8 @@ struct AttnWs {
 };
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st);
+bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d);
+hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st);
 bool gemm_silu_qa_applies(const QMat &w13, int N);
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st);
