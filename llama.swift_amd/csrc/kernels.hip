@@ -24,11 +24,13 @@
 // Contents, in file order:
 //   helpers (fp16 bit conversions, DPP / shuffle reductions, quad broadcast)
 //   load time      k_repack_q4, k_quantize_offline, k_embed
-//   activations    make_y / quantize_y / k_prep_qa (norm, plain, SiLU*up -> QA)
+//   activations    make_y / quantize_y / k_prep_qa (norm, plain, SiLU*up -> QA), k_prep_fast (register-resident)
 //   decode         k_gemv (fused prologues / epilogues, register ring)
-//   prompt GEMMs   k_gemm_lds (decode tiles), k_gemm_rows (row-lane tiles, SGPR operands),
+//   prompt GEMMs   k_gemm_lds (decode tiles), k_gemm_skinny (2..32 rows: decode tiles, column groups; epilogues
+//                  with RoPE + KV append / SiLU*up -> QA), k_gemm_rows (row-lane tiles, SGPR operands),
 //                  k_gemm_mfma (+ k_tiles_to_rows, k_tiles_to_mtiles, k_qa_to_qb)
-//   attention      k_rope_kv, k_attn (per row), k_attnq_* (lane = query), k_dec_scores, k_dec_pv_blk, k_dec_attn
+//   attention      k_rope_kv, k_attn (per row), k_attnq_* (lane = query), k_dec_scores, k_decn_scores (short
+//                  evals), k_dec_pv_blk (decode and short evals), k_dec_attn
 //   misc           k_argmax, k_advance, k_add
 //   launchers      init_kernel_attrs, launch_* (kernel selection rules live next to the launch)
 #include <hip/hip_runtime.h>
