@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "llamahip_internal.h"
 
@@ -28,6 +29,33 @@ __device__ __forceinline__ float h2f(uint16_t h) { return (float) __builtin_bit_
 template <int WT> struct WElem;
 template <> struct WElem<0> { typedef float T; static __device__ __forceinline__ float widen(float v) { return v; } static __device__ __forceinline__ float act(float x) { return x; } };
 template <> struct WElem<1> { typedef uint16_t T; static __device__ __forceinline__ float widen(uint16_t v) { return h2f(v); } static __device__ __forceinline__ float act(float x) { return h2f(f2h_rne(x)); } };
+
+// a lane's 8 consecutive operands of one group, kept as loaded (16 / 32 bytes) and widened at use: unpacked
+// fp16 values would take one VGPR each (k_dense_mv: 170 VGPRs instead of 110)
+typedef uint32_t du4 __attribute__((ext_vector_type(4)));
+typedef float df4 __attribute__((ext_vector_type(4)));
+template <int WT> struct WVec8;
+// fp16 operands stay packed (two per VGPR) and are widened INSIDE the FMA: v_fma_mix_f32 reads its first
+// source as the low / high half of a register (op_sel) and multiplies-adds in fp32 with one rounding --
+// exactly fma((float) h, x, acc).  hipcc emits v_cvt_f32_f16 + v_fma_f32 for the C++ form and unpacks a
+// whole batch first (246 VGPRs, or spills under a register cap), hence inline assembly.
+template <> struct WVec8<1> {
+    du4 v;
+    __device__ __forceinline__ void load(const uint16_t *p) { v = __builtin_nontemporal_load((const du4 *) p); }
+    __device__ __forceinline__ void fma_into(float &acc, int u, float x) const {
+        const uint32_t word = u < 2 ? v.x : u < 4 ? v.y : u < 6 ? v.z : v.w;
+        if (u & 1) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(word), "v"(x));
+        else       asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(word), "v"(x));
+    }
+};
+template <> struct WVec8<0> {
+    df4 a, b;
+    __device__ __forceinline__ void load(const float *p) { a = __builtin_nontemporal_load((const df4 *) p); b = __builtin_nontemporal_load((const df4 *) p + 1); }
+    __device__ __forceinline__ void fma_into(float &acc, int u, float x) const {
+        const float wv = u == 0 ? a.x : u == 1 ? a.y : u == 2 ? a.z : u == 3 ? a.w : u == 4 ? b.x : u == 5 ? b.y : u == 6 ? b.z : b.w;
+        acc = fmaf(wv, x, acc);
+    }
+};
 
 constexpr int RG = 4;      // weight rows per half-wave
 
@@ -57,6 +85,100 @@ template <int WT>
 __global__ void k_dense_perm_act(const float *__restrict__ x, long x_stride, int K, float *__restrict__ xp) {
     const int n = blockIdx.x;
     for (int e = threadIdx.x; e < K; e += blockDim.x) xp[(size_t) n * K + perm_index(e, K)] = WElem<WT>::act(x[(size_t) n * x_stride + e]);
+}
+
+// Activation preparation fused with the rounding / permutation above (one launch instead of k_prep_qa with an
+// fp32 side output + k_dense_perm_act: 16 instead of 61 us per layer at 7B shapes).  One thread per 16
+// contiguous elements; NORM keeps a row in one workgroup (two block-wide double sums), the other modes are
+// sliced over gridDim.y.  Arithmetic = make_y in kernels.hip:
+//   MODE 1 plain    y = in0
+//   MODE 2 norm     y = w * ((float)(x - mean) * scale)      ggml_norm + ggml_mul (ggml.c:5327-5385, :4555)
+//   MODE 3 SiLU*up  y = silu_lut(in0) * in1                  (ggml.c:1956-1963, .mm:678-680)
+__device__ __forceinline__ double dense_block_sum(double v, double *red) {
+    for (int msk = 32; msk > 0; msk >>= 1) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __shfl_xor(lo, msk); hi = __shfl_xor(hi, msk);
+        v += __hiloint2double(hi, lo);
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();                                       // (red may still be read by the previous call)
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; i++) s += red[i];
+    return s;
+}
+template <int MODE, int WT>
+__global__ void __launch_bounds__(1024)
+k_dense_prep(const float *__restrict__ in0, const float *__restrict__ in1, long in_stride, long in1_stride, int K,
+             float *__restrict__ xp, const uint16_t *__restrict__ T_silu) {
+    __shared__ double red[16];
+    const int n = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int nh = K >> 4;
+    const int hi = blockIdx.y * nt + tid;
+    const bool live = hi < nh;
+    const int hc = min(hi, nh - 1);
+    const df4 *a4 = (const df4 *) (in0 + (size_t) n * in_stride) + hc * 4;
+    df4 xa[4], xb[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) xa[v] = a4[v];
+    if (MODE == PREP_NORM) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) xb[v] = ((const df4 *) in1)[hc * 4 + v];
+    } else if (MODE == PREP_SILU_MUL) {
+        const df4 *b4 = (const df4 *) (in1 + (size_t) n * in1_stride) + hc * 4;
+#pragma unroll
+        for (int v = 0; v < 4; v++) xb[v] = b4[v];
+    }
+    if (MODE == PREP_NORM) {
+        double s1 = 0.0;
+        if (live) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) { s1 += (double) xa[v].x; s1 += (double) xa[v].y; s1 += (double) xa[v].z; s1 += (double) xa[v].w; }
+        }
+        const double mean = dense_block_sum(s1, red) / (double) K;
+        double s2 = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const double v0 = (double) xa[v].x - mean, v1 = (double) xa[v].y - mean;
+            const double v2 = (double) xa[v].z - mean, v3 = (double) xa[v].w - mean;
+            xa[v].x = (float) v0; xa[v].y = (float) v1; xa[v].z = (float) v2; xa[v].w = (float) v3;
+            if (live) { s2 += v0 * v0; s2 += v1 * v1; s2 += v2 * v2; s2 += v3 * v3; }
+        }
+        const double sum2 = dense_block_sum(s2, red);
+        const float scale = (float) (1.0 / sqrt(sum2 / (double) K + (double) 1e-5f));
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            xa[v].x = xb[v].x * (xa[v].x * scale); xa[v].y = xb[v].y * (xa[v].y * scale);
+            xa[v].z = xb[v].z * (xa[v].z * scale); xa[v].w = xb[v].w * (xa[v].w * scale);
+        }
+    } else if (MODE == PREP_SILU_MUL) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            xa[v].x = h2f(T_silu[f2h_rne(xa[v].x)]) * xb[v].x; xa[v].y = h2f(T_silu[f2h_rne(xa[v].y)]) * xb[v].y;
+            xa[v].z = h2f(T_silu[f2h_rne(xa[v].z)]) * xb[v].z; xa[v].w = h2f(T_silu[f2h_rne(xa[v].w)]) * xb[v].w;
+        }
+    }
+    if (!live) return;
+    // The fp32 products above must exist as fp32 values before they are rounded to fp16: left alone, hipcc
+    // folds `(_Float16) (a * b)` into v_fma_mixlo_f16 -- ONE rounding of the exact product -- while the
+    // reference rounds the product to fp32 (ggml_mul) and that to fp16 (the mat-mul's INIT phase).  Rare
+    // (a few elements per thousand rows), and enough to flip logits in the 4th digit.
+#pragma unroll
+    for (int v = 0; v < 4; v++) asm volatile("" : "+v"(xa[v].x), "+v"(xa[v].y), "+v"(xa[v].z), "+v"(xa[v].w));
+    // element e = hi*16 + i  ->  g*256 + l*st + sidx  (perm_index): the 16 elements share g and sidx
+    const long e0 = (long) hi * 16;
+    const long g = e0 >> 8;
+    const int within = (int) (e0 & 255), l0 = within & 31, sidx = within >> 5;
+    const int gs = (int) min((long) 256, (long) K - g * 256), stp = gs >> 5;
+    float *o = xp + (size_t) n * K + g * 256 + sidx;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        o[(size_t) (l0 + 4 * v + 0) * stp] = WElem<WT>::act(xa[v].x);
+        o[(size_t) (l0 + 4 * v + 1) * stp] = WElem<WT>::act(xa[v].y);
+        o[(size_t) (l0 + 4 * v + 2) * stp] = WElem<WT>::act(xa[v].z);
+        o[(size_t) (l0 + 4 * v + 3) * stp] = WElem<WT>::act(xa[v].w);
+    }
 }
 
 // y[n][m] (+ resid[n][m]) = dot(W[m][:], xp[n][:]) on permuted operands.  grid (ceil(M / (8 * RG)), ceil(N / NC)), 256 threads.
@@ -138,6 +260,99 @@ k_dense_mm(const void *__restrict__ wv, int M, int K, const float *__restrict__ 
         }
 }
 
+// Decode (one activation row): the same 32 chains per row, software-pipelined.  k_dense_mm issues a batch
+// of loads, waits for all of it, consumes it, and only then issues the next: the memory pipe idles half
+// the time (2.5 TB/s).  Here two register buffers of UG groups alternate -- the loads of batch b + 1 are in
+// flight while batch b is consumed -- in a straight-line loop body (no branch around a load, so the
+// compiler's vmcnt waits stay counted; the prefetch past the end is a clamped re-read that is never
+// consumed); groups that do not fill a double batch and the tail group run un-pipelined afterwards.
+//   grid ceil(M / (HW * RG)), block HW * 32 threads (HW half-waves of RG rows each)
+template <int WT, int EPI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))   // <= 128 VGPRs: keeps the operands packed until use
+k_dense_mv(const void *__restrict__ wv, int M, int K, const float *__restrict__ xp,
+           float *__restrict__ y, const float *__restrict__ resid) {
+    typedef typename WElem<WT>::T T;
+    const T *w = (const T *) wv;
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, nhw = blockDim.x >> 5;
+    const int m0 = (blockIdx.x * nhw + hw) * RG;
+    const T *wr[RG];
+#pragma unroll
+    for (int r = 0; r < RG; r++) wr[r] = w + (size_t) min(m0 + r, M - 1) * K;
+    float acc[RG];
+#pragma unroll
+    for (int r = 0; r < RG; r++) acc[r] = 0.0f;
+    const int ng = K >> 8;
+    constexpr int UG = WT == 1 ? 2 : 1;                    // groups per buffer (fp32 weights are twice the registers)
+    WVec8<WT> wq[2][UG][RG];
+    df4 xq[2][UG][2];
+#define LD_LOADB(B, G0)                                                                            \
+    _Pragma("unroll")                                                                              \
+    for (int v = 0; v < UG; v++) {                                                                 \
+        const size_t at = (size_t) min((G0) + v, ng - 1) * 256 + l * 8;                            \
+        _Pragma("unroll")                                                                          \
+        for (int r = 0; r < RG; r++) wq[B][v][r].load(wr[r] + at);                                 \
+        xq[B][v][0] = *(const df4 *) (xp + at); xq[B][v][1] = *(const df4 *) (xp + at + 4);        \
+    }
+#define LD_CONSUMEB(B)                                                                             \
+    _Pragma("unroll")                                                                              \
+    for (int v = 0; v < UG; v++)                                                                   \
+        _Pragma("unroll")                                                                          \
+        for (int u = 0; u < 8; u++)                                                                \
+            _Pragma("unroll")                                                                      \
+            for (int r = 0; r < RG; r++) wq[B][v][r].fma_into(acc[r], u, xq[B][v][u >> 2][u & 3]);
+    const int ngm = ng / (2 * UG) * (2 * UG);              // groups covered by whole double batches
+    if (ngm) {
+        LD_LOADB(0, 0)
+        for (int g0 = 0; g0 < ngm; g0 += 2 * UG) {
+            LD_LOADB(1, g0 + UG)
+            __builtin_amdgcn_sched_barrier(0);             // the next batch goes out BEFORE the wait for this one
+            LD_CONSUMEB(0)
+            __builtin_amdgcn_sched_barrier(0);
+            LD_LOADB(0, g0 + 2 * UG)
+            __builtin_amdgcn_sched_barrier(0);
+            LD_CONSUMEB(1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef LD_LOADB
+#undef LD_CONSUMEB
+    for (int g = ngm; g < ng; g++) {                       // leftover full groups
+        const size_t at = (size_t) g * 256 + l * 8;
+        T wl[RG][8];
+        float xl[8];
+#pragma unroll
+        for (int r = 0; r < RG; r++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) wl[r][u] = wr[r][at + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) xl[u] = xp[at + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int r = 0; r < RG; r++) acc[r] = fmaf(WElem<WT>::widen(wl[r][u]), xl[u], acc[r]);
+    }
+    const int st = (K & 255) >> 5;                         // tail group: st < 8 steps
+    for (int u = 0; u < st; u++) {
+        const size_t at = (size_t) ng * 256 + l * st + u;
+        const float xa = xp[at];
+#pragma unroll
+        for (int r = 0; r < RG; r++) acc[r] = fmaf(WElem<WT>::widen(wr[r][at]), xa, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RG; r++) {
+        float s = acc[r];
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (l == 0 && m0 + r < M) {
+            if (EPI == EPI_RESID) s = s + resid[m0 + r];
+            y[m0 + r] = s;
+        }
+    }
+}
+
 template <int WT>
 __global__ void k_embed_dense(const int32_t *__restrict__ tokens, const void *__restrict__ emb, float *__restrict__ x, int d) {
     typedef typename WElem<WT>::T T;
@@ -149,7 +364,18 @@ __global__ void k_embed_dense(const int32_t *__restrict__ tokens, const void *__
 template <int WT, int NC>
 hipError_t go(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
               const float *resid, long resid_stride, hipStream_t st, float *scratch) {
-    hipLaunchKernelGGL(k_dense_perm_act<WT>, dim3(N), dim3(256), 0, st, x, x_stride, w.K, scratch);
+    if (x) hipLaunchKernelGGL(k_dense_perm_act<WT>, dim3(N), dim3(256), 0, st, x, x_stride, w.K, scratch);     // x == nullptr: scratch already holds the prepared rows
+    static const bool old_mv = getenv("LLAMAHIP_DENSE_MM1") != nullptr;      // measurement: the un-pipelined kernel for one row too
+    if (N == 1 && !old_mv) {
+        // small matrices: 4 half-waves per workgroup so that every CU gets one (a 4096-row matrix is 256 workgroups)
+        const int nhw = (w.M + 8 * RG - 1) / (8 * RG) >= 512 ? 8 : 4;
+        const dim3 g1((w.M + nhw * RG - 1) / (nhw * RG));
+        if (epi == EPI_RESID)
+            hipLaunchKernelGGL((k_dense_mv<WT, EPI_RESID>), g1, dim3(nhw * 32), 0, st, w.w, w.M, w.K, scratch, y, resid);
+        else
+            hipLaunchKernelGGL((k_dense_mv<WT, EPI_STORE>), g1, dim3(nhw * 32), 0, st, w.w, w.M, w.K, scratch, y, resid);
+        return hipGetLastError();
+    }
     const dim3 grid((w.M + 8 * RG - 1) / (8 * RG), (N + NC - 1) / NC);
     if (epi == EPI_RESID)
         hipLaunchKernelGGL((k_dense_mm<WT, NC, EPI_RESID>), grid, dim3(256), 0, st, w.w, w.M, w.K, scratch, N, y, y_stride, resid, resid_stride);
@@ -328,6 +554,28 @@ hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride
                                     : go<1, 8>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st, scratch);
     return N == 1 ? go<0, 1>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st, scratch)
                   : go<0, 8>(w, epi, x, x_stride, N, y, y_stride, resid, resid_stride, st, scratch);
+}
+
+// norm / plain / SiLU*up -> rounded, permuted activation rows in `scratch` (then launch_dense_mm with x = nullptr).
+// false = not available for this weight type / row width: use launch_prep + launch_dense_mm.
+bool dense_prep_applies(int wtype, int mode, int K) {
+    static const bool off = getenv("LLAMAHIP_DENSE_NO_FUSED_PREP") != nullptr;     // measurement
+    static const int mask = getenv("LLAMAHIP_DENSE_FUSED_MODES") ? atoi(getenv("LLAMAHIP_DENSE_FUSED_MODES")) : 14;   // bit per PREP_* mode
+    return !off && ((mask >> mode) & 1) && (wtype == 0 || wtype == 1) && K % 32 == 0 && (mode != PREP_NORM || K / 16 <= 1024);
+}
+hipError_t launch_dense_prep(int mode, int wtype, const float *in0, const float *in1, long in_stride, long in1_stride,
+                             int K, int N, float *scratch, const uint16_t *T_silu, hipStream_t st) {
+    const int nh = K / 16;
+    const int nt = mode == PREP_NORM ? (nh + 63) / 64 * 64 : 256;
+    const dim3 grid(N, mode == PREP_NORM ? 1 : (nh + nt - 1) / nt);
+#define LD_PREP(MODE, WT) hipLaunchKernelGGL((k_dense_prep<MODE, WT>), grid, dim3(nt), 0, st, in0, in1, in_stride, in1_stride, K, scratch, T_silu)
+    if (wtype == 1) {
+        if (mode == PREP_NORM) LD_PREP(PREP_NORM, 1); else if (mode == PREP_SILU_MUL) LD_PREP(PREP_SILU_MUL, 1); else LD_PREP(PREP_PLAIN, 1);
+    } else {
+        if (mode == PREP_NORM) LD_PREP(PREP_NORM, 0); else if (mode == PREP_SILU_MUL) LD_PREP(PREP_SILU_MUL, 0); else LD_PREP(PREP_PLAIN, 0);
+    }
+#undef LD_PREP
+    return hipGetLastError();
 }
 
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st) {

@@ -400,12 +400,29 @@ int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const flo
         HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
     float *y = m->dbg_y;                                  // fp32 activations of the next mat-mul: [N][max(d, F)]
+    // activation preparation + mat-mul.  f16 / f32 weights: one fused launch writes the rounded, permuted rows
+    // straight into the mat-mul's operand buffer; Q4_1: fp32 rows, expanded by the mat-mul itself.
+    auto prep_mm = [&](const DMat &w, int epi, int mode, const float *in0, const float *in1, long in_stride, long in1_stride,
+                       int K, int rows, float *out, long out_stride, const float *resid, long resid_stride) -> hipError_t {
+        if (dense_prep_applies(w.wtype, mode, K)) {
+            hipError_t e = launch_dense_prep(mode, w.wtype, in0, in1, in_stride, in1_stride, K, rows, m->tmp, m->T_silu, st);
+            if (e != hipSuccess) return e;
+            return launch_dense_mm(w, epi, nullptr, K, rows, out, out_stride, resid, resid_stride, st, m->tmp);
+        }
+        const float *src = in0;
+        long src_stride = in_stride;
+        if (mode != PREP_PLAIN) {
+            hipError_t e = launch_prep(mode, in0, in1, in_stride, in1_stride, K, rows, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st);
+            if (e != hipSuccess) return e;
+            src = y; src_stride = K;
+        }
+        return launch_dense_mm(w, epi, src, src_stride, rows, out, out_stride, resid, resid_stride, st, m->tmp);
+    };
     for (int il = m->l0; il < m->l1; il++) {
         const Layer &L = m->layers[il - m->l0];
         const size_t kv_at = ((size_t) m->cur_seq * (m->l1 - m->l0) + (il - m->l0)) * C * d;
         float *Kl = m->Kc + kv_at, *Vl = m->Vc + kv_at;
-        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);          // .mm:570-575
-        HIP_TRY(launch_dense_mm(L.dqkv, EPI_STORE, y, d, N, m->qkv, 3L * d, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                   // .mm:580-582
+        HIP_TRY(prep_mm(L.dqkv, EPI_STORE, PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qkv, 3L * d, nullptr, 0), LLAMAHIP_ERR_PREDICT);             // .mm:570-582
         if (N == 1) {
             // one row: the decode attention kernels of the Q4_0 path (position from device memory, fp32 output)
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, m->merged, m->qa1_A, m->qa1_d, m->T_exp, m->d_state, st), LLAMAHIP_ERR_PREDICT);
@@ -413,19 +430,15 @@ int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const flo
             HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);                             // .mm:586-611
             HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT); // .mm:614-646
         }
-        HIP_TRY(launch_dense_mm(L.dwo, EPI_RESID, m->merged, d, N, m->x1, d, m->x, d, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                     // .mm:649-654
-        HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);              // .mm:660-665
-        HIP_TRY(launch_dense_mm(L.dw13, EPI_STORE, y, d, N, m->gu, 2L * F, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                    // .mm:668-675
-        HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
-        HIP_TRY(launch_dense_mm(L.dw2, EPI_RESID, y, F, N, m->x, d, m->x1, d, st, m->tmp), LLAMAHIP_ERR_PREDICT);                                             // .mm:682-687
+        HIP_TRY(prep_mm(L.dwo, EPI_RESID, PREP_PLAIN, m->merged, nullptr, d, 0, d, N, m->x1, d, m->x, d), LLAMAHIP_ERR_PREDICT);                          // .mm:649-654
+        HIP_TRY(prep_mm(L.dw13, EPI_STORE, PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->gu, 2L * F, nullptr, 0), LLAMAHIP_ERR_PREDICT);                  // .mm:660-675
+        HIP_TRY(prep_mm(L.dw2, EPI_RESID, PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->x, d, m->x1, d), LLAMAHIP_ERR_PREDICT);               // .mm:678-687
     }
     if (m->last_stage) {
         if (want_all) {
-            HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, N, m->logits, V, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(prep_mm(m->doutput, EPI_STORE, PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->logits, V, nullptr, 0), LLAMAHIP_ERR_PREDICT);
         } else {
-            HIP_TRY(launch_prep(PREP_NORM, m->x + (size_t) (N - 1) * d, m->norm_w, d, 0, d, 1, m->qa_A, m->qa_d, y, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_dense_mm(m->doutput, EPI_STORE, y, d, 1, m->logits + (size_t) (N - 1) * V, V, nullptr, 0, st, m->tmp), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(prep_mm(m->doutput, EPI_STORE, PREP_NORM, m->x + (size_t) (N - 1) * d, m->norm_w, d, 0, d, 1, m->logits + (size_t) (N - 1) * V, V, nullptr, 0), LLAMAHIP_ERR_PREDICT);
         }
     }
     return 0;

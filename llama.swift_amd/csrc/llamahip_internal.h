@@ -47,6 +47,9 @@ struct DMat {
 hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
                            const float *resid, long resid_stride, hipStream_t st, float *scratch = nullptr);
 hipError_t launch_q41_repack(const uint8_t *raw_rows, DMat &w, hipStream_t st);
+bool dense_prep_applies(int wtype, int mode, int K);
+hipError_t launch_dense_prep(int mode, int wtype, const float *in0, const float *in1, long in_stride, long in1_stride,
+                             int K, int N, float *scratch, const uint16_t *T_silu, hipStream_t st);
 hipError_t launch_dense_perm_rows(const void *raw_rows, DMat &w, int row0, int rows, hipStream_t st);
 hipError_t launch_quantize_q41_offline(const void *src, int f16, uint8_t *dst, long nrows, int nb, hipStream_t st);
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st);
