@@ -2445,7 +2445,8 @@ hipError_t init_kernel_attrs() {
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
-    LH_ATTR_SK(1); LH_ATTR_SK(2); LH_ATTR_SK(3); LH_ATTR_SK(4);
+    LH_ATTR_SK(1); LH_ATTR_SK(2); LH_ATTR_SK(3); LH_ATTR_SK(4); LH_ATTR_SK(5);
+    LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
     LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn);
@@ -2696,7 +2697,7 @@ static int skinny_pick_nc(const QMat &w, int N) {
     int nc = 4;
     while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
     if (nc > N) nc = N;
-    if (skinny_nc >= 1 && skinny_nc <= 4) nc = skinny_nc;
+    if (skinny_nc >= 1 && skinny_nc <= 5) nc = skinny_nc;
     while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
     const int ncg = (N + nc - 1) / nc;
     return (N + ncg - 1) / ncg;                            // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
@@ -2710,6 +2711,7 @@ bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
 hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
     const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
+    case 5:  return launch_gemm_skinny_rope_t<5>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 4:  return launch_gemm_skinny_rope_t<4>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 3:  return launch_gemm_skinny_rope_t<3>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 2:  return launch_gemm_skinny_rope_t<2>(wqkv, qa_A, qa_d, N, ncg, ra, st);
@@ -2727,6 +2729,7 @@ hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const floa
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
     const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
+    case 5:  return launch_gemm_skinny_silu_t<5>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 3:  return launch_gemm_skinny_silu_t<3>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 2:  return launch_gemm_skinny_silu_t<2>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
@@ -2809,6 +2812,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
 #define LH_SK_ARGS w, epi, qa_A, qa_d, N, ncg, y, y_stride, resid, resid_stride, st
 #define LH_SK_CASE(NCV) case NCV: return rg == 2 ? launch_gemm_skinny_t<NCV, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
         switch (nc) {
+        LH_SK_CASE(5);
         LH_SK_CASE(4);
         LH_SK_CASE(3);
         LH_SK_CASE(2);
