@@ -149,7 +149,7 @@ struct llamahip_model {
     uint32_t *qa_A = nullptr;
     float *qa_d = nullptr;
     uint8_t *qb_ws = nullptr;            // [ws_cap][KpMax] int8 operand of the matrix-core prompt GEMM
-    uint32_t *qaF_A = nullptr;           // short evals: QA operand of w2 written by the fused w1|w3 epilogue, [32][Kp(n_ff)]
+    uint32_t *qaF_A = nullptr;           // short evals: QA operand of w2 written by the fused w1|w3 epilogue, [64][Kp(n_ff)]
     float *qaF_d = nullptr;              //   (zeroed once: the blocks that pad n_ff to a multiple of 256 are never written)
     float *dbg_y = nullptr, *dbg_p = nullptr, *dbg_kqv = nullptr;
     int32_t *d_out_tokens = nullptr;     // greedy decode results
@@ -338,10 +338,10 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     HIP_TRY(hipMalloc((void **) &m->qb_ws, n * KpMax), LLAMAHIP_ERR_PREDICT);      // int8 operand of the matrix-core GEMM
     if (!m->qaF_A) {
         const size_t KpF = ((F + 255) / 256) * 256;
-        HIP_TRY(hipMalloc((void **) &m->qaF_A, 32 * KpF), LLAMAHIP_ERR_PREDICT);
-        HIP_TRY(hipMalloc((void **) &m->qaF_d, 32 * (KpF / 32) * 4), LLAMAHIP_ERR_PREDICT);
-        HIP_TRY(hipMemset(m->qaF_A, 0, 32 * KpF), LLAMAHIP_ERR_PREDICT);
-        HIP_TRY(hipMemset(m->qaF_d, 0, 32 * (KpF / 32) * 4), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMalloc((void **) &m->qaF_A, 64 * KpF), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMalloc((void **) &m->qaF_d, 64 * (KpF / 32) * 4), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(m->qaF_A, 0, 64 * KpF), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(m->qaF_d, 0, 64 * (KpF / 32) * 4), LLAMAHIP_ERR_PREDICT);
     }
     HIP_TRY(hipMalloc((void **) &m->dbg_y, n * std::max(d, F) * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->dbg_p, H * n * C * 4), LLAMAHIP_ERR_PREDICT);
@@ -476,7 +476,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
 
     // short prompt chunks (the reference evaluates prompts 8 tokens at a time, .mm / LlamaRunner n_batch) take
     // the decode-shaped attention; LLAMAHIP_SHORT_MAX = 0 switches it off (measurement)
-    static const int short_max = getenv("LLAMAHIP_SHORT_MAX") ? atoi(getenv("LLAMAHIP_SHORT_MAX")) : 32;
+    static const int short_max = getenv("LLAMAHIP_SHORT_MAX") ? atoi(getenv("LLAMAHIP_SHORT_MAX")) : 60;
     const bool short_chunk = N >= 2 && N <= short_max && m->attn_ws.S && N <= m->attn_ws.NB && dh % 32 == 0 && dh <= 256;
     int32_t *state = (io && io->state) ? io->state : m->d_state;
     const float *x_first = (io && fused && m->l1 > m->l0) ? io->x_first : nullptr;
@@ -553,7 +553,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         }
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (dmp && !sink->put(11, m->dbg_y, (int64_t) N * d)) goto dump_fail;
-        if (short_chunk && !dmp && m->w13_interleaved && N <= 32 && gemm_silu_qa_applies(L.w13, N)) {
+        if (short_chunk && !dmp && m->w13_interleaved && N <= 64 && gemm_silu_qa_applies(L.w13, N)) {
             // short evals: w1 | w3, SiLU * up and the quantization for w2 in one launch (.mm:668-680)
             const long KpF = ((long) F + 255) / 256 * 256;
             HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, N, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st), LLAMAHIP_ERR_PREDICT);

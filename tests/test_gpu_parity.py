@@ -171,18 +171,18 @@ def test_prompt_continuation_and_ragged_batches(L, oracle, tmp_path, nth):
 @pytest.mark.parametrize("nth", [1, 4, 8])
 def test_short_chunks_vs_oracle(L, oracle, tmp_path, nth):
     """The reference feeds a prompt n_batch = 8 tokens at a time, so short evals are THE prompt path of the
-    drop-in: 2..32 rows take the column-grouped decode-shaped GEMM (k_gemm_skinny) and the per-row
-    attention that quantizes its output for wo (k_decn_scores / k_dec_pv_blk<true>); 33 is the first size
-    past both.  n_embd 320 / n_ff 896 leave padded QA blocks (K not a multiple of 256) that these
+    drop-in: 2..60 rows take the column-grouped decode-shaped GEMM (k_gemm_skinny, with RoPE + KV append and
+    SiLU * up -> QA in its epilogues) and the per-row attention that quantizes its output for wo
+    (k_decn_scores / k_dec_pv_blk<true>); 61 is the first size past both.  n_embd 320 / n_ff 896 leave padded QA blocks (K not a multiple of 256) that these
     kernels must zero themselves."""
     hp = synth.HParams(n_vocab=96, n_embd=320, n_mult=64, n_head=5, n_layer=2)
     path = str(tmp_path / "m.bin")
     synth.write_model(path, hp, synth.random_tensors(hp, seed=77))
-    om = oracle.load(path, 192)
-    prompt = synth.synth_prompt(180, hp.n_vocab, seed=5)
-    with L.Model(path, n_ctx=192) as gm:
+    om = oracle.load(path, 352)
+    prompt = synth.synth_prompt(348, hp.n_vocab, seed=5)
+    with L.Model(path, n_ctx=352) as gm:
         n_past = 0
-        for n in (8, 8, 2, 3, 4, 5, 7, 9, 12, 16, 17, 24, 32, 33):     # 180 tokens
+        for n in (8, 8, 2, 3, 4, 5, 7, 9, 12, 16, 17, 24, 32, 33, 47, 60, 61):     # 348 tokens
             chunk = prompt[n_past:n_past + n]
             a = gm.eval_debug(chunk, n_past, nth, all_logits=True)
             b = om.eval(chunk, n_past, nth, all_logits=True)
