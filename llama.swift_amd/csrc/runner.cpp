@@ -49,11 +49,21 @@ int32_t llamahip_tokenize(const llamahip_model *m, const char *text_c, int32_t b
     if (bos) res.push_back(1);
     // longest match at every position; among equally long matches the highest id wins because the
     // reference walks id_to_token in ascending id order and only skips strictly shorter tokens
+    // (utils.cpp:275-311).  The reference tries the whole vocabulary at every position (32 000 string
+    // compares per token: ~0.1 s for a 2 000-character prompt, as long as evaluating it here); only tokens
+    // that start with the byte at `pos` can match, so they are bucketed by first byte once per call, in
+    // ascending id order -- the same candidates in the same order, the same result.
+    std::vector<std::vector<int32_t>> by_first(256);
+    for (int32_t id = 0; id < n_vocab; id++) {
+        uint32_t len = 0;
+        const char *tok = llamahip_token_text(m, id, &len);
+        if (len > 0) by_first[(unsigned char) tok[0]].push_back(id);
+    }
     size_t pos = 0;
-    for (;;) {
+    while (pos < text.size()) {
         size_t best_len = 0;
         int32_t best_id = 0;
-        for (int32_t id = 0; id < n_vocab; id++) {
+        for (int32_t id : by_first[(unsigned char) text[pos]]) {
             uint32_t len = 0;
             const char *tok = llamahip_token_text(m, id, &len);
             if (len < best_len) continue;
