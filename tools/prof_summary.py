@@ -10,7 +10,7 @@ if title:
     print("#", title)
 print(f"{'calls':>8} {'avg_us':>9} {'min_us':>8} {'max_us':>8} {'total_ms':>9} {'pct':>6}  kernel")
 for r in rows:
-    n = r["Name"]
+    n = r["Name"].replace("(anonymous namespace)::", "")
     n = n[:n.index("(")] if "(" in n else n
     print(f"{int(r['Calls']):8d} {float(r['AverageNs'])/1e3:9.2f} {float(r['MinNs'])/1e3:8.2f} {float(r['MaxNs'])/1e3:8.2f} "
           f"{float(r['TotalDurationNs'])/1e6:9.2f} {float(r['Percentage']):6.2f}  {n}")
