@@ -103,6 +103,26 @@ __global__ void __launch_bounds__(256) k_rounds_slots(unsigned *slots /*[512 * 1
     }
     if (acc == 12345.678f) sink[0] = acc;
 }
+// variant: LOCAL hand-offs -- groups of G workgroups synchronise among themselves only (a head's 12 producer
+// workgroups and its consumers in a fused wq|wk|wv + attention kernel): one counter per group, 64 bytes apart
+template <int G>
+__global__ void __launch_bounds__(256) k_rounds_groups(unsigned *counters /*[64 * 16]*/, int rounds, unsigned *fail, float *sink) {
+    const unsigned grp = blockIdx.x / G, members = min((unsigned) G, gridDim.x - grp * G);
+    float acc = threadIdx.x;
+    for (int r = 0; r < rounds; r++) {
+        for (int i = 0; i < 64; i++) acc = acc * 1.0001f + 0.5f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counters + 16 * grp, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = members * (unsigned) (r + 1);
+            int spins = 0;
+            while (__hip_atomic_load(counters + 16 * grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+                if (++spins > (1 << 22)) { *fail = 1; break; }
+        }
+        __syncthreads();
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
 __global__ void k_empty(float *sink) { if (threadIdx.x == 9999) sink[0] = 1.0f; }
 
 int main() {
@@ -154,6 +174,22 @@ int main() {
             unsigned f = 0;
             CHECK(hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost));
             if (pass) printf("per-workgroup slots (stores + polls, no RMW), %3d workgroups: %.2f us per round%s\n", n, us / rr, f ? "  (SPIN GAVE UP)" : "");
+        }
+    unsigned *gc;
+    CHECK(hipMalloc(&gc, 64 * 16 * 4));
+    for (int G : { 4, 12, 32 })
+        for (int pass = 0; pass < 2; pass++) {
+            CHECK(hipMemset(gc, 0, 64 * 16 * 4)); CHECK(hipMemset(fail, 0, 4));
+            const int rr = pass ? rounds : 10;
+            auto t0 = std::chrono::steady_clock::now();
+            if (G == 4) hipLaunchKernelGGL(k_rounds_groups<4>, dim3(256), dim3(256), 0, 0, gc, rr, fail, sink);
+            else if (G == 12) hipLaunchKernelGGL(k_rounds_groups<12>, dim3(256), dim3(256), 0, 0, gc, rr, fail, sink);
+            else hipLaunchKernelGGL(k_rounds_groups<32>, dim3(256), dim3(256), 0, 0, gc, rr, fail, sink);
+            CHECK(hipDeviceSynchronize());
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            unsigned f = 0;
+            CHECK(hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost));
+            if (pass) printf("local hand-offs, 256 workgroups in groups of %2d: %.2f us per round%s\n", G, us / rr, f ? "  (SPIN GAVE UP)" : "");
         }
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
