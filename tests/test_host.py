@@ -117,6 +117,50 @@ def test_tokenizer_matches_reference_vectors(L, tmp_path):
         m.token_text(10 ** 6)
 
 
+def test_tokenizer_equals_the_whole_vocabulary_scan(L, tmp_path):
+    """The tokenizer buckets the vocabulary by first byte; the reference (utils.cpp:275-311) tries every token at
+    every position.  Same result by construction -- checked here against a literal restatement of the
+    reference loop on a vocabulary built to be nasty: duplicate strings (the highest id must win), prefixes of
+    one another, empty entries, multi-byte UTF-8, and text with bytes no token starts with (tokenization stops)."""
+    import synth
+    rng = np.random.default_rng(11)
+    alphabet = [b"a", b"b", b"ab", b"abc", b"abcd", b"b", b"bc", b"", b"c", b"ca", b"\xc3\xa9", b"\xc3", b"ab", b" ", b" a", b"abca"]
+    vocab = [b"", b"", b""] + alphabet
+    while len(vocab) < 64:
+        k = int(rng.integers(1, 5))
+        vocab.append(b"".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), k)))
+    hp = synth.HParams(n_vocab=64, n_embd=64, n_mult=32, n_head=1, n_layer=1)
+    path = str(tmp_path / "v.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=1), vocab=vocab)
+    m = L.Model(path, n_ctx=16, flags=HOST_ONLY)
+
+    def reference(text: bytes, bos: bool):
+        res = [1] if bos else []
+        pos = 0
+        while True:
+            best_len, best_id = 0, 0
+            for tid, tok in enumerate(vocab):                     # ascending id, only strictly shorter tokens are skipped
+                if len(tok) < best_len or len(tok) > len(text) - pos:
+                    continue
+                if text[pos:pos + len(tok)] == tok:
+                    best_len, best_id = len(tok), tid
+            if best_len == 0:
+                break
+            res.append(best_id)
+            pos += best_len
+        return res
+
+    texts = [b"", b"abcabcd abca", b"ab ab\xc3\xa9c", b"abzab", b"\xc3\xa9\xc3", b" a a  abcdabcd" * 40]
+    for _ in range(40):
+        k = int(rng.integers(1, 30))
+        texts.append(b"".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), k)))
+    for t in texts:
+        if b"\x00" in t:
+            continue
+        for bos in (True, False):
+            assert m.tokenize(t, bos).tolist() == reference(t, bos), (t, bos)
+
+
 def test_sampler_matches_reference_sequence(L, tmp_path):
     m, _ = _golden_model(L, tmp_path)
     t = np.load(os.path.join(G, "text.npz"))
