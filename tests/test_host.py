@@ -175,6 +175,44 @@ def test_sampler_matches_reference_sequence(L, tmp_path):
     assert got == t["sampler_ids"].tolist()
 
 
+def test_tokenizer_and_sampler_against_the_reference_build(L, ref, tmp_path):
+    """The host utilities next to the reference's OWN utils.cpp (oracle/_ref): random texts over the model's
+    vocabulary, and 400 sampling steps on logits with many exact ties (so that std::partial_sort's handling of
+    equal scores at the top_k boundary matters) and repeated tokens in the penalty window -- same ids, same
+    mt19937 draws.  (The sampler's window lookup is a byte map here, std::find per logit there.)"""
+    import synth
+    m, g = _golden_model(L, tmp_path)
+    rm = ref.load(str(tmp_path / "tiny.bin"), 64)
+    rng = np.random.default_rng(2024)
+    pieces = [m.token_text(i) for i in range(m.n_vocab)]
+    pieces = [p for p in pieces if p and b"\x00" not in p]
+    for _ in range(60):
+        text = b"".join(pieces[int(i)] for i in rng.integers(0, len(pieces), int(rng.integers(1, 40))))
+        try:
+            t = text.decode()
+        except UnicodeDecodeError:
+            continue
+        for bos in (True, False):
+            assert np.array_equal(m.tokenize(text, bos), rm.tokenize(t, bos)), text
+    V = m.n_vocab
+    rl = ref.L
+    rs = rl.refllama_sampler_new(-1, 64)
+    s = L.Sampler(seed=-1, repeat_last_n=64)
+    try:
+        for step in range(400):
+            lg = (rng.integers(-6, 7, V) * 0.5).astype(np.float32)           # 13 distinct values: ties everywhere
+            if step % 3 == 0:
+                lg += rng.standard_normal(V).astype(np.float32) * np.float32(0.01)
+            kw = dict(repeat_penalty=1.3, top_k=int(min(V, rng.integers(1, 41))), top_p=float(np.float32(0.95)), temp=float(np.float32(0.8)))
+            a = s.sample(m, lg, **kw)
+            b = int(rl.refllama_sampler_sample(rm.h, rs, lg, kw["repeat_penalty"], kw["top_k"], kw["top_p"], kw["temp"]))
+            assert a == b, (step, a, b)
+            s.accept(a)
+            rl.refllama_sampler_accept(rs, b)
+    finally:
+        rl.refllama_sampler_free(rs)
+
+
 def test_runner_reports_load_failure_like_the_bridge(L, tmp_path):
     states, tokens = [], []
     r = L.LlamaRunner(str(tmp_path / "missing.bin"))
