@@ -105,6 +105,9 @@ typedef struct llamahip_sampler llamahip_sampler;
 llamahip_sampler *llamahip_sampler_new(int32_t seed, int32_t repeat_last_n);
 void              llamahip_sampler_free(llamahip_sampler *s);
 void              llamahip_sampler_accept(llamahip_sampler *s, int32_t id);   /* .mm:867-868, 882-883 */
+/* gpt_random_prompt(rng)  (utils.cpp:102-119): the prompt the caller substitutes for an empty one (.mm:774-776);
+ * consumes one draw of the sampler's rng, exactly as the reference's shared std::mt19937 does. */
+const char       *llamahip_sampler_random_prompt(llamahip_sampler *s);
 /* llama_sample_top_p_top_k  (utils.cpp:345-428) */
 int32_t llamahip_sample_top_p_top_k(const llamahip_model *m, llamahip_sampler *s, const float *logits,
                                     double repeat_penalty, int32_t top_k, double top_p, double temp);

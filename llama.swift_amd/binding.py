@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
     L.llamahip_sampler_new.restype = vp
     L.llamahip_sampler_free.argtypes = [vp]
     L.llamahip_sampler_accept.argtypes = [vp, i32]
+    L.llamahip_sampler_random_prompt.argtypes = [vp]
+    L.llamahip_sampler_random_prompt.restype = cp
     L.llamahip_sample_top_p_top_k.argtypes = [vp, vp, vp, C.c_double, i32, C.c_double, C.c_double]
     L.llamahip_sample_top_p_top_k.restype = i32
     L.llamahip_decode_greedy.argtypes = [vp, i32, i32, i32, i32, vp, vp, cp, sz]
@@ -327,6 +329,10 @@ class Sampler:
 
     def accept(self, tid: int) -> None:
         lib().llamahip_sampler_accept(self._s, int(tid))
+
+    def random_prompt(self) -> str:
+        """gpt_random_prompt on this sampler's rng (utils.cpp:102-119; .mm:774-776)."""
+        return lib().llamahip_sampler_random_prompt(self._s).decode()
 
     def sample(self, model: Model, logits: np.ndarray, repeat_penalty: float = 1.3, top_k: int = 40,
                top_p: float = float(np.float32(0.95)), temp: float = float(np.float32(0.8))) -> int:

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <random>
@@ -630,8 +631,8 @@ extern "C" {
 
 const char *llamahip_version(void) { return "llamahip 0.1 (gfx950)"; }
 
-int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
-                        llamahip_model **out, char *err, size_t err_cap) {
+static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts *opts,
+                           llamahip_model **out, char *err, size_t err_cap) {
     const double t0 = now_ms();
     if (!out || !path) { set_err(err, err_cap, "null argument"); return LLAMAHIP_ERR_LOAD; }
     *out = nullptr;
@@ -653,6 +654,9 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
         return LLAMAHIP_ERR_LOAD;
     }
     if (F % 8 != 0) { set_err(err, err_cap, "unsupported n_ff %d (must be a multiple of 8)", F); return LLAMAHIP_ERR_LOAD; }
+    // hp.n_rot is read and ignored, like the reference: llama_eval derives the rotated span from
+    // n_embd / n_head (.mm:528) and never looks at the header field (.mm:48,130), so a file whose n_rot
+    // differs evaluates identically there and here
     if (layer_end < 0) layer_end = hp.n_layer;
     if (layer_begin < 0 || layer_begin >= layer_end || layer_end > hp.n_layer) {
         set_err(err, err_cap, "bad layer range [%d, %d) for n_layer %d", layer_begin, layer_end, hp.n_layer);
@@ -710,20 +714,21 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
     for (const auto &kv : m->file.tensors) if (kv.second.q4) max_bytes = std::max(max_bytes, (size_t) kv.second.nbytes());
     uint8_t *d_stage = nullptr;
     HIP_TRY(hipMalloc((void **) &d_stage, std::max<size_t>(max_bytes, 256)), LLAMAHIP_ERR_LOAD);
+    struct StageGuard { uint8_t *&p; ~StageGuard() { if (p) { (void) hipFree(p); p = nullptr; } } } stage_guard{ d_stage };   // freed on every return path
     std::vector<uint8_t> h_stage;
     int rc = 0;
-#define LOAD_TRY(x) do { rc = (x); if (rc != 0) { (void) hipFree(d_stage); return rc; } } while (0)
+#define LOAD_TRY(x) do { rc = (x); if (rc != 0) return rc; } while (0)
 
     if (m->first_stage) {
         const TensorInfo &t = m->file.tensors.at("tok_embeddings.weight");
         h_stage.resize((size_t) t.nbytes());
-        if (!m->file.read_tensor(t.name, h_stage.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); (void) hipFree(d_stage); return LLAMAHIP_ERR_LOAD; }
+        if (!m->file.read_tensor(t.name, h_stage.data(), e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
         HIP_TRY(hipMalloc((void **) &m->tok_emb, h_stage.size()), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemcpy(m->tok_emb, h_stage.data(), h_stage.size(), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
         m->weight_bytes += (int64_t) h_stage.size();
     }
     m->dense = (hp.f16 != 2);
-    if (m->dense && (d % 64 != 0 || F % 64 != 0)) { (void) hipFree(d_stage); set_err(err, err_cap, "f16 / f32 / Q4_1 model: n_embd and n_ff must be multiples of 64"); return LLAMAHIP_ERR_LOAD; }
+    if (m->dense && (d % 64 != 0 || F % 64 != 0)) { set_err(err, err_cap, "f16 / f32 / Q4_1 model: n_embd and n_ff must be multiples of 64"); return LLAMAHIP_ERR_LOAD; }
     m->layers.resize(m->l1 - m->l0);
     if (m->dense) {
         if (m->last_stage) {
@@ -786,6 +791,7 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
     }
 #undef LOAD_TRY
     (void) hipFree(d_stage);
+    d_stage = nullptr;
 
     // ---- KV cache (.mm:290-304); zero-initialised (the reference leaves malloc garbage)
     const size_t kv_elems = (size_t) m->n_seq * (m->l1 - m->l0) * n_ctx * d;
@@ -817,6 +823,21 @@ int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *op
     m->t_load_ms = now_ms() - t0;
     *out = m.release();
     return LLAMAHIP_OK;
+}
+
+// No C++ exception may cross the C ABI (std::bad_alloc on a corrupt header would abort the host process).
+int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
+                        llamahip_model **out, char *err, size_t err_cap) {
+    try {
+        return model_load_impl(path, n_ctx, opts, out, err, err_cap);
+    } catch (const std::exception &ex) {
+        if (out) *out = nullptr;
+        set_err(err, err_cap, "failed to load model '%s': %s", path ? path : "(null)", ex.what());
+    } catch (...) {
+        if (out) *out = nullptr;
+        set_err(err, err_cap, "failed to load model '%s': unknown exception", path ? path : "(null)");
+    }
+    return LLAMAHIP_ERR_LOAD;
 }
 
 void llamahip_model_free(llamahip_model *m) { delete m; }

@@ -20,6 +20,13 @@ struct File {
     bool seek(int64_t off) { return fseeko(f, (off_t) off, SEEK_SET) == 0; }
     bool skip(int64_t n) { return fseeko(f, (off_t) n, SEEK_CUR) == 0; }
     int64_t tell() { return (int64_t) ftello(f); }
+    int64_t size() {                       // -1 if the stream is not seekable
+        const off_t at = ftello(f);
+        if (at < 0 || fseeko(f, 0, SEEK_END) != 0) return -1;
+        const off_t end = ftello(f);
+        (void) fseeko(f, at, SEEK_SET);
+        return (int64_t) end;
+    }
 };
 
 std::string fmt(const char *f, ...) __attribute__((format(printf, 1, 2)));
@@ -84,7 +91,12 @@ bool ModelFile::open(const std::string &path, int32_t n_ctx, int32_t force_parts
     hp.n_vocab = h[0]; hp.n_embd = h[1]; hp.n_mult = h[2]; hp.n_head = h[3];
     hp.n_layer = h[4]; hp.n_rot = h[5]; hp.f16 = h[6];
     hp.n_ctx = n_ctx;
-    if (hp.n_vocab <= 0 || hp.n_embd <= 0 || hp.n_mult <= 0 || hp.n_head <= 0 || hp.n_layer <= 0) {
+    // bounds before anything is sized from the header (a corrupt n_vocab used to reach std::vector::resize):
+    // the same cap as the quantize tool's, and every vocabulary entry needs at least its 4-byte length
+    const int64_t fsize = fin.size();
+    if (hp.n_vocab <= 0 || hp.n_embd <= 0 || hp.n_mult <= 0 || hp.n_head <= 0 || hp.n_layer <= 0 ||
+        hp.n_vocab > (1 << 24) || hp.n_embd > (1 << 20) || hp.n_mult > (1 << 20) || hp.n_head > hp.n_embd || hp.n_layer > (1 << 16) ||
+        (fsize >= 0 && (int64_t) hp.n_vocab * 4 > fsize)) {
         err = fmt("invalid model file '%s' (bad hyper-parameters)", path.c_str());
         return false;
     }

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -37,7 +38,21 @@ bool ends_with_weight(const std::string &name) {          // std::regex_match(na
 
 }  // namespace
 
+static int quantize_file_impl(const char *fname_inp, const char *fname_out, int32_t itype, char *err, size_t err_cap);
+
+// No C++ exception may cross the C ABI.
 extern "C" int llamahip_quantize_file(const char *fname_inp, const char *fname_out, int32_t itype, char *err, size_t err_cap) {
+    try {
+        return quantize_file_impl(fname_inp, fname_out, itype, err, err_cap);
+    } catch (const std::exception &ex) {
+        set_err(err, err_cap, "quantize failed: %s", ex.what());
+    } catch (...) {
+        set_err(err, err_cap, "quantize failed: unknown exception");
+    }
+    return LLAMAHIP_ERR_LOAD;
+}
+
+static int quantize_file_impl(const char *fname_inp, const char *fname_out, int32_t itype, char *err, size_t err_cap) {
     using namespace lh;
     if (!fname_inp || !fname_out) { set_err(err, err_cap, "null file name"); return LLAMAHIP_ERR_LOAD; }
     if (itype != 2 && itype != 3) {                        // quantize.cpp:35-39: 2 = Q4_0, 3 = Q4_1

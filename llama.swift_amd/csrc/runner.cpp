@@ -87,6 +87,15 @@ llamahip_sampler *llamahip_sampler_new(int32_t seed, int32_t repeat_last_n) {
 
 void llamahip_sampler_free(llamahip_sampler *s) { delete s; }
 
+// gpt_random_prompt (utils.cpp:102-119): the prompt -[LlamaPredictOperation main] substitutes for an empty one
+// (.mm:774-776).  It draws from the SAME mt19937 the sampler uses afterwards, so the draw is part of the
+// sampled-token sequence of an empty-prompt run.
+const char *llamahip_sampler_random_prompt(llamahip_sampler *s) {
+    if (!s) return "The";
+    static const char *const prompts[10] = { "So", "Once upon a time", "When", "The", "After", "If", "import", "He", "She", "They" };
+    return prompts[s->rng() % 10];
+}
+
 void llamahip_sampler_accept(llamahip_sampler *s, int32_t id) {
     if (!s || s->last_n_tokens.empty()) return;
     s->last_n_tokens.erase(s->last_n_tokens.begin());
@@ -96,6 +105,10 @@ void llamahip_sampler_accept(llamahip_sampler *s, int32_t id) {
 int32_t llamahip_sample_top_p_top_k(const llamahip_model *m, llamahip_sampler *s, const float *logits,
                                     double repeat_penalty, int32_t top_k, double top_p, double temp) {
     const int n_logits = llamahip_n_vocab(m);
+    if (!s || !logits || n_logits <= 0) return -1;
+    // the reference indexes cand.begin() + top_k unchecked (utils.cpp:389-395: undefined behaviour for a
+    // vocabulary smaller than top_k); clamping changes nothing for real vocabularies
+    top_k = std::min(std::max(top_k, 1), (int32_t) n_logits);
     std::vector<std::pair<double, int32_t>> &cand = s->cand;
     cand.clear();
     cand.reserve(n_logits);
@@ -216,6 +229,8 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     post(LLAMA_EVENT_STARTED_GENERATING_OUTPUT, nullptr, 0, 0);                     // .mm:800
 
     const int32_t n_vocab = llamahip_n_vocab(model);
+    llamahip_sampler *sampler = llamahip_sampler_new(cfg.seed, repeat_last_n);       // rng: .mm:773, window: .mm:827-829
+    if (prompt.empty()) prompt = llamahip_sampler_random_prompt(sampler);             // .mm:774-776 (one rng draw)
     std::vector<int32_t> embd_inp(prompt.size() + 2);
     const int32_t n_inp = llamahip_tokenize(model, prompt.c_str(), 1, embd_inp.data(), (int32_t) embd_inp.size());   // .mm:810
     embd_inp.resize(n_inp);
@@ -228,6 +243,7 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     std::vector<float> logits(n_vocab);
     auto fail = [&](void) {
         post(LLAMA_EVENT_FAILED, err, (uint32_t) strlen(err), LLAMAHIP_ERR_PREDICT);
+        llamahip_sampler_free(sampler);
         release();
         return (int32_t) LLAMAHIP_ERR_PREDICT;
     };
@@ -237,16 +253,12 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
         if (n_ctx >= 4 && llamahip_eval(model, n_threads, 0, warm, 4, logits.data(), err, sizeof(err)) != 0) return fail();
     }
 
-    llamahip_sampler *sampler = llamahip_sampler_new(cfg.seed, repeat_last_n);
     std::vector<int32_t> embd;
     int32_t n_past = 0, remaining = n_predict;
     size_t consumed = 0;
     while (remaining > 0) {                                                         // .mm:834
         if (!embd.empty()) {
-            if (llamahip_eval(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), logits.data(), err, sizeof(err)) != 0) {
-                llamahip_sampler_free(sampler);
-                return fail();
-            }
+            if (llamahip_eval(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), logits.data(), err, sizeof(err)) != 0) return fail();
         }
         n_past += (int32_t) embd.size();
         embd.clear();

@@ -513,6 +513,14 @@ void refllama_sampler_accept(void * sp, int32_t id) { // .mm:867-868 / 882-883
     s->last_n.erase(s->last_n.begin());
     s->last_n.push_back(id);
 }
+// gpt_random_prompt(rng) on the sampler's rng: what -[LlamaPredictOperation main] does for an empty prompt
+// (.mm:774-776) -- the draw comes out of the same mt19937 the sampler uses afterwards
+int refllama_sampler_random_prompt(void * sp, char * out, int cap) {
+    RefSampler * s = (RefSampler *) sp;
+    const std::string p = gpt_random_prompt(s->rng);
+    snprintf(out, cap, "%s", p.c_str());
+    return (int) p.size();
+}
 int32_t refllama_sampler_sample(void * h, void * sp, const float * logits,
                                 double repeat_penalty, int top_k, double top_p, double temp) {
     RefModel * m = (RefModel *) h;

@@ -64,6 +64,7 @@ class RefLib:
         L.refllama_sampler_new.argtypes = [C.c_int32, C.c_int]
         L.refllama_sampler_free.argtypes = [C.c_void_p]
         L.refllama_sampler_accept.argtypes = [C.c_void_p, C.c_int32]
+        L.refllama_sampler_random_prompt.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.refllama_sampler_sample.restype = C.c_int32
         L.refllama_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, f32p, C.c_double, C.c_int, C.c_double, C.c_double]
         L.ref_init_tables()

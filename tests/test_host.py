@@ -213,6 +213,71 @@ def test_tokenizer_and_sampler_against_the_reference_build(L, ref, tmp_path):
         rl.refllama_sampler_free(rs)
 
 
+def test_empty_prompt_draws_the_reference_random_prompt(L, ref, tmp_path):
+    """-[LlamaPredictOperation main] replaces an empty prompt by gpt_random_prompt(rng) (.mm:774-776), which
+    consumes one draw of the rng the sampler uses afterwards: same prompt, same sampled ids after it."""
+    import ctypes as C
+    m, _ = _golden_model(L, tmp_path)
+    rm = ref.load(str(tmp_path / "tiny.bin"), 64)
+    rng = np.random.default_rng(5)
+    for seed in (-1, 0, 1, 7, 12345):
+        s = L.Sampler(seed=seed, repeat_last_n=64)
+        rs = ref.L.refllama_sampler_new(seed, 64)
+        try:
+            buf = C.create_string_buffer(64)
+            ref.L.refllama_sampler_random_prompt(rs, buf, 64)
+            assert s.random_prompt() == buf.value.decode()
+            for _ in range(8):
+                lg = rng.standard_normal(m.n_vocab).astype(np.float32)
+                a = s.sample(m, lg)
+                b = int(ref.L.refllama_sampler_sample(rm.h, rs, lg, 1.3, 40, float(np.float32(0.95)), float(np.float32(0.8))))
+                assert a == b
+                s.accept(a); ref.L.refllama_sampler_accept(rs, b)
+        finally:
+            ref.L.refllama_sampler_free(rs)
+
+
+def test_sampler_clamps_top_k_to_the_vocabulary(L, tmp_path):
+    """top_k larger than the vocabulary (the bridge hard-codes 40; the reference reads past its candidate
+    array there, utils.cpp:389-395) must still return a valid id."""
+    import synth
+    hp = synth.HParams(n_vocab=32, n_embd=128, n_mult=64, n_head=1, n_layer=1)
+    path = str(tmp_path / "v32.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=2))
+    rng = np.random.default_rng(1)
+    with L.Model(path, n_ctx=8, flags=4) as m:
+        s = L.Sampler(seed=3, repeat_last_n=64)
+        for _ in range(50):
+            tid = s.sample(m, rng.standard_normal(32).astype(np.float32), top_k=40)
+            assert 0 <= tid < 32
+            s.accept(tid)
+        assert 0 <= s.sample(m, rng.standard_normal(32).astype(np.float32), top_k=0) < 32
+
+
+def test_corrupt_headers_are_load_errors_not_aborts(L, tmp_path):
+    """A header with an absurd n_vocab used to reach std::vector::resize and abort the host process through
+    the C ABI.  The header's n_rot is NOT validated: the reference reads it (.mm:130) and then rotates
+    n_embd / n_head dims regardless (.mm:528), so any value loads and evaluates identically."""
+    import synth
+    hp = synth.HParams(n_vocab=64, n_embd=128, n_mult=64, n_head=1, n_layer=1)
+    path = str(tmp_path / "ok.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=2))
+    raw = bytearray(open(path, "rb").read())
+    bad = bytearray(raw); bad[4:8] = (0x7fffffff).to_bytes(4, "little")           # n_vocab
+    open(str(tmp_path / "bad_vocab.bin"), "wb").write(bad)
+    with pytest.raises(L.LlamaHipError, match="bad hyper-parameters") as e:
+        L.Model(str(tmp_path / "bad_vocab.bin"), n_ctx=8, flags=4)
+    assert e.value.code == -1000
+    bad = bytearray(raw); bad[4:8] = (1 << 23).to_bytes(4, "little")              # plausible count, file far too short
+    open(str(tmp_path / "bad_vocab2.bin"), "wb").write(bad)
+    with pytest.raises(L.LlamaHipError):
+        L.Model(str(tmp_path / "bad_vocab2.bin"), n_ctx=8, flags=4)
+    odd = bytearray(raw); odd[24:28] = (7).to_bytes(4, "little")                  # n_rot (6th hparam): ignored as in the reference
+    open(str(tmp_path / "odd_rot.bin"), "wb").write(odd)
+    with L.Model(str(tmp_path / "odd_rot.bin"), n_ctx=8, flags=4) as m:
+        assert m.n_embd == 128
+
+
 def test_runner_reports_load_failure_like_the_bridge(L, tmp_path):
     states, tokens = [], []
     r = L.LlamaRunner(str(tmp_path / "missing.bin"))
