@@ -73,10 +73,11 @@ def lib() -> C.CDLL:
     # runtime first, a later torch.cuda init would pair it with torch's bundled HSA runtime and find
     # no GPUs -- so when torch is installed, let it load its runtime first (torch is only plumbing
     # here: device tensors for the pipeline hand-off and torch.distributed).
-    try:
-        import torch  # noqa: F401
-    except Exception:
-        pass
+    if not os.environ.get("LLAMAHIP_NO_TORCH"):          # (measurement tools that never touch torch skip its slow import)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, cp, sz = C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t
     L.llamahip_version.restype = cp

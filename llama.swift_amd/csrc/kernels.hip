@@ -46,6 +46,7 @@ namespace lh {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 typedef float    f32x2 __attribute__((ext_vector_type(2)));
+typedef double   f64x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -146,6 +147,18 @@ __device__ double block_sum_d(double v, double *red, int phase = 0) {
     double s = 0.0;
     for (int i = 0; i < nw; i++) s += r[i];
     return s;
+}
+// two sums with one barrier (at most 8 waves: 16 doubles per phase)
+__device__ void block_sum_d2(double &a, double &b, double *red, int phase = 0) {
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    double *r = red + (phase & 1) * 16;
+    if ((threadIdx.x & 63) == 0) { r[2 * w] = a; r[2 * w + 1] = b; }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < nw; i++) { sa += r[2 * i]; sb += r[2 * i + 1]; }
+    a = sa; b = sb;
 }
 __device__ float block_max_f(float v, double *red, int phase = 0) {
     v = wave_max_f(v);
@@ -273,6 +286,32 @@ __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__res
     }
 }
 
+// decode: the embedding row of one token, plus the {sum x, sum x^2} pair (double) the first layer's norm-fused
+// mat-vec folds instead of reducing the row itself (PREP_NORMP).  One workgroup; same dequantization.
+__global__ void __launch_bounds__(256)
+k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb, float *__restrict__ x, int d,
+             f64x2 *__restrict__ part_out) {
+    __shared__ double red[32];
+    const int tok = tokens[0];
+    const uint8_t *row = emb + (size_t) tok * (d / 32) * 20;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < d / 2; i += blockDim.x) {       // one byte = two elements
+        const int b = i >> 4, j = i & 15;
+        const uint8_t *blk = row + b * 20;
+        const uint32_t bits = blk[0] | (blk[1] << 8) | (blk[2] << 16) | ((uint32_t) blk[3] << 24);
+        const float dd = __builtin_bit_cast(float, bits);
+        const uint32_t q = blk[4 + j];
+        const float v0 = (float) ((int) (q & 0xF) - 8) * dd, v1 = (float) ((int) (q >> 4) - 8) * dd;
+        x[2 * i + 0] = v0;
+        x[2 * i + 1] = v1;
+        s1 += (double) v0; s1 += (double) v1;
+        s2 += (double) v0 * (double) v0; s2 += (double) v1 * (double) v1;
+    }
+    s1 = block_sum_d(s1, red, 0);
+    s2 = block_sum_d(s2, red, 1);
+    if (threadIdx.x == 0) part_out[0] = f64x2{ s1, s2 };
+}
+
 // ------------------------------------------------------------------------------------------------
 // activation preparation: [norm * weight | silu(gate) * up | plain]  ->  Q4_0 activation operands
 // ------------------------------------------------------------------------------------------------
@@ -320,7 +359,10 @@ constexpr int LB_DEFAULT = 8;
 // layout: [0] = launch counter, [1] = capacity, entry e at 8*(1+e): {5 stamps, ngroups, nchunks, PRE*16+EPI}
 __device__ unsigned long long *g_phase_probe = nullptr;
 #if LH_PHASE_PROBE
-#if LH_PHASE_PROBE == 2      /* prologue detail: entry | ring issued | mean known | scale known | prologue done */
+#if LH_PHASE_PROBE == 3      /* timeline: EVERY workgroup appends {5 stamps, kind << 32 | block, ngroups << 32 | nchunks, wall clock} */
+#define LH_STAMP(IDX) do { probe_t[IDX] = __builtin_readcyclecounter(); } while (0)
+#define LH_STAMP2(IDX) do { } while (0)
+#elif LH_PHASE_PROBE == 2      /* prologue detail: entry | ring issued | mean known | scale known | prologue done */
 #define LH_STAMP(IDX) do { if (probe_e && (IDX) < 2) probe_e[IDX] = __builtin_readcyclecounter(); } while (0)
 #define LH_STAMP2(IDX) do { if (probe_e) probe_e[IDX] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -672,7 +714,8 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
        const float *__restrict__ in0, const float *__restrict__ in1, int K,
        float *__restrict__ y, const float *__restrict__ resid,
        const uint16_t *__restrict__ T_silu,
-       uint32_t *__restrict__ out_A, float *__restrict__ out_d) {
+       uint32_t *__restrict__ out_A, float *__restrict__ out_d,
+       const f64x2 *__restrict__ part_in, int npart, f64x2 *__restrict__ part_out) {
     extern __shared__ double smem_d[];
     // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
     // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
@@ -691,7 +734,10 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     //  block: hoisted out of it they become 64-bit VGPR pairs and the SGPR-base addressing no longer matches)
     uint32_t vw_ = voff_w, vs_ = voff_s;
 #define LH_OPAQUE_OFFSETS() { vw_ = voff_w; vs_ = voff_s; asm volatile("" : "+v"(vw_), "+v"(vs_)); }
-#if LH_PHASE_PROBE
+#if LH_PHASE_PROBE == 3
+    unsigned long long probe_t[5] = { 0, 0, 0, 0, 0 };
+    const unsigned long long probe_wall = wall_clock64();
+#elif LH_PHASE_PROBE
     unsigned long long *probe_e = nullptr;
     if (g_phase_probe && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
         unsigned long long *pb = g_phase_probe;
@@ -722,8 +768,9 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     // whole norm -> quantize pipeline stays in registers (no LDS staging of y, no one-thread-per-block
     // serial quantizer: the prologue is VALU work repeated by every workgroup, so its instruction
     // count matters as much as the mat-vec's).
-    constexpr bool REGPRE = (PRE == PRE_QA || PRE == PREP_NORM || PRE == PREP_PLAIN);
-    constexpr int MAXH = (PRE == PREP_NORM || PRE == PREP_PLAIN) ? PG : 1;   // half-block granules per thread
+    constexpr bool NORMLIKE = (PRE == PREP_NORM || PRE == PREP_NORMP);
+    constexpr bool REGPRE = (PRE == PRE_QA || NORMLIKE || PRE == PREP_PLAIN);
+    constexpr int MAXH = (NORMLIKE || PRE == PREP_PLAIN) ? PG : 1;   // half-block granules per thread
     constexpr int MAXQA = (PRE == PRE_QA) ? PG : 1, MAXQD = (PG + 7) / 8;    // QA granules per thread (da is 1/8 of A)
     f32x4 xa[MAXH][4], xb[MAXH][4];
     u32x4 qg[MAXQA], qh[MAXQD];
@@ -731,18 +778,33 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     const int nh = K >> 4;                                   // half-blocks in the row
     // (trip counts are wave-uniform; a skipped load only makes the compiler's vmcnt for these
     //  prologue loads stricter -- they are all older than the weight loads, which stay in flight)
-    if (PRE == PREP_NORM || PRE == PREP_PLAIN) {
+    // PREP_NORMP: the producer of the row (an EPI_RESID mat-vec, or k_embed_part) left per-workgroup
+    // {sum x, sum x^2} in double; wave 0 folds them (same data, same order in every workgroup -> identical
+    // statistics everywhere) and the row itself is never reduced.  PNP pairs per lane cover up to 64 * PNP
+    // producer workgroups.
+    constexpr int PNP = (PRE == PREP_NORMP) ? 8 : 1;
+    f64x2 pp[PNP];
+    const int npl = (npart + 63) >> 6;
+    if (NORMLIKE || PRE == PREP_PLAIN) {
         const int ng = (nh + nt - 1) / nt;
 #pragma unroll
         for (int u = 0; u < MAXH; u++) {
-            if (u < ng) {
+            // (waves whose granules all lie past the row issue nothing: w1|w3 runs 8 waves on a 4-wave row)
+            if (u < ng && (tid & ~63) + u * nt < nh) {
                 const int hi = min(tid + u * nt, nh - 1);
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     xa[u][v] = ((const f32x4 *) in0)[hi * 4 + v];
-                    if (PRE == PREP_NORM) xb[u][v] = ((const f32x4 *) in1)[hi * 4 + v];
+                    if (NORMLIKE) xb[u][v] = ((const f32x4 *) in1)[hi * 4 + v];
                 }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; v++) { xa[u][v] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; xb[u][v] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; }
             }
+        }
+        if (PRE == PREP_NORMP && wave == 0) {          // one wave folds the pairs for the workgroup
+#pragma unroll
+            for (int u = 0; u < PNP; u++) if (u < npl) pp[u] = part_in[min(lane + u * 64, npart - 1)];
         }
     }
     // the residual operand of the epilogue is fetched here too, not at the end of the kernel where it
@@ -781,16 +843,44 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         for (int u = 0; u < MAXQD; u++) { const int gi = tid + u * nt; if (gi < nchunks * 2) ((u32x4 *) ldsD)[gi] = qh[u]; }
         __syncthreads();
     } else if (REGPRE) {
-        if (PRE == PREP_NORM) {
+        if (NORMLIKE) {
             // ggml_norm + ggml_mul (ggml.c:5327-5385, :4555) on register-resident x
-            double s1 = 0.0;
+            // The statistics: S1 = sum x, S2 = sum x^2 (double; x^2 is exact there), either handed over by the
+            // producer (PREP_NORMP) or reduced here with ONE barrier.  Then
+            //     mean = S1 / K,   sum (x - mean)^2 = S2 - mean * S1.
+            // Both forms of the second moment carry a few 2^-53 of rounding (the reference's own sum rounds every
+            // (x - mean)^2 and every addition) and the result is narrowed to fp32 afterwards: the same class of
+            // agreement as the re-ordered double sums this prologue always had (DESIGN.md "norm").  When the mean
+            // dominates (K * mean^2 above a quarter of sum x^2) the subtraction would cancel, and the reference's
+            // two-pass form runs instead (also with npart < 0: measurement switch).
+            double S1 = 0.0, S2 = 0.0;
+            if (PRE == PREP_NORMP) {
+                if (wave == 0) {
 #pragma unroll
-            for (int u = 0; u < MAXH; u++)
-                if (tid + u * nt < nh) {
-#pragma unroll
-                    for (int v = 0; v < 4; v++) { s1 += (double) xa[u][v].x; s1 += (double) xa[u][v].y; s1 += (double) xa[u][v].z; s1 += (double) xa[u][v].w; }
+                    for (int u = 0; u < PNP; u++)
+                        if (u < npl && lane + u * 64 < npart) { S1 += pp[u].x; S2 += pp[u].y; }
+                    S1 = wave_sum_d(S1);
+                    S2 = wave_sum_d(S2);
+                    if (lane == 0) { red[0] = S1; red[1] = S2; }
                 }
-            const double mean = block_sum_d(s1, red, 0) / (double) K;
+                __syncthreads();
+                S1 = red[0]; S2 = red[1];
+            } else {
+#pragma unroll
+                for (int u = 0; u < MAXH; u++)
+                    if (tid + u * nt < nh) {
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            const double x0 = (double) xa[u][v].x, x1 = (double) xa[u][v].y, x2 = (double) xa[u][v].z, x3 = (double) xa[u][v].w;
+                            S1 += x0; S1 += x1; S1 += x2; S1 += x3;
+                            S2 = __builtin_fma(x0, x0, S2); S2 = __builtin_fma(x1, x1, S2); S2 = __builtin_fma(x2, x2, S2); S2 = __builtin_fma(x3, x3, S2);
+                        }
+                    }
+                block_sum_d2(S1, S2, red, 0);
+            }
+            const double mean = S1 / (double) K;
+            double sum2 = __builtin_fma(-mean, S1, S2);
+            const bool fast = npart >= 0 && mean * S1 <= 0.25 * S2;        // (false for NaNs too); identical in every wave of the launch
             LH_STAMP2(2);
             double s2 = 0.0;
 #pragma unroll
@@ -801,10 +891,10 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
                         const double v0 = (double) xa[u][v].x - mean, v1 = (double) xa[u][v].y - mean;
                         const double v2 = (double) xa[u][v].z - mean, v3 = (double) xa[u][v].w - mean;
                         xa[u][v].x = (float) v0; xa[u][v].y = (float) v1; xa[u][v].z = (float) v2; xa[u][v].w = (float) v3;
-                        s2 += v0 * v0; s2 += v1 * v1; s2 += v2 * v2; s2 += v3 * v3;
+                        if (!fast) { s2 += v0 * v0; s2 += v1 * v1; s2 += v2 * v2; s2 += v3 * v3; }
                     }
                 }
-            const double sum2 = block_sum_d(s2, red, 1);
+            if (!fast) sum2 = block_sum_d(s2, red, 1);
             const float scale = (float) (1.0 / sqrt(sum2 / (double) K + (double) 1e-5f));
             LH_STAMP2(3);
 #pragma unroll
@@ -959,11 +1049,42 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             if (lane == 0) out_d[b] = dd;
             if (y && lane < 32) y[b * 32 + i] = act;
         }
-    } else if (valid && k == 0 && m < M) {
+    } else {
+        const bool live = valid && k == 0 && m < M;
         if (EPI == EPI_RESID) acc = acc + resid_v;
-        y[m] = acc;
+        if (live) y[m] = acc;
+        if (EPI == EPI_RESID && part_out) {
+            // this workgroup's share of the next norm's statistics (consumed by a PREP_NORMP prologue): sum y and
+            // sum y^2 over its rows, in double (y^2 is exact there), folded in a fixed order
+            const double yd = live ? (double) acc : 0.0;
+            const double s1 = wave_sum_d(yd), s2 = wave_sum_d(yd * yd);
+            if (nw == 1) {
+                if (lane == 0) part_out[blockIdx.x] = f64x2{ s1, s2 };
+            } else {
+                if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
+                __syncthreads();
+                if (tid == 0) {
+                    double t1 = red[0], t2 = red[1];
+                    for (int w2_ = 1; w2_ < nw; w2_++) { t1 += red[2 * w2_]; t2 += red[2 * w2_ + 1]; }
+                    part_out[blockIdx.x] = f64x2{ t1, t2 };
+                }
+            }
+        }
     }
     LH_STAMP(4);
+#if LH_PHASE_PROBE == 3
+    if (g_phase_probe && threadIdx.x == 0) {
+        unsigned long long *pb = g_phase_probe;
+        const unsigned long long slot = atomicAdd(pb, 1ull);
+        if (slot < pb[1]) {
+            unsigned long long *e = pb + 8 * (1 + slot);
+            for (int i = 0; i < 5; i++) e[i] = probe_t[i];
+            e[5] = ((unsigned long long) (PRE * 16 + EPI) << 48) | ((unsigned long long) nchunks << 32) | blockIdx.x;
+            e[6] = wall_clock64();          // s_memtime is per-XCD: launches are lined up on the 100 MHz wall clock
+            e[7] = probe_wall;
+        }
+    }
+#endif
 }
 
 // Prompt path on the decode tiles (runs when the handle has no row-lane copy): NC activation rows
@@ -2442,6 +2563,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PRE_QA, EPI_STORE, 4); LH_ATTR_G1(PRE_QA, EPI_STORE, 12); LH_ATTR_G1(PRE_QA, EPI_RESID, 4); LH_ATTR_G1(PRE_QA, EPI_RESID, 12);
     LH_ATTR_G1(PREP_NORM, EPI_STORE, 1); LH_ATTR_G1(PREP_NORM, EPI_STORE, 2); LH_ATTR_G1(PREP_PLAIN, EPI_RESID, 1); LH_ATTR_G1(PREP_PLAIN, EPI_RESID, 2);
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
+    LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
@@ -2476,6 +2598,12 @@ hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int
 }
 
 size_t prep_lds_bytes(int K) { return 32 * sizeof(double) + ((size_t) K + K / 32 + 64) * sizeof(float); }
+
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_embed_part, dim3(1), dim3(256), 0, st, token, emb, x, d, (f64x2 *) part_out);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
 
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
@@ -2554,12 +2682,13 @@ template <int PRE, int EPI, int PG>
 static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, const float *qa_d,
                                  const float *in0, const float *in1, float *y, const float *resid,
                                  const uint16_t *T_silu,
-                                 uint32_t *out_A, float *out_d, hipStream_t st) {
+                                 uint32_t *out_A, float *out_d, const NormPart &np, hipStream_t st) {
     const int grid = (w.ngroups + nw - 1) / nw;
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     if (PRE == PREP_SILU_MUL) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
-#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d)
+#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d, (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out)
+    if (np.out && grid > NORM_PART_MAX) return hipErrorInvalidValue;
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
     static const bool no_full = getenv("LLAMAHIP_NO_FULL") != nullptr;      // tuning override (measurement only)
@@ -2584,12 +2713,37 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
 // Workgroup size and prologue register budget.  fp32 prologues (norm / plain) keep K/4 float4
 // granules in registers, PRE_QA keeps the nchunks*16 granules of the A array: small budgets (PG 4)
 // keep the kernel near 128 VGPRs so 4 waves per SIMD stay resident; the large budget covers wide rows.
+// workgroup size of the decode mat-vec for a (prologue, matrix) pair -- also what sizes the partial-sum
+// array an EPI_RESID launch writes (gemv_resid_parts)
+static int gemv_pick_nw_qa(const QMat &w, int *pg) {
+    static const int resid_waves = getenv("LLAMAHIP_QA_WAVES") ? atoi(getenv("LLAMAHIP_QA_WAVES")) : 0;      // tuning override (measurement only)
+    if ((resid_waves == 2 || resid_waves == 4) && w.nchunks * 16 <= 4 * resid_waves * 64) { *pg = 4; return resid_waves; }
+    int nw = pick_waves(w.ngroups);
+    const int need = w.nchunks * 16;
+    // two waves share a staged operand where one would do (7B wo: 5.4 -> 5.15 us in situ, and half as many
+    // partial-sum pairs for the next norm to fold)
+    if (nw < 2 && resid_waves != 1) nw = 2;
+    // prefer the small budget; grow the workgroup (up to 4 waves) before growing the budget
+    while (nw < 4 && need > 4 * nw * 64) nw *= 2;
+    if (need <= 4 * nw * 64) { *pg = 4; return nw; }
+    nw = pick_waves(w.ngroups);
+    while (nw < 4 && need > 12 * nw * 64) nw *= 2;
+    if (need <= 12 * nw * 64) { *pg = 12; return nw; }
+    *pg = 0;
+    return 0;
+}
+int gemv_resid_parts(const QMat &w) {
+    int pg = 0;
+    const int nw = gemv_pick_nw_qa(w, &pg);
+    return nw ? (w.ngroups + nw - 1) / nw : 0;
+}
+
 template <int PRE, int EPI>
 static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float *qa_d,
                                 const float *in0, const float *in1, float *y, const float *resid,
                                 const uint16_t *T_silu,
-                                uint32_t *out_A, float *out_d, hipStream_t st) {
-#define LH_PGARGS w, nw, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, st
+                                uint32_t *out_A, float *out_d, const NormPart &np, hipStream_t st) {
+#define LH_PGARGS w, nw, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, np, st
     if constexpr (EPI == EPI_SILU_QA) {
         // 8 waves = 4 gate row-groups + the 4 matching up row-groups (interleaved layout)
         const int nw = 8;
@@ -2601,13 +2755,10 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
     } else {
         int nw = pick_waves(w.ngroups);
         if constexpr (PRE == PRE_QA) {
-            const int need = w.nchunks * 16;
-            // prefer the small budget; grow the workgroup (up to 4 waves) before growing the budget
-            while (nw < 4 && need > 4 * nw * 64) nw *= 2;
-            if (need <= 4 * nw * 64) return launch_gemv_pg<PRE, EPI, 4>(LH_PGARGS);
-            nw = pick_waves(w.ngroups);
-            while (nw < 4 && need > 12 * nw * 64) nw *= 2;
-            if (need <= 12 * nw * 64) return launch_gemv_pg<PRE, EPI, 12>(LH_PGARGS);
+            int pg = 0;
+            nw = gemv_pick_nw_qa(w, &pg);
+            if (pg == 4) return launch_gemv_pg<PRE, EPI, 4>(LH_PGARGS);
+            if (pg == 12) return launch_gemv_pg<PRE, EPI, 12>(LH_PGARGS);
         } else {
             const int need = w.K / 16;            // half-block granules (32 VGPRs each with the norm weight)
             while (nw < 4 && need > 1 * nw * 64) nw *= 2;
@@ -2622,13 +2773,22 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu,
-                       uint32_t *out_A, float *out_d, hipStream_t st) {
-#define LH_ARGS w, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, st
+                       uint32_t *out_A, float *out_d, hipStream_t st, const NormPart *npp) {
+    // LLAMAHIP_NORM_MODE (measurement only): 0 = the reference's two-pass statistics in the prologue, 1 = one-pass
+    // statistics in the prologue, 2 (default) = statistics handed over by the producer where the caller offers them
+    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;
+    NormPart np = npp ? *npp : NormPart();
+    if (norm_mode < 2) np = NormPart();
+    if (pre == PREP_NORM && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX) pre = PREP_NORMP;
+    else { np.in = nullptr; np.n_in = norm_mode == 0 ? -1 : 0; }
+#define LH_ARGS w, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, np, st
     // only the (prologue, epilogue) pairs the forward pass uses are instantiated
     if (pre == PRE_QA && epi == EPI_STORE)        return launch_gemv_t<PRE_QA, EPI_STORE>(LH_ARGS);
     if (pre == PRE_QA && epi == EPI_RESID)        return launch_gemv_t<PRE_QA, EPI_RESID>(LH_ARGS);
     if (pre == PREP_NORM && epi == EPI_STORE)     return launch_gemv_t<PREP_NORM, EPI_STORE>(LH_ARGS);
     if (pre == PREP_NORM && epi == EPI_SILU_QA)   return launch_gemv_t<PREP_NORM, EPI_SILU_QA>(LH_ARGS);
+    if (pre == PREP_NORMP && epi == EPI_STORE)    return launch_gemv_t<PREP_NORMP, EPI_STORE>(LH_ARGS);
+    if (pre == PREP_NORMP && epi == EPI_SILU_QA)  return launch_gemv_t<PREP_NORMP, EPI_SILU_QA>(LH_ARGS);
     if (pre == PREP_PLAIN && epi == EPI_RESID)    return launch_gemv_t<PREP_PLAIN, EPI_RESID>(LH_ARGS);
     if (pre == PREP_SILU_MUL && epi == EPI_RESID) return launch_gemv_t<PREP_SILU_MUL, EPI_RESID>(LH_ARGS);
 #undef LH_ARGS

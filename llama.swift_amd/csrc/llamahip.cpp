@@ -163,6 +163,8 @@ struct llamahip_model {
     uint32_t *qa1_A = nullptr, *qa2_A = nullptr;   // QA operands: attention output (K = d), FFN activation (K = F)
     float *qa1_d = nullptr, *qa2_d = nullptr;
     bool w13_interleaved = false;
+    double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
+                                                     // a: of the row in x (attention / final norm), b: of the row in x1 (ffn norm)
     int n_seq = 1, cur_seq = 0;          // KV caches: [seq][layer][n_ctx][d]
     AttnWs attn_ws;                      // many-row prompt attention workspace (allocated with the first eval of >= 32 tokens)
     std::map<int, hipGraphExec_t> decode_graphs;   // keyed by nth * 4096 + seq
@@ -204,6 +206,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens);
+    free_dev(npart_a); free_dev(npart_b);
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
     for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
@@ -482,7 +485,17 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     int32_t *state = (io && io->state) ? io->state : m->d_state;
     const float *x_first = (io && fused && m->l1 > m->l0) ? io->x_first : nullptr;
     float *x_last = (io && fused && m->l1 > m->l0) ? io->x_last : nullptr;
+    // decode: the producer of every residual-stream row (embedding, wo and w2 mat-vecs) hands {sum, sum of
+    // squares} of the row to the norm-fused mat-vec that consumes it, which then needs no reduction of its own
+    // (k_gemv PREP_NORMP).  LLAMAHIP_NORM_MODE=0 / 1 restore the self-contained prologues (measurement only).
+    static const bool no_norm_part = getenv("LLAMAHIP_NORM_MODE") && atoi(getenv("LLAMAHIP_NORM_MODE")) < 2;
+    const bool use_part = fused && m->w13_interleaved && !no_norm_part;
+    int n_part_x = 0;                                       // pairs in npart_a valid for the row currently in x (0: none)
     if (m->first_stage) {
+        if (use_part) {
+            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st), LLAMAHIP_ERR_PREDICT);
+            n_part_x = 1;
+        } else
         HIP_TRY(launch_embed((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
     } else if (!x_first) {
         HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
@@ -499,12 +512,20 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             // the context position is read from m->d_state by the attention kernels
             const float *xa = (il == m->l0 && x_first) ? x_first : m->x;      // residual stream into this layer
             float *xo = (il == m->l1 - 1 && x_last) ? x_last : m->x;           // ... and out of it
-            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            NormPart np_qkv, np_wo, np_w13, np_w2;
+            if (use_part) {
+                const int pw = gemv_resid_parts(L.wo), p2 = gemv_resid_parts(L.w2);
+                if (n_part_x > 0) { np_qkv.in = m->npart_a; np_qkv.n_in = n_part_x; }
+                if (pw > 0 && pw <= NORM_PART_MAX) { np_wo.out = m->npart_b; np_w13.in = m->npart_b; np_w13.n_in = pw; }
+                n_part_x = 0;
+                if (p2 > 0 && p2 <= NORM_PART_MAX) { np_w2.out = m->npart_a; n_part_x = p2; }
+            }
+            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo), LLAMAHIP_ERR_PREDICT);
             if (m->w13_interleaved) {
-                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, st), LLAMAHIP_ERR_PREDICT);
-                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, st, &np_w13), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, nullptr, nullptr, st, &np_w2), LLAMAHIP_ERR_PREDICT);
             } else {
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
                 HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, xo, m->x1, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
@@ -585,7 +606,9 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         // last (.mm:724-725); only the last row is computed here unless every row is requested.
         const int V = hp.n_vocab;
         if (fused) {
-            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
+            NormPart np_out;
+            if (n_part_x > 0 && m->l1 > m->l0) { np_out.in = m->npart_a; np_out.n_in = n_part_x; }      // (x_last is null on the last stage: the row is in m->x)
+            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, nullptr, nullptr, st, &np_out), LLAMAHIP_ERR_PREDICT);
         } else if (want_all) {
             HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, N, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
@@ -806,6 +829,10 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipMemset(m->d_state, 0, 2 * sizeof(int32_t)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->sc, (size_t) H * n_ctx * 4), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->part, (size_t) H * 64 * dh * 4), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->npart_a, 0, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->npart_b, 0, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->qa1_A, Kp_d), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->qa1_d, Kp_d / 32 * 4), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->qa2_A, Kp_F), LLAMAHIP_ERR_LOAD);

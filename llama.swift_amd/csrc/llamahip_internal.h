@@ -9,7 +9,8 @@ namespace lh {
 constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 64 fp32 scales
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
-enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3 };
+// (PREP_NORMP: PREP_NORM with the row's {sum x, sum x^2} supplied by its producer -- k_gemv only, selected by launch_gemv)
+enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3 };
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
 struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; };
@@ -65,9 +66,19 @@ hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
                        hipStream_t st);
+// Norm statistics handed from the producer of a residual-stream row to the norm-fused mat-vec that reads it
+// (decode only): an EPI_RESID launch with `out` set writes one {sum y, sum y^2} pair of doubles per workgroup
+// (gemv_resid_parts(w) of them); a PREP_NORM launch with `in` / `n_in` set folds them instead of reducing the
+// row itself.  n_in <= NORM_PART_MAX.
+constexpr int NORM_PART_MAX = 512;
+struct NormPart { const double *in = nullptr; int n_in = 0; double *out = nullptr; };
+int gemv_resid_parts(const QMat &w);
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
-                       const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st);
+                       const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
+                       const NormPart *np = nullptr);
+// embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st);
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st,
