@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- decode tokens/sec of the Q4_0 LLaMA hot path on MI355X + HBM roofline of the GEMV.
+"""bench.py -- decode tokens/sec of the Q4_0 LLaMA hot path on MI355X + the HBM roofline of its mat-vecs.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched through
 ``python -m torch.distributed.run --nproc-per-node N ...``); rank 0 prints ONE JSON line.
@@ -12,19 +12,36 @@ the prompt is synthetic token ids.  One *step* = one decoded token = one pass of
 next step on the device.  `value` = tokens/s with everything resident in HBM (logits are not copied
 back per token inside the timed region; the PCIe-inclusive rate is reported as `value_pcie`).
 
-N > 1: the model is layer-sharded into N pipeline stages (one process per GPU); N independent
-greedy sequences are kept in flight round-robin so every stage is busy, and the residual stream
-crosses stages with point-to-point RCCL send/recv.  value = all sequences'
-tokens / time, scaling = "weak" (one sequence per GPU).
+Objects next to the contract's fields (N = 1):
+  roofline      the dominant kernel of the decode step AS IT RUNS IN THE STEP: the w1|w3 mat-vec with its norm
+                prologue and SiLU*up -> Q4_0 epilogue.  Its average duration (and that of every other launch of
+                the captured step) comes from a rocprofv3 --kernel-trace run of the same decode loop in a child
+                process, dispatches labelled by their position in the token's launch sequence; `achieved` =
+                algorithmic bytes / that duration.  `end_to_end_frac` prices the whole step (weights + fp32 KV +
+                small) against 8 TB/s; `probe_back_to_back` keeps the stand-alone PRE_QA / STORE variant that
+                round 1 reported (it never runs in the step).
+  parity        the tokens of the timed run against the CPU path on the same file and prompt (as many as the CPU
+                budget covers) and max |delta logit| at the last compared step: the gate SURVEY.md 8(d) attaches
+                to every performance number.
+  cpu_baseline  the reference's own ggml.c (oracle/_ref; the standalone restatement if that did not travel) on the
+                host: 8 threads (the reference default) and, as `all_cores`, min(nproc, 64) threads.
+  prefill       exact-path prompt evaluation: one 504-token eval, the reference's 9-token chunks, and
+                configs[2] (2048 tokens in one eval at n_ctx 2560) with its useful-op rate against the int8
+                matrix-core peak and its fp32 FMA rate against the vector peak.
 
-Extra objects:  "roofline" for the dominant kernel (k_gemv, the Q4_0 x Q4_0 decode GEMV) and
-"cpu_baseline" (the reference's own ggml.c, oracle/_ref, timed on the host cores on a bounded sample).
+N > 1: the model is layer-sharded into N pipeline stages (one process per GPU); independent greedy sequences are
+kept in flight round-robin so every stage is busy, and the residual stream crosses stages with point-to-point RCCL
+send/recv.  value = all sequences' tokens / time, scaling = "weak".
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -40,6 +57,9 @@ MODELS = {
     "tiny": dict(n_vocab=512, n_embd=512, n_mult=64, n_head=4, n_layer=4),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INT8_MFMA_PEAK_TOPS = 5000.0   # dense int8 matrix-core peak: 2x the 2.5 PFLOP/s bf16 figure (MI355X_MICROARCH.md: i8 = 2x K)
+FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak (MI355X_MICROARCH.md)
+PROMPT = np.array([1, 17, 291, 4001, 29, 512, 77, 1234], np.int32)
 
 
 def log(*a):
@@ -71,61 +91,175 @@ def gemv_bytes(M, K):
     return M * (K // 32) * 20 + (K // 32) * 20 + 4 * M
 
 
-def cpu_baseline(path: str, n_threads: int, budget_s: float, n_ctx: int) -> dict:
-    """The reference's own ggml.c (oracle/_ref, built in place from /root/reference) on the host
-    cores: greedy decode on the same model file, bounded by `budget_s` seconds of wall time."""
+def decode_roles(cfg):
+    """The launches of one captured decode step, in order, with the algorithmic bytes of the mat-vecs."""
+    d, F, V, L = cfg["n_embd"], n_ff(cfg), cfg["n_vocab"], cfg["n_layer"]
+    layer = [("wq|wk|wv", gemv_bytes(3 * d, d)), ("attn_scores", None), ("attn_softmax_pv", None), ("wo", gemv_bytes(d, d)),
+             ("w1|w3", gemv_bytes(2 * F, d)), ("w2", gemv_bytes(d, F))]
+    return layer, ("output", gemv_bytes(V, d)), L
+
+
+def token_bytes(cfg, t):
+    """Algorithmic bytes of one decoded token at position t: W + KV(t) + small."""
+    d, F, V, L = cfg["n_embd"], n_ff(cfg), cfg["n_vocab"], cfg["n_layer"]
+    W = (L * (4 * d * d + 3 * d * F) + V * d) // 32 * 20
+    kv = L * 2 * (t + 1) * d * 4 + L * 2 * d * 4
+    small = (2 * L + 1) * d * 4 + d // 32 * 20 + 4 * V
+    return W + kv + small
+
+
+# ------------------------------------------------------------------------------------------------ CPU path
+def cpu_decode(path: str, n_threads: int, budget_s: float, n_ctx: int, want_tokens: int) -> dict:
+    """Greedy decode on the CPU path from the bench prompt, bounded by `budget_s` seconds / `want_tokens` tokens."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import reflib
     kind = "reference" if reflib.have_ref() else "port"
     lib = reflib.RefLib() if kind == "reference" else reflib.OracleLib()
-    m = lib.load(path, n_ctx, 1) if kind == "reference" else lib.load(path, n_ctx, 1)
-    prompt = np.array([1, 17, 291, 4001, 29, 512, 77, 1234], np.int32)
+    m = lib.load(path, n_ctx, 1)
+    prompt = PROMPT.copy()
     logits = m.eval(prompt, 0, n_threads)["logits"]
-    tok, n_past, n = int(np.argmax(logits)), len(prompt), 0
+    tok, n_past, toks = int(np.argmax(logits)), len(prompt), []
+    first = tok
     t0 = time.time()
-    while time.time() - t0 < budget_s and n_past < n_ctx:
+    while time.time() - t0 < budget_s and n_past < n_ctx and len(toks) < want_tokens:
         logits = m.eval(np.array([tok], np.int32), n_past, n_threads)["logits"]
-        tok = int(np.argmax(logits)); n_past += 1; n += 1
+        tok = int(np.argmax(logits)); n_past += 1; toks.append(tok)
     dt = time.time() - t0
     m.close()
-    return {"value": n / dt, "unit": "tokens/s", "cores": n_threads, "kind": kind,
-            "sample": f"{n} greedy decode tokens after an 8-token prompt, same synthetic model file, {dt:.1f}s wall, "
-                      f"{n_threads} threads (reference default numThreads=8, Sources/llama/LlamaRunner.swift:17)",
-            "host_cpus": os.cpu_count()}
+    return dict(kind=kind, first=first, toks=toks, last_logits=logits, dt=dt, threads=n_threads)
 
 
+# ------------------------------------------------------------------------------------------------ in-situ profile
+def insitu_child(args, cfg, path):
+    """(child of rocprofv3) the decode loop only: prompt, warm-up, `steps` greedy tokens on the device."""
+    import llama_swift_amd as L
+    m = L.Model(path, n_ctx=args.n_ctx)
+    logits = m.eval(PROMPT % cfg["n_vocab"], 0, args.threads)
+    tok = int(np.argmax(logits))
+    w = m.decode_greedy(tok, len(PROMPT), max(args.warmup, 1), args.threads)
+    m.decode_greedy(int(w[-1]), len(PROMPT) + max(args.warmup, 1), args.steps, args.threads)
+    m.close()
+
+
+def parse_kernel_trace(outdir, cfg):
+    """Label every dispatch of the decode loop by its position in the token's launch sequence (embedding -> per
+    layer {wq|wk|wv, scores, soft_max * V, wo, w1|w3, w2} -> output -> argmax) and average the durations."""
+    files = glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True)
+    if not files:
+        return None
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            low = {k.lower(): v for k, v in r.items()}
+            name = low.get("kernel_name", "")
+            try:
+                rows.append((int(low["start_timestamp"]), int(low["end_timestamp"]), name))
+            except (KeyError, ValueError):
+                continue
+    rows.sort()
+    layer, out_role, nl = decode_roles(cfg)
+    seq_len = 1 + nl * len(layer) + 2
+    dur = {}
+    names = {}
+    ntok = 0
+    i = 0
+    while i < len(rows):
+        if "k_embed" in rows[i][2] and i + seq_len <= len(rows) and "k_argmax" in rows[i + seq_len - 1][2]:
+            seg = rows[i:i + seq_len]
+            ok = all("k_gemv" in seg[1 + il * len(layer) + j][2] for il in range(nl) for j in (0, 3, 4, 5)) and "k_gemv" in seg[seq_len - 2][2]
+            if ok:
+                ntok += 1
+                for il in range(nl):
+                    for j, (role, _) in enumerate(layer):
+                        s = seg[1 + il * len(layer) + j]
+                        dur.setdefault(role, []).append((s[1] - s[0]) * 1e-3)
+                        names[role] = s[2]
+                for role, s in (("embed", seg[0]), (out_role[0], seg[seq_len - 2]), ("argmax", seg[seq_len - 1])):
+                    dur.setdefault(role, []).append((s[1] - s[0]) * 1e-3)
+                    names[role] = s[2]
+                dur.setdefault("token_span", []).append((seg[-1][1] - seg[0][0]) * 1e-3)
+                i += seq_len
+                continue
+        i += 1
+    if ntok == 0:
+        return None
+    short = lambda n: n[:n.index("(")] if "(" in n else n
+    return {"tokens": ntok, "us": {k: float(np.mean(v)) for k, v in dur.items()}, "kernel": {k: short(v).replace("void ", "") for k, v in names.items()}}
+
+
+def insitu_profile(args, cfg):
+    """Run the decode loop under rocprofv3 --kernel-trace in a child process and return per-launch averages."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    outdir = tempfile.mkdtemp(prefix="llamahip_insitu_", dir="/tmp")
+    steps = min(args.steps, 96)
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", outdir, "-o", "insitu", "--",
+           sys.executable, os.path.abspath(__file__), "--insitu-child", "--model", args.model, "--n_ctx", str(args.n_ctx),
+           "--steps", str(steps), "--warmup", str(args.warmup), "--threads", str(args.threads), "--seed", str(args.seed)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+    except Exception as e:          # the profile must never cost the headline line
+        return None, repr(e)
+    if r.returncode != 0:
+        return None, f"rocprofv3 rc={r.returncode}: {r.stderr[-300:]}"
+    prof = parse_kernel_trace(outdir, cfg)
+    if args.save_profile and prof:
+        stats = glob.glob(os.path.join(outdir, "**", "*kernel_stats.csv"), recursive=True)
+        with open(args.save_profile, "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --insitu-child --model {args.model} --steps {steps} --warmup {args.warmup}"
+                    f"   (the decode loop bench.py times, {prof['tokens']} tokens labelled by launch position)\n")
+            f.write("# in-situ average per launch of the captured decode step, microseconds:\n")
+            for k, v in prof["us"].items():
+                f.write(f"#   {k:16s} {v:8.2f}   {prof['kernel'].get(k, '')}\n")
+            if stats:
+                rows = list(csv.DictReader(open(stats[0])))
+                f.write(f"{'calls':>8} {'avg_us':>9} {'min_us':>8} {'max_us':>8} {'total_ms':>9} {'pct':>6}  kernel\n")
+                for row in rows:
+                    n = row["Name"]
+                    n = n[:n.index("(")] if "(" in n else n
+                    f.write(f"{int(row['Calls']):8d} {float(row['AverageNs']) / 1e3:9.2f} {float(row['MinNs']) / 1e3:8.2f} {float(row['MaxNs']) / 1e3:8.2f} "
+                            f"{float(row['TotalDurationNs']) / 1e6:9.2f} {float(row['Percentage']):6.2f}  {n}\n")
+    shutil.rmtree(outdir, ignore_errors=True)
+    return prof, None if prof else "no decode token sequence found in the kernel trace"
+
+
+# ------------------------------------------------------------------------------------------------ the single-GPU run
 def run_single(args, cfg, path):
     import llama_swift_amd as L
+    import torch
     t0 = time.time()
     m = L.Model(path, n_ctx=args.n_ctx)
     t_load = time.time() - t0
     log(f"[bench] loaded in {t_load:.1f}s: {m.stats()}")
-    prompt = np.array([1, 17, 291, 4001, 29, 512, 77, 1234], np.int32) % cfg["n_vocab"]
+    prompt = PROMPT % cfg["n_vocab"]
     prompt[0] = 1
     logits = m.eval(prompt, 0, args.threads)
-    tok, n_past = int(np.argmax(logits)), len(prompt)
+    first, n_past = int(np.argmax(logits)), len(prompt)
     steps = min(args.steps, args.n_ctx - n_past - args.warmup)
+    tok, warm = first, np.zeros(0, np.int32)
     if args.warmup > 0:
-        w = m.decode_greedy(tok, n_past, args.warmup, args.threads)
-        tok, n_past = int(w[-1]), n_past + args.warmup
-    import torch
+        warm = m.decode_greedy(tok, n_past, args.warmup, args.threads)
+        tok, n_past = int(warm[-1]), n_past + args.warmup
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = m.decode_greedy(tok, n_past, steps, args.threads)       # synchronises before returning
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # PCIe-inclusive variant: the reference boundary (llama_eval returning host logits every token)
+    gpu_trace = [int(x) for x in warm] + [int(x) for x in out]     # every token generated after the prompt's pick `first`
+    # PCIe-inclusive variant: the reference boundary (llama_eval returning host logits every token); its tokens must
+    # be those of the device-resident loop
     n_pcie = min(64, steps)
-    m2_past = n_past
     t1 = time.perf_counter()
-    tk = tok
+    tk, pcie_toks = tok, []
     for i in range(n_pcie):
-        lg = m.eval(np.array([tk], np.int32), m2_past + i, args.threads)
-        tk = int(np.argmax(lg))
+        lg = m.eval(np.array([tk], np.int32), n_past + i, args.threads)
+        tk = int(np.argmax(lg)); pcie_toks.append(tk)
     dt_pcie = time.perf_counter() - t1
-    same = bool(np.array_equal(out[:n_pcie], np.array([int(x) for x in out[:n_pcie]])))
-    # roofline: the decode GEMV kernel on every resident matrix kind, cycling over all layers so the
-    # weights stream from HBM (one pass over the model is 4.1 GB >> 256 MB Infinity Cache)
+    pcie_same = pcie_toks == [int(x) for x in out[:n_pcie]]
+    # stand-alone probe of the mat-vec kernel (PRE_QA / STORE variant, back-to-back launches cycling over the layers):
+    # kept as a secondary figure -- this variant never runs in the decode step
     shapes = []
     tot_bytes = tot_us = 0.0
     for which in range(5):
@@ -150,38 +284,43 @@ def run_single(args, cfg, path):
     prefill = {"one_eval": {"tokens": int(len(ptoks)), "tokens_per_s": len(ptoks) / dt_pre},
                "reference_9_token_chunks": {"tokens": int(n9), "tokens_per_s": n9 / dt_9},
                "note": "exact path (bit-identical to the reference); host logits copy included"}
+
+    def gpu_logits_at(n_tokens):
+        """logits of the step that consumed generated token n_tokens - 1 (for the parity gate)."""
+        lg0 = m.eval(prompt, 0, args.threads)
+        t_ = int(np.argmax(lg0))
+        _, last = m.decode_greedy(t_, len(prompt), n_tokens, args.threads, want_logits=True)
+        return last
+    res = dict(steps=steps, dt=dt, t_load=t_load, value_pcie=n_pcie / dt_pcie, pcie_same=pcie_same, shapes=shapes,
+               gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, prefill=prefill, first=first, gpu_trace=gpu_trace,
+               n_past0=n_past, gpu_logits_at=gpu_logits_at, model=m)
+    return res
+
+
+def prefill_2048(args, cfg, path):
+    """configs[2]: one 2048-token eval at n_ctx 2560 (second handle), with the rates the north star asks for."""
+    import llama_swift_amd as L
+    n_ctx, N = 2560, 2048
+    m = L.Model(path, n_ctx=n_ctx)
+    rng = np.random.default_rng(9)
+    ptoks = rng.integers(3, cfg["n_vocab"], N).astype(np.int32)
+    ptoks[0] = 1
+    m.eval(ptoks, 0, args.threads)
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter(); m.eval(ptoks, 0, args.threads); best = min(best, time.perf_counter() - t0)
     m.close()
-    # the reference's user-facing flow (LlamaRunner.run: load once, 8-token prompt batches, one llama_eval and one
-    # host-side top-k / top-p sample per token, token text through the event callback) -- not the headline metric
-    runner_info = None
-    try:
-        from llama_swift_amd import LlamaRunner, Config
-        stamps = []
-        rn = LlamaRunner(path)
-        cfgr = Config(numThreads=args.threads, numTokens=320, n_ctx=args.n_ctx, keepModel=True)
-        prompt_text = "".join("tok%05d" % t for t in rng.integers(3, cfg["n_vocab"], 16))
-        rn.run(prompt_text, cfgr)                                             # loads the model, warms up
-        rn.run(prompt_text, cfgr, tokenHandler=lambda _t: stamps.append(time.perf_counter()))
-        rn.close()
-        if len(stamps) > 64:
-            gen = stamps[-257:] if len(stamps) >= 257 + 17 else stamps[17:]   # generated tokens only (the prompt is echoed first)
-            runner_info = {"sampled_tokens_per_s": (len(gen) - 1) / (gen[-1] - gen[0]), "tokens": len(gen) - 1,
-                           "note": "LlamaRunner.run with its default sampling (top_k 40, top_p 0.95, temp 0.8, repeat penalty 1.3 on the host), model kept from a previous run"}
-    except Exception as e:                                                    # the runner leg must never cost the headline line
-        log(f"[bench] runner leg skipped: {e}")
-    # a measured ceiling next to the nominal 8 TB/s: device-to-device copy of 1 GiB (read + write)
-    src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-    dst = torch.empty_like(src)
-    dst.copy_(src); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        dst.copy_(src)
-    e1.record(); torch.cuda.synchronize()
-    copy_gbps = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del src, dst
-    return dict(steps=steps, dt=dt, tokens=out, t_load=t_load, value_pcie=n_pcie / dt_pcie, shapes=shapes,
-                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, same=same, prefill=prefill, copy_gbps=copy_gbps, runner=runner_info)
+    d, F, V, Lr = cfg["n_embd"], n_ff(cfg), cfg["n_vocab"], cfg["n_layer"]
+    useful = 2.0 * N * Lr * (4 * d * d + 3 * d * F) + 2.0 * V * d            # SURVEY.md 8d: mat-mul ops, last row of the lm head only
+    fma_flops = useful / 4.0                                                  # the exact path: 8 fp32 FMAs per 32-element block and output
+    return {"tokens": N, "n_ctx": n_ctx, "seconds": best, "tokens_per_s": N / best,
+            "roofline": {"useful_ops": useful, "useful_TOPs": useful / best / 1e12, "int8_mfma_peak_TOPs": INT8_MFMA_PEAK_TOPS,
+                         "frac_of_int8_mfma_peak": useful / best / 1e12 / INT8_MFMA_PEAK_TOPS,
+                         "fp32_fma_TFLOPs": fma_flops / best / 1e12, "fp32_valu_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
+                         "frac_of_fp32_valu_peak": fma_flops / best / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                         "bound": "fp32 VALU issue: the reference's arithmetic needs 8 separately rounded fp32 FMA chains per Q4_0 block and "
+                                  "output (ggml.c:1415-1466); only the integer block sums run on the matrix cores (one masked "
+                                  "v_mfma_i32_32x32x32_i8 per chain), so the int8 fraction is structurally <= 1/8 of what the pipe could do"}}
 
 
 def main():
@@ -196,11 +335,18 @@ def main():
     ap.add_argument("--gemv-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-insitu", action="store_true", help="skip the rocprofv3 child that times the launches of the decode step")
+    ap.add_argument("--no-prefill-2048", action="store_true")
+    ap.add_argument("--save-profile", default="", help="write the in-situ kernel table (rocprofv3 summary) to this file")
+    ap.add_argument("--insitu-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cfg = MODELS[args.model]
+
+    if args.insitu_child:
+        return insitu_child(args, cfg, model_path(args.model, cfg, args.seed))
 
     if world > 1 or args.gpus > 1 or os.environ.get("LLAMAHIP_FORCE_PIPELINE"):      # FORCE: exercise the N > 1 code path on one GPU
         # every stream of a rank (compute, one per RCCL communicator) gets its own hardware queue, so
@@ -214,22 +360,91 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the HIP path)")
     path = model_path(args.model, cfg, args.seed)
     r = run_single(args, cfg, path)
+    m = r.pop("model")
     tps = r["steps"] / r["dt"]
-    F = n_ff(cfg)
-    d = cfg["n_embd"]
-    dom = max(r["shapes"], key=lambda s: s["algo_bytes"] * (1 if s["name"] == "output" else cfg["n_layer"]))
-    all_gemv = r["gemv_bytes_per_token"] / (r["gemv_us_per_token"] * 1e-6) / 1e9
-    achieved = dom["GBps"]
+    ms_step = r["dt"] * 1e3 / r["steps"]
+
+    # ---- parity gate + CPU baselines (the CPU path decodes the same prompt: its tokens check the timed run)
+    parity = {"checked": False}
+    cpu_base = None
+    if not args.no_cpu_baseline and args.cpu_seconds > 0:
+        try:
+            want = args.warmup + r["steps"]
+            c = cpu_decode(path, 8, args.cpu_seconds, args.n_ctx, want)
+            n = min(len(c["toks"]), len(r["gpu_trace"]))
+            bad = [i for i in range(n) if c["toks"][i] != r["gpu_trace"][i]]
+            dl = None
+            if n > 0 and not bad and c["first"] == r["first"]:
+                dl = float(np.abs(r["gpu_logits_at"](n) - c["last_logits"]).max())
+            parity = {"checked": True, "against": c["kind"] + " CPU path, 8 threads", "tokens_compared": n, "tokens_in_timed_run_covered": max(0, n - args.warmup),
+                      "timed_run_fully_covered": n >= want, "identical": not bad and c["first"] == r["first"], "first_divergence": bad[0] if bad else None,
+                      "max_abs_dlogit_at_last_compared_step": dl, "tolerance": 1e-3,
+                      "pcie_loop_tokens_equal_device_loop": r["pcie_same"]}
+            cpu_base = {"value": len(c["toks"]) / c["dt"], "unit": "tokens/s", "cores": 8, "kind": c["kind"],
+                        "sample": f"{len(c['toks'])} greedy decode tokens after an 8-token prompt, same synthetic model file, {c['dt']:.1f}s wall, "
+                                  f"8 threads (reference default numThreads=8, Sources/llama/LlamaRunner.swift:17)",
+                        "host_cpus": os.cpu_count()}
+            nall = min(os.cpu_count() or 8, 64)
+            if nall > 8:
+                c2 = cpu_decode(path, nall, min(8.0, args.cpu_seconds), args.n_ctx, 10 ** 9)
+                cpu_base["all_cores"] = {"value": len(c2["toks"]) / c2["dt"], "unit": "tokens/s", "cores": nall,
+                                         "sample": f"{len(c2['toks'])} tokens, {c2['dt']:.1f}s wall, n_threads = min(nproc, 64) = {nall} "
+                                                   f"(the thread pool busy-spins, ggml.c:9061-9107; more threads than this only slow it down)"}
+        except Exception as e:  # the checker must never take the measurement down
+            cpu_base = {"value": None, "error": repr(e)}
+    m.close()
+
+    # ---- roofline of the decode step's launches, in situ
+    layer_roles, out_role, nl = decode_roles(cfg)
+    role_bytes = dict([(k, v) for k, v in layer_roles if v] + [out_role])
+    prof, prof_err = (None, "skipped") if args.no_insitu else insitu_profile(args, cfg)
+    probe = {"note": "stand-alone k_gemv<PRE_QA, EPI_STORE> launched back to back over all layers (HIP events); never runs in the decode step",
+             "per_shape": [{k: s[k] for k in ("name", "M", "K", "us_per_launch", "GBps")} for s in r["shapes"]],
+             "all_gemv_launches_of_a_token": {"GBps": r["gemv_bytes_per_token"] / (r["gemv_us_per_token"] * 1e-6) / 1e9}}
+    t_mid = r["n_past0"] + r["steps"] // 2
+    e2e_bytes = token_bytes(cfg, t_mid)
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "end_to_end": {"bytes_per_token": e2e_bytes, "at_position": t_mid, "GBps": e2e_bytes / (ms_step * 1e-3) / 1e9,
+                           "frac": e2e_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           "note": "W + KV(t) + small of SURVEY.md 8d at the middle position of the timed run / ms_per_step / 8 TB/s"},
+            "end_to_end_frac": e2e_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "probe_back_to_back": probe}
     traffic = None
     try:        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), committed under profiles/
         tj = json.load(open(os.path.join(ROOT, "profiles", "gemv_traffic.json")))
-        traffic = tj["per_launch"][dom["name"]]["traffic_bytes"] if args.model == "7B" else None
+        traffic = tj["per_launch"]["w1|w3"]["traffic_bytes"] if args.model == "7B" else None
     except Exception:
         pass
+    if prof:
+        per = []
+        gb = gu = 0.0
+        for role, b in role_bytes.items():
+            us = prof["us"].get(role)
+            if us is None:
+                continue
+            per.append({"name": role, "kernel": prof["kernel"].get(role), "us": us, "algorithmic_bytes": b, "GBps": b / us / 1e3, "frac": b / us / 1e3 / HBM_PEAK_GBPS})
+            mult = 1 if role == "output" else nl
+            gb += b * mult; gu += us * mult
+        dom = max(per, key=lambda p: p["algorithmic_bytes"] * (1 if p["name"] == "output" else nl))
+        roof.update({"kernel": f"{dom['kernel']} -- the {dom['name']} mat-vec as it runs in the captured decode step (norm prologue, SiLU*up -> Q4_0 epilogue); "
+                               f"{dom['algorithmic_bytes'] * nl / gb * 100:.0f}% of the mat-vec bytes of a token",
+                     "achieved": dom["GBps"], "frac": dom["frac"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "us_per_launch": dom["us"],
+                     "traffic": traffic, "traffic_source": "profiles/gemv_traffic.json (separate rocprofv3 --pmc passes, committed; not measured in this run)" if traffic else None,
+                     "method": f"rocprofv3 --kernel-trace of the same decode loop in a child process ({prof['tokens']} tokens); every dispatch labelled by its position in the "
+                               "token's launch sequence; average kernel duration",
+                     "in_situ_per_launch": per,
+                     "other_launches_us": {k: v for k, v in prof["us"].items() if k not in role_bytes},
+                     "all_gemv_launches_of_a_token": {"GBps": gb / gu / 1e3, "frac": gb / gu / 1e3 / HBM_PEAK_GBPS, "bytes": gb, "us": gu}})
+    else:
+        dom = max(r["shapes"], key=lambda s: s["algo_bytes"] * (1 if s["name"] == "output" else nl))
+        roof.update({"kernel": "lh::k_gemv PRE_QA / STORE PROBE VARIANT on w1|w3 (the in-situ profile was unavailable: " + str(prof_err) + ")",
+                     "achieved": dom["GBps"], "frac": dom["GBps"] / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": dom["algo_bytes"],
+                     "us_per_launch": dom["us_per_launch"], "traffic": traffic, "method": "HIP events over back-to-back launches (probe variant, not in situ)"})
+
     result = {
         "metric": "decode tokens/sec LLaMA-7B Q4_0 @1 GPU; % HBM-roofline on Q4_0 GEMV",
         "value": tps, "unit": "tokens/s", "n_gpus": 1, "steps": r["steps"], "warmup": args.warmup,
-        "ms_per_step": r["dt"] * 1e3 / r["steps"], "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "q4_0 x q4_0 -> int32 block sums, fp32 scales/accumulate",
         "data": "synthetic (random-init 7B-architecture weights in the reference file format, synthetic token ids)",
         "config": {"workload": f"LLaMA-{args.model} Q4_0 single-token decode, greedy, n_ctx {args.n_ctx}, "
@@ -237,27 +452,35 @@ def main():
                    "n_threads_semantics": args.threads, "parallelism": "1 GPU"},
         "value_pcie": r["value_pcie"],
         "load_s": r["t_load"],
-        "prefill": r["prefill"],
-        "runner": r.get("runner"),
-        "roofline": {"bound": "hbm",
-                     "kernel": f"lh::k_gemv, the Q4_0 x Q4_0 decode GEMV, on its dominant shape {dom['name']} "
-                               f"(M={dom['M']}, K={dom['K']}: {dom['algo_bytes'] * cfg['n_layer'] / r['gemv_bytes_per_token'] * 100:.0f}% of the GEMV bytes of a token)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": dom["algo_bytes"], "us_per_launch": dom["us_per_launch"],
-                     "measured_d2d_copy_GBps": r["copy_gbps"], "frac_of_measured_copy": achieved / r["copy_gbps"],
-                     "all_gemv_launches_of_a_token": {"achieved": all_gemv, "frac": all_gemv / HBM_PEAK_GBPS,
-                                                      "bytes": r["gemv_bytes_per_token"], "us": r["gemv_us_per_token"]},
-                     "per_shape": [{k: s[k] for k in ("name", "M", "K", "us_per_launch", "GBps")} for s in r["shapes"]],
-                     "note": "algorithmic bytes per launch = M*(K/32)*20 + (K/32)*20 + 4*M (SURVEY.md 8d); duration = HIP-event "
-                             "average on the launch stream over back-to-back launches cycling through all 32 layers (cold weights; "
-                             "includes the inter-launch dispatch gap that rocprofv3's kernel duration excludes); traffic = HBM "
-                             "bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_i_gemv_pmc.txt, tools/pmc_pass.sh)"},
+        "roofline": roof,
+        "parity": parity,
     }
-    if not args.no_cpu_baseline and args.cpu_seconds > 0:
+    if cpu_base is not None:
+        result["cpu_baseline"] = cpu_base
+    result["prefill"] = r["prefill"]
+    if not args.no_prefill_2048 and args.model in ("7B", "13B"):
         try:
-            result["cpu_baseline"] = cpu_baseline(path, 8, args.cpu_seconds, args.n_ctx)
-        except Exception as e:  # the checker must never take the measurement down
-            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+            result["prefill"]["configs2_2048_tokens_one_eval"] = prefill_2048(args, cfg, path)
+        except Exception as e:
+            result["prefill"]["configs2_2048_tokens_one_eval"] = {"error": repr(e)}
+    # the reference's user-facing flow (LlamaRunner.run: load once, 8-token prompt batches, one llama_eval and one
+    # host-side top-k / top-p sample per token, token text through the event callback) -- not the headline metric
+    try:
+        from llama_swift_amd import Config, LlamaRunner
+        rng = np.random.default_rng(7)
+        stamps = []
+        rn = LlamaRunner(path)
+        cfgr = Config(numThreads=args.threads, numTokens=320, n_ctx=args.n_ctx, keepModel=True)
+        prompt_text = "".join("tok%05d" % t for t in rng.integers(3, cfg["n_vocab"], 16))
+        rn.run(prompt_text, cfgr)                                             # loads the model, warms up
+        rn.run(prompt_text, cfgr, tokenHandler=lambda _t: stamps.append(time.perf_counter()))
+        rn.close()
+        if len(stamps) > 64:
+            gen = stamps[-257:] if len(stamps) >= 257 + 17 else stamps[17:]   # generated tokens only (the prompt is echoed first)
+            result["runner"] = {"sampled_tokens_per_s": (len(gen) - 1) / (gen[-1] - gen[0]), "tokens": len(gen) - 1,
+                                "note": "LlamaRunner.run with its default sampling (top_k 40, top_p 0.95, temp 0.8, repeat penalty 1.3), model kept from a previous run"}
+    except Exception as e:                                                    # the runner leg must never cost the headline line
+        log(f"[bench] runner leg skipped: {e}")
     if rank == 0:
         print(json.dumps(result), flush=True)
 

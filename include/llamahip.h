@@ -209,6 +209,11 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
 int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t first_token, int32_t n_steps,
                                      uint64_t *records, int64_t cap, char *err, size_t err_cap);
 
+/* Launch counts of the multi-row mat-mul kernel families since process start, in the order
+ * {matrix-core (k_gemm_mfma), short-eval (k_gemm_skinny), row-per-lane (k_gemm_rows), LDS-staged, mat-vec}:
+ * lets a test assert that a shape took the path it is meant to.  Returns the number of families. */
+int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap);
+
 typedef struct llamahip_stats {
     int32_t struct_size;
     int64_t weight_bytes_device;   /* repacked Q4_0 bytes resident in HBM */

@@ -21,6 +21,7 @@ from .binding import (  # noqa: F401
     bench_gemv_names,
     build,
     declared_symbols,
+    gemm_paths,
     lib,
     op_mul_mat_q4_0,
     op_quantize_row_q4_0,

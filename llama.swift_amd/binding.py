@@ -114,8 +114,17 @@ def lib() -> C.CDLL:
     L.llamahip_op_quantize_row_q4_0.argtypes = [vp, i32, vp, cp, sz]
     L.llamahip_bench_gemv.argtypes = [vp, i32, i32, i32, i32, C.POINTER(_GemvBench), cp, sz]
     L.llamahip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.llamahip_debug_gemm_paths.argtypes = [vp, i32]
+    L.llamahip_debug_gemm_paths.restype = i32
     _lib = L
     return L
+
+
+def gemm_paths() -> dict:
+    """Launch counts of the multi-row mat-mul kernel families since process start (llamahip_debug_gemm_paths)."""
+    a = np.zeros(8, np.int64)
+    n = lib().llamahip_debug_gemm_paths(a.ctypes.data_as(C.c_void_p), 8)
+    return dict(zip(("mfma", "skinny", "rows", "lds", "gemv"), a[:n].tolist()))
 
 
 def version() -> str:

@@ -2950,6 +2950,9 @@ hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
 //   matrix has a row-lane copy: one k_gemm_rows launch (column-group width: see below)
 //   else: LDS-staged column tiles of 16 (the last one clamped), small remainders as 8 / 4 columns
 //   a single row always goes through the decode GEMV
+// which kernel family served a mat-mul (tests assert that the full-size shapes take the path they are meant to)
+long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0 };
+
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws) {
     // Matrix-core path when its 64 x 64-output workgroups fill the chip twice over (measured crossover
@@ -2958,6 +2961,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
     const long mfma_wgs = (long) ((w.nrb32 + 1) / 2) * ((N + 63) / 64);
     if (w.mt && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
         // matrix-core path: needs the int8 operand (QB) of these N activation rows
+        g_gemm_path_counts[GEMM_PATH_MFMA]++;
         hipError_t e = launch_qa_to_qb(qa_A, qb_ws, w.nchunks, N, st);
         if (e != hipSuccess) return e;
         return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
@@ -2970,6 +2974,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         static const int skinny_rg = getenv("LLAMAHIP_SKINNY_RG") ? atoi(getenv("LLAMAHIP_SKINNY_RG")) : 0;
         const int nc = skinny_pick_nc(w, N), ncg = (N + nc - 1) / nc;
         const int rg = skinny_rg == 2 ? 2 : 1;
+        g_gemm_path_counts[GEMM_PATH_SKINNY]++;
 #define LH_SK_ARGS w, epi, qa_A, qa_d, N, ncg, y, y_stride, resid, resid_stride, st
 #define LH_SK_CASE(NCV) case NCV: return rg == 2 ? launch_gemm_skinny_t<NCV, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
         switch (nc) {
@@ -2993,6 +2998,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         for (int cand : { 4, 2 })
             if ((long) w.nrb * ((N + cand - 1) / cand) >= 2048) { nc = cand; break; }
         if (force_nc) nc = force_nc;
+        g_gemm_path_counts[GEMM_PATH_ROWS]++;
 #define LH_ROWS_ARGS w, epi, qa_A, qa_d, N, y, y_stride, resid, resid_stride, st
         switch (nc) {
         case 16: return launch_gemm_rows_t<16, true, 2>(LH_ROWS_ARGS);
@@ -3003,6 +3009,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         }
 #undef LH_ROWS_ARGS
     }
+    g_gemm_path_counts[N == 1 ? GEMM_PATH_GEMV : GEMM_PATH_LDS]++;
     int n0 = 0;
     while (n0 < N) {
         const int rem = N - n0;

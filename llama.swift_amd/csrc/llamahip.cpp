@@ -1184,6 +1184,11 @@ int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t 
     return n;
 }
 
+int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap) {
+    for (int i = 0; i < cap && i < GEMM_PATH_COUNT; i++) out[i] = g_gemm_path_counts[i];
+    return GEMM_PATH_COUNT;
+}
+
 int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out) {
     if (!m || !out) return LLAMAHIP_ERR_UNKNOWN;
     out->struct_size = (int32_t) sizeof(*out);

@@ -79,6 +79,8 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
                        const NormPart *np = nullptr);
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
 hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st);
+enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_COUNT = 5 };
+extern long g_gemm_path_counts[GEMM_PATH_COUNT];     // launches per kernel family of launch_gemm (process-wide; tests)
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st,

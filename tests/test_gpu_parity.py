@@ -454,6 +454,96 @@ def test_7b_logits_and_greedy_tokens_vs_oracle(L, oracle, model7b):
         assert same(last, lo), describe(last, lo)
 
 
+@pytest.fixture(scope="module")
+def trace7b(model7b):
+    """BASELINE.json configs[0] / [1]: greedy generation on the 7B file at n_ctx 512 by the CPU path, 8 threads --
+    the reference's own ggml.c (oracle/_ref) when it travelled with the snapshot, else the standalone
+    restatement.  One token per llama_eval, as the bridge does (.mm:834-896): 504 tokens after an 8-token prompt
+    fill the context; the first 128 of them are configs[0].  Keeps the top-2 logit margin of every step."""
+    import reflib
+    lib = reflib.RefLib() if reflib.have_ref() else reflib.OracleLib()
+    m = lib.load(model7b, 512)
+    prompt = synth.synth_prompt(8, 32000, seed=2)
+    lg = m.eval(prompt, 0, 8)["logits"]
+    first = int(np.argmax(lg))
+    toks, margins, t = [], [], first
+    for i in range(504):
+        lg = m.eval(np.array([t], np.int32), 8 + i, 8)["logits"]
+        t = int(np.argmax(lg))
+        top2 = np.partition(lg, -2)[-2:]
+        toks.append(t); margins.append(float(top2[1] - top2[0]))
+    m.close()
+    return dict(prompt=prompt, first=first, toks=np.array(toks, np.int32), margins=np.array(margins), last=lg)
+
+
+def _trace_report(got, want, margins):
+    bad = np.flatnonzero(np.asarray(got) != np.asarray(want)[:len(got)])
+    if not bad.size:
+        return "identical"
+    i = int(bad[0])
+    return (f"first divergence at generated token {i} (context position {8 + i}): gpu {int(got[i])} vs cpu {int(want[i])}; "
+            f"cpu top-2 logit margin there {margins[i]:.3e}; smallest margin before it {margins[:i + 1].min():.3e}")
+
+
+def test_7b_greedy_trace_128_tokens_vs_cpu_path(L, model7b, trace7b):
+    """configs[0]: LLaMA-7B, 8 threads, greedy 128 tokens -- token for token, one host-driven llama_eval per token
+    (the drop-in boundary), logits of the last step bit for bit."""
+    with L.Model(model7b, n_ctx=512) as gm:
+        lg = gm.eval(trace7b["prompt"], 0, 8)
+        t = int(np.argmax(lg))
+        assert t == trace7b["first"]
+        got = []
+        for i in range(128):
+            lg = gm.eval(np.array([t], np.int32), 8 + i, 8)
+            t = int(np.argmax(lg)); got.append(t)
+        assert got == trace7b["toks"][:128].tolist(), _trace_report(got, trace7b["toks"], trace7b["margins"])
+
+
+def test_7b_greedy_trace_512_context_vs_cpu_path(L, model7b, trace7b):
+    """configs[1]: LLaMA-7B single-token decode over the whole 512-token context on the device-resident greedy
+    loop (hipGraph replay, on-device argmax) -- all 504 generated tokens and the final logits against the CPU path."""
+    with L.Model(model7b, n_ctx=512) as gm:
+        lg = gm.eval(trace7b["prompt"], 0, 8)
+        assert int(np.argmax(lg)) == trace7b["first"]
+        got, last = gm.decode_greedy(trace7b["first"], 8, 504, 8, want_logits=True)
+        assert got.tolist() == trace7b["toks"].tolist(), _trace_report(got, trace7b["toks"], trace7b["margins"])
+        assert same(last, trace7b["last"]), describe(last, trace7b["last"])
+
+
+def test_7b_width_2048_token_prefill_vs_oracle(L, oracle, tmp_path):
+    """configs[2]: a 2048-token prompt in ONE eval at n_ctx 2560 on LLaMA-7B's matrix shapes (n_embd 4096, n_ff
+    11008, 32 heads; 2 layers and a 4000-entry vocabulary so that the CPU side stays at ~15 s): every mat-mul
+    takes the matrix-core kernel by the production selection rule (no LLAMAHIP_MFMA_MIN), attention the
+    lane-per-query kernels at T = 2048.  All 2048 rows of logits, bit for bit."""
+    kw = dict(n_vocab=4000, n_embd=4096, n_mult=256, n_head=32, n_layer=2)
+    path = synth_tool(tmp_path / "w7b.bin", seed=11, **kw)
+    prompt = synth.synth_prompt(2048, kw["n_vocab"], seed=5)
+    om = oracle.load(path, 2560)
+    want = om.eval(prompt, 0, 8, all_logits=True)
+    om.close()
+    before = L.gemm_paths()
+    with L.Model(path, n_ctx=2560) as gm:
+        got = gm.eval_debug(prompt, 0, 8)
+        after = L.gemm_paths()
+        assert after["mfma"] - before["mfma"] >= 4 * kw["n_layer"], (before, after)      # wq|wk|wv, wo, w1|w3, w2 of every layer
+        # (only the lm head over all 2048 rows -- a debug-eval extra, it has no prompt copies -- takes another kernel)
+        assert after["rows"] == before["rows"] and after["lds"] - before["lds"] <= 1 and after["skinny"] == before["skinny"], (before, after)
+        assert same(got["logits"], want["logits"]), "last row: " + describe(got["logits"], want["logits"])
+        for r in (0, 1, 63, 64, 777, 1500, 2046):
+            assert same(got["logits_all"][r], want["logits_all"][r]), f"row {r}: " + describe(got["logits_all"][r], want["logits_all"][r])
+        assert same(got["logits_all"], want["logits_all"]), describe(got["logits_all"], want["logits_all"])
+        # ... and decode continues from that context exactly as the CPU path does
+        om = oracle.load(path, 2560)
+        om.eval(prompt, 0, 8)
+        t = int(np.argmax(want["logits"]))
+        toks = gm.decode_greedy(t, 2048, 3, 8)
+        for i in range(3):
+            lo = om.eval(np.array([t], np.int32), 2048 + i, 8)["logits"]
+            t = int(np.argmax(lo))
+            assert int(toks[i]) == t, f"decode step {i} after the 2048-token prompt"
+        om.close()
+
+
 def test_7b_full_context_properties(L, model7b):
     """Size-independent properties over the whole 512-token context (no oracle in the loop):
     the graph-replayed device loop, the eager fused path and the unfused per-op path must agree

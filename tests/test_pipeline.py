@@ -187,6 +187,43 @@ def test_two_stages_on_one_gpu_equal_the_whole_model(L, tmp_path):
 
 
 @pytest.mark.gpu
+def test_stage_handles_vs_the_oracle_layer_ranges(L, oracle, tmp_path):
+    """A stage handle against the CPU restatement of the SAME layer range (orc_eval_range), not against the
+    whole-model HIP path: the residual stream a stage hands on (hidden_out) and the last stage's logits, bit for
+    bit, for a 9-token prompt chunk and for single-token steps (the fused decode schedule), with an uneven split."""
+    import torch
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=4)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=23))
+    om = oracle.load(path, 64)
+    cuts = [0, 1, 3, 4]
+    stages = [L.Model(path, n_ctx=64, layer_begin=a, layer_end=b) for a, b in zip(cuts[:-1], cuts[1:])]
+    d = hp.n_embd
+    toks, n_past = synth.synth_prompt(9, hp.n_vocab, seed=6), 0
+    for step in range(5):
+        N = len(toks)
+        h_gpu = [torch.empty(N * d, dtype=torch.float32, device="cuda") for _ in range(2)]
+        # CPU: stage by stage
+        want_h, hin = [], None
+        for si, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            hout, logits = om.eval_range(a, b, n_past, tokens=toks if si == 0 else None, hidden_in=hin, n_threads=8)
+            want_h.append(hout); hin = hout
+        # GPU: the same chain through llamahip_eval_stage
+        stages[0].eval_stage(n_past, tokens=toks, hidden_out=h_gpu[0].data_ptr())
+        stages[1].eval_stage(n_past, n_tokens=N, hidden_in=h_gpu[0].data_ptr(), hidden_out=h_gpu[1].data_ptr())
+        lg = stages[2].eval_stage(n_past, n_tokens=N, hidden_in=h_gpu[1].data_ptr(), want_logits=True)
+        for si in range(2):
+            got = h_gpu[si].cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), want_h[si].view(np.uint32)), f"step {step}: hidden_out of stage {si} differs from orc_eval_range"
+        assert np.array_equal(lg.view(np.uint32), logits.view(np.uint32)), f"step {step}: logits"
+        n_past += N
+        toks = np.array([int(np.argmax(logits))], np.int32)
+    for m in stages:
+        m.close()
+    om.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, 1])          # hipGraph replay / eager launches on the caller's stream
 def test_stream_ordered_stage_steps_single_rank(L, tmp_path, flags):
     """pipeline_decode on one rank: llamahip_stage_bind/step/trace (device-side position and greedy
