@@ -214,6 +214,10 @@ int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t 
  * lets a test assert that a shape took the path it is meant to.  Returns the number of families. */
 int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap);
 
+/* Bit 0 / bit 1: the decode kernels evaluate the reference's SiLU / exp fp16 tables with device arithmetic instead of
+ * gathering them -- enabled only after a load-time check that all 65 536 entries are reproduced.  0 before any load. */
+int32_t llamahip_debug_lut_math(void);
+
 typedef struct llamahip_stats {
     int32_t struct_size;
     int64_t weight_bytes_device;   /* repacked Q4_0 bytes resident in HBM */

@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
     L.llamahip_op_quantize_row_q4_0.argtypes = [vp, i32, vp, cp, sz]
     L.llamahip_bench_gemv.argtypes = [vp, i32, i32, i32, i32, C.POINTER(_GemvBench), cp, sz]
     L.llamahip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.llamahip_debug_lut_math.restype = i32
     L.llamahip_debug_gemm_paths.argtypes = [vp, i32]
     L.llamahip_debug_gemm_paths.restype = i32
     _lib = L

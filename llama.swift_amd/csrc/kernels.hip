@@ -39,6 +39,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "llamahip_internal.h"
 
 namespace lh {
@@ -56,6 +58,19 @@ __device__ __forceinline__ uint16_t f2h_bits(float f) {          // _cvtss_sh(x,
 }
 __device__ __forceinline__ float h2f_bits(uint16_t h) {          // _cvtsh_ss / table_f32_f16 (ggml.c:161,263-267)
     return __half2float(__ushort_as_half(h));
+}
+
+// The reference's fp16 look-up tables evaluated instead of gathered: table[i] = f2h((float) g((double) h2f(i))) with
+// g = x / (1 + exp(-x)) (SiLU, ggml.c:2387) or exp (ggml.c:2386), built by the HOST's libm.  A table has 65 536 entries,
+// so whether the device's double-precision exp reproduces every one of them is CHECKED exhaustively at load time
+// (launch_check_lut_math); only then do the decode kernels take this path -- it replaces a dependent gather from
+// global memory (a full round trip under load) at the tail of the w1|w3 mat-vec and in the middle of soft_max.
+__device__ __forceinline__ uint16_t silu_math_bits(uint16_t h) {
+    const float f = h2f_bits(h);
+    return f2h_bits((float) ((double) f / (1.0 + exp((double) -f))));
+}
+__device__ __forceinline__ uint16_t exp_math_bits(uint16_t h) {
+    return f2h_bits((float) exp((double) h2f_bits(h)));
 }
 
 template <int Q>
@@ -707,16 +722,66 @@ __device__ __forceinline__ float fold8(float acc) {
 #ifndef LH_GEMV_PAD
 #define LH_GEMV_PAD 1
 #endif
-template <int PRE, int EPI, int D, bool RING, int PG>
-__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256, EPI == EPI_SILU_QA ? 4 : 1)
-k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
-       const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d,
-       const float *__restrict__ in0, const float *__restrict__ in1, int K,
-       float *__restrict__ y, const float *__restrict__ resid,
-       const uint16_t *__restrict__ T_silu,
-       uint32_t *__restrict__ out_A, float *__restrict__ out_d,
-       const f64x2 *__restrict__ part_in, int npart, f64x2 *__restrict__ part_out) {
-    extern __shared__ double smem_d[];
+// In-launch hand-off between two dependent mat-vecs of ONE launch (k_gemv_pair): the producer role's blocks end
+// with {write-through (sc1) stores of their outputs, every wave drains its stores, one agent-scope atomic on one of 8
+// shard counters -> the last block of a shard bumps the top counter -> the last shard publishes 8 "go" words}; the
+// consumer role's blocks put their first D weight chunks in flight, then ONE lane polls its go word (relaxed
+// agent-scope loads + s_sleep), takes one agent-scope acquire, and only then reads the producer's outputs.
+// Counters are zeroed once per token (memset node) and count monotonically over the layers: `epoch` = 1-based index
+// of the pair within the token.  Every block of the launch is resident at once (host-checked), so a waiting block
+// can never starve the block it waits for; the spin is bounded all the same (err word set, results invalid).
+// Measured with tools/pair_probe.hip (profiles/r02_pair_probe.txt): w1|w3 -> w2 in one launch saves 2.3 us of 23,
+// because w2 -- 512 waves, latency bound -- hides its ramp, its first chunks and the launch boundary under w1|w3;
+// for wo -> w1|w3 and w2 -> wq|wk|wv the hand-off costs what the boundary did, those stay separate launches.
+constexpr int SYNC_SHARDS = 8;      // words, 64 B apart: 8 shard counters | top counter | 8 go words | time-out word (SYNC_BYTES)
+enum { SYNC_NONE = 0, SYNC_WAIT = 1, SYNC_ARRIVE = 2 };
+struct GemvArgs {
+    const uint8_t *wt; int ngroups, nchunks, M, gmapF8;
+    const uint32_t *qa_A; const float *qa_d;
+    const float *in0, *in1; int K;
+    float *y; const float *resid;
+    const uint16_t *T_silu;
+    uint32_t *out_A; float *out_d;
+    const f64x2 *part_in; int npart; f64x2 *part_out;
+    uint32_t *sync; int sync_blocks, sync_epoch;      // hand-off words, blocks of the producer role, 1-based epoch
+    int lut_math;                                     // bit 0: evaluate SiLU instead of gathering it (verified at load time)
+};
+
+__device__ __forceinline__ void sync_arrive(uint32_t *sync, int blk, int nblocks, int epoch) {
+    // (the caller has drained its stores and passed a barrier; one lane)
+    const int nsh = nblocks < SYNC_SHARDS ? nblocks : SYNC_SHARDS;
+    const int sh = blk % nsh, in_shard = (nblocks - sh + nsh - 1) / nsh;
+    const uint32_t old = __hip_atomic_fetch_add(sync + sh * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == (uint32_t) in_shard * (uint32_t) epoch) {
+        const uint32_t t = __hip_atomic_fetch_add(sync + SYNC_SHARDS * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1 == (uint32_t) nsh * (uint32_t) epoch)
+            for (int i = 0; i < SYNC_SHARDS; i++) __hip_atomic_store(sync + (SYNC_SHARDS + 1 + i) * 16, (uint32_t) epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void sync_wait(uint32_t *sync, int blk, int epoch) {
+    // one lane; the caller follows with a barrier
+    uint32_t *go = sync + (SYNC_SHARDS + 1 + blk % SYNC_SHARDS) * 16;
+    unsigned spins = 0;
+    while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t) epoch) {
+        if (++spins > (1u << 21)) { __hip_atomic_store(sync + (2 * SYNC_SHARDS + 1) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // ~1 s: give up loudly
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+//   SYNC : SYNC_NONE | SYNC_WAIT (consumer role of k_gemv_pair: weights first, then the hand-off, then the prologue's
+//          own loads) | SYNC_ARRIVE (producer role: write-through stores + arrival)
+//   PB   : the block has more waves than this role uses (`nw` active waves; the others only keep the barriers)
+template <int PRE, int EPI, int D, bool RING, int PG, int SYNC, bool PB>
+__device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, const int nw, double *smem_d) {
+    const uint8_t *__restrict__ wt = ga.wt;
+    const int ngroups = ga.ngroups, nchunks = ga.nchunks, M = ga.M, gmapF8 = ga.gmapF8, K = ga.K, npart = ga.npart;
+    const uint32_t *__restrict__ qa_A = ga.qa_A; const float *__restrict__ qa_d = ga.qa_d;
+    const float *__restrict__ in0 = ga.in0; const float *__restrict__ in1 = ga.in1;
+    float *__restrict__ y = ga.y; const float *__restrict__ resid = ga.resid;
+    const uint16_t *__restrict__ T_silu = ga.T_silu;
+    uint32_t *__restrict__ out_A = ga.out_A; float *__restrict__ out_d = ga.out_d;
+    const f64x2 *__restrict__ part_in = ga.part_in; f64x2 *__restrict__ part_out = ga.part_out;
     // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
     // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
     // index clamp -- their addresses are `loop base + immediate` instead of three VALU per chunk.
@@ -725,9 +790,10 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     float *ldsD = (float *) (ldsA + (nchunks + PADC) * 64);
     // (LH_GEMV_SADDR, off: with a provably uniform wave index the row-group base lives in SGPRs and every
     //  weight load is `global_load ... v_off, s[base]` with a constant per-lane offset -- measured slower here)
-    const int tid = threadIdx.x, lane = tid & 63, wave = LH_GEMV_SADDR ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), nw = blockDim.x >> 6;
-    const int g = blockIdx.x * nw + wave;
-    const bool valid = g < ngroups;
+    const int tid = threadIdx.x, lane = tid & 63, wave = LH_GEMV_SADDR ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    const bool active = !PB || wave < nw;
+    const int g = blk * nw + wave;
+    const bool valid = active && g < ngroups;
     const uint8_t *wbase = wt + (size_t) (valid ? g : 0) * (nchunks + 1) * TILE_BYTES;
     const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + (lane & 3) * 2) * 4u;
     // (an empty asm per loop trip keeps the 32 -> 64-bit extension of these lane offsets inside the loop
@@ -739,7 +805,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     const unsigned long long probe_wall = wall_clock64();
 #elif LH_PHASE_PROBE
     unsigned long long *probe_e = nullptr;
-    if (g_phase_probe && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+    if (g_phase_probe && blk == (int) gridDim.x / 2 && threadIdx.x == 0) {
         unsigned long long *pb = g_phase_probe;
         const unsigned long long slot = atomicAdd(pb, 1ull);
         if (slot < pb[1]) { probe_e = pb + 8 * (1 + slot); probe_e[5] = ngroups; probe_e[6] = nchunks; probe_e[7] = PRE * 16 + EPI; }
@@ -774,7 +840,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     constexpr int MAXQA = (PRE == PRE_QA) ? PG : 1, MAXQD = (PG + 7) / 8;    // QA granules per thread (da is 1/8 of A)
     f32x4 xa[MAXH][4], xb[MAXH][4];
     u32x4 qg[MAXQA], qh[MAXQD];
-    const int nt = blockDim.x;
+    const int nt = nw * 64;
     const int nh = K >> 4;                                   // half-blocks in the row
     // (trip counts are wave-uniform; a skipped load only makes the compiler's vmcnt for these
     //  prologue loads stricter -- they are all older than the weight loads, which stay in flight)
@@ -785,7 +851,9 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     constexpr int PNP = (PRE == PREP_NORMP) ? 8 : 1;
     f64x2 pp[PNP];
     const int npl = (npart + 63) >> 6;
-    if (NORMLIKE || PRE == PREP_PLAIN) {
+    float resid_v = 0.0f;
+    auto phase1 = [&]() {
+    if ((NORMLIKE || PRE == PREP_PLAIN) && active) {
         const int ng = (nh + nt - 1) / nt;
 #pragma unroll
         for (int u = 0; u < MAXH; u++) {
@@ -809,38 +877,49 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     }
     // the residual operand of the epilogue is fetched here too, not at the end of the kernel where it
     // would add a memory round trip to every wave's critical path
-    float resid_v = 0.0f;
-    if (EPI == EPI_RESID) {
+    if (EPI == EPI_RESID && active) {
         int lg0 = g;
-        if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+        if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
         resid_v = resid[min(lg0 * 8 + (lane >> 3), M - 1)];
     }
-    if (PRE == PRE_QA) {
+    if (PRE == PRE_QA && active) {
         const int nqa = (nchunks * 16 + nt - 1) / nt, nqd = (nchunks * 2 + nt - 1) / nt;
 #pragma unroll
         for (int u = 0; u < MAXQA; u++) if (u < nqa) qg[u] = ((const u32x4 *) qa_A)[min(tid + u * nt, nchunks * 16 - 1)];
 #pragma unroll
         for (int u = 0; u < MAXQD; u++) if (u < nqd) qh[u] = ((const u32x4 *) qa_d)[min(tid + u * nt, nchunks * 2 - 1)];
     }
+    };
     // ---- phase 2: put the first D weight chunks in flight (they do not depend on the activations).
     // The scheduling barriers pin the issue order phase 1 -> phase 2 -> phase 3.
+    // (SYNC_WAIT: the weights go first, the activations do not exist yet; their loads follow the hand-off and
+    //  retire behind weight loads that landed long before)
+    if (SYNC != SYNC_WAIT) phase1();
     __builtin_amdgcn_sched_barrier(0);
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < D; i++) LH_LOADW(i, i)
+        for (int i = 0; i < D; i++) LH_LOADW(i, i)
+    }
     __builtin_amdgcn_sched_barrier(0);
+    if (SYNC == SYNC_WAIT) {
+        if (tid == 0) sync_wait(ga.sync, blk, ga.sync_epoch);
+        __syncthreads();
+        phase1();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- phase 3: prologue arithmetic while the weights stream in
     LH_STAMP(1);
     double *red = (double *) (ldsD + (nchunks + PADC) * 8);
-    for (int i = tid; i < PADC * 72; i += nt) {              // zero the padding chunks (A: 64 dwords, d: 8 floats each)
+    for (int i = active ? tid : PADC * 72; i < PADC * 72; i += nt) {              // zero the padding chunks (A: 64 dwords, d: 8 floats each)
         if (i < PADC * 64) ldsA[nchunks * 64 + i] = 0u;
         else ldsD[nchunks * 8 + (i - PADC * 64)] = 0.0f;
     }
     if (PRE == PRE_QA) {
 #pragma unroll
-        for (int u = 0; u < MAXQA; u++) { const int gi = tid + u * nt; if (gi < nchunks * 16) ((u32x4 *) ldsA)[gi] = qg[u]; }
+        for (int u = 0; u < MAXQA; u++) { const int gi = tid + u * nt; if (active && gi < nchunks * 16) ((u32x4 *) ldsA)[gi] = qg[u]; }
 #pragma unroll
-        for (int u = 0; u < MAXQD; u++) { const int gi = tid + u * nt; if (gi < nchunks * 2) ((u32x4 *) ldsD)[gi] = qh[u]; }
+        for (int u = 0; u < MAXQD; u++) { const int gi = tid + u * nt; if (active && gi < nchunks * 2) ((u32x4 *) ldsD)[gi] = qh[u]; }
         __syncthreads();
     } else if (REGPRE) {
         if (NORMLIKE) {
@@ -868,7 +947,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             } else {
 #pragma unroll
                 for (int u = 0; u < MAXH; u++)
-                    if (tid + u * nt < nh) {
+                    if (active && tid + u * nt < nh) {
 #pragma unroll
                         for (int v = 0; v < 4; v++) {
                             const double x0 = (double) xa[u][v].x, x1 = (double) xa[u][v].y, x2 = (double) xa[u][v].z, x3 = (double) xa[u][v].w;
@@ -885,7 +964,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             double s2 = 0.0;
 #pragma unroll
             for (int u = 0; u < MAXH; u++)
-                if (tid + u * nt < nh) {
+                if (active && tid + u * nt < nh) {
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
                         const double v0 = (double) xa[u][v].x - mean, v1 = (double) xa[u][v].y - mean;
@@ -910,7 +989,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
 #pragma unroll
         for (int u = 0; u < MAXH; u++) {
             const int hi = tid + u * nt;                       // half-block index; block = hi >> 1, half = hi & 1
-            const bool live = hi < nh;
+            const bool live = active && hi < nh;
             float amax = 0.0f;
             if (live) {
 #pragma unroll
@@ -941,7 +1020,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             if (live && half == 0) ldsD[b] = dd;
         }
         // zero the padded blocks (K not a multiple of 256)
-        for (int b = K / 32 + tid; b < nbp; b += nt) {
+        for (int b = active ? K / 32 + tid : nbp; b < nbp; b += nt) {
             const int c = b >> 3, j = b & 7;
 #pragma unroll
             for (int k = 0; k < 8; k++) ldsA[(c * 8 + k) * 8 + j] = 0;
@@ -998,6 +1077,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     }
     LH_STAMP(2);
     LH_STAMP2(4);
+    if (active) {
     LH_LDSLOAD(0, 0)
     int c0 = 0;
     if (RING) {
@@ -1017,6 +1097,7 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         LH_CONSUME(i, c0 + i)
         __builtin_amdgcn_sched_barrier(0);
     }
+    }
 #undef LH_LDSLOAD
 #undef LH_CONSUME
 #undef LH_LOADW
@@ -1025,17 +1106,18 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
     LH_STAMP(3);
     acc = fold8(acc);
     int lg = g;
-    if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+    if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
     const int m = lg * 8 + (lane >> 3);
     if (EPI == EPI_SILU_QA) {
         // 8 waves: waves 0-3 hold gate rows b*32 .. b*32+31, waves 4-7 the matching up rows (b = blockIdx.x)
         float *gu = (float *) red;                      // prologue scratch is free again
-        __syncthreads();
+        if (!(ga.lut_math & 8)) __syncthreads();
         if (k == 0) gu[wave * 8 + (lane >> 3)] = acc;
         __syncthreads();
-        if (wave == 0) {
+        if (wave == 0 && !(ga.lut_math & 4)) {
             const int i = lane & 31;
-            const float act = h2f_bits(T_silu[f2h_bits(gu[i])]) * gu[32 + i];
+            const uint16_t gh = f2h_bits(gu[i]);
+            const float act = h2f_bits((ga.lut_math & 1) ? silu_math_bits(gh) : T_silu[gh]) * gu[32 + i];
             float amax = fabsf(act);
             amax = max_lanes_0_31(amax);
             const float dd = amax / 7.0f;
@@ -1044,10 +1126,21 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             const int kk = lane & 7;
             const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
             const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
-            const int b = blockIdx.x, c = b >> 3, j = b & 7;
-            if (lane < 8) out_A[(c * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
-            if (lane == 0) out_d[b] = dd;
+            const int b = blk, c = b >> 3, j = b & 7;
+            const uint32_t dw = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+            if (SYNC == SYNC_ARRIVE) {       // write-through: the consumer role of this launch reads them on another XCD
+                if (lane < 8) __hip_atomic_store(out_A + (c * 8 + kk) * 8 + j, dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store((uint32_t *) out_d + b, __builtin_bit_cast(uint32_t, dd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane < 8) out_A[(c * 8 + kk) * 8 + j] = dw;
+                if (lane == 0) out_d[b] = dd;
+            }
             if (y && lane < 32) y[b * 32 + i] = act;
+        }
+        if (SYNC == SYNC_ARRIVE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the arrival
+            __syncthreads();
+            if (tid == 0) sync_arrive(ga.sync, blk, ga.sync_blocks, ga.sync_epoch);
         }
     } else {
         const bool live = valid && k == 0 && m < M;
@@ -1059,14 +1152,14 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
             const double yd = live ? (double) acc : 0.0;
             const double s1 = wave_sum_d(yd), s2 = wave_sum_d(yd * yd);
             if (nw == 1) {
-                if (lane == 0) part_out[blockIdx.x] = f64x2{ s1, s2 };
+                if (lane == 0) part_out[blk] = f64x2{ s1, s2 };
             } else {
                 if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
                 __syncthreads();
                 if (tid == 0) {
                     double t1 = red[0], t2 = red[1];
                     for (int w2_ = 1; w2_ < nw; w2_++) { t1 += red[2 * w2_]; t2 += red[2 * w2_ + 1]; }
-                    part_out[blockIdx.x] = f64x2{ t1, t2 };
+                    part_out[blk] = f64x2{ t1, t2 };
                 }
             }
         }
@@ -1079,12 +1172,31 @@ k_gemv(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmap
         if (slot < pb[1]) {
             unsigned long long *e = pb + 8 * (1 + slot);
             for (int i = 0; i < 5; i++) e[i] = probe_t[i];
-            e[5] = ((unsigned long long) (PRE * 16 + EPI) << 48) | ((unsigned long long) nchunks << 32) | blockIdx.x;
+            e[5] = ((unsigned long long) (PRE * 16 + EPI) << 48) | ((unsigned long long) nchunks << 32) | (unsigned) blk;
             e[6] = wall_clock64();          // s_memtime is per-XCD: launches are lined up on the 100 MHz wall clock
             e[7] = probe_wall;
         }
     }
 #endif
+}
+
+
+template <int PRE, int EPI, int D, bool RING, int PG>
+__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256, EPI == EPI_SILU_QA ? 4 : 1)
+k_gemv(const GemvArgs ga) {
+    extern __shared__ double smem_d[];
+    gemv_body<PRE, EPI, D, RING, PG, SYNC_NONE, false>(ga, blockIdx.x, blockDim.x >> 6, smem_d);
+}
+
+// One launch, two dependent mat-vecs: blocks [0, gridA) run role A (w1|w3: norm prologue, SiLU*up -> Q4_0 epilogue,
+// arrival), blocks [gridA, gridA + gridB) role B (w2: weights in flight, hand-off, QA copy, mat-vec + residual)
+// on `nwB` of the block's 8 waves.  See the hand-off notes above gemv_body.
+template <int PREA, int DA, int PGB, int DB, bool RINGB>
+__global__ void __launch_bounds__(512, 4)
+k_gemv_pair(const GemvArgs a, const GemvArgs b, const int gridA, const int nwB) {
+    extern __shared__ double smem_d[];
+    if ((int) blockIdx.x < gridA) gemv_body<PREA, EPI_SILU_QA, DA, true, 1, SYNC_ARRIVE, false>(a, blockIdx.x, 8, smem_d);
+    else gemv_body<PRE_QA, EPI_RESID, DB, RINGB, PGB, SYNC_WAIT, true>(b, blockIdx.x - gridA, nwB, smem_d);
 }
 
 // Prompt path on the decode tiles (runs when the handle has no row-lane copy): NC activation rows
@@ -2378,7 +2490,7 @@ __global__ void __launch_bounds__(1024)
 k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth,
              float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
              const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st,
-             int n_past0, long qa_strideA, long qa_strideD) {
+             int n_past0, long qa_strideA, long qa_strideD, int lut_math) {
     extern __shared__ double smem_d[];
     double *red = smem_d;
     float *p = (float *) (smem_d + 32);
@@ -2406,7 +2518,8 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     mx = block_max_f(mx, red, 0);
     double sum = 0.0;
     for (int t = tid; t < T; t += nt) {
-        const float e = h2f_bits(T_exp[f2h_bits(p[t] - mx)]);
+        const uint16_t xh = f2h_bits(p[t] - mx);
+        const float e = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
         p[t] = e;
         sum += (double) e;
     }
@@ -2564,6 +2677,8 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_NORM, EPI_STORE, 1); LH_ATTR_G1(PREP_NORM, EPI_STORE, 2); LH_ATTR_G1(PREP_PLAIN, EPI_RESID, 1); LH_ATTR_G1(PREP_PLAIN, EPI_RESID, 2);
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
     LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
+    LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
+    LH_ATTR((k_gemv_pair<PREP_NORMP, 4, 4, 10, true>)); LH_ATTR((k_gemv_pair<PREP_NORM, 4, 4, 10, true>));
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
@@ -2573,6 +2688,35 @@ hipError_t init_kernel_attrs() {
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
     LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn);
 #undef LH_ATTR
+    return hipSuccess;
+}
+
+// counts[0] / counts[1]: entries of the SiLU / exp table (non-NaN inputs) the device formulas do NOT reproduce
+__global__ void k_check_lut_math(const uint16_t *__restrict__ T_silu, const uint16_t *__restrict__ T_exp, uint32_t *__restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 65536u) return;
+    const uint16_t h = (uint16_t) i;
+    if ((h & 0x7C00u) == 0x7C00u && (h & 0x03FFu)) return;          // NaN inputs: payloads are not compared
+    if (silu_math_bits(h) != T_silu[i]) atomicAdd(counts, 1u);
+    if (exp_math_bits(h) != T_exp[i]) atomicAdd(counts + 1, 1u);
+}
+int g_lut_math = 0;          // bit 0: SiLU, bit 1: exp (bits 2, 3: epilogue ablation switches of LLAMAHIP_EPI_ABLATE, measurement only) -- set by launch_check_lut_math (process-wide: the tables are the same for every model)
+hipError_t launch_check_lut_math(const uint16_t *T_silu, const uint16_t *T_exp, hipStream_t st) {
+    static const bool off = getenv("LLAMAHIP_NO_LUT_MATH") != nullptr;       // measurement only
+    uint32_t *d_counts = nullptr, h[2] = { 1, 1 };
+    hipError_t e = hipMalloc((void **) &d_counts, 8);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_counts, 0, 8, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_check_lut_math, dim3(256), dim3(256), 0, st, T_silu, T_exp, d_counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_counts, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void) hipFree(d_counts);
+    if (e != hipSuccess) return e;
+    g_lut_math = off ? 0 : ((h[0] == 0 ? 1 : 0) | (h[1] == 0 ? 2 : 0));
+    if (const char *ab = getenv("LLAMAHIP_EPI_ABLATE")) g_lut_math |= (atoi(ab) & 3) << 2;
     return hipSuccess;
 }
 
@@ -2687,7 +2831,9 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     if (PRE == PREP_SILU_MUL) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
-#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d, (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out)
+    const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d,
+                          (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out, nullptr, 0, 0, g_lut_math };
+#define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, ga)
     if (np.out && grid > NORM_PART_MAX) return hipErrorInvalidValue;
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
@@ -2748,6 +2894,7 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
         // 8 waves = 4 gate row-groups + the 4 matching up row-groups (interleaved layout)
         const int nw = 8;
         if (!w.gmapF8 || w.ngroups % 8 != 0 || w.K / 16 > 1 * 512) return hipErrorInvalidValue;
+        if (PRE == PRE_QA && w.nchunks * 16 > 512) return hipErrorInvalidValue;      // (measurement variant only)
         return launch_gemv_pg<PRE, EPI, 1>(LH_PGARGS);
     } else if constexpr (PRE == PREP_SILU_MUL) {
         const int nw = pick_waves(w.ngroups);
@@ -2770,6 +2917,67 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
 #undef LH_PGARGS
 }
 
+// ---- w1|w3 and w2 of a layer in one launch (k_gemv_pair).  Applies to the shapes whose two roles use the kernel
+// variants instantiated below AND whose blocks are all resident at once; everything else keeps two launches.
+static size_t gemv_lds_bytes(const QMat &w, int depth_pad) {
+    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
+    lds = (lds + 15) & ~(size_t) 15;
+    return lds + (LH_GEMV_PAD ? (size_t) depth_pad * 288 : 0);
+}
+static const void *pair_kernel(bool normp) {
+    return normp ? (const void *) k_gemv_pair<PREP_NORMP, 4, 4, 10, true> : (const void *) k_gemv_pair<PREP_NORM, 4, 4, 10, true>;
+}
+bool gemv_pair_applies(const QMat &w13, const QMat &w2) {
+    // OFF by default: in the real decode step the fused launch takes what the two launches took (7B: 22.6 us against
+    // 13.35 + 8.49 us of kernel time, 688.6 against 684.8 tokens/s; profiles/r02_b_pair_ab.txt) -- the hand-off costs what
+    // the boundary did, as MI355X_MICROARCH.md's price list says of every all-to-all seam.  LLAMAHIP_PAIR=1 enables it.
+    static const bool off = getenv("LLAMAHIP_PAIR") == nullptr || getenv("LLAMAHIP_NO_PAIR") != nullptr;
+    if (off || !w13.gmapF8 || w13.ngroups % 8 != 0 || w13.K / 16 > 512) return false;
+    if (w13.ngroups < 2048 || pick_depth(w13.nchunks, w13.ngroups) != 4) return false;       // role A: k_gemv<*, SILU_QA, 4, ring, 1>
+    int pg = 0;
+    const int nwB = gemv_pick_nw_qa(w2, &pg);
+    if (pg != 4 || nwB < 1 || nwB > 8 || w2.nchunks <= 16 || pick_depth(w2.nchunks, w2.ngroups) != 10) return false;   // role B: k_gemv<QA, RESID, 10, ring, 4>
+    const int gridA = w13.ngroups / 8, gridB = (w2.ngroups + nwB - 1) / nwB;
+    const size_t lds = std::max(gemv_lds_bytes(w13, 4), gemv_lds_bytes(w2, 10));
+    // Every block resident at once (occupancy API x CUs; SGPR use is far below the range where the API over-reports,
+    // MI355X_MICROARCH.md "Residency and cooperative launch").  Independently of that, a waiting role-B block cannot
+    // starve a role-A block: blocks are handed out in index order per XCD, role A has the lower indices and never
+    // waits for anything -- and the spin is bounded.
+    static int occ[2] = { -1, -1 }, ncu = 0;
+    static size_t occ_lds[2] = { 0, 0 };
+    for (int v = 0; v < 2; v++) {
+        if (occ[v] < 0 || occ_lds[v] != lds) {
+            int o = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, pair_kernel(v == 1), 512, lds) != hipSuccess) o = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+            occ[v] = o; occ_lds[v] = lds; ncu = prop.multiProcessorCount;
+        }
+    }
+    const int per_cu = std::min(occ[0], occ[1]);
+    return per_cu >= 1 && (long) gridA + gridB <= (long) ncu * per_cu;
+}
+
+hipError_t launch_gemv_pair(const QMat &w13, const QMat &w2, const float *x_in, const float *norm_w, const NormPart &np13,
+                            uint32_t *qa2_A, float *qa2_d, float *y, const float *resid, const NormPart &np2,
+                            const uint16_t *T_silu, uint32_t *sync, int epoch, hipStream_t st) {
+    int pg = 0;
+    const int nwB = gemv_pick_nw_qa(w2, &pg);
+    const int gridA = w13.ngroups / 8, gridB = (w2.ngroups + nwB - 1) / nwB;
+    const size_t lds = std::max(gemv_lds_bytes(w13, 4), gemv_lds_bytes(w2, 10));
+    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;
+    const bool normp = norm_mode >= 2 && np13.in && np13.n_in > 0 && np13.n_in <= NORM_PART_MAX;
+    if (np2.out && gridB > NORM_PART_MAX) return hipErrorInvalidValue;
+    const GemvArgs a = { w13.tiles, w13.ngroups, w13.nchunks, w13.M, w13.gmapF8, nullptr, nullptr, x_in, norm_w, w13.K, nullptr, nullptr, T_silu,
+                         qa2_A, qa2_d, normp ? (const f64x2 *) np13.in : nullptr, normp ? np13.n_in : (norm_mode == 0 ? -1 : 0), nullptr, sync, gridA, epoch, g_lut_math };
+    const GemvArgs b = { w2.tiles, w2.ngroups, w2.nchunks, w2.M, w2.gmapF8, qa2_A, qa2_d, nullptr, nullptr, w2.K, y, resid, T_silu,
+                         nullptr, nullptr, nullptr, 0, norm_mode >= 2 ? (f64x2 *) np2.out : nullptr, sync, gridA, epoch, g_lut_math };
+    if (normp) hipLaunchKernelGGL((k_gemv_pair<PREP_NORMP, 4, 4, 10, true>), dim3(gridA + gridB), dim3(512), lds, st, a, b, gridA, nwB);
+    else       hipLaunchKernelGGL((k_gemv_pair<PREP_NORM, 4, 4, 10, true>), dim3(gridA + gridB), dim3(512), lds, st, a, b, gridA, nwB);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu,
@@ -2789,6 +2997,7 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
     if (pre == PREP_NORM && epi == EPI_SILU_QA)   return launch_gemv_t<PREP_NORM, EPI_SILU_QA>(LH_ARGS);
     if (pre == PREP_NORMP && epi == EPI_STORE)    return launch_gemv_t<PREP_NORMP, EPI_STORE>(LH_ARGS);
     if (pre == PREP_NORMP && epi == EPI_SILU_QA)  return launch_gemv_t<PREP_NORMP, EPI_SILU_QA>(LH_ARGS);
+    if (pre == PRE_QA && epi == EPI_SILU_QA)      return launch_gemv_t<PRE_QA, EPI_SILU_QA>(LH_ARGS);        // llamahip_bench_gemv variant
     if (pre == PREP_PLAIN && epi == EPI_RESID)    return launch_gemv_t<PREP_PLAIN, EPI_RESID>(LH_ARGS);
     if (pre == PREP_SILU_MUL && epi == EPI_RESID) return launch_gemv_t<PREP_SILU_MUL, EPI_RESID>(LH_ARGS);
 #undef LH_ARGS
@@ -3078,7 +3287,7 @@ hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, 
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
     hipLaunchKernelGGL(k_dec_pv_blk<true>, dim3(H, dh / 32, N), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp,
-                       (const int32_t *) nullptr, n_past, (long) Kp / 4, (long) Kp / 32);
+                       (const int32_t *) nullptr, n_past, (long) Kp / 4, (long) Kp / 32, g_lut_math);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3104,7 +3313,7 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
     LH_LAUNCH_CHECK();
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;      // whole waves: the DPP reductions need every lane live
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L);
+    hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L, g_lut_math);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

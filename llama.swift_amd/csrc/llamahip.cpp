@@ -163,6 +163,7 @@ struct llamahip_model {
     uint32_t *qa1_A = nullptr, *qa2_A = nullptr;   // QA operands: attention output (K = d), FFN activation (K = F)
     float *qa1_d = nullptr, *qa2_d = nullptr;
     bool w13_interleaved = false;
+    uint32_t *d_sync = nullptr;          // in-launch hand-off words of the fused w1|w3 + w2 launch (k_gemv_pair), SYNC_BYTES
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
                                                      // a: of the row in x (attention / final norm), b: of the row in x1 (ffn norm)
     int n_seq = 1, cur_seq = 0;          // KV caches: [seq][layer][n_ctx][d]
@@ -206,7 +207,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens);
-    free_dev(npart_a); free_dev(npart_b);
+    free_dev(npart_a); free_dev(npart_b); free_dev(d_sync);
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
     for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
@@ -491,6 +492,10 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     static const bool no_norm_part = getenv("LLAMAHIP_NORM_MODE") && atoi(getenv("LLAMAHIP_NORM_MODE")) < 2;
     const bool use_part = fused && m->w13_interleaved && !no_norm_part;
     int n_part_x = 0;                                       // pairs in npart_a valid for the row currently in x (0: none)
+    // decode: w1|w3 and w2 of a layer share one launch where the shapes allow (k_gemv_pair); its hand-off counters
+    // run monotonically over the layers of a token and are cleared here, once per token
+    const bool use_pair = fused && m->w13_interleaved && m->l1 > m->l0 && gemv_pair_applies(m->layers[0].w13, m->layers[0].w2);
+    if (use_pair) HIP_TRY(hipMemsetAsync(m->d_sync, 0, SYNC_CLEAR_BYTES, st), LLAMAHIP_ERR_PREDICT);
     if (m->first_stage) {
         if (use_part) {
             HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st), LLAMAHIP_ERR_PREDICT);
@@ -523,7 +528,9 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo), LLAMAHIP_ERR_PREDICT);
-            if (m->w13_interleaved) {
+            if (use_pair) {
+                HIP_TRY(launch_gemv_pair(L.w13, L.w2, m->x1, L.ffn_norm, np_w13, m->qa2_A, m->qa2_d, xo, m->x1, np_w2, m->T_silu, m->d_sync, il - m->l0 + 1, st), LLAMAHIP_ERR_PREDICT);
+            } else if (m->w13_interleaved) {
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, st, &np_w13), LLAMAHIP_ERR_PREDICT);
                 HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, nullptr, nullptr, st, &np_w2), LLAMAHIP_ERR_PREDICT);
             } else {
@@ -624,6 +631,17 @@ dump_fail:
     return LLAMAHIP_ERR_PREDICT;
 }
 
+// The in-launch hand-off of k_gemv_pair bounds its spin; a time-out leaves a sticky word (results are invalid then).
+// Read after the stream has been synchronised.
+int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
+    uint32_t w = 0;
+    uint32_t *word = m->d_sync + (SYNC_BYTES - 64) / 4;
+    if (!m->d_sync || hipMemcpy(&w, word, 4, hipMemcpyDeviceToHost) != hipSuccess || w == 0) return 0;
+    (void) hipMemset(word, 0, 4);
+    set_err(err, err_cap, "decode step: in-launch hand-off between w1|w3 and w2 timed out (set LLAMAHIP_NO_PAIR=1 to use separate launches)");
+    return LLAMAHIP_ERR_PREDICT;
+}
+
 int check_eval_args(llamahip_model *m, int n_past, const int32_t *tokens, int N, bool need_tokens, char *err, size_t err_cap) {
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (m->host_only) { set_err(err, err_cap, "model was loaded with LLAMAHIP_FLAG_HOST_ONLY: no device state, cannot evaluate"); return LLAMAHIP_ERR_PREDICT; }
@@ -717,6 +735,7 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipMalloc((void **) &m->T_exp, te.size() * 2), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemcpy(m->T_silu, ts.data(), ts.size() * 2, hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemcpy(m->T_exp, te.data(), te.size() * 2, hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(launch_check_lut_math(m->T_silu, m->T_exp, m->stream), LLAMAHIP_ERR_LOAD);
         const int dh = d / H;
         std::vector<double> sc((size_t) n_ctx * dh);
         for (int p = 0; p < n_ctx; p++) {
@@ -829,6 +848,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipMemset(m->d_state, 0, 2 * sizeof(int32_t)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->sc, (size_t) H * n_ctx * 4), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->part, (size_t) H * 64 * dh * 4), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->d_sync, SYNC_BYTES), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->d_sync, 0, SYNC_BYTES), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->npart_a, 0, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
@@ -910,6 +931,7 @@ int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     if (logits_all) HIP_TRY(hipMemcpyAsync(logits_all, m->logits, (size_t) N * V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    if (N == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
     m->n_evals++;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
@@ -1002,6 +1024,7 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
     if (out_tokens) HIP_TRY(hipMemcpyAsync(out_tokens, m->d_out_tokens, (size_t) n_steps * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    if ((rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
     m->n_evals += n_steps;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
@@ -1184,6 +1207,8 @@ int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t 
     return n;
 }
 
+int32_t llamahip_debug_lut_math(void) { return g_lut_math; }
+
 int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap) {
     for (int i = 0; i < cap && i < GEMM_PATH_COUNT; i++) out[i] = g_gemm_path_counts[i];
     return GEMM_PATH_COUNT;
@@ -1279,8 +1304,12 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     // layer < 0: cycle over every resident layer so consecutive launches stream DIFFERENT weights
     // from HBM (one cycle of the smallest 7B matrix kind is 336 MB > the 256 MB Infinity Cache)
+    const int variant = which >> 4;          // 0 QA/STORE (probe), 1 NORM/STORE, 2 NORM/SILU_QA, 3 QA/SILU_QA: prologue / epilogue ablation
+    which &= 15;
     std::vector<const QMat *> mats;
+    std::vector<const float *> norms;
     auto pick = [&](const Layer &L) -> const QMat * {
+        norms.push_back(which == 2 ? L.ffn_norm : L.attention_norm);
         return which == 0 ? &L.qkv : which == 1 ? &L.wo : which == 2 ? &L.w13 : which == 3 ? &L.w2 : nullptr;
     };
     if (which == 4) { if (m->last_stage) mats.push_back(&m->output); }
@@ -1299,7 +1328,17 @@ int llamahip_bench_gemv(llamahip_model *m, int32_t which, int32_t layer, int32_t
     HIP_TRY(launch_prep(PREP_PLAIN, m->tmp, nullptr, q->K, 0, q->K, 1, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
     float *yout = which == 4 ? m->logits : m->gu;     // gu (2F floats) is large enough for every layer matrix
-    auto run = [&](const QMat *w) { return launch_gemv(*w, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, nullptr, nullptr, m->stream); };
+    if (variant && (which == 4 || (variant >= 2 && which != 2) || (variant == 1 && which != 0 && which != 2))) { set_err(err, err_cap, "variant %d does not apply to matrix %d", variant, which); return LLAMAHIP_ERR_PREDICT; }
+    size_t ri = 0;
+    auto run = [&](const QMat *w) {
+        const float *nw_ = norms.empty() ? nullptr : norms[ri++ % norms.size()];
+        switch (variant) {
+        case 1:  return launch_gemv(*w, PREP_NORM, EPI_STORE, nullptr, nullptr, m->tmp, nw_, yout, nullptr, m->T_silu, nullptr, nullptr, m->stream);
+        case 2:  return launch_gemv(*w, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->tmp, nw_, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, m->stream);
+        case 3:  return launch_gemv(*w, PRE_QA, EPI_SILU_QA, m->qa_A, m->qa_d, nullptr, nullptr, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, m->stream);
+        default: return launch_gemv(*w, PRE_QA, EPI_STORE, m->qa_A, m->qa_d, nullptr, nullptr, yout, nullptr, m->T_silu, nullptr, nullptr, m->stream);
+        }
+    };
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipEventCreate(&e1), LLAMAHIP_ERR_PREDICT);

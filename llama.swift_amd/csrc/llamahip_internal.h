@@ -56,6 +56,10 @@ hipError_t launch_quantize_q41_offline(const void *src, int f16, uint8_t *dst, l
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st);
 
 hipError_t init_kernel_attrs();
+// exhaustive check (all 65 536 entries) that the device's double-precision formulas reproduce the host-built SiLU /
+// exp tables; enables the gather-free paths of the decode kernels when they do (g_lut_math)
+extern int g_lut_math;
+hipError_t launch_check_lut_math(const uint16_t *T_silu, const uint16_t *T_exp, hipStream_t st);
 hipError_t set_phase_probe(unsigned long long *dev_buf);
 
 hipError_t launch_add(const float *a, const float *b, float *c, long n, hipStream_t st);
@@ -77,6 +81,14 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
                        const NormPart *np = nullptr);
+// w1|w3 and w2 of a decode step in ONE launch with an in-launch hand-off (k_gemv_pair); `sync` = SYNC_BYTES of
+// device memory zeroed once per token, `epoch` = 1-based index of the pair within the token
+constexpr int SYNC_BYTES = (2 * 8 + 2) * 64;           // the last 64 B hold the sticky time-out word
+constexpr int SYNC_CLEAR_BYTES = (2 * 8 + 1) * 64;     // what the per-token memset clears
+bool gemv_pair_applies(const QMat &w13, const QMat &w2);
+hipError_t launch_gemv_pair(const QMat &w13, const QMat &w2, const float *x_in, const float *norm_w, const NormPart &np13,
+                            uint32_t *qa2_A, float *qa2_d, float *y, const float *resid, const NormPart &np2,
+                            const uint16_t *T_silu, uint32_t *sync, int epoch, hipStream_t st);
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
 hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st);
 enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_COUNT = 5 };

@@ -45,5 +45,5 @@ for at in [int(x) for x in args.at.split(",")]:
         toks = m.decode_greedy(tok, at, steps, args.threads)
         best = min(best, time.perf_counter() - t0)
     out.append(f"ctx {at}..{at + steps}: {steps / best:7.1f} tok/s {best / steps * 1e3:6.3f} ms/tok crc {zlib.crc32(np.asarray(toks, np.int32).tobytes()):08x}")
-print(" | ".join(out), flush=True)
+print(" | ".join(out), f"| lut_math {L.lib().llamahip_debug_lut_math()}", flush=True)
 m.close()
