@@ -65,6 +65,13 @@ typedef struct llamahip_opts {
                                         LDS-staged GEMM.
                                         Results are bit-identical either way. */
 
+#define LLAMAHIP_FLAG_FAST_PREFILL 16 /* OPT-IN, NOT the reference's arithmetic: multi-token evals that take the matrix-core
+                                        GEMM (>= 64 rows at the 7B shapes) add each Q4_0 block's 32 integer products in one
+                                        MFMA and run ONE fp32 accumulation chain per output instead of the reference's eight
+                                        (ggml.c:1415-1466).  Same weights, same activation codes; sums re-associated, so logits
+                                        agree to rounding only (and a flipped activation code downstream moves them by ~1e-3).
+                                        Decode and short evals are unaffected.  Never the default. */
+
 /* ---- the drop-in boundary ------------------------------------------------------------------ */
 
 /* Replaces llama_model_load(fname, model, vocab, n_ctx, &error)  (.mm:98).

@@ -1846,7 +1846,12 @@ __global__ void k_qa_to_qb(const uint32_t *__restrict__ qa_A, uint8_t *__restric
     *(u32x4 *) (qb + ((size_t) n * nbp + b) * 32 + kg * 16) = u32x4{ out[0], out[1], out[2], out[3] };
 }
 
-template <int EPI>
+//   FAST (LLAMAHIP_FLAG_FAST_PREFILL, opt-in, NOT the reference's arithmetic): one unmasked MFMA per Q4_0 block -- the
+//        whole 32-element integer sum -- and ONE fp32 FMA chain per output instead of eight: 8x fewer MFMAs, conversions
+//        and FMAs.  Sums are re-associated (the 8 lane partials of _mm256_madd_epi16 are added as integers before the
+//        scale), so logits agree with the exact path only to rounding and the next activation quantization can flip
+//        codes; never used for parity claims.
+template <int EPI, bool FAST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
             const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
@@ -1889,9 +1894,10 @@ k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
         if (tid < 64) *(f32x4 *) (&sDa[buf][tid * 4]) = gd;
     };
 
-    f32x2 acc[8][8];                                        // [chain][pair of adjacent C/D registers]
+    constexpr int NCH = FAST ? 1 : 8;
+    f32x2 acc[NCH][8];                                      // [chain][pair of adjacent C/D registers]
 #pragma unroll
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < NCH; k++)
 #pragma unroll
         for (int r = 0; r < 8; r++) acc[k][r] = f32x2{ 0.0f, 0.0f };
     i32x16v cm;
@@ -1923,11 +1929,23 @@ k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
                 sc[2 * g + 0] = f32x2{ dw.x, dw.y } * da2;
                 sc[2 * g + 1] = f32x2{ dw.z, dw.w } * da2;
             }
+            if constexpr (FAST) {
+                const i32x4v Bi = { (int) B.x, (int) B.y, (int) B.z, (int) B.w };
+                const i32x16v Df = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bi, cm, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int d0 = Df[2 * r], d1 = Df[2 * r + 1];
+                    const f32x2 qv = f32x2{ __builtin_bit_cast(float, d0), __builtin_bit_cast(float, d1) } - f32x2{ 786432.0f, 786432.0f };
+                    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[0][r]) : "v"(sc[r]), "v"(qv));
+                }
+                continue;
+            }
             // chain k: B with every byte but that chain's 4 elements zeroed.  Two MFMAs stay in flight
             // ahead of the packed conversion + FMA of a chain.  Left alone, the scheduler issues all 32
             // MFMAs of a quad first and spills their 512 result registers, so the order is pinned with
             // empty volatile asms (they keep their program order): "use" all 16 accumulators of chain k,
             // then "define" the operand of chain k + 2.
+            if constexpr (!FAST) {
             i32x16v D[2];
 #define LH_MFMA(K, PIN)                                                                            \
             {                                                                                      \
@@ -1954,6 +1972,7 @@ k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
                 asm volatile("" :: "v"(acc[k][0]), "v"(acc[k][1]), "v"(acc[k][2]), "v"(acc[k][3]),
                              "v"(acc[k][4]), "v"(acc[k][5]), "v"(acc[k][6]), "v"(acc[k][7]));
             }
+            }
 #undef LH_MFMA
         }
         if (q + 1 < nq) stash(buf ^ 1);
@@ -1967,8 +1986,8 @@ k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int m = mb + (r & 3) + 8 * (r >> 2);
-#define LH_A(K) ((r & 1) ? acc[K][r >> 1].y : acc[K][r >> 1].x)
-            float v = ((LH_A(0) + LH_A(4)) + (LH_A(2) + LH_A(6))) + ((LH_A(1) + LH_A(5)) + (LH_A(3) + LH_A(7)));
+#define LH_A(K) ((r & 1) ? acc[(K) % NCH][r >> 1].y : acc[(K) % NCH][r >> 1].x)
+            float v = FAST ? LH_A(0) : ((LH_A(0) + LH_A(4)) + (LH_A(2) + LH_A(6))) + ((LH_A(1) + LH_A(5)) + (LH_A(3) + LH_A(7)));
 #undef LH_A
             if (m < M) {
                 if (EPI == EPI_RESID) v = v + resid[(size_t) n * resid_stride + m];
@@ -3136,14 +3155,14 @@ hipError_t launch_qa_to_qb(const uint32_t *qa_A, uint8_t *qb, int nchunks, int N
 }
 
 static hipError_t launch_gemm_mfma(const QMat &w, int epi, const uint8_t *qb, const float *qa_d, int ncols,
-                                   float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+                                   float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, bool fast) {
     const int nct = (ncols + 63) / 64, nq = w.nchunks * 2;
     const int nrp = (w.nrb32 + 1) / 2;
     const int grid = ((nrp + 7) / 8) * nct * 8;
-    if (epi == EPI_RESID)
-        hipLaunchKernelGGL((k_gemm_mfma<EPI_RESID>), dim3(grid), dim3(256), 0, st, w.mt, w.nrb32, nq, w.M, qb, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
-    else
-        hipLaunchKernelGGL((k_gemm_mfma<EPI_STORE>), dim3(grid), dim3(256), 0, st, w.mt, w.nrb32, nq, w.M, qb, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+#define LH_MF(E, F) hipLaunchKernelGGL((k_gemm_mfma<E, F>), dim3(grid), dim3(256), 0, st, w.mt, w.nrb32, nq, w.M, qb, qa_d, ncols, nct, y, y_stride, resid, resid_stride)
+    if (epi == EPI_RESID) { if (fast) LH_MF(EPI_RESID, true); else LH_MF(EPI_RESID, false); }
+    else                  { if (fast) LH_MF(EPI_STORE, true); else LH_MF(EPI_STORE, false); }
+#undef LH_MF
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3163,7 +3182,7 @@ hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
 long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0 };
 
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
-                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws) {
+                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws, bool fast) {
     // Matrix-core path when its 64 x 64-output workgroups fill the chip twice over (measured crossover
     // against the row-per-lane kernel on MI355X: N ~ 256 for the 7B matrices; 1.25x faster at N = 1024).
     static const int mfma_min = getenv("LLAMAHIP_MFMA_MIN") ? atoi(getenv("LLAMAHIP_MFMA_MIN")) : 0;     // measurement override
@@ -3173,7 +3192,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         g_gemm_path_counts[GEMM_PATH_MFMA]++;
         hipError_t e = launch_qa_to_qb(qa_A, qb_ws, w.nchunks, N, st);
         if (e != hipSuccess) return e;
-        return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
+        return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st, fast);
     }
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
     // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put

@@ -473,6 +473,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         return forward_dense(m, n_threads, n_past, N, hidden_in, want_all, state_on_device && N == 1, err, err_cap);
     }
     const bool fused = (N == 1) && !debug && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
+    const bool fast_prefill = (m->flags & LLAMAHIP_FLAG_FAST_PREFILL) != 0 && !debug;      // opt-in re-associated prompt GEMM (llamahip.h)
     if (fused && !state_on_device) {
         // host-driven single-token eval: publish the position to the device-resident state
         const int32_t hs[2] = { n_past, 0 };
@@ -550,7 +551,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             const RopeKvArgs ra = { m->sincos, m->qr, Kl, Vl, n_past, d, dh };
             HIP_TRY(launch_gemm_rope_kv(L.qkv, m->qa_A, m->qa_d, N, ra, st), LLAMAHIP_ERR_PREDICT);
         } else
-        HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
+        HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
         if (dmp) {
             for (int which = 0; which < 3; which++) {           // q, k, v are column slices of qkv[N][3d]
                 HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) d * 4, m->qkv + (size_t) which * d, (size_t) 3 * d * 4, (size_t) d * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
@@ -573,12 +574,12 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         HIP_TRY(launch_prep(PREP_PLAIN, m->merged, nullptr, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
         }
         if (dmp) {
-            HIP_TRY(launch_gemm(L.wo, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);      // .mm:649-651
+            HIP_TRY(launch_gemm(L.wo, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);      // .mm:649-651
             if (!sink->put(9, m->tmp, (int64_t) N * d)) goto dump_fail;
             HIP_TRY(launch_add(m->tmp, m->x, m->x1, (long) N * d, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:654
             if (!sink->put(10, m->x1, (int64_t) N * d)) goto dump_fail;
         } else {
-            HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, N, m->x1, d, m->x, d, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, N, m->x1, d, m->x, d, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);
         }
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (dmp && !sink->put(11, m->dbg_y, (int64_t) N * d)) goto dump_fail;
@@ -586,10 +587,10 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             // short evals: w1 | w3, SiLU * up and the quantization for w2 in one launch (.mm:668-680)
             const long KpF = ((long) F + 255) / 256 * 256;
             HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, N, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, N, m->x, d, m->x1, d, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);      // .mm:682-687
+            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, N, m->x, d, m->x1, d, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);      // .mm:682-687
             continue;
         }
-        HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, N, m->gu, 2L * F, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);     // .mm:668-675
+        HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, N, m->gu, 2L * F, nullptr, 0, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);     // .mm:668-675
         if (dmp) {
             HIP_TRY(hipMemcpy2DAsync(m->tmp, (size_t) F * 4, m->gu + F, (size_t) 2 * F * 4, (size_t) F * 4, N, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
             if (!sink->put(12, m->tmp, (int64_t) N * F)) goto dump_fail;       // w3 output ("tmp" in the reference)
@@ -599,12 +600,12 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:678-680
         if (dmp && !sink->put(14, m->dbg_y, (int64_t) N * F)) goto dump_fail;
         if (dmp) {
-            HIP_TRY(launch_gemm(L.w2, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);      // .mm:682-684
+            HIP_TRY(launch_gemm(L.w2, EPI_STORE, m->qa_A, m->qa_d, N, m->tmp, d, nullptr, 0, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);      // .mm:682-684
             if (!sink->put(15, m->tmp, (int64_t) N * d)) goto dump_fail;
             HIP_TRY(launch_add(m->tmp, m->x1, m->x, (long) N * d, st), LLAMAHIP_ERR_PREDICT);                                   // .mm:687
             if (!sink->put(16, m->x, (int64_t) N * d)) goto dump_fail;
         } else {
-            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qa_A, m->qa_d, N, m->x, d, m->x1, d, st, m->qb_ws), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qa_A, m->qa_d, N, m->x, d, m->x1, d, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);
         }
     }
 

@@ -96,7 +96,7 @@ extern long g_gemm_path_counts[GEMM_PATH_COUNT];     // launches per kernel fami
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st,
-                       uint8_t *qb_ws = nullptr);
+                       uint8_t *qb_ws = nullptr, bool fast = false);
 hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, const double *tab,
                           float *qr, float *Kc, float *Vc, int n_past, int N, hipStream_t st);
 // workspace of the many-row prompt attention (k_attnq_*): scores [H][T_cap][NB] fp32 + per-query max / 1/sum
