@@ -119,6 +119,21 @@ const char       *llamahip_sampler_random_prompt(llamahip_sampler *s);
 int32_t llamahip_sample_top_p_top_k(const llamahip_model *m, llamahip_sampler *s, const float *logits,
                                     double repeat_penalty, int32_t top_k, double top_p, double temp);
 
+/* The same sampler with its first half on the device ("avoids the 128 KB logits copy per token"):
+ * llamahip_eval_topk = llamahip_eval + candidate scores (temperature, repetition penalty over `last_n_tokens`) + the
+ * top_k selection of utils.cpp:345-395.  With *exact == 1, cand_scores / cand_ids [0, min(top_k, n_vocab)) are the
+ * reference's candidates after its partial_sort, and llamahip_sample_from_candidates finishes the draw (soft-max,
+ * top-p cut, std::discrete_distribution on the sampler's mt19937: utils.cpp:397-428) -- same ids, same rng draws.
+ * With *exact == 0 (two equal scores whose order only libstdc++'s partial_sort defines, a NaN, n_vocab > 32768 or
+ * top_k > 64) logits_out holds the n_vocab logits and the caller uses llamahip_sample_top_p_top_k as before.
+ * cand_scores / cand_ids: room for 64 entries; logits_out: n_vocab floats. */
+int llamahip_eval_topk(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t n_tokens,
+                       const int32_t *last_n_tokens, int32_t n_last, double repeat_penalty, int32_t top_k, double temp,
+                       double *cand_scores, int32_t *cand_ids, int32_t *exact, float *logits_out, char *err, size_t err_cap);
+int32_t llamahip_sample_from_candidates(llamahip_sampler *s, const double *scores, const int32_t *ids, int32_t n, double top_p);
+/* the sampler's last_n_tokens window (oldest first); returns its length */
+int32_t llamahip_sampler_window(const llamahip_sampler *s, int32_t *out, int32_t cap);
+
 /* ---- extensions -------------------------------------------------------------------------------- */
 
 /* Greedy decode loop kept on the device: step i evaluates one token at n_past + i, takes
@@ -194,6 +209,9 @@ int llamahip_quantize_file(const char *fname_inp, const char *fname_out, int32_t
  * (replaces ggml_compute_forward_mul_mat_q4_0_f32, ggml.c:5987-6285). */
 int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const float *x, int32_t N,
                              float *y, char *err, size_t err_cap);
+/* the device half of llamahip_eval_topk on caller-supplied logits (n_vocab <= 32768, top_k <= 64) */
+int llamahip_op_topk(const float *logits, int32_t n_vocab, const int32_t *last_n_tokens, int32_t n_last, double repeat_penalty,
+                     int32_t top_k, double temp, double *cand_scores, int32_t *cand_ids, int32_t *exact, char *err, size_t err_cap);
 /* runtime activation quantizer (ggml.c:456-523): x[k] -> k/32 blocks of 20 bytes */
 int llamahip_op_quantize_row_q4_0(const float *x, int32_t k, void *y, char *err, size_t err_cap);
 

@@ -25,6 +25,7 @@ from .binding import (  # noqa: F401
     lib,
     op_mul_mat_q4_0,
     op_quantize_row_q4_0,
+    op_topk,
     quantize_file,
     version,
 )

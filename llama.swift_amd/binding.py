@@ -95,6 +95,11 @@ def lib() -> C.CDLL:
     L.llamahip_sampler_new.restype = vp
     L.llamahip_sampler_free.argtypes = [vp]
     L.llamahip_sampler_accept.argtypes = [vp, i32]
+    L.llamahip_eval_topk.argtypes = [vp, i32, i32, vp, i32, vp, i32, C.c_double, i32, C.c_double, vp, vp, vp, vp, cp, sz]
+    L.llamahip_sample_from_candidates.argtypes = [vp, vp, vp, i32, C.c_double]
+    L.llamahip_sample_from_candidates.restype = i32
+    L.llamahip_sampler_window.argtypes = [vp, vp, i32]
+    L.llamahip_sampler_window.restype = i32
     L.llamahip_sampler_random_prompt.argtypes = [vp]
     L.llamahip_sampler_random_prompt.restype = cp
     L.llamahip_sample_top_p_top_k.argtypes = [vp, vp, vp, C.c_double, i32, C.c_double, C.c_double]
@@ -112,6 +117,7 @@ def lib() -> C.CDLL:
     L.llamahip_tensor_bytes.restype = C.c_int64
     L.llamahip_op_mul_mat_q4_0.argtypes = [vp, i32, i32, vp, i32, vp, cp, sz]
     L.llamahip_op_quantize_row_q4_0.argtypes = [vp, i32, vp, cp, sz]
+    L.llamahip_op_topk.argtypes = [vp, i32, vp, i32, C.c_double, i32, C.c_double, vp, vp, vp, cp, sz]
     L.llamahip_bench_gemv.argtypes = [vp, i32, i32, i32, i32, C.POINTER(_GemvBench), cp, sz]
     L.llamahip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.llamahip_debug_lut_math.restype = i32
@@ -239,6 +245,22 @@ class Model:
                 off += n
         return res
 
+    def eval_topk(self, tokens, n_past: int, sampler: "Sampler", repeat_penalty: float = 1.3, top_k: int = 40,
+                  temp: float = float(np.float32(0.8)), n_threads: int = 8):
+        """llamahip_eval_topk: returns (exact, scores[k], ids[k], logits or None)."""
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        win = np.zeros(1024, np.int32)
+        nw = lib().llamahip_sampler_window(sampler._s, _ptr(win), 1024)
+        sc, ids = np.zeros(64, np.float64), np.zeros(64, np.int32)
+        exact = C.c_int32(0)
+        logits = np.empty(self.n_vocab, np.float32)
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_eval_topk(self._h, n_threads, n_past, _ptr(tokens), tokens.size, _ptr(win), nw, repeat_penalty, top_k, temp,
+                                      _ptr(sc), _ptr(ids), C.byref(exact), _ptr(logits), err, len(err))
+        _check(rc, err)
+        k = min(top_k, self.n_vocab)
+        return bool(exact.value), sc[:k], ids[:k], (None if exact.value else logits)
+
     def set_seq(self, seq: int) -> None:
         err = C.create_string_buffer(1024)
         _check(lib().llamahip_set_seq(self._h, seq, err, len(err)), err)
@@ -341,6 +363,10 @@ class Sampler:
     def accept(self, tid: int) -> None:
         lib().llamahip_sampler_accept(self._s, int(tid))
 
+    def sample_from_candidates(self, scores, ids, top_p: float = float(np.float32(0.95))) -> int:
+        scores, ids = np.ascontiguousarray(scores, np.float64), np.ascontiguousarray(ids, np.int32)
+        return int(lib().llamahip_sample_from_candidates(self._s, _ptr(scores), _ptr(ids), len(ids), top_p))
+
     def random_prompt(self) -> str:
         """gpt_random_prompt on this sampler's rng (utils.cpp:102-119; .mm:774-776)."""
         return lib().llamahip_sampler_random_prompt(self._s).decode()
@@ -357,6 +383,17 @@ class Sampler:
                 self._s = None
         except Exception:
             pass
+
+
+def op_topk(logits, window, repeat_penalty: float = 1.3, top_k: int = 40, temp: float = float(np.float32(0.8))):
+    """Device half of the sampler on host logits: returns (exact, scores[top_k], ids[top_k])."""
+    logits = np.ascontiguousarray(logits, np.float32)
+    window = np.ascontiguousarray(window, np.int32)
+    sc, ids, exact = np.zeros(64, np.float64), np.zeros(64, np.int32), C.c_int32(0)
+    err = C.create_string_buffer(512)
+    rc = lib().llamahip_op_topk(_ptr(logits), logits.size, _ptr(window), window.size, repeat_penalty, top_k, temp, _ptr(sc), _ptr(ids), C.byref(exact), err, len(err))
+    _check(rc, err)
+    return bool(exact.value), sc[:top_k], ids[:top_k]
 
 
 def op_mul_mat_q4_0(wq: np.ndarray, x: np.ndarray) -> np.ndarray:

@@ -2664,6 +2664,114 @@ k_argmax(const float *__restrict__ logits, int V, int32_t *__restrict__ out, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sampler front end on the device: llama_sample_top_p_top_k's candidate scores and its top-k selection
+// (utils.cpp:345-395), so that a sampled decode step returns k (score, id) pairs instead of n_vocab logits.
+//   score_i = logit_i * (1 / temp) [* or / repeat_penalty for ids in the last-n window]      in double, as the host does
+//   the k largest, sorted descending (std::partial_sort with a.first > b.first)
+// std::partial_sort is not stable: where two scores are EQUAL the reference's order (and which of two equal
+// scores at the k-th place survives) is whatever libstdc++'s heap does with the whole 32 000-entry sequence.
+// That cannot be reproduced from a candidate set, so the kernel reports `exact` = 0 whenever an equality could
+// matter (a tie among the k + at the boundary, or a NaN) and the caller falls back to the host path on the full
+// logits; with exact = 1 the k pairs are unambiguous and identical to the reference's cand[0..k).
+// One workgroup of 1024 threads, <= 32 values per thread (n_vocab <= 32768), order-preserving 64-bit keys:
+//   1. the maximum of every group of 16 threads (512 values, DPP row reduction): 64 group maxima.  Their minimum T is a
+//      LOWER bound of the k-th largest value overall for any k <= 64 (64 values >= T exist), so each of the k best is
+//      >= T -- and only a few hundred other values are;
+//   2. the values >= T are collected (at most 768, else `exact` = 0) and ranked against each other; the k + 1 best
+//      decide the answer and whether an equality is in play.
+// (Measured and dropped: radix select -- its top-byte histogram is 32 000 atomics on a handful of LDS words, 48 us;
+//  ranking 1024 per-thread maxima against each other -- a million LDS reads, 55 us.)
+// flags[0] = exact, flags[1] = number of values collected.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v, unsigned long long o) { return o > v ? o : v; }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const int lo = __builtin_amdgcn_mov_dpp((int) (uint32_t) v, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int) (uint32_t) (v >> 32), CTRL, 0xF, 0xF, true);
+    return ((unsigned long long) (uint32_t) hi << 32) | (uint32_t) lo;
+}
+__global__ void __launch_bounds__(1024)
+k_topk_candidates(const float *__restrict__ logits, int V, const int32_t *__restrict__ window, int n_window,
+                  double scale, double repeat_penalty, int k,
+                  double *__restrict__ out_score, int32_t *__restrict__ out_id, int32_t *__restrict__ flags) {
+    constexpr int NPT = 32, LCAP = 768;
+    __shared__ uint32_t seen[1024];                    // bitmap of the last-n window (n_vocab <= 32768)
+    __shared__ unsigned long long gmax[64];
+    __shared__ unsigned long long list_key[LCAP];
+    __shared__ int32_t list_id[LCAP];
+    __shared__ uint32_t n_list, bad;
+    const int tid = threadIdx.x;
+    seen[tid] = 0u;
+    if (tid == 0) { n_list = 0u; bad = 0u; }
+    __syncthreads();
+    if (tid < n_window) { const int id = window[tid]; if (id >= 0 && id < V) atomicOr(&seen[id >> 5], 1u << (id & 31)); }
+    __syncthreads();
+    unsigned long long key[NPT], best = 0ull;
+    float lv[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT; u++) lv[u] = logits[min(tid + u * 1024, V - 1)];
+#pragma unroll
+    for (int u = 0; u < NPT; u++) {
+        const int i = tid + u * 1024;
+        unsigned long long kk = 0ull;                  // below every real key
+        if (i < V) {
+            const float lf = lv[u];
+            double sc;
+            if ((seen[i >> 5] >> (i & 31)) & 1u) sc = lf < 0.0f ? (double) lf * scale * repeat_penalty : (double) lf * scale / repeat_penalty;   // utils.cpp:363-368
+            else sc = (double) lf * scale;
+            if (sc != sc) bad = 1u;
+            const unsigned long long b = (unsigned long long) __double_as_longlong(sc);
+            kk = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+            if (kk == 0ull) kk = 1ull;
+        }
+        key[u] = kk;
+        best = kk > best ? kk : best;
+    }
+    // maximum over each 16-lane DPP row, then the minimum of the 64 row maxima
+    best = dpp_max_u64(best, dpp_u64<DPP_QUAD_XOR1>(best));
+    best = dpp_max_u64(best, dpp_u64<DPP_QUAD_XOR2>(best));
+    best = dpp_max_u64(best, dpp_u64<DPP_ROW_HALF_MIRROR>(best));
+    best = dpp_max_u64(best, dpp_u64<DPP_ROW_MIRROR>(best));
+    if ((tid & 15) == 0) gmax[tid >> 4] = best;
+    __syncthreads();
+    unsigned long long T = gmax[0];
+    for (int j = 1; j < 64; j++) { const unsigned long long o = gmax[j]; T = o < T ? o : T; }
+    if (T == 0ull) {                                   // a group without a real value: V < 1024 * ... (tiny vocabularies) -- host path
+        if (tid == 0) { flags[0] = 0; flags[1] = 0; }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < NPT; u++) {
+        if (key[u] >= T) {
+            const uint32_t at = atomicAdd(&n_list, 1u);
+            if (at < (uint32_t) LCAP) { list_key[at] = key[u]; list_id[at] = tid + u * 1024; }
+        }
+    }
+    __syncthreads();
+    const int n = (int) (n_list < (uint32_t) LCAP ? n_list : (uint32_t) LCAP);
+    if (n_list > (uint32_t) LCAP) bad = 1u;            // (a flood of equal values at T)
+    if (tid < n) {
+        const unsigned long long mine = list_key[tid];
+        const int my_id = list_id[tid];
+        int rank = 0;
+        bool dup = false;
+        for (int j = 0; j < n; j++) {
+            const unsigned long long o = list_key[j];
+            dup = dup || (j != tid && o == mine);
+            rank += (o > mine || (o == mine && list_id[j] < my_id)) ? 1 : 0;
+        }
+        if (rank <= k && dup) bad = 1u;                // an equality among the k best or between the k-th and its runner-up
+        if (rank < k) {
+            const unsigned long long b = (mine >> 63) ? (mine & 0x7fffffffffffffffull) : ~mine;
+            out_score[rank] = __longlong_as_double((long long) b);
+            out_id[rank] = my_id;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { flags[0] = (bad == 0u && n >= k) ? 1 : 0; flags[1] = n; }
+}
+
 // a pipeline stage that does not pick the token still has to advance its device-resident position
 __global__ void k_advance(int32_t *__restrict__ st) {
     if (threadIdx.x == 0) { st[0] += 1; st[1] += 1; }
@@ -3333,6 +3441,14 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;      // whole waves: the DPP reductions need every lane live
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
     hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L, g_lut_math);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *window, int n_window, double scale, double repeat_penalty, int k,
+                                  double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st) {
+    if (V > 32768 || k < 1 || k > 64 || n_window > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_topk_candidates, dim3(1), dim3(1024), 0, st, logits, V, window, n_window, scale, repeat_penalty, k, out_score, out_id, flags);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -154,6 +154,7 @@ struct llamahip_model {
     float *qaF_d = nullptr;              //   (zeroed once: the blocks that pad n_ff to a multiple of 256 are never written)
     float *dbg_y = nullptr, *dbg_p = nullptr, *dbg_kqv = nullptr;
     int32_t *d_out_tokens = nullptr;     // greedy decode results
+    void *d_topk = nullptr;              // sampler front end on the device: [1024 window ids][64 scores][64 ids][2 flags]
     int out_tokens_cap = 0;
 
     // decode-path state (device resident so a captured graph can be replayed unchanged)
@@ -163,6 +164,8 @@ struct llamahip_model {
     uint32_t *qa1_A = nullptr, *qa2_A = nullptr;   // QA operands: attention output (K = d), FFN activation (K = F)
     float *qa1_d = nullptr, *qa2_d = nullptr;
     bool w13_interleaved = false;
+    bool prompt_copies = false;          // the row-lane / matrix-core copies of the layer matrices exist (ensure_prompt_copies)
+    bool pair_used = false;              // a fused w1|w3 + w2 launch ran since the time-out word was last read
     uint32_t *d_sync = nullptr;          // in-launch hand-off words of the fused w1|w3 + w2 launch (k_gemv_pair), SYNC_BYTES
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
                                                      // a: of the row in x (attention / final norm), b: of the row in x1 (ffn norm)
@@ -206,7 +209,7 @@ llamahip_model::~llamahip_model() {
     free_dev(d_tokens); free_dev(x); free_dev(x1); free_dev(qkv); free_dev(qr); free_dev(merged); free_dev(gu);
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
-    free_dev(d_out_tokens);
+    free_dev(d_out_tokens); free_dev(d_topk);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_sync);
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
@@ -283,19 +286,38 @@ int alloc_qmat(QMat &q, int M, int K, llamahip_model *m, char *err, size_t err_c
     return 0;
 }
 
-// second resident copy in row-lane tiles for the prompt-path GEMM (k_gemm_rows); built from the
-// finished decode tiles, skipped with LLAMAHIP_FLAG_NO_PREFILL_COPY (the LDS-staged GEMM then runs)
+// The two extra resident copies of a layer matrix that the many-row prompt GEMMs read: row-lane tiles
+// (k_gemm_rows) and matrix-core tiles (k_gemm_mfma), both derived on the device from the decode tiles.  They are
+// built LAZILY, by the first eval of more than 60 rows (shorter evals -- the reference's 9-token prompt chunks -- and
+// decode run on the decode tiles alone): a handle that only ever decodes keeps one copy of its weights (7B: 4.4 GB
+// instead of 13 GB).  LLAMAHIP_FLAG_NO_PREFILL_COPY never builds them (the LDS-staged GEMM then serves long
+// prompts); LLAMAHIP_EAGER_PREFILL_COPY=1 builds them at load time (measurement: keeps the first long eval's
+// time free of the 10-20 ms build).
 int make_rows(QMat &q, llamahip_model *m, char *err, size_t err_cap) {
     if (m->flags & LLAMAHIP_FLAG_NO_PREFILL_COPY) return 0;
-    q.nrb = (q.M + 63) / 64;
-    HIP_TRY(hipMalloc((void **) &q.rows, q.rows_bytes()), LLAMAHIP_ERR_LOAD);
-    m->weight_bytes += (int64_t) q.rows_bytes();
-    HIP_TRY(launch_tiles_to_rows(q, m->stream), LLAMAHIP_ERR_LOAD);
-    // ... and the matrix-core tiles for long prompts (k_gemm_mfma)
-    q.nrb32 = (q.M + 31) / 32;
-    HIP_TRY(hipMalloc((void **) &q.mt, q.mt_bytes()), LLAMAHIP_ERR_LOAD);
-    m->weight_bytes += (int64_t) q.mt_bytes();
-    HIP_TRY(launch_tiles_to_mtiles(q, m->stream), LLAMAHIP_ERR_LOAD);
+    if (!q.rows) {
+        q.nrb = (q.M + 63) / 64;
+        HIP_TRY(hipMalloc((void **) &q.rows, q.rows_bytes()), LLAMAHIP_ERR_PREDICT);
+        m->weight_bytes += (int64_t) q.rows_bytes();
+        HIP_TRY(launch_tiles_to_rows(q, m->stream), LLAMAHIP_ERR_PREDICT);
+    }
+    if (!q.mt) {
+        q.nrb32 = (q.M + 31) / 32;
+        HIP_TRY(hipMalloc((void **) &q.mt, q.mt_bytes()), LLAMAHIP_ERR_PREDICT);
+        m->weight_bytes += (int64_t) q.mt_bytes();
+        HIP_TRY(launch_tiles_to_mtiles(q, m->stream), LLAMAHIP_ERR_PREDICT);
+    }
+    return 0;
+}
+constexpr int PROMPT_COPY_MIN_ROWS = 61;       // evals up to 60 rows take k_gemm_skinny on the decode tiles
+int ensure_prompt_copies(llamahip_model *m, int N, char *err, size_t err_cap) {
+    if (N < PROMPT_COPY_MIN_ROWS || m->dense || m->prompt_copies || (m->flags & LLAMAHIP_FLAG_NO_PREFILL_COPY)) return 0;
+    for (Layer &L : m->layers)
+        for (QMat *q : { &L.qkv, &L.wo, &L.w13, &L.w2 }) {
+            const int rc = make_rows(*q, m, err, err_cap);
+            if (rc) return rc;
+        }
+    m->prompt_copies = true;
     return 0;
 }
 
@@ -496,7 +518,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     // decode: w1|w3 and w2 of a layer share one launch where the shapes allow (k_gemv_pair); its hand-off counters
     // run monotonically over the layers of a token and are cleared here, once per token
     const bool use_pair = fused && m->w13_interleaved && m->l1 > m->l0 && gemv_pair_applies(m->layers[0].w13, m->layers[0].w2);
-    if (use_pair) HIP_TRY(hipMemsetAsync(m->d_sync, 0, SYNC_CLEAR_BYTES, st), LLAMAHIP_ERR_PREDICT);
+    if (use_pair) { m->pair_used = true; HIP_TRY(hipMemsetAsync(m->d_sync, 0, SYNC_CLEAR_BYTES, st), LLAMAHIP_ERR_PREDICT); }
     if (m->first_stage) {
         if (use_part) {
             HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st), LLAMAHIP_ERR_PREDICT);
@@ -637,6 +659,8 @@ dump_fail:
 int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
     uint32_t w = 0;
     uint32_t *word = m->d_sync + (SYNC_BYTES - 64) / 4;
+    if (!m->pair_used) return 0;         // (the check is a device round trip: only when the hand-off was in play)
+    m->pair_used = false;
     if (!m->d_sync || hipMemcpy(&w, word, 4, hipMemcpyDeviceToHost) != hipSuccess || w == 0) return 0;
     (void) hipMemset(word, 0, 4);
     set_err(err, err_cap, "decode step: in-launch hand-off between w1|w3 and w2 timed out (set LLAMAHIP_NO_PAIR=1 to use separate launches)");
@@ -812,10 +836,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         LOAD_TRY(upload_q4(m.get(), p + "attention.wq.weight", L.qkv, 0, d_stage, h_stage, err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "attention.wk.weight", L.qkv, d, d_stage, h_stage, err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "attention.wv.weight", L.qkv, 2 * d, d_stage, h_stage, err, err_cap));
-        LOAD_TRY(make_rows(L.qkv, m.get(), err, err_cap));
         LOAD_TRY(alloc_qmat(L.wo, d, d, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "attention.wo.weight", L.wo, 0, d_stage, h_stage, err, err_cap));
-        LOAD_TRY(make_rows(L.wo, m.get(), err, err_cap));
         LOAD_TRY(alloc_qmat(L.w13, 2 * F, d, m.get(), err, err_cap));
         if (m->w13_interleaved) {
             // every 8 tile groups = 32 rows of w1 followed by the same 32 rows of w3 (k_repack_q4)
@@ -826,10 +848,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w1.weight", L.w13, 0, d_stage, h_stage, err, err_cap));
             LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w3.weight", L.w13, F, d_stage, h_stage, err, err_cap));
         }
-        LOAD_TRY(make_rows(L.w13, m.get(), err, err_cap));
         LOAD_TRY(alloc_qmat(L.w2, d, F, m.get(), err, err_cap));
         LOAD_TRY(upload_q4(m.get(), p + "feed_forward.w2.weight", L.w2, 0, d_stage, h_stage, err, err_cap));
-        LOAD_TRY(make_rows(L.w2, m.get(), err, err_cap));
     }
     }
 #undef LOAD_TRY
@@ -868,6 +888,7 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
 
     rc = ensure_workspace(m.get(), 16, err, err_cap);
     if (rc != 0) return LLAMAHIP_ERR_LOAD;
+    if (getenv("LLAMAHIP_EAGER_PREFILL_COPY") && ensure_prompt_copies(m.get(), PROMPT_COPY_MIN_ROWS, err, err_cap) != 0) return LLAMAHIP_ERR_LOAD;
     HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_LOAD);
     m->t_load_ms = now_ms() - t0;
     *out = m.release();
@@ -906,10 +927,10 @@ const char *llamahip_token_text(const llamahip_model *m, int32_t id, uint32_t *l
     return s.c_str();
 }
 
-int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
-                        const int32_t *tokens, int32_t N, float *logits_last, float *logits_all,
-                        int32_t dump_layer, float *dump, int64_t dump_cap, int64_t *dump_sizes,
-                        char *err, size_t err_cap) {
+static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                     const int32_t *tokens, int32_t N, float *logits_last, float *logits_all,
+                     int32_t dump_layer, float *dump, int64_t dump_cap, int64_t *dump_sizes,
+                     bool sync, char *err, size_t err_cap) {
     int rc = check_eval_args(m, n_past, tokens, N, true, err, err_cap);
     if (rc) return rc;
     if (!m->first_stage || !m->last_stage) { set_err(err, err_cap, "llamahip_eval on a pipeline-stage handle: use llamahip_eval_stage"); return LLAMAHIP_ERR_PREDICT; }
@@ -918,6 +939,8 @@ int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
     rc = ensure_workspace(m, N, err, err_cap);
     if (rc) return rc;
     rc = ensure_attn_ws(m, N, err, err_cap);
+    if (rc) return rc;
+    rc = ensure_prompt_copies(m, N, err, err_cap);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     DumpSink sink;
@@ -931,16 +954,60 @@ int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
     const size_t V = m->hp.n_vocab;
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     if (logits_all) HIP_TRY(hipMemcpyAsync(logits_all, m->logits, (size_t) N * V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    m->n_evals++;
+    if (!sync) return LLAMAHIP_OK;          // (llamahip_eval_topk: more work follows on the stream before the one synchronisation)
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
     if (N == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
-    m->n_evals++;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
+}
+
+int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                        const int32_t *tokens, int32_t N, float *logits_last, float *logits_all,
+                        int32_t dump_layer, float *dump, int64_t dump_cap, int64_t *dump_sizes,
+                        char *err, size_t err_cap) {
+    return eval_impl(m, n_threads, n_past, tokens, N, logits_last, logits_all, dump_layer, dump, dump_cap, dump_sizes, true, err, err_cap);
 }
 
 int llamahip_eval(llamahip_model *m, int32_t n_threads, int32_t n_past,
                   const int32_t *tokens, int32_t n_tokens, float *logits_out, char *err, size_t err_cap) {
     return llamahip_eval_debug(m, n_threads, n_past, tokens, n_tokens, logits_out, nullptr, -1, nullptr, 0, nullptr, err, err_cap);
+}
+
+// llamahip_eval + the candidate selection of llama_sample_top_p_top_k on the device (utils.cpp:345-395): 816 bytes come
+// back instead of n_vocab logits.  *exact = 0 (a tie that only libstdc++'s partial_sort can order, a NaN, or an
+// unsupported size): logits_out then holds the full row and the caller samples on the host as before.
+int llamahip_eval_topk(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t n_tokens,
+                       const int32_t *last_n_tokens, int32_t n_last, double repeat_penalty, int32_t top_k, double temp,
+                       double *cand_scores, int32_t *cand_ids, int32_t *exact, float *logits_out, char *err, size_t err_cap) {
+    if (!cand_scores || !cand_ids || !exact || !logits_out) { set_err(err, err_cap, "llamahip_eval_topk: null output"); return LLAMAHIP_ERR_PREDICT; }
+    *exact = 0;
+    const int V = m ? m->hp.n_vocab : 0;
+    const int k = std::min(std::max(top_k, 1), V);
+    const bool device_ok = m && !m->host_only && V <= 32768 && k <= 64 && n_last >= 0 && n_last <= 1024 && (n_last == 0 || last_n_tokens);
+    if (!device_ok) return llamahip_eval(m, n_threads, n_past, tokens, n_tokens, logits_out, err, err_cap);
+    const double t0 = now_ms();
+    int rc = eval_impl(m, n_threads, n_past, tokens, n_tokens, nullptr, nullptr, -1, nullptr, 0, nullptr, false, err, err_cap);   // logits stay on the device, no wait
+    if (rc) return rc;
+    if (!m->d_topk) HIP_TRY(hipMalloc(&m->d_topk, 1024 * 4 + 64 * 8 + 64 * 4 + 8), LLAMAHIP_ERR_PREDICT);
+    int32_t *d_win = (int32_t *) m->d_topk;
+    double *d_sc = (double *) ((char *) m->d_topk + 4096);
+    int32_t *d_id = (int32_t *) ((char *) m->d_topk + 4096 + 512), *d_fl = d_id + 64;
+    if (n_last > 0) HIP_TRY(hipMemcpyAsync(d_win, last_n_tokens, (size_t) n_last * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    const float *row = m->logits + (size_t) (n_tokens - 1) * V;
+    HIP_TRY(launch_topk_candidates(row, V, d_win, n_last, 1.0 / temp, repeat_penalty, k, d_sc, d_id, d_fl, m->stream), LLAMAHIP_ERR_PREDICT);
+    struct { double sc[64]; int32_t id[64]; int32_t fl[2]; } h;
+    HIP_TRY(hipMemcpyAsync(&h, d_sc, sizeof(h), hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    if (n_tokens == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
+    m->t_eval_ms += now_ms() - t0;
+    if (h.fl[0] == 1) {
+        for (int i = 0; i < k; i++) { cand_scores[i] = h.sc[i]; cand_ids[i] = h.id[i]; }
+        *exact = 1;
+        return LLAMAHIP_OK;
+    }
+    HIP_TRY(hipMemcpy(logits_out, row, (size_t) V * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    return LLAMAHIP_OK;
 }
 
 int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
@@ -954,6 +1021,8 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
     rc = ensure_workspace(m, N, err, err_cap);
     if (rc) return rc;
     rc = ensure_attn_ws(m, N, err, err_cap);
+    if (rc) return rc;
+    rc = ensure_prompt_copies(m, N, err, err_cap);
     if (rc) return rc;
     if (m->first_stage) HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     rc = forward(m, n_threads, n_past, N, (const float *) hidden_in, false, false, -1, nullptr, err, err_cap);
@@ -1275,6 +1344,30 @@ int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const flo
     if (st) (void) hipStreamDestroy(st);
     free_dev(d_w); free_dev(q.tiles); free_dev(q.rows); free_dev(d_x); free_dev(d_y); free_dev(d_qA); free_dev(d_qd);
     return rc;
+}
+
+// the device half of the sampler on caller-supplied logits (parity tests): see llamahip_eval_topk
+int llamahip_op_topk(const float *logits, int32_t n_vocab, const int32_t *last_n_tokens, int32_t n_last, double repeat_penalty,
+                     int32_t top_k, double temp, double *cand_scores, int32_t *cand_ids, int32_t *exact, char *err, size_t err_cap) {
+    int rc = need_device(err, err_cap);
+    if (rc) return rc;
+    if (!logits || !cand_scores || !cand_ids || !exact || n_vocab < 1 || n_vocab > 32768 || top_k < 1 || top_k > 64 || top_k > n_vocab || n_last < 0 || n_last > 1024) {
+        set_err(err, err_cap, "llamahip_op_topk: bad arguments"); return LLAMAHIP_ERR_PREDICT;
+    }
+    float *d_l = nullptr; void *d_w = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_l, (size_t) n_vocab * 4), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc(&d_w, 4096 + 512 + 256 + 8), LLAMAHIP_ERR_PREDICT);
+    int32_t *d_win = (int32_t *) d_w; double *d_sc = (double *) ((char *) d_w + 4096); int32_t *d_id = (int32_t *) ((char *) d_w + 4096 + 512), *d_fl = d_id + 64;
+    struct { double sc[64]; int32_t id[64]; int32_t fl[2]; } h;
+    hipError_t e = hipMemcpy(d_l, logits, (size_t) n_vocab * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_last > 0) e = hipMemcpy(d_win, last_n_tokens, (size_t) n_last * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_topk_candidates(d_l, n_vocab, d_win, n_last, 1.0 / temp, repeat_penalty, top_k, d_sc, d_id, d_fl, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&h, d_sc, sizeof(h), hipMemcpyDeviceToHost);
+    (void) hipFree(d_l); (void) hipFree(d_w);
+    HIP_TRY(e, LLAMAHIP_ERR_PREDICT);
+    *exact = h.fl[0];
+    for (int i = 0; i < top_k; i++) { cand_scores[i] = h.sc[i]; cand_ids[i] = h.id[i]; }
+    return LLAMAHIP_OK;
 }
 
 int llamahip_op_quantize_row_q4_0(const float *x, int32_t k, void *y, char *err, size_t err_cap) {

@@ -122,6 +122,9 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st);
 hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st);
 hipError_t launch_advance(int32_t *state, hipStream_t st);
+// sampler front end (utils.cpp:345-395): the k best candidate scores of the last row of logits, on the device
+hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *window, int n_window, double scale, double repeat_penalty, int k,
+                                  double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st);
 hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st);
 
 }  // namespace lh

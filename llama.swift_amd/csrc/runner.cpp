@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -38,6 +39,38 @@ struct llama_runner_bridge {
     int32_t kept_n_ctx = 0;              // ... and the context size it was loaded with
     int64_t loads = 0;                   // model loads performed by this bridge (tests)
 };
+
+// llama_sample_top_p_top_k from the soft-max on (utils.cpp:397-428): `cand` = the top_k candidates, best first
+static int32_t finish_sample(llamahip_sampler *s, std::vector<std::pair<double, int32_t>> &cand, double top_p) {
+    double maxl = -INFINITY;
+    for (const auto &c : cand) maxl = std::max(maxl, c.first);
+    std::vector<double> probs;
+    probs.reserve(cand.size());
+    double sum = 0.0;
+    for (const auto &c : cand) {
+        const double p = exp(c.first - maxl);
+        probs.push_back(p);
+        sum += p;
+    }
+    for (auto &p : probs) p /= sum;
+
+    if (top_p < 1.0f) {
+        double cumsum = 0.0f;
+        for (int i = 0; i < (int) probs.size(); i++) {
+            cumsum += probs[i];
+            if (cumsum >= top_p) {
+                probs.resize(i + 1);
+                cand.resize(i + 1);
+                break;
+            }
+        }
+        cumsum = 1.0 / cumsum;
+        for (auto &p : probs) p *= cumsum;
+    }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    const int idx = dist(s->rng);
+    return cand[idx].second;
+}
 
 extern "C" {
 
@@ -132,34 +165,24 @@ int32_t llamahip_sample_top_p_top_k(const llamahip_model *m, llamahip_sampler *s
                       [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
     cand.resize(top_k);
 
-    double maxl = -INFINITY;
-    for (const auto &c : cand) maxl = std::max(maxl, c.first);
-    std::vector<double> probs;
-    probs.reserve(cand.size());
-    double sum = 0.0;
-    for (const auto &c : cand) {
-        const double p = exp(c.first - maxl);
-        probs.push_back(p);
-        sum += p;
-    }
-    for (auto &p : probs) p /= sum;
+    return finish_sample(s, cand, top_p);
+}
 
-    if (top_p < 1.0f) {
-        double cumsum = 0.0f;
-        for (int i = 0; i < (int) probs.size(); i++) {
-            cumsum += probs[i];
-            if (cumsum >= top_p) {
-                probs.resize(i + 1);
-                cand.resize(i + 1);
-                break;
-            }
-        }
-        cumsum = 1.0 / cumsum;
-        for (auto &p : probs) p *= cumsum;
-    }
-    std::discrete_distribution<> dist(probs.begin(), probs.end());
-    const int idx = dist(s->rng);
-    return cand[idx].second;
+// the same, from candidates selected on the device (llamahip_eval_topk with *exact == 1): cand[0..n) of the reference
+// after its partial_sort + resize (utils.cpp:389-395)
+int32_t llamahip_sample_from_candidates(llamahip_sampler *s, const double *scores, const int32_t *ids, int32_t n, double top_p) {
+    if (!s || !scores || !ids || n < 1) return -1;
+    std::vector<std::pair<double, int32_t>> &cand = s->cand;
+    cand.clear();
+    for (int i = 0; i < n; i++) cand.emplace_back(scores[i], ids[i]);
+    return finish_sample(s, cand, top_p);
+}
+
+int32_t llamahip_sampler_window(const llamahip_sampler *s, int32_t *out, int32_t cap) {
+    if (!s) return 0;
+    const int32_t n = (int32_t) s->last_n_tokens.size();
+    for (int32_t i = 0; i < n && i < cap; i++) out[i] = s->last_n_tokens[i];
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -241,6 +264,9 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     }
 
     std::vector<float> logits(n_vocab);
+    double cand_scores[64];
+    int32_t cand_ids[64];
+    static const bool host_sampler = getenv("LLAMAHIP_HOST_SAMPLER") != nullptr;      // measurement: always copy the logits and select on the host
     auto fail = [&](void) {
         post(LLAMA_EVENT_FAILED, err, (uint32_t) strlen(err), LLAMAHIP_ERR_PREDICT);
         llamahip_sampler_free(sampler);
@@ -257,8 +283,19 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     int32_t n_past = 0, remaining = n_predict;
     size_t consumed = 0;
     while (remaining > 0) {                                                         // .mm:834
+        bool have_cand = false;
         if (!embd.empty()) {
-            if (llamahip_eval(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), logits.data(), err, sizeof(err)) != 0) return fail();
+            // the logits of this eval are sampled next iff the prompt is used up (.mm:851): then the candidate scores and
+            // the top-k selection run on the device and 816 bytes come back instead of 128 KB (exact = 0: a tie only
+            // libstdc++'s partial_sort can order -- the full row came back and the host path below decides)
+            const bool samples_next = embd_inp.size() <= consumed && !cfg.greedy && !host_sampler;
+            if (samples_next) {
+                int32_t win[64], exact = 0;
+                const int32_t nw = llamahip_sampler_window(sampler, win, 64);
+                if (llamahip_eval_topk(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), win, std::min(nw, 64), repeat_penalty, top_k, temp,
+                                       cand_scores, cand_ids, &exact, logits.data(), err, sizeof(err)) != 0) return fail();
+                have_cand = exact == 1;
+            } else if (llamahip_eval(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), logits.data(), err, sizeof(err)) != 0) return fail();
         }
         n_past += (int32_t) embd.size();
         embd.clear();
@@ -266,6 +303,8 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
             int32_t id;
             if (cfg.greedy) {
                 id = (int32_t) (std::max_element(logits.begin(), logits.end()) - logits.begin());   // first maximum = lowest index
+            } else if (have_cand) {
+                id = llamahip_sample_from_candidates(sampler, cand_scores, cand_ids, std::min(top_k, n_vocab), top_p);
             } else {
                 id = llamahip_sample_top_p_top_k(model, sampler, logits.data(), repeat_penalty, top_k, top_p, temp);
             }
