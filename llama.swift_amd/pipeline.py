@@ -73,6 +73,48 @@ class Stage(Protocol):
         ...
 
 
+ERR_PREDICT = -1001          # LlamaErrorCodePredictionFailed (Sources/llamaObjCxx/headers/LlamaError.h:18)
+
+
+class PipelineError(RuntimeError):
+    """A stage lost its peer (or the schedule stopped making progress): what the bridge reports as PredictionFailed."""
+
+    def __init__(self, message: str):
+        super().__init__(f"[com.alexrozanski.llama.error {ERR_PREDICT}] {message}")
+        self.code, self.message = ERR_PREDICT, message
+
+
+def run_guarded(fn, rank: int, world: int, limit_s: float, what: str, on_timeout=None):
+    """Runs one pipeline schedule call with the two failure paths a multi-rank decode has:
+      * a peer that went away surfaces as an exception of the transport (gloo: connection reset; RCCL: an async error
+        on the work handle) -> re-raised as PipelineError (code -1001, message names the rank and the call);
+      * a peer that hangs (or an RCCL receive that never matches) surfaces as NOTHING -> a watchdog ends the process
+        after `limit_s` seconds without the call returning: message on stderr, exit code 3 (a blocked collective cannot
+        be interrupted from Python, and a stuck rank must not keep its GPU and its launcher forever).
+    `on_timeout` (tests) replaces the process exit."""
+    import threading
+
+    def _expired():
+        msg = f"[pipeline] rank {rank}/{world}: no progress for {limit_s:.0f} s in {what} -- PredictionFailed ({ERR_PREDICT}), leaving"
+        os.write(2, (msg + "\n").encode())
+        if on_timeout:
+            on_timeout(msg)
+        else:
+            os._exit(3)
+
+    timer = threading.Timer(limit_s, _expired)
+    timer.daemon = True
+    timer.start()
+    try:
+        return fn()
+    except PipelineError:
+        raise
+    except Exception as e:                       # transport errors are RuntimeError / DistBackendError, worded by the backend
+        raise PipelineError(f"rank {rank}/{world}: {what} failed: {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}") from e
+    finally:
+        timer.cancel()
+
+
 def layer_range(n_layer: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous, as even as possible; earlier stages take the remainder."""
     base, rem = divmod(n_layer, world)
@@ -262,16 +304,18 @@ def bench_main(args, cfg, model_path_fn, log):
     os.dup2(2, 1)
 
     # a multi-rank run that stops making progress (a peer died, a hand-off never matched) must not hang the
-    # caller forever: after `limit` seconds without the JSON line, say so and leave
+    # caller forever: every schedule call below runs under run_guarded (transport error -> PipelineError, silence ->
+    # exit code 3 after `limit` seconds), and the whole bench under one more timer of the same length
     limit = float(os.environ.get("LLAMAHIP_PIPE_WATCHDOG_S", "900"))
 
     def _abort():
-        os.write(2, f"[bench] rank {rank}/{world}: no result after {limit:.0f} s -- aborting\n".encode())
+        os.write(2, f"[bench] rank {rank}/{world}: no result after {limit:.0f} s -- PredictionFailed ({ERR_PREDICT}), aborting\n".encode())
         os._exit(3)
 
     watchdog = threading.Timer(limit, _abort)
     watchdog.daemon = True
     watchdog.start()
+    guard = lambda fn, what: run_guarded(fn, rank, world, limit, what)
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
@@ -291,34 +335,48 @@ def bench_main(args, cfg, model_path_fn, log):
     steps = min(args.steps, args.n_ctx - 8 - args.warmup - 1)
     # prompt round (8 tokens per sequence): host-synchronous schedule, untimed
     if sync_schedule:
-        toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + args.warmup, token_group)
+        toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + args.warmup, token_group), "pipeline_rounds (prompt + warm-up)")
         last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        toks2, n_past = pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group)
+        toks2, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group), "pipeline_rounds (timed decode)")
         dist.barrier(); torch.cuda.synchronize()
     else:
-        toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group)
+        toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt)")
         for s in range(S):
             stage.bind(s, n_past[s], int(toks[s, -1]))
         lane = torch.cuda.Stream()               # the decode loop's own stream: receives, stage steps and sends are ordered on it
-        with torch.cuda.stream(lane):
-            pipeline_decode(stage, rank, world, dist, S, args.warmup, fwd_groups, token_group)      # untimed; captures the graphs
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+        def decode(n):
+            with torch.cuda.stream(lane):
+                pipeline_decode(stage, rank, world, dist, S, n, fwd_groups, token_group)
+            torch.cuda.synchronize()
+        guard(lambda: decode(args.warmup), "pipeline_decode (warm-up)")                                # untimed; captures the graphs
+        dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.cuda.stream(lane):
-            pipeline_decode(stage, rank, world, dist, S, steps, fwd_groups, token_group)
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        guard(lambda: decode(steps), "pipeline_decode (timed)")
+        dist.barrier(); torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
+    # roofline of this rank's dominant mat-vec (w1|w3) on ITS layers: the stand-alone probe variant of the kernel
+    # (PRE_QA / STORE, back-to-back launches over the stage's layers, HIP events) -- the in-situ rocprofv3 labelling of
+    # bench.py's single-GPU line needs a profiler child per rank and is not attempted under torchrun
+    roof = None
+    try:
+        r = stage.model.bench_gemv(2, -1, 1, 10)
+        roof = {"bound": "hbm", "kernel": "lh::k_gemv PRE_QA / STORE probe variant on w1|w3 of rank 0's layers (not in situ)", "achieved": r["GBps"], "peak": 8000.0,
+                "unit": "GB/s", "frac": r["GBps"] / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": r["algo_bytes"], "us_per_launch": r["us_per_launch"],
+                "per_stage_weight_bytes": stage.model.stats()["weight_bytes_device"]}
+    except Exception as e:                       # measurement extras never cost the headline line
+        roof = {"error": repr(e)}
     if rank == 0:
         total = S * steps
         print(json.dumps({
-            "metric": "decode tokens/sec LLaMA-7B Q4_0 @1 GPU; % HBM-roofline on Q4_0 GEMV",
+            "metric": f"decode tokens/sec LLaMA-{args.model} Q4_0 @{world} GPUs (layer pipeline, {S} sequences in flight); % HBM-roofline on Q4_0 GEMV",
             "value": total / dt, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "q4_0 x q4_0 -> int32 block sums, fp32 scales/accumulate",
@@ -328,6 +386,9 @@ def bench_main(args, cfg, model_path_fn, log):
                                    f"a step = one token for every sequence",
                        "parallelism": f"pp{world} (RCCL p2p hand-off of the fp32 residual stream)",
                        "sequences": S, "tokens_timed": total},
+            "roofline": roof,
+            "cpu_baseline": None,
+            "cpu_baseline_note": "timed at N = 1 only (bench.py --gpus 1)",
             "single_stream_tokens_per_s_estimate": steps / dt,
             "schedule": "host-synchronous" if sync_schedule else "stream-ordered (hipGraph stage steps, device-side greedy pick)",
         }), flush=True)

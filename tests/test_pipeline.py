@@ -102,6 +102,62 @@ def _worker(rank, world, path, n_layer, init_file, rounds, out_file):
     dist.destroy_process_group()
 
 
+def _failing_worker(rank, world, path, n_layer, init_file, mode, out_dir):
+    """rank 1 goes away (mode "exit": the process dies; mode "hang": it stops taking part) after the prompt round."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    import time
+
+    import torch
+    import torch.distributed as dist
+    from llama_swift_amd.pipeline import PipelineError, pipeline_rounds, run_guarded
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    token_group = dist.new_group(list(range(world)))
+    stage = OracleStage(path, 64, rank, world, 2, n_layer)
+    prompts = [synth.synth_prompt(5 + s, 96, seed=10 + s) for s in range(2)]
+    toks, n_past = pipeline_rounds(stage, rank, world, dist, torch, prompts, [0, 0], 1, token_group)
+    if rank == 1:
+        if mode == "exit":
+            os._exit(7)
+        time.sleep(3600)                           # hang: alive, silent
+    last = [np.array([toks[s, -1]], np.int32) for s in range(2)]
+    try:
+        run_guarded(lambda: pipeline_rounds(stage, rank, world, dist, torch, last, n_past, 4, token_group), rank, world, 6.0, "pipeline_rounds (decode)")
+    except PipelineError as e:
+        open(os.path.join(out_dir, "rank0.err"), "w").write(f"{e.code} {e.message}")
+        os._exit(4)
+    os._exit(0)                                    # must not happen: the peer is gone
+
+
+@pytest.mark.parametrize("mode", ["exit", "hang"])
+def test_pipeline_peer_failure_is_reported_not_hung(built, tmp_path, mode):
+    """A stage whose peer dies or hangs must end with a non-zero exit code and a PredictionFailed (-1001) message within
+    the watchdog limit -- never wait forever (HIP/RCCL errors map to -1001 during eval; the bridge posts
+    `failed` once)."""
+    import multiprocessing as mp
+    import time
+    hp = synth.HParams(n_vocab=96, n_embd=256, n_mult=64, n_head=2, n_layer=2)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=31))
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, path, 2, str(tmp_path / "rdv"), mode, str(tmp_path))) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    procs[0].join(90)
+    took = time.time() - t0
+    alive = procs[0].is_alive()
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+        p.join()
+    assert not alive, "rank 0 was still waiting for its dead peer after 90 s"
+    assert procs[0].exitcode in (3, 4), procs[0].exitcode           # 4: transport error -> PipelineError; 3: watchdog
+    if procs[0].exitcode == 4:
+        msg = open(str(tmp_path / "rank0.err")).read()
+        assert msg.startswith("-1001 ") and "rank 0/2" in msg, msg
+    assert took < 80
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_pipeline_schedule_gloo(built, tmp_path, world):
     import torch.multiprocessing as mp
