@@ -2990,18 +2990,18 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
 // array an EPI_RESID launch writes (gemv_resid_parts)
 static int gemv_pick_nw_qa(const QMat &w, int *pg) {
     static const int resid_waves = getenv("LLAMAHIP_QA_WAVES") ? atoi(getenv("LLAMAHIP_QA_WAVES")) : 0;      // tuning override (measurement only)
-    if ((resid_waves == 2 || resid_waves == 4) && w.nchunks * 16 <= 4 * resid_waves * 64) { *pg = 4; return resid_waves; }
-    int nw = pick_waves(w.ngroups);
+    // Workgroups of ngroups / 256 waves (1, 2 or 4): ONE workgroup per CU where the matrix has fewer than 1024
+    // row-groups.  Measured on the 7B decode step: w2 (512 row-groups) as 256 x 2 waves with the 12-granule operand
+    // budget 7.60 us, as 128 x 4 waves with the 4-granule budget 8.52 us, as 512 x 1 wave 7.99 us; wo as 256 x 2 waves
+    // 5.15 us against 5.41 us as 512 x 1 (profiles/r02_d_small_matvec_ab.txt).  The operand budget (4 or 12 granules
+    // of 16 B per thread) follows from the workgroup size, not the other way round.
+    int nw = w.ngroups >= 1024 ? 4 : w.ngroups >= 512 ? 2 : 1;
+    if (resid_waves == 1 || resid_waves == 2 || resid_waves == 4) nw = resid_waves;
     const int need = w.nchunks * 16;
-    // two waves share a staged operand where one would do (7B wo: 5.4 -> 5.15 us in situ, and half as many
-    // partial-sum pairs for the next norm to fold)
-    if (nw < 2 && resid_waves != 1) nw = 2;
-    // prefer the small budget; grow the workgroup (up to 4 waves) before growing the budget
-    while (nw < 4 && need > 4 * nw * 64) nw *= 2;
-    if (need <= 4 * nw * 64) { *pg = 4; return nw; }
-    nw = pick_waves(w.ngroups);
-    while (nw < 4 && need > 12 * nw * 64) nw *= 2;
-    if (need <= 12 * nw * 64) { *pg = 12; return nw; }
+    for (; nw <= 4; nw *= 2) {
+        if (need <= 4 * nw * 64) { *pg = 4; return nw; }
+        if (need <= 12 * nw * 64) { *pg = 12; return nw; }
+    }
     *pg = 0;
     return 0;
 }
