@@ -202,6 +202,7 @@ llamahip_model::~llamahip_model() {
         free_dev(l.qkv.tiles); free_dev(l.wo.tiles); free_dev(l.w13.tiles); free_dev(l.w2.tiles);
         free_dev(l.qkv.rows); free_dev(l.wo.rows); free_dev(l.w13.rows); free_dev(l.w2.rows);
         free_dev(l.qkv.mt); free_dev(l.wo.mt); free_dev(l.w13.mt); free_dev(l.w2.mt);
+        free_dev(l.qkv.mt16); free_dev(l.wo.mt16); free_dev(l.w13.mt16); free_dev(l.w2.mt16);
         free_dev(l.dqkv.w); free_dev(l.dwo.w); free_dev(l.dw13.w); free_dev(l.dw2.w);
         free_dev(l.dqkv.w2); free_dev(l.dwo.w2); free_dev(l.dw13.w2); free_dev(l.dw2.w2);
     }
@@ -301,11 +302,20 @@ int make_rows(QMat &q, llamahip_model *m, char *err, size_t err_cap) {
         m->weight_bytes += (int64_t) q.rows_bytes();
         HIP_TRY(launch_tiles_to_rows(q, m->stream), LLAMAHIP_ERR_PREDICT);
     }
-    if (!q.mt) {
-        q.nrb32 = (q.M + 31) / 32;
-        HIP_TRY(hipMalloc((void **) &q.mt, q.mt_bytes()), LLAMAHIP_ERR_PREDICT);
+    // matrix-core tiles: fp16 two-chain order for the exact path; the int8 order only for a handle opened with
+    // LLAMAHIP_FLAG_FAST_PREFILL (or LLAMAHIP_MFMA_I8=1: the round-1 exact kernel, for A/B) -- one of the two, same size
+    static const bool want_i8 = getenv("LLAMAHIP_MFMA_I8") != nullptr;
+    q.nrb32 = (q.M + 31) / 32;
+    if ((m->flags & LLAMAHIP_FLAG_FAST_PREFILL) || want_i8) {
+        if (!q.mt) {
+            HIP_TRY(hipMalloc((void **) &q.mt, q.mt_bytes()), LLAMAHIP_ERR_PREDICT);
+            m->weight_bytes += (int64_t) q.mt_bytes();
+            HIP_TRY(launch_tiles_to_mtiles(q, m->stream), LLAMAHIP_ERR_PREDICT);
+        }
+    } else if (!q.mt16) {
+        HIP_TRY(hipMalloc((void **) &q.mt16, q.mt_bytes()), LLAMAHIP_ERR_PREDICT);
         m->weight_bytes += (int64_t) q.mt_bytes();
-        HIP_TRY(launch_tiles_to_mtiles(q, m->stream), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(launch_tiles_to_mt16(q, m->stream), LLAMAHIP_ERR_PREDICT);
     }
     return 0;
 }
@@ -362,7 +372,7 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     HIP_TRY(hipMalloc((void **) &m->logits, n * V * 4), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->qa_A, n * KpMax), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMalloc((void **) &m->qa_d, n * (KpMax / 32) * 4), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipMalloc((void **) &m->qb_ws, n * KpMax), LLAMAHIP_ERR_PREDICT);      // int8 operand of the matrix-core GEMM
+    HIP_TRY(hipMalloc((void **) &m->qb_ws, n * KpMax * 2), LLAMAHIP_ERR_PREDICT);  // fp16 (or int8) operand of the matrix-core GEMM
     if (!m->qaF_A) {
         const size_t KpF = ((F + 255) / 256) * 256;
         HIP_TRY(hipMalloc((void **) &m->qaF_A, 64 * KpF), LLAMAHIP_ERR_PREDICT);

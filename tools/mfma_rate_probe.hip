@@ -17,7 +17,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <int WHICH>
-__global__ void k_probe(float *sink, int iters) {
+__global__ void __launch_bounds__(512) k_probe(float *sink, int iters) {
     const int lane = threadIdx.x & 63;
     float s = 0.0f;
     if constexpr (WHICH == 0) {
@@ -34,16 +34,15 @@ __global__ void k_probe(float *sink, int iters) {
         s = (float) (c0[0] + c1[1] + c2[2] + c3[3]);
     } else if constexpr (WHICH == 1) {
         h4 a = { (_Float16) lane, 1, 2, 3 }, b = { 1, 2, 3, 4 };
-        f32x32v c0 = {}, c1 = {}, c2 = {}, c3 = {};
+        f32x32v c0 = {}, c1 = {};
         for (int i = 0; i < iters; i++) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 c0 = __builtin_amdgcn_mfma_f32_32x32x4f16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x4f16(a, b, c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x4f16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x4f16(a, b, c3, 0, 0, 0);
             }
             asm volatile("" : "+v"(a));
         }
-        s = c0[0] + c1[17] + c2[3] + c3[30];
+        s = c0[0] + c1[17];
     } else if constexpr (WHICH == 2) {
         h4 a = { (_Float16) lane, 1, 2, 3 }, b = { 1, 2, 3, 4 };
         f32x16v c0 = {}, c1 = {}, c2 = {}, c3 = {};
