@@ -57,6 +57,7 @@ MODELS = {
     "tiny": dict(n_vocab=512, n_embd=512, n_mult=64, n_head=4, n_layer=4),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2500.0        # dense fp16 (MI355X_MICROARCH.md)
 INT8_MFMA_PEAK_TOPS = 5000.0   # dense int8 matrix-core peak: 2x the 2.5 PFLOP/s bf16 figure (MI355X_MICROARCH.md: i8 = 2x K)
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak (MI355X_MICROARCH.md)
 PROMPT = np.array([1, 17, 291, 4001, 29, 512, 77, 1234], np.int32)
@@ -314,13 +315,16 @@ def prefill_2048(args, cfg, path):
     useful = 2.0 * N * Lr * (4 * d * d + 3 * d * F) + 2.0 * V * d            # mat-mul ops, last row of the lm head only
     fma_flops = useful / 4.0                                                  # the exact path: 8 fp32 FMAs per 32-element block and output
     return {"tokens": N, "n_ctx": n_ctx, "seconds": best, "tokens_per_s": N / best,
-            "roofline": {"useful_ops": useful, "useful_TOPs": useful / best / 1e12, "int8_mfma_peak_TOPs": INT8_MFMA_PEAK_TOPS,
-                         "frac_of_int8_mfma_peak": useful / best / 1e12 / INT8_MFMA_PEAK_TOPS,
+            "roofline": {"useful_ops": useful, "useful_TOPs": useful / best / 1e12,
+                         "f16_mfma_peak_TFLOPs": F16_MFMA_PEAK_TFLOPS, "frac_of_f16_mfma_peak": useful / best / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                         "int8_mfma_peak_TOPs": INT8_MFMA_PEAK_TOPS, "frac_of_int8_mfma_peak": useful / best / 1e12 / INT8_MFMA_PEAK_TOPS,
                          "fp32_fma_TFLOPs": fma_flops / best / 1e12, "fp32_valu_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
                          "frac_of_fp32_valu_peak": fma_flops / best / 1e12 / FP32_VALU_PEAK_TFLOPS,
                          "bound": "fp32 VALU issue: the reference's arithmetic needs 8 separately rounded fp32 FMA chains per Q4_0 block and "
-                                  "output (ggml.c:1415-1466); only the integer block sums run on the matrix cores (one masked "
-                                  "v_mfma_i32_32x32x32_i8 per chain), so the int8 fraction is structurally <= 1/8 of what the pipe could do"}}
+                                  "output (ggml.c:1415-1466), 3.3e12 plain v_fma_f32 for this eval.  Only the 4-element integer sums of a chain "
+                                  "run on the matrix cores (exact in fp16 -> fp32: v_mfma_f32_32x32x4_2b_f16, two chains per issue, "
+                                  "lh::k_gemm_mfma16), which keeps that pipe ~60% busy with K = 4 issues; the whole eval (attention, "
+                                  "norms, quantizers included) is divided by the peaks here"}}
 
 
 def main():

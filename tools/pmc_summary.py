@@ -36,7 +36,7 @@ def agg(path):
 q, f, w = agg(sys.argv[1]), agg(sys.argv[2]), agg(sys.argv[3])
 lines = [
     "# rocprofv3 --pmc passes over tools/gemv_probe.py: the decode GEMV kernel lh::k_gemv<PRE_QA, STORE> on every matrix kind of the",
-    "# synthetic LLaMA-7B model, launches cycling through all 32 layers (cold weights) -- MI355X, round-1 final kernels.",
+    "# synthetic LLaMA-7B model, launches cycling through all 32 layers (cold weights) -- MI355X, the kernels of the build the file name says.",
     "# pass 1: --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE",
     "# pass 2: --pmc FETCH_SIZE        pass 3: --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum        (separate passes, --kernel-trace only)",
     "# FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read",

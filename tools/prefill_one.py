@@ -5,7 +5,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault("LLAMAHIP_NO_TORCH", "1")
+if not os.environ.get("LLAMAHIP_WITH_TORCH"):      # (rocprofv3 crashes on the system HIP runtime here: profile with torch's)
+    os.environ.setdefault("LLAMAHIP_NO_TORCH", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402

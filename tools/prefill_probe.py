@@ -15,6 +15,7 @@ rng = np.random.default_rng(0)
 m = L.Model(path, n_ctx=2560)
 toks = rng.integers(3, 32000, 2048).astype(np.int32); toks[0] = 1
 m.eval(toks[:9], 0)                                   # warm up
+m.eval(toks[:64], 0)                                  # builds the prompt-only weight copies (first eval of 61+ rows)
 t0 = time.perf_counter()
 n_past = 0
 for c0 in range(0, 504, 9):
