@@ -40,6 +40,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "llamahip_internal.h"
 
@@ -305,7 +306,7 @@ __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__res
 // mat-vec folds instead of reducing the row itself (PREP_NORMP).  One workgroup; same dequantization.
 __global__ void __launch_bounds__(256)
 k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb, float *__restrict__ x, int d,
-             f64x2 *__restrict__ part_out) {
+             f64x2 *__restrict__ part_out, uint32_t *__restrict__ epoch) {
     __shared__ double red[32];
     const int tok = tokens[0];
     const uint8_t *row = emb + (size_t) tok * (d / 32) * 20;
@@ -325,6 +326,7 @@ k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb
     s1 = block_sum_d(s1, red, 0);
     s2 = block_sum_d(s2, red, 1);
     if (threadIdx.x == 0) part_out[0] = f64x2{ s1, s2 };
+    if (epoch && threadIdx.x == 0) epoch[0] += 1u;       // one forward pass = one epoch of the tagged hand-offs (k_qkv_attn)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -735,6 +737,23 @@ __device__ __forceinline__ float fold8(float acc) {
 // for wo -> w1|w3 and w2 -> wq|wk|wv the hand-off costs what the boundary did, those stay separate launches.
 constexpr int SYNC_SHARDS = 8;      // words, 64 B apart: 8 shard counters | top counter | 8 go words | time-out word (SYNC_BYTES)
 enum { SYNC_NONE = 0, SYNC_WAIT = 1, SYNC_ARRIVE = 2 };
+// 8-byte granule {value, tag}: written with one 8-byte store, read with one 8-byte load that bypasses the L1 (sc1), so a
+// reader sees the value together with its tag or not at all.  The spin is bounded; running out raises the fault word.
+__device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, bool nowait) {
+    uint64_t v;
+    int spins = 0;
+    for (;;) {
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t) (v >> 32) == tag || nowait) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 20)) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    return __builtin_bit_cast(float, (uint32_t) v);
+}
+__device__ __forceinline__ void store_tagged(uint64_t *p, float v, uint32_t tag) {
+    __hip_atomic_store(p, (uint64_t) __builtin_bit_cast(uint32_t, v) | ((uint64_t) tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 struct GemvArgs {
     const uint8_t *wt; int ngroups, nchunks, M, gmapF8;
     const uint32_t *qa_A; const float *qa_d;
@@ -782,6 +801,8 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     const uint16_t *__restrict__ T_silu = ga.T_silu;
     uint32_t *__restrict__ out_A = ga.out_A; float *__restrict__ out_d = ga.out_d;
     const f64x2 *__restrict__ part_in = ga.part_in; f64x2 *__restrict__ part_out = ga.part_out;
+    // (EPI_STORE_TAG: the tag of this launch's output granules, read up front -- not a dependent load at the tail)
+    const uint32_t store_tag = EPI == EPI_STORE_TAG ? ((__builtin_nontemporal_load(ga.sync) << 7) | (uint32_t) ga.sync_epoch) : 0u;
     // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
     // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
     // index clamp -- their addresses are `loop base + immediate` instead of three VALU per chunk.
@@ -1145,6 +1166,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     } else {
         const bool live = valid && k == 0 && m < M;
         if (EPI == EPI_RESID) acc = acc + resid_v;
+        if (EPI == EPI_STORE_TAG) {                     // ga.sync -> the epoch word, ga.sync_epoch = layer (k_qkv_attn)
+            if (live) store_tagged((uint64_t *) y + m, acc, store_tag);
+        } else
         if (live) y[m] = acc;
         if (EPI == EPI_RESID && part_out) {
             // this workgroup's share of the next norm's statistics (consumed by a PREP_NORMP prologue): sum y and
@@ -2828,6 +2852,296 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_dec_attn_x: k_dec_scores + k_dec_pv_blk<false> in ONE launch with a hand-off that stays inside one XCD.
+// The scores -> soft_max . V seam is per head, and the workgroups of head h (grid (H, n_ctx / 32), linear id
+// h + H * y, H a multiple of 8) all sit on XCD h % 8 (round-robin dispatch, checked by the load-time self-test
+// k_xcd_selftest and by tools/xcd_barrier_probe.hip), i.e. behind ONE L2.  So the hand-off needs no device-scope
+// traffic (that is what makes a cross-XCD hand-off cost 6-12 us): the score workgroups' stores are acknowledged by
+// that L2 (s_waitcnt vmcnt(0)), their arrival is an atomic add WITHOUT scope bits (executes in the L2), the waiting
+// workgroups poll it and then read the scores with sc1 loads (bypass the per-CU L1, hit the L2): ~1 us for the
+// round trip against 2.3-2.7 us for a kernel boundary plus the second kernel's ramp (profiles/r02_g_xcd_barrier.txt).
+//   grid (H, dh / 32 + n_ctx / 32).  Workgroup (h, y), y < dh / 32: soft_max . V for columns [32 y, 32 y + 32): requests
+//                     the first V rows of its chains, waits for the head's n_past / 32 + 1 arrivals, then the
+//                     k_dec_pv_blk body; the last of them to finish clears the head's two counters.
+//                     y >= dh / 32: the k_dec_scores body for keys [32 (y - dh / 32), +32) if that slice starts at or
+//                     before n_past, then arrive.
+// The waiting workgroups have the LOWEST linear ids of the grid (dispatched first) and wait only for workgroups
+// that need no resources they hold (4 H waiters of 256 threads against a chip that holds 2 048 such workgroups), so
+// the spin always ends; it is bounded anyway and a time-out raises the sticky fault word in pinned host memory
+// (results of that launch are then invalid; the host reports PredictionFailed after the next synchronisation).
+// Arithmetic identical to the two kernels.  256 threads (nth <= 8); dynamic LDS as k_dec_pv_blk.
+//   sync: [H][32] dwords (arrivals, finished waiters, padding to one 128-byte line per head)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float load_f32_sc1(const float *p) {
+    return __builtin_bit_cast(float, __hip_atomic_load((const uint32_t *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+struct AttnXArgs {
+    const float *qkv; int d, dh; const double *sincos_tab; float *Kc, *Vc, *sc; int n_ctx, nth; float kq_scale;
+    float *merged; uint32_t *qa_A; float *qa_d; const uint16_t *T_exp; const int32_t *st; uint32_t *sync, *fault; int lut_math;
+    // k_qkv_attn only: data-tagged hand-offs.  qkv2[3 d] / sc2[H][n_ctx] hold {fp32 bits, tag} 8-byte granules,
+    // tag = epoch[0] << 7 | layer: a reader polls the granule itself until the tag is this launch's
+    const uint64_t *qkv2; uint64_t *sc2; const uint32_t *epoch; int layer;
+};
+// role of workgroup (h, yy): yy < ncb: soft_max . V for column block yy; else scores for key slice yy - ncb.
+// QKV_WAIT (k_qkv_attn): the head's q / k / v rows come from mat-vec workgroups of the SAME launch as tagged granules
+// (qkv2); the K rows of the slice are requested first, then the rotating threads poll their own q / k / v granules.  The
+// scores go to the soft_max . V workgroups as tagged granules too (sc2): no counters, no store-acknowledge wait, no
+// separate poll -- a hand-off is one store and one load that sees it.
+template <bool QKV_WAIT>
+__device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, const int yy, double *smem_d) {
+    const float *__restrict__ qkv = aa.qkv; const int d = aa.d, dh = aa.dh; const double *__restrict__ sincos_tab = aa.sincos_tab;
+    float *__restrict__ Kc = aa.Kc, *__restrict__ Vc = aa.Vc; float *sc = aa.sc; const int n_ctx = aa.n_ctx, nth = aa.nth; const float kq_scale = aa.kq_scale;
+    float *__restrict__ merged = aa.merged; uint32_t *__restrict__ qa_A = aa.qa_A; float *__restrict__ qa_d = aa.qa_d;
+    const uint16_t *__restrict__ T_exp = aa.T_exp; const int32_t *__restrict__ st = aa.st; uint32_t *sync = aa.sync, *fault = aa.fault; const int lut_math = aa.lut_math;
+    const int ncb = dh / 32, tid = threadIdx.x;
+#if LH_PHASE_PROBE == 3        /* timeline probe (tools/attn_timeline.py): kind 0xA0 = score workgroup, 0xA1 = soft_max . V workgroup */
+    unsigned long long probe_t[5] = { 0, 0, 0, 0, 0 };
+    const unsigned long long probe_wall = wall_clock64();
+#define LH_ASTAMP(IDX) do { probe_t[IDX] = __builtin_readcyclecounter(); } while (0)
+#define LH_AFLUSH(KIND) do { if (g_phase_probe && tid == 0) { unsigned long long *pb = g_phase_probe; const unsigned long long slot = atomicAdd(pb, 1ull); \
+        if (slot < pb[1]) { unsigned long long *e = pb + 8 * (1 + slot); for (int i = 0; i < 5; i++) e[i] = probe_t[i]; \
+            e[5] = ((unsigned long long) (KIND) << 48) | ((unsigned long long) yy << 32) | (unsigned) h; e[6] = wall_clock64(); e[7] = probe_wall; } } } while (0)
+#else
+#define LH_ASTAMP(IDX) do { } while (0)
+#define LH_AFLUSH(KIND) do { } while (0)
+#endif
+    LH_ASTAMP(0);
+    const int n_past = st[0];
+    uint32_t *cnt = sync + h * 32;
+    if (yy >= ncb) {
+        // ---- score workgroup: keys [t0, t0 + 32)
+        const int t0 = (yy - ncb) * DEC_TS;
+        if (t0 > n_past) return;
+        float *qs = (float *) smem_d, *kn = qs + dh;
+        const bool owns_new = n_past < t0 + DEC_TS;
+        const double *tab = sincos_tab + (size_t) n_past * dh;
+        const float *q = qkv + h * dh, *kk = qkv + d + h * dh, *vv = qkv + 2 * d + h * dh;
+        const int hw = tid >> 5, l = tid & 31;
+        constexpr int KPH = DEC_TS / 8;
+        const int tb = t0 + hw * KPH;
+        float kv[KPH][8];
+        auto load_keys = [&]() {
+#pragma unroll
+            for (int u = 0; u < KPH; u++) {
+                const int t = min(tb + u, n_past);      // (row n_past itself comes from LDS below: whatever this returns for it is not used)
+                const float *kr = Kc + (size_t) t * d + h * dh;
+#pragma unroll
+                for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
+            }
+        };
+        const bool nowait = (lut_math & 0x100) != 0;          // (measurement-only "no wait" switch, results invalid)
+        const uint32_t tag = QKV_WAIT ? ((aa.epoch[0] << 7) | (uint32_t) aa.layer) : 0u;
+        if (QKV_WAIT) load_keys();                              // in flight while the mat-vec workgroups finish
+        if (tid < dh / 2) {
+            const int e = 2 * tid;
+            const double cs = tab[e], sn = tab[e + 1];
+            const uint64_t *q2 = aa.qkv2 + h * dh, *k2 = q2 + d, *v2 = q2 + 2 * d;
+            const double x0 = (double) (QKV_WAIT ? poll_tagged(q2 + e, tag, fault, nowait) : q[e]), x1 = (double) (QKV_WAIT ? poll_tagged(q2 + e + 1, tag, fault, nowait) : q[e + 1]);
+            qs[e] = (float) (x0 * cs - x1 * sn);
+            qs[e + 1] = (float) (x0 * sn + x1 * cs);
+            if (owns_new) {
+                const double k0 = (double) (QKV_WAIT ? poll_tagged(k2 + e, tag, fault, nowait) : kk[e]), k1 = (double) (QKV_WAIT ? poll_tagged(k2 + e + 1, tag, fault, nowait) : kk[e + 1]);
+                const float r0 = (float) (k0 * cs - k1 * sn), r1 = (float) (k0 * sn + k1 * cs);
+                kn[e] = r0; kn[e + 1] = r1;
+                Kc[(size_t) n_past * d + h * dh + e] = r0;
+                Kc[(size_t) n_past * d + h * dh + e + 1] = r1;
+                Vc[(size_t) n_past * d + h * dh + e] = QKV_WAIT ? poll_tagged(v2 + e, tag, fault, nowait) : vv[e];
+                Vc[(size_t) n_past * d + h * dh + e + 1] = QKV_WAIT ? poll_tagged(v2 + e + 1, tag, fault, nowait) : vv[e + 1];
+                // the new V row must be in the L2 before any score of this workgroup is (a soft_max . V workgroup reads it once it
+                // has seen the tagged scores): drain these stores on this side of the barrier
+                if (QKV_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        LH_ASTAMP(1);
+        if (!QKV_WAIT) load_keys();
+#pragma unroll
+        for (int u = 0; u < KPH; u++) {
+            const int t = tb + u;
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i * 32 < dh) {
+                    const float kval = (t == n_past) ? kn[i * 32 + l] : kv[u][i];
+                    s = fmaf(kval, qs[i * 32 + l], s);
+                }
+            }
+            s = tree32_to_lane0(s);
+            if (l == 0 && t <= n_past) {
+                if (QKV_WAIT) store_tagged(aa.sc2 + (size_t) h * n_ctx + t, s * kq_scale, tag);
+                else sc[(size_t) h * n_ctx + t] = s * kq_scale;
+            }
+        }
+        if (QKV_WAIT) { LH_ASTAMP(2); LH_ASTAMP(3); LH_ASTAMP(4); LH_AFLUSH(0xA0); return; }
+        // publish: every wave's stores (scores; the new K / V rows) are acknowledged by the L2, then one arrival
+        LH_ASTAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        LH_ASTAMP(3);
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if LH_PHASE_PROBE == 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        LH_ASTAMP(4);
+        LH_AFLUSH(0xA0);
+        return;
+    }
+    // ---- soft_max . V workgroup for columns [32 cb, 32 cb + 32): k_dec_pv_blk<false> with 256 threads.  The first 32
+    // rows of every V*P chain do not depend on the scores: they are requested BEFORE the wait and arrive while the score
+    // workgroups run (the row with the new token's V is the last one of the last chain: never among them unless the
+    // context is shorter than the batch, in which case the batch is fetched after the wait instead).
+    const int cb = yy, nt = 256;
+    const int T = n_past + 1;
+    const int c = tid & 31, sub = tid >> 5, nsub = nt >> 5;
+    const int dc = (T + nth - 1) / nth;
+    const int col = h * dh + cb * 32 + c;
+    const float *vcol = Vc + col;
+    const int ta0 = dc * sub, t10 = min(ta0 + dc, T);
+    // rows [ta0, ta0 + 32) of chain `sub` are old rows (< n_past) iff ta0 + 32 <= n_past or they are clamped below t10 - 1 < n_past
+    const bool early = sub < nth && ta0 < t10 && min(ta0 + 31, t10 - 1) < n_past;      // wave-uniform per 32-lane half; both halves of a wave differ only in `sub`
+    float va[16], vb[16];
+    if (early) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(ta0 + u, t10 - 1) * d];
+#pragma unroll
+        for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(ta0 + 16 + u, t10 - 1) * d];
+    }
+    if (!QKV_WAIT) {
+        if (tid == 0) {
+            const uint32_t need = (uint32_t) (n_past / DEC_TS + 1);
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 20)) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+        __syncthreads();
+    }
+    LH_ASTAMP(1);
+    double *red = smem_d;
+    float *p = (float *) (smem_d + 32);
+    float *part = p + n_ctx;
+    const float *row = sc + (size_t) h * n_ctx;
+    float mx = -INFINITY;
+    if (QKV_WAIT) {
+        const uint32_t tag = (aa.epoch[0] << 7) | (uint32_t) aa.layer;
+        const bool nowait = (lut_math & 0x100) != 0;
+        for (int t = tid; t < T; t += nt) { const float v = poll_tagged(aa.sc2 + (size_t) h * n_ctx + t, tag, fault, nowait); p[t] = v; mx = fmaxf(mx, v); }
+    } else
+    for (int t = tid; t < T; t += nt) { const float v = load_f32_sc1(row + t); p[t] = v; mx = fmaxf(mx, v); }
+    mx = block_max_f(mx, red, 0);
+    double sum = 0.0;
+    for (int t = tid; t < T; t += nt) {
+        const uint16_t xh = f2h_bits(p[t] - mx);
+        const float e = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
+        p[t] = e;
+        sum += (double) e;
+    }
+    sum = block_sum_d(sum, red, 1);
+    const float inv = (float) (1.0 / sum);
+    for (int t = tid; t < T; t += nt) p[t] *= inv;
+    __syncthreads();
+    LH_ASTAMP(2);
+    for (int th = sub; th < nth; th += nsub) {
+        const int ta = dc * th, t1 = min(ta + dc, T);
+        float acc = 0.0f;
+        if (!(early && th == sub)) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(ta + u, t1 - 1) * d];
+#pragma unroll
+            for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(ta + 16 + u, t1 - 1) * d];
+        }
+        for (int tb = ta; tb < t1; tb += 32) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float pe = (tb + u < t1) ? p[min(tb + u, T - 1)] : 0.0f;
+                acc = fmaf(va[u], pe, acc);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(tb + 32 + u, t1 - 1) * d];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float pe = (tb + 16 + u < t1) ? p[min(tb + 16 + u, T - 1)] : 0.0f;
+                acc = fmaf(vb[u], pe, acc);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(tb + 48 + u, t1 - 1) * d];
+        }
+        part[th * 32 + c] = acc;
+    }
+    __syncthreads();
+    LH_ASTAMP(3);
+    if (tid < 32) {
+        float s = part[tid];
+        for (int th = 1; th < nth; th++) s += part[th * 32 + tid];          // thread order (ggml.c:5553-5577)
+        if (merged) merged[col] = s;
+        float amax = fabsf(s);
+        amax = max_lanes_0_31(amax);
+        const float dd = amax / 7.0f;
+        const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+        const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
+        const int kk = tid & 7;
+        const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+        const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+        const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
+        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+        if (tid == 0) qa_d[b] = dd;
+    }
+    // the last soft_max . V workgroup of the head to get here clears the counters for the next launch (every one of them
+    // has passed the poll, every score workgroup has arrived: nobody touches them again in this launch)
+    if (!QKV_WAIT && tid == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (done == (uint32_t) (ncb - 1)) {
+            __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_exchange(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    LH_ASTAMP(4);
+    LH_AFLUSH(0xA1);
+}
+#undef LH_ASTAMP
+#undef LH_AFLUSH
+
+__global__ void __launch_bounds__(256)
+k_dec_attn_x(const AttnXArgs aa) {
+    extern __shared__ double smem_d[];
+    attn_x_body<false>(aa, blockIdx.x, blockIdx.y, smem_d);
+}
+
+// wq|wk|wv mat-vec AND the attention in one launch.  The seam is per head as well: head h's scores need only head h's
+// 3 dh output rows.  Blocks [0, gridA) are the mat-vec's workgroups (4 waves = 32 rows), PERMUTED so that the 3 dh / 32
+// workgroups that own head h's q, k and v rows sit on XCD h % 8 (block b: XCD b % 8, slot b / 8 -> (head of that XCD, part)):
+// they store their rows as tagged 8-byte granules {value, epoch << 7 | layer} (EPI_STORE_TAG) which the readers poll.  Blocks [gridA, ...) are the attention workgroups
+// of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
+// request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
+// soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
+template <int PRE>
+__global__ void __launch_bounds__(256)
+k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
+    extern __shared__ double smem_d[];
+    const int b = blockIdx.x;
+    if (b < gridA) {
+        const int ncb = aa.dh / 32, wph = 3 * ncb;
+        const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
+        const int h = xcd + 8 * j;
+        gemv_body<PRE, EPI_STORE_TAG, 8, true, 1, SYNC_NONE, false>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules
+        return;
+    }
+    const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
+    attn_x_body<true>(aa, h, y, smem_d);
+}
+
+// load-time self-test of the assumption above: out[b] = XCC_ID of workgroup b of a (H, Y) grid
+__global__ void k_xcd_selftest(uint32_t *out) {
+    if (threadIdx.x == 0) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        out[blockIdx.x + gridDim.x * blockIdx.y] = id & 0xf;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // greedy argmax, lowest index on ties (harness definition of temperature 0)
 // ------------------------------------------------------------------------------------------------
 // st (optional): st[0] = n_past, st[1] = decode step index -- both advanced here so a captured
@@ -3036,7 +3350,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
-    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn);
+    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP>)); LH_ATTR((k_qkv_attn<PREP_NORM>));
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -3093,8 +3407,8 @@ hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int
 
 size_t prep_lds_bytes(int K) { return 32 * sizeof(double) + ((size_t) K + K / 32 + 64) * sizeof(float); }
 
-hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_embed_part, dim3(1), dim3(256), 0, st, token, emb, x, d, (f64x2 *) part_out);
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch) {
+    hipLaunchKernelGGL(k_embed_part, dim3(1), dim3(256), 0, st, token, emb, x, d, (f64x2 *) part_out, epoch);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3667,12 +3981,43 @@ hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, 
     return hipSuccess;
 }
 
+// true when every workgroup of a (H, Y) grid that shares blockIdx.x also shares an XCD (what k_dec_attn_x relies on)
+bool xcd_selftest(int H, int Y, hipStream_t st) {
+    uint32_t *d_out = nullptr;
+    const size_t n = (size_t) H * Y;
+    if (hipMalloc((void **) &d_out, n * 4) != hipSuccess) return false;
+    std::vector<uint32_t> out(n, 0xffffffffu);
+    bool ok = hipMemsetAsync(d_out, 0xff, n * 4, st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_xcd_selftest, dim3(H, Y), dim3(64), 0, st, d_out);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(out.data(), d_out, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    (void) hipFree(d_out);
+    if (!ok) return false;
+    for (int h = 0; h < H; h++)
+        for (int y = 0; y < Y; y++)
+            if (out[h + (size_t) H * y] != out[h] || out[h] > 15u) return false;
+    return true;
+}
+
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
-                           const uint16_t *T_exp, const int32_t *state, hipStream_t st) {
+                           const uint16_t *T_exp, const int32_t *state, hipStream_t st, uint32_t *xsync, uint32_t *fault) {
     const int dh = d / H;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     (void) part;
+    // scores and soft_max . V in one launch with an XCD-local hand-off (k_dec_attn_x); the caller passes xsync only
+    // after xcd_selftest() confirmed the placement it relies on
+    if (xsync && fault && nth <= 8 && dh % 32 == 0 && dh <= 256 && H % 8 == 0) {
+        const int nsl = (n_ctx + DEC_TS - 1) / DEC_TS;
+        const size_t lds_pv = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
+        const size_t lds = std::max(lds_pv, (size_t) 2 * dh * sizeof(float));
+        const AttnXArgs aa = { qkv, d, dh, tab, Kc, Vc, sc, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, xsync, fault, g_lut_math, nullptr, nullptr, nullptr, 0 };
+        hipLaunchKernelGGL(k_dec_attn_x, dim3(H, dh / 32 + nsl), dim3(256), lds, st, aa);
+        LH_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     // The single-launch variant (k_dec_attn) measured SLOWER on MI355X (13.3 us vs 4.9 + 5.7 us per layer at
     // 7B, n_ctx 512: its 16-wave workgroups serialise four phases that the split version spreads over
     // 8x more workgroups); it stays selectable for comparison only.
@@ -3689,6 +4034,49 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;      // whole waves: the DPP reductions need every lane live
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
     hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L, g_lut_math);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// wq|wk|wv mat-vec + decode attention in ONE launch (k_qkv_attn).  Applies to the shapes its mat-vec role is instantiated
+// for (the 8-deep ring, 4-wave, one-granule variant: K = 4096) and head layouts whose workgroups line up with heads.
+bool qkv_attn_applies(const QMat &w, int d, int H, int nth) {
+    static const bool off = getenv("LLAMAHIP_NO_QKV_ATTN") != nullptr;
+    if (off || H % 8 != 0 || d % H != 0) return false;
+    const int dh = d / H;
+    if (dh % 32 != 0 || dh > 256 || nth > 8 || w.gmapF8 || w.M != 3 * d || w.K != d || w.ngroups != 3 * d / 8) return false;
+    int nw = pick_waves(w.ngroups);
+    const int need = w.K / 16;                  // as launch_gemv_t: the one-granule, 4-wave, 8-deep-ring variant or nothing
+    while (nw < 4 && need > nw * 64) nw *= 2;
+    if (w.nchunks != 16 || w.ngroups < 1024 || nw != 4 || need > 256 || pick_depth(w.nchunks, w.ngroups) != 8) return false;
+    return true;
+}
+hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
+                           int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
+                           const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st) {
+    const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
+    const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
+    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // as launch_gemv
+    const bool normp = norm_mode >= 2 && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX;
+    const size_t lds_mv = gemv_lds_bytes(w, 8);
+    const size_t lds_pv = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
+    const size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
+    // the mat-vec role writes tagged granules: y -> qkv2, sync -> the epoch word, sync_epoch = layer
+    const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
+                          (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math };
+    static const int nowait = getenv("LLAMAHIP_ATTN_NOWAIT") ? 0x100 : 0;       // measurement only: the polls pass at once, RESULTS ARE INVALID
+    const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait,
+                           qkv2, sc2, epoch, layer };
+    const int grid = gridA + H * (nsl + dh / 32);
+    if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H);
+    else       hipLaunchKernelGGL((k_qkv_attn<PREP_NORM>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+__global__ void k_bump_epoch(uint32_t *epoch) { epoch[0] += 1u; }
+hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st) {
+    hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(1), 0, st, epoch);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -167,6 +167,11 @@ struct llamahip_model {
     bool prompt_copies = false;          // the row-lane / matrix-core copies of the layer matrices exist (ensure_prompt_copies)
     bool pair_used = false;              // a fused w1|w3 + w2 launch ran since the time-out word was last read
     uint32_t *d_sync = nullptr;          // in-launch hand-off words of the fused w1|w3 + w2 launch (k_gemv_pair), SYNC_BYTES
+    uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
+    uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
+    uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
+    uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
+    uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
                                                      // a: of the row in x (attention / final norm), b: of the row in x1 (ffn norm)
     int n_seq = 1, cur_seq = 0;          // KV caches: [seq][layer][n_ctx][d]
@@ -211,7 +216,8 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    free_dev(npart_a); free_dev(npart_b); free_dev(d_sync);
+    free_dev(npart_a); free_dev(npart_b); free_dev(d_sync); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch);
+    if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
     for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
@@ -462,7 +468,7 @@ int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const flo
         HIP_TRY(prep_mm(L.dqkv, EPI_STORE, PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qkv, 3L * d, nullptr, 0), LLAMAHIP_ERR_PREDICT);             // .mm:570-582
         if (N == 1) {
             // one row: the decode attention kernels of the Q4_0 path (position from device memory, fp32 output)
-            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, m->merged, m->qa1_A, m->qa1_d, m->T_exp, m->d_state, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, m->merged, m->qa1_A, m->qa1_d, m->T_exp, m->d_state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
         } else {
             HIP_TRY(launch_rope_kv(m->qkv, 3L * d, d, dh, m->sincos, m->qr, Kl, Vl, n_past, N, st), LLAMAHIP_ERR_PREDICT);                             // .mm:586-611
             HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, nullptr, nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT); // .mm:614-646
@@ -529,9 +535,12 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     // run monotonically over the layers of a token and are cleared here, once per token
     const bool use_pair = fused && m->w13_interleaved && m->l1 > m->l0 && gemv_pair_applies(m->layers[0].w13, m->layers[0].w2);
     if (use_pair) { m->pair_used = true; HIP_TRY(hipMemsetAsync(m->d_sync, 0, SYNC_CLEAR_BYTES, st), LLAMAHIP_ERR_PREDICT); }
+    // decode: wq|wk|wv + attention as one launch with tagged hand-offs (k_qkv_attn); one forward pass = one epoch
+    const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
+    if (use_qkvx && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (m->first_stage) {
         if (use_part) {
-            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_qkvx ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);
             n_part_x = 1;
         } else
         HIP_TRY(launch_embed((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
@@ -558,8 +567,13 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
                 n_part_x = 0;
                 if (p2 > 0 && p2 <= NORM_PART_MAX) { np_w2.out = m->npart_a; n_part_x = p2; }
             }
+            if (use_qkvx) {
+                HIP_TRY(launch_qkv_attn(L.qkv, xa, L.attention_norm, np_qkv, m->d_qkv2, m->d_sc2, m->d_epoch, il - m->l0, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
+                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st), LLAMAHIP_ERR_PREDICT);
+            } else {
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
+            }
             HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo), LLAMAHIP_ERR_PREDICT);
             if (use_pair) {
                 HIP_TRY(launch_gemv_pair(L.w13, L.w2, m->x1, L.ffn_norm, np_w13, m->qa2_A, m->qa2_d, xo, m->x1, np_w2, m->T_silu, m->d_sync, il - m->l0 + 1, st), LLAMAHIP_ERR_PREDICT);
@@ -669,6 +683,11 @@ dump_fail:
 int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
     uint32_t w = 0;
     uint32_t *word = m->d_sync + (SYNC_BYTES - 64) / 4;
+    if (m->h_fault && *(volatile uint32_t *) m->h_fault) {
+        *(volatile uint32_t *) m->h_fault = 0;
+        set_err(err, err_cap, "decode step: the in-launch hand-off of the attention kernel timed out (set LLAMAHIP_NO_ATTN_X=1 to use two launches)");
+        return LLAMAHIP_ERR_PREDICT;
+    }
     if (!m->pair_used) return 0;         // (the check is a device round trip: only when the hand-off was in play)
     m->pair_used = false;
     if (!m->d_sync || hipMemcpy(&w, word, 4, hipMemcpyDeviceToHost) != hipSuccess || w == 0) return 0;
@@ -881,6 +900,21 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipMalloc((void **) &m->part, (size_t) H * 64 * dh * 4), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->d_sync, SYNC_BYTES), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->d_sync, 0, SYNC_BYTES), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipHostMalloc((void **) &m->h_fault, 64, hipHostMallocMapped), LLAMAHIP_ERR_LOAD);
+        *m->h_fault = 0;
+        HIP_TRY(hipHostGetDevicePointer((void **) &m->d_fault, m->h_fault, 0), LLAMAHIP_ERR_LOAD);
+        // decode attention as one launch needs every workgroup of a head behind one L2: check the placement on this
+        // device before relying on it (LLAMAHIP_NO_ATTN_X: keep the two launches)
+        if (!getenv("LLAMAHIP_NO_ATTN_X") && H % 8 == 0 && xcd_selftest(H, (int) (d / H / 32) + (n_ctx + 31) / 32, m->stream)) {
+            HIP_TRY(hipMalloc((void **) &m->d_attn_sync, (size_t) H * 32 * 4), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_attn_sync, 0, (size_t) H * 32 * 4), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_qkv2, (size_t) 3 * d * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_qkv2, 0, (size_t) 3 * d * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_sc2, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_sc2, 0, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
+        }
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->npart_a, 0, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);

@@ -11,7 +11,7 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
 // (PREP_NORMP: PREP_NORM with the row's {sum x, sum x^2} supplied by its producer -- k_gemv only, selected by launch_gemv)
 enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4 /* k_qkv_attn: rows as {value, tag} granules */ };
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
 struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; };
 
@@ -92,7 +92,7 @@ hipError_t launch_gemv_pair(const QMat &w13, const QMat &w2, const float *x_in, 
                             uint32_t *qa2_A, float *qa2_d, float *y, const float *resid, const NormPart &np2,
                             const uint16_t *T_silu, uint32_t *sync, int epoch, hipStream_t st);
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
-hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st);
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr);
 enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_COUNT = 5 };
 extern long g_gemm_path_counts[GEMM_PATH_COUNT];     // launches per kernel family of launch_gemm (process-wide; tests)
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
@@ -121,7 +121,15 @@ hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, 
                              const uint16_t *T_exp, hipStream_t st);
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
-                           const uint16_t *T_exp, const int32_t *state, hipStream_t st);
+                           const uint16_t *T_exp, const int32_t *state, hipStream_t st,
+                           uint32_t *xsync = nullptr, uint32_t *fault = nullptr);     // xsync: H * 32 zeroed dwords -> single-launch k_dec_attn_x
+bool xcd_selftest(int H, int Y, hipStream_t st);
+// wq|wk|wv mat-vec + decode attention as one launch (k_qkv_attn); xsync / fault as launch_dec_attn
+bool qkv_attn_applies(const QMat &w, int d, int H, int nth);
+hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
+                           int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
+                           const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st);
+hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
 hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st);
 hipError_t launch_advance(int32_t *state, hipStream_t st);
 // sampler front end (utils.cpp:345-395): the k best candidate scores of the last row of logits, on the device
