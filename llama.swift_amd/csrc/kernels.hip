@@ -3116,7 +3116,7 @@ k_dec_attn_x(const AttnXArgs aa) {
 // of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
-template <int PRE>
+template <int PRE, int D, int PG>
 __global__ void __launch_bounds__(256)
 k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
     extern __shared__ double smem_d[];
@@ -3125,7 +3125,7 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) 
         const int ncb = aa.dh / 32, wph = 3 * ncb;
         const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
         const int h = xcd + 8 * j;
-        gemv_body<PRE, EPI_STORE_TAG, 8, true, 1, SYNC_NONE, false>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules
+        gemv_body<PRE, EPI_STORE_TAG, D, true, PG, SYNC_NONE, false>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules
         return;
     }
     const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
@@ -3350,7 +3350,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
-    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP>)); LH_ATTR((k_qkv_attn<PREP_NORM>));
+    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -4040,16 +4040,27 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
 
 // wq|wk|wv mat-vec + decode attention in ONE launch (k_qkv_attn).  Applies to the shapes its mat-vec role is instantiated
 // for (the 8-deep ring, 4-wave, one-granule variant: K = 4096) and head layouts whose workgroups line up with heads.
+// the mat-vec role of k_qkv_attn is instantiated for (ring depth, granules per thread) = (8, 1) [7B], (10, 2) [13B], (4, 2) [65B]:
+// what launch_gemv_t / launch_gemv_pg pick for wq|wk|wv of those models; returns 0 when the shape takes another variant
+static int qkv_attn_variant(const QMat &w) {
+    int nw = pick_waves(w.ngroups);
+    const int need = w.K / 16;                  // as launch_gemv_t
+    while (nw < 4 && need > nw * 64) nw *= 2;
+    if (nw != 4) return 0;
+    const int pg = need <= 256 ? 1 : need <= 512 ? 2 : 0;
+    if (!pg || (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024))) return 0;          // (whole-row-in-flight variant: small models)
+    const int D = pick_depth(w.nchunks, w.ngroups);
+    if (D == 8 && pg == 1) return 1;
+    if (D == 10 && pg == 2) return 2;
+    if (D == 4 && pg == 2) return 3;
+    return 0;
+}
 bool qkv_attn_applies(const QMat &w, int d, int H, int nth) {
     static const bool off = getenv("LLAMAHIP_NO_QKV_ATTN") != nullptr;
     if (off || H % 8 != 0 || d % H != 0) return false;
     const int dh = d / H;
     if (dh % 32 != 0 || dh > 256 || nth > 8 || w.gmapF8 || w.M != 3 * d || w.K != d || w.ngroups != 3 * d / 8) return false;
-    int nw = pick_waves(w.ngroups);
-    const int need = w.K / 16;                  // as launch_gemv_t: the one-granule, 4-wave, 8-deep-ring variant or nothing
-    while (nw < 4 && need > nw * 64) nw *= 2;
-    if (w.nchunks != 16 || w.ngroups < 1024 || nw != 4 || need > 256 || pick_depth(w.nchunks, w.ngroups) != 8) return false;
-    return true;
+    return qkv_attn_variant(w) != 0;
 }
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
@@ -4058,7 +4069,8 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // as launch_gemv
     const bool normp = norm_mode >= 2 && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX;
-    const size_t lds_mv = gemv_lds_bytes(w, 8);
+    const int variant = qkv_attn_variant(w);
+    const size_t lds_mv = gemv_lds_bytes(w, variant == 1 ? 8 : variant == 2 ? 10 : 4);
     const size_t lds_pv = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
     const size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
     // the mat-vec role writes tagged granules: y -> qkv2, sync -> the epoch word, sync_epoch = layer
@@ -4068,8 +4080,10 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait,
                            qkv2, sc2, epoch, layer };
     const int grid = gridA + H * (nsl + dh / 32);
-    if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H);
-    else       hipLaunchKernelGGL((k_qkv_attn<PREP_NORM>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H);
+#define LH_GOX(D, PG) { if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
+                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); }
+    if (variant == 1) LH_GOX(8, 1) else if (variant == 2) LH_GOX(10, 2) else if (variant == 3) LH_GOX(4, 2) else return hipErrorInvalidValue;
+#undef LH_GOX
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -234,6 +234,21 @@ def test_matrix_core_prompt_gemm_forced_on_small_models():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("switch", ["LLAMAHIP_NO_QKV_ATTN", "LLAMAHIP_NO_ATTN_X"])
+def test_decode_attention_fallback_paths(switch):
+    """The decode step runs wq|wk|wv + attention as one launch with in-launch hand-offs (k_qkv_attn) where the shapes allow;
+    the paths it replaces stay in the library for every other shape: the single-launch attention with per-head counters
+    (k_dec_attn_x: LLAMAHIP_NO_QKV_ATTN=1) and the two-launch attention (LLAMAHIP_NO_ATTN_X=1).  The switches are read once
+    per process, hence the subprocess; same parity tests, same oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ, **{switch: "1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "wider_models or greedy_trace_128 or tiny_model_golden or prompt_continuation"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_context_overflow_and_bad_tokens_are_errors(L, tmp_path):
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=64, n_head=2, n_layer=1)
     path = str(tmp_path / "m.bin")
