@@ -764,6 +764,7 @@ struct GemvArgs {
     const f64x2 *part_in; int npart; f64x2 *part_out;
     uint32_t *sync; int sync_blocks, sync_epoch;      // hand-off words, blocks of the producer role, 1-based epoch
     int lut_math;                                     // bit 0: evaluate SiLU instead of gathering it (verified at load time)
+    uint32_t *fault;                                  // PRE_QA_TAG: sticky fault word (a bounded poll that ran out)
 };
 
 __device__ __forceinline__ void sync_arrive(uint32_t *sync, int blk, int nblocks, int epoch) {
@@ -802,7 +803,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     uint32_t *__restrict__ out_A = ga.out_A; float *__restrict__ out_d = ga.out_d;
     const f64x2 *__restrict__ part_in = ga.part_in; f64x2 *__restrict__ part_out = ga.part_out;
     // (EPI_STORE_TAG: the tag of this launch's output granules, read up front -- not a dependent load at the tail)
-    const uint32_t store_tag = EPI == EPI_STORE_TAG ? ((__builtin_nontemporal_load(ga.sync) << 7) | (uint32_t) ga.sync_epoch) : 0u;
+    const uint32_t store_tag = (EPI == EPI_STORE_TAG || PRE == PRE_QA_TAG) ? ((__builtin_nontemporal_load(ga.sync) << 7) | (uint32_t) ga.sync_epoch) : 0u;
     // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
     // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
     // index clamp -- their addresses are `loop base + immediate` instead of three VALU per chunk.
@@ -936,7 +937,58 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         if (i < PADC * 64) ldsA[nchunks * 64 + i] = 0u;
         else ldsD[nchunks * 8 + (i - PADC * 64)] = 0.0f;
     }
-    if (PRE == PRE_QA) {
+    if (PRE == PRE_QA_TAG) {
+        // the quantized activation row comes from workgroups of the SAME launch (other XCDs) as tagged 8-byte granules
+        // {dword, tag}: qa_A -> nchunks * 64 of them, qa_d -> nchunks * 8.  Every thread polls its own granules, four
+        // loads in flight per round; the weights of this workgroup are already on their way (phase 2).
+        const uint64_t *ta = (const uint64_t *) qa_A;            // [block][9] granules: 8 chain dwords + the scale
+        const int na = nchunks * 64, ntot = na + nchunks * 8;
+        const bool nowait = (ga.lut_math & 0x100) != 0;              // (measurement-only switch, results invalid)
+        // Throttle: 128 workgroups polling 9 KB each through the fabric would compete with the mat-vec that is still streaming
+        // (measured: the launch got SLOWER).  Only wave 0 watches the scale granules (1 KB, the last thing a producer writes),
+        // sleeping between looks; when they are all there the whole workgroup runs the tag-checked copy, which then passes
+        // on its first or second round.
+        if (wave == 0 && !nowait) {
+            const int nd = nchunks * 8;
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+                for (int gi = lane; gi < nd; gi += 64)
+                    ok = ok && (uint32_t) (__hip_atomic_load(ta + gi * 9 + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == store_tag;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 18)) break;             // (the copy below raises the fault word if the data never comes)
+            }
+        }
+        __syncthreads();
+        for (int base = 0; base < ntot; base += nt * 4) {
+            uint64_t v[4] = { 0, 0, 0, 0 };
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int gi = base + tid + u * nt;
+                    if (active && gi < ntot) {
+                        // granule of LDS dword gi = (chunk cc, chain kk, block j): the producer of block cc * 8 + j wrote its 8 chain dwords
+                        // and its scale as 9 CONTIGUOUS granules (one 72-byte write-through burst per producer, not 9 scattered ones)
+                        const int src = gi < na ? (((gi >> 6) * 8 + (gi & 7)) * 9 + ((gi >> 3) & 7)) : ((gi - na) * 9 + 8);
+                        v[u] = __hip_atomic_load(ta + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (uint32_t) (v[u] >> 32) == store_tag;
+                    }
+                }
+                if (ok || nowait) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 20)) { __hip_atomic_store(ga.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int gi = base + tid + u * nt;
+                if (active && gi < ntot) { if (gi < na) ldsA[gi] = (uint32_t) v[u]; else ldsD[gi - na] = __builtin_bit_cast(float, (uint32_t) v[u]); }
+            }
+        }
+        __syncthreads();
+    } else if (PRE == PRE_QA) {
 #pragma unroll
         for (int u = 0; u < MAXQA; u++) { const int gi = tid + u * nt; if (active && gi < nchunks * 16) ((u32x4 *) ldsA)[gi] = qg[u]; }
 #pragma unroll
@@ -2882,6 +2934,7 @@ struct AttnXArgs {
     // k_qkv_attn only: data-tagged hand-offs.  qkv2[3 d] / sc2[H][n_ctx] hold {fp32 bits, tag} 8-byte granules,
     // tag = epoch[0] << 7 | layer: a reader polls the granule itself until the tag is this launch's
     const uint64_t *qkv2; uint64_t *sc2; const uint32_t *epoch; int layer;
+    uint64_t *qat_A, *qat_d;      // non-null: the wo mat-vec is a role of the same launch and takes the quantized row as tagged granules
 };
 // role of workgroup (h, yy): yy < ncb: soft_max . V for column block yy; else scores for key slice yy - ncb.
 // QKV_WAIT (k_qkv_attn): the head's q / k / v rows come from mat-vec workgroups of the SAME launch as tagged granules
@@ -3085,8 +3138,17 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
         const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
         const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
         const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
-        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+        const uint32_t dwq = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+        if (QKV_WAIT && aa.qat_A) {
+            // consumed by the wo role of this launch on all XCDs: 9 contiguous write-through granules {dword, tag} per Q4_0 block
+            // (its 8 chain dwords, then its scale)
+            const uint32_t tagq = (aa.epoch[0] << 7) | (uint32_t) aa.layer;
+            if (tid < 8) __hip_atomic_store(aa.qat_A + (b * 9 + kk), (uint64_t) dwq | ((uint64_t) tagq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(aa.qat_A + (b * 9 + 8), (uint64_t) __builtin_bit_cast(uint32_t, dd) | ((uint64_t) tagq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = dwq;
         if (tid == 0) qa_d[b] = dd;
+        }
     }
     // the last soft_max . V workgroup of the head to get here clears the counters for the next launch (every one of them
     // has passed the poll, every score workgroup has arrived: nobody touches them again in this launch)
@@ -3116,9 +3178,9 @@ k_dec_attn_x(const AttnXArgs aa) {
 // of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
-template <int PRE, int D, int PG>
+template <int PRE, int D, int PG, bool WO>
 __global__ void __launch_bounds__(256)
-k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
+k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int gridA, const int H) {
     extern __shared__ double smem_d[];
     const int b = blockIdx.x;
     if (b < gridA) {
@@ -3129,6 +3191,12 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) 
         return;
     }
     const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
+    if (WO && y >= aa.dh / 32 + (aa.n_ctx + DEC_TS - 1) / DEC_TS) {
+        // the wo mat-vec of the layer (WO): 4-wave workgroups behind the attention's; their weight rows are in flight while the
+        // attention runs, the quantized attention output arrives as tagged granules from the soft_max . V workgroups (all XCDs)
+        gemv_body<PRE_QA_TAG, EPI_RESID, 16, false, 1, SYNC_NONE, false>(gw, a - H * (aa.dh / 32 + (aa.n_ctx + DEC_TS - 1) / DEC_TS), 4, smem_d);
+        return;
+    }
     attn_x_body<true>(aa, h, y, smem_d);
 }
 
@@ -3350,7 +3418,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
-    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));
+    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1, true>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1, true>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2, false>));
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -4062,27 +4130,46 @@ bool qkv_attn_applies(const QMat &w, int d, int H, int nth) {
     if (dh % 32 != 0 || dh > 256 || nth > 8 || w.gmapF8 || w.M != 3 * d || w.K != d || w.ngroups != 3 * d / 8) return false;
     return qkv_attn_variant(w) != 0;
 }
+// wo as a role of the same launch: the 7B shapes (whole 4096-wide rows in flight, no padding blocks)
+bool qkv_attn_fuses_wo(const QMat &wqkv, const QMat &wo) {
+    // OFF by default (LLAMAHIP_WO_FUSE=1 enables it): measured on the 7B decode step the launch with the wo role takes
+    // 21.5 us against 15.1 + 4.8 us as two launches (profiles/r02_g_wo_fuse_ab.txt) -- and 15.4 against 9.9 us even with
+    // every poll disabled: the 128 trailing workgroups only get their slots and their 10.5 MB of weights when the first
+    // mat-vec's stream ends, so nothing of wo's latency is hidden and its hand-off comes on top.
+    static const bool off = getenv("LLAMAHIP_WO_FUSE") == nullptr || getenv("LLAMAHIP_NO_WO_FUSE") != nullptr;
+    return !off && qkv_attn_variant(wqkv) == 1 && !wo.gmapF8 && wo.nchunks == 16 && wo.K % 256 == 0 && wo.ngroups % 4 == 0 && wo.ngroups < 1024 && wo.M == wo.ngroups * 8;
+}
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
-                           const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st) {
+                           const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
+                           const QMat *wo, uint64_t *qat_A, uint64_t *qat_d, float *wo_y, const float *wo_resid, const NormPart *np_wo) {
     const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // as launch_gemv
     const bool normp = norm_mode >= 2 && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX;
     const int variant = qkv_attn_variant(w);
+    const bool fuse_wo = wo && qat_A && qat_d && qkv_attn_fuses_wo(w, *wo);
     const size_t lds_mv = gemv_lds_bytes(w, variant == 1 ? 8 : variant == 2 ? 10 : 4);
     const size_t lds_pv = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
-    const size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
+    size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
+    if (fuse_wo) lds = std::max(lds, gemv_lds_bytes(*wo, 0));
     // the mat-vec role writes tagged granules: y -> qkv2, sync -> the epoch word, sync_epoch = layer
-    const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
-                          (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math };
     static const int nowait = getenv("LLAMAHIP_ATTN_NOWAIT") ? 0x100 : 0;       // measurement only: the polls pass at once, RESULTS ARE INVALID
+    const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
+                          (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math, fault };
+    GemvArgs gw = ga;
+    if (fuse_wo) {
+        const NormPart npw = (np_wo && norm_mode >= 2) ? *np_wo : NormPart();
+        if (npw.out && wo->ngroups / 4 > NORM_PART_MAX) return hipErrorInvalidValue;
+        gw = GemvArgs{ wo->tiles, wo->ngroups, wo->nchunks, wo->M, wo->gmapF8, (const uint32_t *) qat_A, (const float *) qat_d, nullptr, nullptr, wo->K, wo_y, wo_resid, T_silu,
+                       nullptr, nullptr, nullptr, 0, (f64x2 *) npw.out, epoch, 0, layer, g_lut_math | nowait, fault };
+    }
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait,
-                           qkv2, sc2, epoch, layer };
-    const int grid = gridA + H * (nsl + dh / 32);
-#define LH_GOX(D, PG) { if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
-                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); }
-    if (variant == 1) LH_GOX(8, 1) else if (variant == 2) LH_GOX(10, 2) else if (variant == 3) LH_GOX(4, 2) else return hipErrorInvalidValue;
+                           qkv2, sc2, epoch, layer, fuse_wo ? qat_A : nullptr, fuse_wo ? qat_d : nullptr };
+    const int grid = gridA + H * (nsl + dh / 32) + (fuse_wo ? wo->ngroups / 4 : 0);
+#define LH_GOX(D, PG, WO) { if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); \
+                            else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); }
+    if (variant == 1 && fuse_wo) LH_GOX(8, 1, true) else if (variant == 1) LH_GOX(8, 1, false) else if (variant == 2) LH_GOX(10, 2, false) else if (variant == 3) LH_GOX(4, 2, false) else return hipErrorInvalidValue;
 #undef LH_GOX
     LH_LAUNCH_CHECK();
     return hipSuccess;

@@ -169,6 +169,7 @@ struct llamahip_model {
     uint32_t *d_sync = nullptr;          // in-launch hand-off words of the fused w1|w3 + w2 launch (k_gemv_pair), SYNC_BYTES
     uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
+    uint64_t *d_qat_A = nullptr, *d_qat_d = nullptr; // ... and the quantized attention output for the wo role: [Kp_d / 4] and [Kp_d / 32] granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
@@ -216,7 +217,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    free_dev(npart_a); free_dev(npart_b); free_dev(d_sync); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch);
+    free_dev(npart_a); free_dev(npart_b); free_dev(d_sync); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_qat_A); free_dev(d_qat_d);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
@@ -560,8 +561,9 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             const float *xa = (il == m->l0 && x_first) ? x_first : m->x;      // residual stream into this layer
             float *xo = (il == m->l1 - 1 && x_last) ? x_last : m->x;           // ... and out of it
             NormPart np_qkv, np_wo, np_w13, np_w2;
+            const bool fuse_wo = use_qkvx && qkv_attn_fuses_wo(L.qkv, L.wo);
             if (use_part) {
-                const int pw = gemv_resid_parts(L.wo), p2 = gemv_resid_parts(L.w2);
+                const int pw = fuse_wo ? L.wo.ngroups / 4 : gemv_resid_parts(L.wo), p2 = gemv_resid_parts(L.w2);
                 if (n_part_x > 0) { np_qkv.in = m->npart_a; np_qkv.n_in = n_part_x; }
                 if (pw > 0 && pw <= NORM_PART_MAX) { np_wo.out = m->npart_b; np_w13.in = m->npart_b; np_w13.n_in = pw; }
                 n_part_x = 0;
@@ -569,11 +571,13 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             }
             if (use_qkvx) {
                 HIP_TRY(launch_qkv_attn(L.qkv, xa, L.attention_norm, np_qkv, m->d_qkv2, m->d_sc2, m->d_epoch, il - m->l0, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
-                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st), LLAMAHIP_ERR_PREDICT);
+                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st,
+                                        fuse_wo ? &L.wo : nullptr, m->d_qat_A, m->d_qat_d, m->x1, xa, &np_wo), LLAMAHIP_ERR_PREDICT);
             } else {
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
             }
+            if (!fuse_wo)
             HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo), LLAMAHIP_ERR_PREDICT);
             if (use_pair) {
                 HIP_TRY(launch_gemv_pair(L.w13, L.w2, m->x1, L.ffn_norm, np_w13, m->qa2_A, m->qa2_d, xo, m->x1, np_w2, m->T_silu, m->d_sync, il - m->l0 + 1, st), LLAMAHIP_ERR_PREDICT);
@@ -912,6 +916,10 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemset(m->d_qkv2, 0, (size_t) 3 * d * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_sc2, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_sc2, 0, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_qat_A, Kp_d / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_qat_A, 0, Kp_d / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_qat_d, Kp_d / 32 * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_qat_d, 0, Kp_d / 32 * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
         }

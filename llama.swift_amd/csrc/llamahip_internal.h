@@ -10,7 +10,7 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
 // (PREP_NORMP: PREP_NORM with the row's {sum x, sum x^2} supplied by its producer -- k_gemv only, selected by launch_gemv)
-enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4 };
+enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PRE_QA_TAG = 5 /* k_qkv_attn: QA handed over inside the launch as {dword, tag} granules */ };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4 /* k_qkv_attn: rows as {value, tag} granules */ };
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
 struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; };
@@ -126,9 +126,12 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
 bool xcd_selftest(int H, int Y, hipStream_t st);
 // wq|wk|wv mat-vec + decode attention as one launch (k_qkv_attn); xsync / fault as launch_dec_attn
 bool qkv_attn_applies(const QMat &w, int d, int H, int nth);
+bool qkv_attn_fuses_wo(const QMat &wqkv, const QMat &wo);          // ... and the wo mat-vec as a further role (qat_A / qat_d: tagged QA granules)
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
-                           const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st);
+                           const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
+                           const QMat *wo = nullptr, uint64_t *qat_A = nullptr, uint64_t *qat_d = nullptr, float *wo_y = nullptr, const float *wo_resid = nullptr,
+                           const NormPart *np_wo = nullptr);
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
 hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st);
 hipError_t launch_advance(int32_t *state, hipStream_t st);

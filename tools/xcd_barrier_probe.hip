@@ -82,6 +82,41 @@ __global__ void __launch_bounds__(256) k_rounds(uint32_t *counters, uint32_t *da
     if (bad) atomicAdd(stale, bad);
 }
 
+// data-tagged hand-off: every lane publishes one 8-byte granule {value, tag}; the reader polls the granule itself.
+//   CROSS = false: the reader is the next member of the group (same XCD): plain 8-byte store, sc1 load
+//   CROSS = true : the reader is workgroup b + 1 (the NEXT XCD): write-through (agent-scope) store, sc1 load
+// NREAD granules per lane are read (1: a neighbour's 2 KB; 4: 8 KB = what a mat-vec workgroup pulls of a quantized activation row)
+template <bool CROSS, int NREAD>
+__global__ void __launch_bounds__(256) k_tagged(unsigned long long *data, uint32_t *stale, uint32_t *timeout, int gs, int rounds, uint32_t epoch0) {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, mem = slot % gs, nb = gridDim.x;
+    __shared__ int s_abort;
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+    uint32_t bad = 0;
+    for (int r = 1; r <= rounds; r++) {
+        const uint32_t tag = epoch0 + r;
+        unsigned long long *mine = data + ((size_t) (r & 1) * 2048 + b) * 256;
+        const unsigned long long v = ((unsigned long long) tag << 32) | (uint32_t) (b * 256 + threadIdx.x);
+        if (CROSS) __hip_atomic_store(mine + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(mine + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int k = 0; k < NREAD; k++) {
+            const int src = CROSS ? (b + 1 + k * 8 + k) % nb : (((slot - mem + (mem + 1 + k) % gs) << 3) | xcd);
+            const unsigned long long *theirs = data + ((size_t) (r & 1) * 2048 + src) * 256;
+            int spins = 0;
+            for (;;) {
+                const unsigned long long w = __hip_atomic_load(theirs + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t) (w >> 32) == tag) { if ((uint32_t) w != (uint32_t) (src * 256 + threadIdx.x)) bad++; break; }
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 18)) { timeout[0] = 1; s_abort = 1; break; }
+            }
+        }
+        __syncthreads();          // (the round's reads are done before this workgroup overwrites the other buffer's slot two rounds later)
+        if (s_abort) return;
+    }
+    if (bad) atomicAdd(stale, bad);
+}
+
 __global__ void __launch_bounds__(256) k_one(uint32_t *data, uint32_t *stale, int gs, uint32_t tag, int phase) {
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, mem = slot % gs;
     uint32_t *mine = data + (size_t) b * 256, *next = data + (size_t) (((slot - mem + (mem + 1) % gs) << 3) | xcd) * 256;
@@ -117,6 +152,25 @@ int main(int argc, char **argv) {
             const char *names[] = { "L2-local atomics, sc1 poll + sc1 data", "device-scope atomics + fences", "L2-local atomics, RMW poll + sc1 data" };
             printf("   %-42s %7.3f us per round   stale reads %u   timeouts %u   workgroups off their group's XCD %d (XCC ids of blocks 0-7: %u %u %u %u %u %u %u %u)\n",
                    names[var], ms * 1e3 / rounds, stale, to, mism, xcc[0], xcc[1], xcc[2], xcc[3], xcc[4], xcc[5], xcc[6], xcc[7]);
+        }
+        {
+            unsigned long long *d_tag; CHECK(hipMalloc((void **) &d_tag, (size_t) 2 * 2048 * 256 * 8)); CHECK(hipMemset(d_tag, 0, (size_t) 2 * 2048 * 256 * 8));
+            for (int var = 0; var < 4; var++) {
+                CHECK(hipMemset(d_stale, 0, 4)); CHECK(hipMemset(d_to, 0, 4));
+                auto launch = [&](int r, uint32_t ep) {
+                    if (var == 0) hipLaunchKernelGGL((k_tagged<false, 1>), dim3(grid), dim3(256), 0, 0, d_tag, d_stale, d_to, gs, r, ep);
+                    if (var == 1) hipLaunchKernelGGL((k_tagged<false, 4>), dim3(grid), dim3(256), 0, 0, d_tag, d_stale, d_to, gs, r, ep);
+                    if (var == 2) hipLaunchKernelGGL((k_tagged<true, 1>), dim3(grid), dim3(256), 0, 0, d_tag, d_stale, d_to, gs, r, ep);
+                    if (var == 3) hipLaunchKernelGGL((k_tagged<true, 4>), dim3(grid), dim3(256), 0, 0, d_tag, d_stale, d_to, gs, r, ep);
+                };
+                launch(10, 1000 + var * 100000); CHECK(hipDeviceSynchronize());
+                CHECK(hipEventRecord(e0, 0)); launch(rounds, 5000 + var * 100000); CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                uint32_t stale, to; CHECK(hipMemcpy(&stale, d_stale, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&to, d_to, 4, hipMemcpyDeviceToHost));
+                const char *names[] = { "tagged granules, same XCD, 2 KB read", "tagged granules, same XCD, 8 KB read", "tagged granules, OTHER XCDs, 2 KB read", "tagged granules, OTHER XCDs, 8 KB read" };
+                printf("   %-42s %7.3f us per round   wrong values %u   timeouts %u\n", names[var], ms * 1e3 / rounds, stale, to);
+            }
+            CHECK(hipFree(d_tag));
         }
         // the same dependency as two kernel launches per round
         CHECK(hipMemset(d_stale, 0, 4));
