@@ -3182,7 +3182,16 @@ template <int PRE, int D, int PG, bool WO>
 __global__ void __launch_bounds__(256)
 k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int gridA, const int H) {
     extern __shared__ double smem_d[];
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (WO) {
+        // the wo mat-vec of the layer: its 4-wave workgroups come FIRST (a multiple of 8 of them, so the XCD placement of the
+        // other roles is unchanged): dispatched at once, their weight rows stream in together with the first mat-vec's and sit
+        // in registers when the quantized attention output arrives as tagged granules from the soft_max . V workgroups.
+        // (They wait for HIGHER block indices, like the soft_max . V workgroups: few enough never to fill the chip.)
+        const int gridW = gw.ngroups / 4;
+        if (b < gridW) { gemv_body<PRE_QA_TAG, EPI_RESID, 16, false, 1, SYNC_NONE, false>(gw, b, 4, smem_d); return; }
+        b -= gridW;
+    }
     if (b < gridA) {
         const int ncb = aa.dh / 32, wph = 3 * ncb;
         const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
@@ -3191,12 +3200,6 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int g
         return;
     }
     const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
-    if (WO && y >= aa.dh / 32 + (aa.n_ctx + DEC_TS - 1) / DEC_TS) {
-        // the wo mat-vec of the layer (WO): 4-wave workgroups behind the attention's; their weight rows are in flight while the
-        // attention runs, the quantized attention output arrives as tagged granules from the soft_max . V workgroups (all XCDs)
-        gemv_body<PRE_QA_TAG, EPI_RESID, 16, false, 1, SYNC_NONE, false>(gw, a - H * (aa.dh / 32 + (aa.n_ctx + DEC_TS - 1) / DEC_TS), 4, smem_d);
-        return;
-    }
     attn_x_body<true>(aa, h, y, smem_d);
 }
 
@@ -4137,7 +4140,7 @@ bool qkv_attn_fuses_wo(const QMat &wqkv, const QMat &wo) {
     // every poll disabled: the 128 trailing workgroups only get their slots and their 10.5 MB of weights when the first
     // mat-vec's stream ends, so nothing of wo's latency is hidden and its hand-off comes on top.
     static const bool off = getenv("LLAMAHIP_WO_FUSE") == nullptr || getenv("LLAMAHIP_NO_WO_FUSE") != nullptr;
-    return !off && qkv_attn_variant(wqkv) == 1 && !wo.gmapF8 && wo.nchunks == 16 && wo.K % 256 == 0 && wo.ngroups % 4 == 0 && wo.ngroups < 1024 && wo.M == wo.ngroups * 8;
+    return !off && qkv_attn_variant(wqkv) == 1 && !wo.gmapF8 && wo.nchunks == 16 && wo.K % 256 == 0 && wo.ngroups % 32 == 0 && wo.ngroups < 1024 && wo.M == wo.ngroups * 8;
 }
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
