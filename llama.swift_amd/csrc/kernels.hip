@@ -739,13 +739,13 @@ constexpr int SYNC_SHARDS = 8;      // words, 64 B apart: 8 shard counters | top
 enum { SYNC_NONE = 0, SYNC_WAIT = 1, SYNC_ARRIVE = 2 };
 // 8-byte granule {value, tag}: written with one 8-byte store, read with one 8-byte load that bypasses the L1 (sc1), so a
 // reader sees the value together with its tag or not at all.  The spin is bounded; running out raises the fault word.
-__device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, bool nowait) {
+__device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, int nowait /* bit 0: pass at once (measurement), bit 1: no sleep between polls */) {
     uint64_t v;
     int spins = 0;
     for (;;) {
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t) (v >> 32) == tag || nowait) break;
-        __builtin_amdgcn_s_sleep(1);
+        if ((uint32_t) (v >> 32) == tag || (nowait & 1)) break;
+        if (!(nowait & 2)) __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 20)) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
     return __builtin_bit_cast(float, (uint32_t) v);
@@ -2983,7 +2983,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
                 for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
             }
         };
-        const bool nowait = (lut_math & 0x100) != 0;          // (measurement-only "no wait" switch, results invalid)
+        const int nowait = ((lut_math & 0x400) ? 1 : 0) | ((lut_math >> 8) & 2);     // (measurement-only switches: 0x400 this hop does not wait, results invalid; 0x200 polls without sleep)
         const uint32_t tag = QKV_WAIT ? ((aa.epoch[0] << 7) | (uint32_t) aa.layer) : 0u;
         if (QKV_WAIT) load_keys();                              // in flight while the mat-vec workgroups finish
         if (tid < dh / 2) {
@@ -3052,13 +3052,16 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
     const float *vcol = Vc + col;
     const int ta0 = dc * sub, t10 = min(ta0 + dc, T);
     // rows [ta0, ta0 + 32) of chain `sub` are old rows (< n_past) iff ta0 + 32 <= n_past or they are clamped below t10 - 1 < n_past
-    const bool early = sub < nth && ta0 < t10 && min(ta0 + 31, t10 - 1) < n_past;      // wave-uniform per 32-lane half; both halves of a wave differ only in `sub`
-    float va[16], vb[16];
+    // VB rows per register batch.  (Measured: 20 -- the most that keeps k_qkv_attn at 128 registers -- changes nothing at
+    // contexts 288 and 400; 24 and 32 drop the launch to 3 and 2 waves per SIMD and the score workgroups lose their slots.)
+    constexpr int VB = 16;
+    const bool early = sub < nth && ta0 < t10 && min(ta0 + 2 * VB - 1, t10 - 1) < n_past;      // wave-uniform per 32-lane half; both halves of a wave differ only in `sub`
+    float va[VB], vb[VB];
     if (early) {
 #pragma unroll
-        for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(ta0 + u, t10 - 1) * d];
+        for (int u = 0; u < VB; u++) va[u] = vcol[(size_t) min(ta0 + u, t10 - 1) * d];
 #pragma unroll
-        for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(ta0 + 16 + u, t10 - 1) * d];
+        for (int u = 0; u < VB; u++) vb[u] = vcol[(size_t) min(ta0 + VB + u, t10 - 1) * d];
     }
     if (!QKV_WAIT) {
         if (tid == 0) {
@@ -3079,7 +3082,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
     float mx = -INFINITY;
     if (QKV_WAIT) {
         const uint32_t tag = (aa.epoch[0] << 7) | (uint32_t) aa.layer;
-        const bool nowait = (lut_math & 0x100) != 0;
+        const int nowait = ((lut_math & 0x800) ? 1 : 0) | ((lut_math >> 8) & 2);
         for (int t = tid; t < T; t += nt) { const float v = poll_tagged(aa.sc2 + (size_t) h * n_ctx + t, tag, fault, nowait); p[t] = v; mx = fmaxf(mx, v); }
     } else
     for (int t = tid; t < T; t += nt) { const float v = load_f32_sc1(row + t); p[t] = v; mx = fmaxf(mx, v); }
@@ -3101,25 +3104,25 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
         float acc = 0.0f;
         if (!(early && th == sub)) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(ta + u, t1 - 1) * d];
+            for (int u = 0; u < VB; u++) va[u] = vcol[(size_t) min(ta + u, t1 - 1) * d];
 #pragma unroll
-            for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(ta + 16 + u, t1 - 1) * d];
+            for (int u = 0; u < VB; u++) vb[u] = vcol[(size_t) min(ta + VB + u, t1 - 1) * d];
         }
-        for (int tb = ta; tb < t1; tb += 32) {
+        for (int tb = ta; tb < t1; tb += 2 * VB) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
+            for (int u = 0; u < VB; u++) {
                 const float pe = (tb + u < t1) ? p[min(tb + u, T - 1)] : 0.0f;
                 acc = fmaf(va[u], pe, acc);
             }
 #pragma unroll
-            for (int u = 0; u < 16; u++) va[u] = vcol[(size_t) min(tb + 32 + u, t1 - 1) * d];
+            for (int u = 0; u < VB; u++) va[u] = vcol[(size_t) min(tb + 2 * VB + u, t1 - 1) * d];
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const float pe = (tb + 16 + u < t1) ? p[min(tb + 16 + u, T - 1)] : 0.0f;
+            for (int u = 0; u < VB; u++) {
+                const float pe = (tb + VB + u < t1) ? p[min(tb + VB + u, T - 1)] : 0.0f;
                 acc = fmaf(vb[u], pe, acc);
             }
 #pragma unroll
-            for (int u = 0; u < 16; u++) vb[u] = vcol[(size_t) min(tb + 48 + u, t1 - 1) * d];
+            for (int u = 0; u < VB; u++) vb[u] = vcol[(size_t) min(tb + 3 * VB + u, t1 - 1) * d];
         }
         part[th * 32 + c] = acc;
     }
@@ -4157,7 +4160,10 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
     if (fuse_wo) lds = std::max(lds, gemv_lds_bytes(*wo, 0));
     // the mat-vec role writes tagged granules: y -> qkv2, sync -> the epoch word, sync_epoch = layer
-    static const int nowait = getenv("LLAMAHIP_ATTN_NOWAIT") ? 0x100 : 0;       // measurement only: the polls pass at once, RESULTS ARE INVALID
+    // measurement only, RESULTS ARE INVALID: LLAMAHIP_ATTN_NOWAIT=1 no poll waits, =2 only the soft_max . V role does not wait, =3 only the score role
+    static const int nw_mode = getenv("LLAMAHIP_ATTN_NOWAIT") ? atoi(getenv("LLAMAHIP_ATTN_NOWAIT")) : 0;
+    static const int nowait = nw_mode == 1 ? (0x100 | 0x400 | 0x800) : nw_mode == 2 ? 0x800 : nw_mode == 3 ? 0x400 : 0;
+    static const int nosleep = (getenv("LLAMAHIP_POLL_SLEEP") && atoi(getenv("LLAMAHIP_POLL_SLEEP")) == 0) ? 0x200 : 0;     // measurement only
     const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
                           (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math, fault };
     GemvArgs gw = ga;
@@ -4167,7 +4173,7 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
         gw = GemvArgs{ wo->tiles, wo->ngroups, wo->nchunks, wo->M, wo->gmapF8, (const uint32_t *) qat_A, (const float *) qat_d, nullptr, nullptr, wo->K, wo_y, wo_resid, T_silu,
                        nullptr, nullptr, nullptr, 0, (f64x2 *) npw.out, epoch, 0, layer, g_lut_math | nowait, fault };
     }
-    const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait,
+    const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep,
                            qkv2, sc2, epoch, layer, fuse_wo ? qat_A : nullptr, fuse_wo ? qat_d : nullptr };
     const int grid = gridA + H * (nsl + dh / 32) + (fuse_wo ? wo->ngroups / 4 : 0);
 #define LH_GOX(D, PG, WO) { if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); \

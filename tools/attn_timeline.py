@@ -41,7 +41,7 @@ rec = rec[order]; kind = kind[order]
 # launches are serialised: a launch = a maximal run of records (by entry time) whose kinds all belong to the attention
 # launch {mat-vec NORMP/STORE or NORM/STORE with 16 chunks, 0xA0 score, 0xA1 soft_max.V} or all do not
 nch = (rec[:, 5] >> 32) & 0xffff
-inatt = (kind == 0xA0) | (kind == 0xA1) | (((kind == 0x40) | (kind == 0x20)) & (nch == 16))
+inatt = (kind == 0xA0) | (kind == 0xA1) | (kind == 0x44) | (kind == 0x24)
 cuts = [0] + [i for i in range(1, len(rec)) if inatt[i] != inatt[i - 1]] + [len(rec)]
 def absd(r, j):            # absolute time of stamp j on the wall clock, microseconds
     return r[:, 7] / 100.0 + (r[:, j] - r[:, 0]) / tpu
@@ -50,7 +50,7 @@ for i0, i1 in zip(cuts[:-1], cuts[1:]):
     if not inatt[i0]:
         continue
     r = rec[i0:i1]; k = kind[i0:i1]
-    rs = r[k == 0xA0]; rp = r[k == 0xA1]; rg = r[(k == 0x40) | (k == 0x20)]
+    rs = r[k == 0xA0]; rp = r[k == 0xA1]; rg = r[(k == 0x44) | (k == 0x24)]
     if len(rs) == 0 or len(rp) == 0:
         continue
     t0 = r[:, 7].min() / 100.0
