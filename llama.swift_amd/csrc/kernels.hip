@@ -739,14 +739,14 @@ constexpr int SYNC_SHARDS = 8;      // words, 64 B apart: 8 shard counters | top
 enum { SYNC_NONE = 0, SYNC_WAIT = 1, SYNC_ARRIVE = 2 };
 // 8-byte granule {value, tag}: written with one 8-byte store, read with one 8-byte load that bypasses the L1 (sc1), so a
 // reader sees the value together with its tag or not at all.  The spin is bounded; running out raises the fault word.
-__device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, int nowait /* bit 0: pass at once (measurement), bit 1: no sleep between polls */) {
+__device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, int nowait /* bit 0: pass at once (measurement), bit 1: no sleep between polls, bit 2: give up after 256 polls (fault-injection test) */) {
     uint64_t v;
     int spins = 0;
     for (;;) {
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t) (v >> 32) == tag || (nowait & 1)) break;
         if (!(nowait & 2)) __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        if (++spins > ((nowait & 4) ? (1 << 8) : (1 << 20))) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
     return __builtin_bit_cast(float, (uint32_t) v);
 }
@@ -1219,7 +1219,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         const bool live = valid && k == 0 && m < M;
         if (EPI == EPI_RESID) acc = acc + resid_v;
         if (EPI == EPI_STORE_TAG) {                     // ga.sync -> the epoch word, ga.sync_epoch = layer (k_qkv_attn)
-            if (live) store_tagged((uint64_t *) y + m, acc, store_tag);
+            if (live) store_tagged((uint64_t *) y + m, acc, store_tag ^ ((ga.lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test -- a tag nobody waits for)
         } else
         if (live) y[m] = acc;
         if (EPI == EPI_RESID && part_out) {
@@ -2983,7 +2983,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
                 for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
             }
         };
-        const int nowait = ((lut_math & 0x400) ? 1 : 0) | ((lut_math >> 8) & 2);     // (measurement-only switches: 0x400 this hop does not wait, results invalid; 0x200 polls without sleep)
+        const int nowait = ((lut_math & 0x400) ? 1 : 0) | ((lut_math >> 8) & 2) | ((lut_math & 0x1000) ? 4 : 0);     // (measurement-only switches: 0x400 this hop does not wait, results invalid; 0x200 polls without sleep; 0x1000 fault-injection test)
         const uint32_t tag = QKV_WAIT ? ((aa.epoch[0] << 7) | (uint32_t) aa.layer) : 0u;
         if (QKV_WAIT) load_keys();                              // in flight while the mat-vec workgroups finish
         if (tid < dh / 2) {
@@ -3082,7 +3082,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
     float mx = -INFINITY;
     if (QKV_WAIT) {
         const uint32_t tag = (aa.epoch[0] << 7) | (uint32_t) aa.layer;
-        const int nowait = ((lut_math & 0x800) ? 1 : 0) | ((lut_math >> 8) & 2);
+        const int nowait = ((lut_math & 0x800) ? 1 : 0) | ((lut_math >> 8) & 2) | ((lut_math & 0x1000) ? 4 : 0);
         for (int t = tid; t < T; t += nt) { const float v = poll_tagged(aa.sc2 + (size_t) h * n_ctx + t, tag, fault, nowait); p[t] = v; mx = fmaxf(mx, v); }
     } else
     for (int t = tid; t < T; t += nt) { const float v = load_f32_sc1(row + t); p[t] = v; mx = fmaxf(mx, v); }
@@ -4164,8 +4164,11 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     static const int nw_mode = getenv("LLAMAHIP_ATTN_NOWAIT") ? atoi(getenv("LLAMAHIP_ATTN_NOWAIT")) : 0;
     static const int nowait = nw_mode == 1 ? (0x100 | 0x400 | 0x800) : nw_mode == 2 ? 0x800 : nw_mode == 3 ? 0x400 : 0;
     static const int nosleep = (getenv("LLAMAHIP_POLL_SLEEP") && atoi(getenv("LLAMAHIP_POLL_SLEEP")) == 0) ? 0x200 : 0;     // measurement only
+    // test only (tests/test_gpu_parity.py): the mat-vec role publishes a wrong tag and every poll gives up after 256 looks -> the
+    // sticky fault word must come back as an error
+    static const int fault_test = getenv("LLAMAHIP_HANDOFF_FAULT_TEST") ? 0x1000 : 0;
     const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
-                          (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math, fault };
+                          (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
     GemvArgs gw = ga;
     if (fuse_wo) {
         const NormPart npw = (np_wo && norm_mode >= 2) ? *np_wo : NormPart();
@@ -4173,7 +4176,7 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
         gw = GemvArgs{ wo->tiles, wo->ngroups, wo->nchunks, wo->M, wo->gmapF8, (const uint32_t *) qat_A, (const float *) qat_d, nullptr, nullptr, wo->K, wo_y, wo_resid, T_silu,
                        nullptr, nullptr, nullptr, 0, (f64x2 *) npw.out, epoch, 0, layer, g_lut_math | nowait, fault };
     }
-    const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep,
+    const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep | fault_test,
                            qkv2, sc2, epoch, layer, fuse_wo ? qat_A : nullptr, fuse_wo ? qat_d : nullptr };
     const int grid = gridA + H * (nsl + dh / 32) + (fuse_wo ? wo->ngroups / 4 : 0);
 #define LH_GOX(D, PG, WO) { if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); \

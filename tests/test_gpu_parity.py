@@ -249,6 +249,31 @@ def test_decode_attention_fallback_paths(switch):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b):
+    """The in-launch hand-offs of the decode step are bounded polls; one that runs out raises a sticky fault word in
+    pinned host memory and the next synchronisation returns PredictionFailed.  LLAMAHIP_HANDOFF_FAULT_TEST makes the
+    mat-vec role of k_qkv_attn publish a tag nobody waits for and shortens the polls (read once per process: subprocess)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, time, numpy as np\n"
+        "import llama_swift_amd as L\n"
+        "m = L.Model(sys.argv[1], n_ctx=64)\n"
+        "m.eval(np.array([1, 5, 9, 13], np.int32), 0, 8)\n"          # a 4-row eval: not the decode path, must still work
+        "t0 = time.time()\n"
+        "try:\n"
+        "    m.eval(np.array([7], np.int32), 4, 8)\n"
+        "    print('NO ERROR')\n"
+        "except L.LlamaHipError as e:\n"
+        "    print('ERR', e.code, str(e)); print('SECONDS', time.time() - t0)\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LLAMAHIP_HANDOFF_FAULT_TEST="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code, model7b], env=env, capture_output=True, text=True, cwd=root, timeout=300)
+    assert "ERR -1001" in r.stdout and "hand-off" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert float(r.stdout.split("SECONDS")[1].split()[0]) < 30.0, r.stdout
+
+
 def test_context_overflow_and_bad_tokens_are_errors(L, tmp_path):
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=64, n_head=2, n_layer=1)
     path = str(tmp_path / "m.bin")
