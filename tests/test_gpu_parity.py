@@ -465,6 +465,31 @@ def test_wider_models_vs_oracle(L, oracle, tmp_path, name, kw, parts):
         assert got.tolist() == want and same(last, lo), name
 
 
+@pytest.mark.parametrize("nth", [1, 3, 5, 8])
+def test_fused_decode_launch_thread_splits_and_slice_boundaries(L, oracle, tmp_path, nth):
+    """k_qkv_attn (wq|wk|wv mat-vec + attention in one launch, tagged hand-offs) at the 7B width for every n_threads the
+    V*P split can take (the chunk boundaries dc = ceil(T / n_threads) move with it), decoding across the 32-key slice
+    boundaries of its score workgroups (context 27 -> 71: slices 1, 2 and 3 come alive at 32 and 64) -- tokens, final
+    logits and the KV rows the launch appended, against the oracle."""
+    path = synth_tool(tmp_path / "m.bin", seed=11, n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2)
+    om = oracle.load(path, 96)
+    with L.Model(path, n_ctx=96) as gm:
+        prompt = synth.synth_prompt(27, 512, seed=4)
+        a, b = gm.eval(prompt, 0, nth), om.eval(prompt, 0, nth)["logits"]
+        assert same(a, b), describe(a, b)
+        tok, want = int(np.argmax(b)), []
+        t = tok
+        for i in range(44):
+            lo = om.eval(np.array([t], np.int32), 27 + i, nth)["logits"]
+            t = int(np.argmax(lo)); want.append(t)
+        got, last = gm.decode_greedy(tok, 27, 44, nth, want_logits=True)
+        assert got.tolist() == want and same(last, lo), (nth, got.tolist(), want)
+        for il in range(2):
+            gk, gv = gm.kv(il, 71)
+            ok, ov = om.kv(il, 71)
+            assert same(gk, ok) and same(gv, ov), f"kv cache layer {il}"
+
+
 # ------------------------------------------------------------------------------------------------ full LLaMA-7B size
 @pytest.fixture(scope="module")
 def model7b(tmp_path_factory):
