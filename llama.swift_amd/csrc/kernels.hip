@@ -4067,12 +4067,25 @@ bool xcd_selftest(int H, int Y, hipStream_t st) {
         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(out.data(), d_out, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
     }
+    if (ok) {
+        for (int h = 0; h < H; h++)
+            for (int y = 0; y < Y; y++)
+                if (out[h + (size_t) H * y] != out[h] || out[h] > 15u) ok = false;
+    }
+    // ... and the same for a one-dimensional grid of that many workgroups of 256 threads (k_qkv_attn): block b on the XCD of block b % 8
+    if (ok) {
+        std::fill(out.begin(), out.end(), 0xffffffffu);
+        ok = hipMemsetAsync(d_out, 0xff, n * 4, st) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_xcd_selftest, dim3((unsigned) n), dim3(256), 0, st, d_out);
+            ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(out.data(), d_out, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipStreamSynchronize(st) == hipSuccess;
+        }
+        for (size_t b = 0; ok && b < n; b++)
+            if (out[b] != out[b & 7] || out[b] > 15u) ok = false;
+    }
     (void) hipFree(d_out);
-    if (!ok) return false;
-    for (int h = 0; h < H; h++)
-        for (int y = 0; y < Y; y++)
-            if (out[h + (size_t) H * y] != out[h] || out[h] > 15u) return false;
-    return true;
+    return ok;
 }
 
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
