@@ -474,6 +474,10 @@ def test_fused_decode_launch_thread_splits_and_slice_boundaries(L, oracle, tmp_p
     path = synth_tool(tmp_path / "m.bin", seed=11, n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2)
     om = oracle.load(path, 96)
     with L.Model(path, n_ctx=96) as gm:
+        # a single token at position 0 (one key, every V*P chain but the first empty), then one at position 1
+        for pos, t in ((0, 1), (1, 17)):
+            a, b = gm.eval(np.array([t], np.int32), pos, nth), om.eval(np.array([t], np.int32), pos, nth)["logits"]
+            assert same(a, b), (pos, describe(a, b))
         prompt = synth.synth_prompt(27, 512, seed=4)
         a, b = gm.eval(prompt, 0, nth), om.eval(prompt, 0, nth)["logits"]
         assert same(a, b), describe(a, b)
