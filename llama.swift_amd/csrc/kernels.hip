@@ -2487,6 +2487,93 @@ k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float
     pmax[((size_t) h * KS + ks) * NB + nl] = mx;
 }
 
+// The same scores with the K rows staged in LDS (round 2): a workgroup = 4 waves = 256 consecutive queries of one head; a
+// tile of 32 keys (16 KB) is fetched with coalesced vector loads (next tile in registers while this one is consumed,
+// two LDS buffers, one barrier per tile) and every lane reads the key's elements as LDS BROADCASTS (wave-uniform
+// address, ds_read_b128).  k_attnq_scores above brings the key row in through the scalar cache instead: its loop carries
+// 134 s_mov + 170 v_mov per key for the SGPR buffer rotation, spills, and every piece waits on lgkmcnt(0) because
+// scalar loads return out of order -- 201 us per launch at 2 048 tokens where the FMAs need ~60.  Measured here: 152 us
+// (2 048-token eval 212.5 -> 202.7 ms): now LDS-bound -- a broadcast ds_read_b128 costs the LDS pipe as much as a spread one
+// (8 clocks per wave), i.e. 2 clocks per key element and wave, the price of the FMA it feeds, and the LDS is shared by the
+// CU's four SIMDs.  Arithmetic identical (same chains, same tree); a wave skips the tiles none of its 64 queries can see
+// (k_attnq_softmax never reads them).
+constexpr int AQ_TK = 32;
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_attnq_scores_lds(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
+                   int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
+    __shared__ f32x4 sK[2][AQ_TK * 32];
+    const int tid = threadIdx.x, wave = tid >> 6, h = blockIdx.y, ks = blockIdx.z;
+    const int q0 = nb0 + (int) blockIdx.x * 256;
+    const int nl = blockIdx.x * 256 + tid, n = nb0 + nl;
+    const int nq = n < N ? n : N - 1;
+    const int Tb = n_past + min(q0 + 256, N);                          // keys any query of this workgroup can see
+    const int Tw = n_past + min(q0 + (wave + 1) * 64, N);               // ... of this wave (its 64-query block, as k_attnq_softmax counts)
+    const int per = (Tb + KS - 1) / KS, t0 = ks * per, t1 = min(Tb, t0 + per);
+    const int tq = n_past + nq;
+    float mx = -INFINITY;
+    if (t0 < t1) {
+        float q[128];
+        {
+            const f32x4 *qp = (const f32x4 *) (qr + (size_t) nq * d + h * 128);
+#pragma unroll
+            for (int i = 0; i < 32; i++) { const f32x4 v = qp[i]; q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w; }
+        }
+        f32x4 g[4];
+#define LH_GLOAD(TBASE)                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                     \
+            const int idx_ = tid + u * 256;                                                                 \
+            g[u] = ((const f32x4 *) (Kc + (size_t) min((TBASE) + (idx_ >> 5), t1 - 1) * d + h * 128))[idx_ & 31]; \
+        }
+        LH_GLOAD(t0)
+#pragma unroll
+        for (int u = 0; u < 4; u++) sK[0][tid + u * 256] = g[u];
+        __syncthreads();
+        int buf = 0;
+        for (int tbase = t0; tbase < t1; tbase += AQ_TK, buf ^= 1) {
+            const bool more = tbase + AQ_TK < t1;
+            if (more) LH_GLOAD(tbase + AQ_TK)
+            const int kend = min(AQ_TK, min(t1, Tw) - tbase);              // (<= 0: nothing of this tile is visible to this wave)
+            for (int kk = 0; kk < kend; kk++) {
+                const int t = tbase + kk;
+                const f32x4 *kr = &sK[buf][kk * 32];
+                float r1[2][8];
+                float c[16];
+#pragma unroll
+                for (int pi = 0; pi < 8; pi++) {
+                    const int base = 32 * (pi & 3) + 16 * (pi >> 2);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const f32x4 kv = kr[base / 4 + j];                  // wave-uniform address: LDS broadcast
+                        c[4 * j + 0] = fmaf(kv.x, q[base + 4 * j + 0], (pi & 3) == 0 ? 0.0f : c[4 * j + 0]);
+                        c[4 * j + 1] = fmaf(kv.y, q[base + 4 * j + 1], (pi & 3) == 0 ? 0.0f : c[4 * j + 1]);
+                        c[4 * j + 2] = fmaf(kv.z, q[base + 4 * j + 2], (pi & 3) == 0 ? 0.0f : c[4 * j + 2]);
+                        c[4 * j + 3] = fmaf(kv.w, q[base + 4 * j + 3], (pi & 3) == 0 ? 0.0f : c[4 * j + 3]);
+                    }
+                    if ((pi & 3) == 3) {
+#pragma unroll
+                        for (int l = 0; l < 8; l++) r1[pi >> 2][l] = c[l] + c[l + 8];
+                    }
+                    asm volatile("" ::: "memory");                          // one or two pieces (16 key elements each) live at a time: left alone the scheduler
+                }                                                           // hoists a whole key's 32 LDS reads and spills the query row
+                float u[8];
+#pragma unroll
+                for (int l = 0; l < 8; l++) u[l] = r1[0][l] + r1[1][l];
+                const float v0 = u[0] + u[4], v1 = u[1] + u[5], v2 = u[2] + u[6], v3 = u[3] + u[7];
+                const float sc = ((v0 + v1) + (v2 + v3)) * kq_scale;
+                if (t <= tq) mx = fmaxf(mx, sc);
+                S[((size_t) h * T + t) * NB + nl] = sc;
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) sK[buf ^ 1][tid + u * 256] = g[u];
+            }
+            __syncthreads();
+        }
+#undef LH_GLOAD
+    }
+    pmax[((size_t) h * KS + ks) * NB + nl] = mx;
+}
+
 __global__ void __launch_bounds__(1024)
 k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__restrict__ inv,
                 int n_past, int N, int nb0, int NB, int T, int KS, const uint16_t *__restrict__ T_exp) {
@@ -4019,6 +4106,15 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
             int KS = (6144 + qb * H - 1) / (qb * H);      // ~2 rounds of 3 waves per SIMD: the waves are latency-bound
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
+            // scores: K rows through LDS broadcasts (k_attnq_scores_lds, 256 queries per workgroup) unless LLAMAHIP_ATTNQ_SCALAR
+            // asks for round 1's scalar-cache variant; ~3 workgroups per CU: KS key slices
+            static const bool scalar_k = getenv("LLAMAHIP_ATTNQ_SCALAR") != nullptr;
+            if (!scalar_k) {
+                const int qb4 = (nb + 255) / 256;
+                KS = (768 + qb4 * H - 1) / (qb4 * H);
+                KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
+                hipLaunchKernelGGL(k_attnq_scores_lds, dim3(qb4, H, KS), dim3(256), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
+            } else
             hipLaunchKernelGGL(k_attnq_scores, dim3(qb, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
