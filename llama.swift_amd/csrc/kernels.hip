@@ -2621,11 +2621,35 @@ k_attnq_pv(const float *__restrict__ S, const float *__restrict__ inv, const flo
 #pragma unroll
     for (int c = 0; c < 32; c++) acc[c] = 0.0f;
     const float *sp = S + ((size_t) h * T + t0) * NB + nl;
-    for (int t = t0; t < t1; t++, sp += NB) {
-        const float p = *sp * iv;                          // soft_max's final scale (ggml.c:7036-7041)
-        const float *vr = Vc + (size_t) t * d + h * 128 + c0;              // wave-uniform: scalar loads
+    // Two keys per trip, the next trip's operands requested before this trip's FMAs (round 2): the loop used to be one
+    // dependent round trip per key -- the lane's probability (vector load) and the value row (two s_load_dwordx16, which only
+    // lgkmcnt(0) can wait for) were requested and awaited inside the same iteration.  The FMA order per column is unchanged.
+    if (t0 < t1) {
+        float pa = sp[0], pb = sp[(size_t) min(1, t1 - 1 - t0) * NB];
+        float va[32], vb[32];
+        {
+            const float *r0 = Vc + (size_t) t0 * d + h * 128 + c0, *r1 = Vc + (size_t) min(t0 + 1, t1 - 1) * d + h * 128 + c0;      // wave-uniform: scalar loads
 #pragma unroll
-        for (int c = 0; c < 32; c++) acc[c] = fmaf(vr[c], p, acc[c]);
+            for (int c = 0; c < 32; c++) { va[c] = r0[c]; vb[c] = r1[c]; }
+        }
+        for (int t = t0; t < t1; t += 2) {
+            const float p0 = pa * iv, p1 = (t + 1 < t1) ? pb * iv : 0.0f;        // soft_max's final scale (ggml.c:7036-7041); a clamped re-read is weighted 0: fma(v, 0, acc) == acc
+            float na[32], nb[32];
+            const int ta = min(t + 2, t1 - 1), tb = min(t + 3, t1 - 1);
+            const float npa = sp[(size_t) (ta - t0) * NB], npb = sp[(size_t) (tb - t0) * NB];
+            {
+                const float *r0 = Vc + (size_t) ta * d + h * 128 + c0, *r1 = Vc + (size_t) tb * d + h * 128 + c0;
+#pragma unroll
+                for (int c = 0; c < 32; c++) { na[c] = r0[c]; nb[c] = r1[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 32; c++) acc[c] = fmaf(va[c], p0, acc[c]);
+#pragma unroll
+            for (int c = 0; c < 32; c++) acc[c] = fmaf(vb[c], p1, acc[c]);
+#pragma unroll
+            for (int c = 0; c < 32; c++) { va[c] = na[c]; vb[c] = nb[c]; }
+            pa = npa; pb = npb;
+        }
     }
     // part[th][h][nl][128]
     f32x4 *o = (f32x4 *) (part + (((size_t) th * gridDim.y + h) * NB + nl) * 128 + c0);
