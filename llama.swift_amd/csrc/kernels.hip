@@ -3293,7 +3293,7 @@ k_dec_attn_x(const AttnXArgs aa) {
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
 template <int PRE, int D, int PG, bool WO>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG == 1 ? 4 : 3)))
 k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int gridA, const int H) {
     extern __shared__ double smem_d[];
     int b = blockIdx.x;
