@@ -23,6 +23,7 @@ for c0 in range(0, 504, 9):
 dt = time.perf_counter() - t0
 print(f"prompt in 9-token chunks (reference behaviour): {n_past} tokens in {dt * 1e3:.1f} ms = {n_past / dt:.0f} tok/s")
 for N in (64, 512, 2048):
+    m.eval(toks[:N], 0)                               # (the first eval of a size allocates its attention workspace)
     t0 = time.perf_counter(); m.eval(toks[:N], 0); dt = time.perf_counter() - t0
     print(f"one eval of {N:5d} tokens: {dt * 1e3:8.1f} ms = {N / dt:7.0f} tok/s")
 m.close()
