@@ -4216,7 +4216,9 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
     (void) part;
     // scores and soft_max . V in one launch with an XCD-local hand-off (k_dec_attn_x); the caller passes xsync only
     // after xcd_selftest() confirmed the placement it relies on
-    if (xsync && fault && nth <= 8 && dh % 32 == 0 && dh <= 256 && H % 8 == 0) {
+    // (contexts beyond 1 024: the score slices no longer fit the chip next to the waiting workgroups at this kernel's 4 waves per
+    //  SIMD -- 525 against 570 tokens/s at context 1 024, 429 against 481 at 2 048 on the 7B -- the two launches below take over)
+    if (xsync && fault && nth <= 8 && dh % 32 == 0 && dh <= 256 && H % 8 == 0 && n_ctx <= 1024) {
         const int nsl = (n_ctx + DEC_TS - 1) / DEC_TS;
         const size_t lds_pv = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
         const size_t lds = std::max(lds_pv, (size_t) 2 * dh * sizeof(float));
