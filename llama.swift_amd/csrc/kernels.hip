@@ -3458,7 +3458,8 @@ k_topk_candidates(const float *__restrict__ logits, int V, const int32_t *__rest
     if ((tid & 15) == 0) gmax[tid >> 4] = best;
     __syncthreads();
     unsigned long long T = gmax[0];
-    for (int j = 1; j < 64; j++) { const unsigned long long o = gmax[j]; T = o < T ? o : T; }
+#pragma unroll
+    for (int j = 1; j < 64; j++) { const unsigned long long o = gmax[j]; T = o < T ? o : T; }      // (unrolled: the 63 LDS reads go out together)
     if (T == 0ull) {                                   // a group without a real value: V < 1024 * ... (tiny vocabularies) -- host path
         if (tid == 0) { flags[0] = 0; flags[1] = 0; }
         return;
@@ -3478,7 +3479,20 @@ k_topk_candidates(const float *__restrict__ logits, int V, const int32_t *__rest
         const int my_id = list_id[tid];
         int rank = 0;
         bool dup = false;
-        for (int j = 0; j < n; j++) {
+        // (eight entries per trip so that their LDS reads are in flight together: rolled, every entry was a dependent LDS round
+        //  trip -- ~300 of them, the largest part of this kernel's 39 us)
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+            unsigned long long o[8]; int oid[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { o[u] = list_key[j + u]; oid[u] = list_id[j + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                dup = dup || (j + u != tid && o[u] == mine);
+                rank += (o[u] > mine || (o[u] == mine && oid[u] < my_id)) ? 1 : 0;
+            }
+        }
+        for (; j < n; j++) {
             const unsigned long long o = list_key[j];
             dup = dup || (j != tid && o == mine);
             rank += (o > mine || (o == mine && list_id[j] < my_id)) ? 1 : 0;
