@@ -4343,9 +4343,141 @@ hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st) {
     return hipSuccess;
 }
 
+// The same selection in two launches (round 2): k_topk_candidates is ONE workgroup, i.e. 16 waves x ~5 000 instructions of
+// fp64 key arithmetic on a single CU -- 34-39 us.  k_topk_keys spreads the per-logit work (penalty, score, order-preserving
+// key, the 64 group maxima) over V / 1024 workgroups; k_topk_select (one workgroup) only compares the finished keys with the
+// threshold and ranks the survivors.  Same groups (element i belongs to group (i % 1024) / 16), same threshold, same flags.
+//   ws: keys[32768] u64 | gmax[64] u64 (zero between calls: k_topk_select clears it) | bad u32
+__global__ void __launch_bounds__(1024)
+k_topk_keys(const float *__restrict__ logits, int V, const int32_t *__restrict__ window, int n_window, double scale, double repeat_penalty,
+            unsigned long long *__restrict__ keys, unsigned long long *__restrict__ gmax, uint32_t *__restrict__ badw) {
+    __shared__ uint32_t seen[1024];
+    const int tid = threadIdx.x, i = blockIdx.x * 1024 + tid;
+    seen[tid] = 0u;
+    __syncthreads();
+    if (tid < n_window) { const int id = window[tid]; if (id >= 0 && id < V) atomicOr(&seen[id >> 5], 1u << (id & 31)); }
+    __syncthreads();
+    unsigned long long kk = 0ull;                      // below every real key
+    if (i < V) {
+        const float lf = logits[i];
+        double sc;
+        if ((seen[i >> 5] >> (i & 31)) & 1u) sc = lf < 0.0f ? (double) lf * scale * repeat_penalty : (double) lf * scale / repeat_penalty;   // utils.cpp:363-368
+        else sc = (double) lf * scale;
+        if (sc != sc) atomicOr(badw, 1u);
+        const unsigned long long b = (unsigned long long) __double_as_longlong(sc);
+        kk = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        if (kk == 0ull) kk = 1ull;
+    }
+    keys[i] = kk;
+    unsigned long long best = kk;
+    best = dpp_max_u64(best, dpp_u64<DPP_QUAD_XOR1>(best));
+    best = dpp_max_u64(best, dpp_u64<DPP_QUAD_XOR2>(best));
+    best = dpp_max_u64(best, dpp_u64<DPP_ROW_HALF_MIRROR>(best));
+    best = dpp_max_u64(best, dpp_u64<DPP_ROW_MIRROR>(best));
+    if ((tid & 15) == 0 && best != 0ull) atomicMax(&gmax[tid >> 4], best);
+}
+
+__global__ void __launch_bounds__(1024)
+k_topk_select(int V, int k, unsigned long long *__restrict__ keys, unsigned long long *__restrict__ gmax, uint32_t *__restrict__ badw,
+              double *__restrict__ out_score, int32_t *__restrict__ out_id, int32_t *__restrict__ flags) {
+    constexpr int NPT = 32, LCAP = 768;
+    __shared__ unsigned long long list_key[LCAP];
+    __shared__ int32_t list_id[LCAP];
+    __shared__ uint32_t n_list, bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) { n_list = 0u; bad = badw[0]; }
+    unsigned long long key[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT; u++) key[u] = keys[tid + u * 1024];              // (entries past V are 0: below every threshold)
+    // threshold = the k-th LARGEST of the 64 group maxima (k <= 64): at least k logits are >= it, so the k best and anything tied
+    // with the k-th are among the survivors -- and only a few more (the minimum of the maxima, as k_topk_candidates uses, lets
+    // 300-700 through, and the rank pass below is quadratic in that)
+    __shared__ unsigned long long s_T;
+    if (tid == 0) s_T = 0ull;
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned long long v = gmax[tid];
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j++) { const unsigned long long o = gmax[j]; r += (o > v || (o == v && j < tid)) ? 1 : 0; }
+        if (r == k - 1) s_T = v;
+    }
+    __syncthreads();                                                           // everybody has read gmax / badw: clear them for the next call
+    const unsigned long long T = s_T;
+    if (tid < 64) gmax[tid] = 0ull;
+    if (tid == 0) badw[0] = 0u;
+    if (T == 0ull) {                                   // a group without a real value (tiny vocabularies) -- host path
+        if (tid == 0) { flags[0] = 0; flags[1] = 0; }
+        return;
+    }
+    // collect: one LDS atomic per WAVE (its survivor count), slots inside the wave's range by ballot prefix -- 512 same-address
+    // atomics (one per wave and key slot) were most of this kernel's time
+    {
+        uint32_t cnt = 0;
+        unsigned long long pass[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) { pass[u] = __ballot(key[u] >= T); cnt += (uint32_t) __popcll(pass[u]); }
+        uint32_t base = 0;
+        if ((tid & 63) == 0 && cnt) base = atomicAdd(&n_list, cnt);
+        base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+        const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            if (key[u] >= T) {
+                const uint32_t at = base + (uint32_t) __popcll(pass[u] & lt);
+                if (at < (uint32_t) LCAP) { list_key[at] = key[u]; list_id[at] = tid + u * 1024; }
+            }
+            base += (uint32_t) __popcll(pass[u]);
+        }
+    }
+    __syncthreads();
+    const int n = (int) (n_list < (uint32_t) LCAP ? n_list : (uint32_t) LCAP);
+    if (n_list > (uint32_t) LCAP) bad = 1u;            // (a flood of equal values at T)
+    if (tid < n) {
+        const unsigned long long mine = list_key[tid];
+        const int my_id = list_id[tid];
+        int rank = 0;
+        bool dup = false;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+            unsigned long long o[8]; int oid[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { o[u] = list_key[j + u]; oid[u] = list_id[j + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                dup = dup || (j + u != tid && o[u] == mine);
+                rank += (o[u] > mine || (o[u] == mine && oid[u] < my_id)) ? 1 : 0;
+            }
+        }
+        for (; j < n; j++) {
+            const unsigned long long o = list_key[j];
+            dup = dup || (j != tid && o == mine);
+            rank += (o > mine || (o == mine && list_id[j] < my_id)) ? 1 : 0;
+        }
+        if (rank <= k && dup) bad = 1u;                // an equality among the k best or between the k-th and its runner-up
+        if (rank < k) {
+            const unsigned long long b = (mine >> 63) ? (mine & 0x7fffffffffffffffull) : ~mine;
+            out_score[rank] = __longlong_as_double((long long) b);
+            out_id[rank] = my_id;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { flags[0] = (bad == 0u && n >= k) ? 1 : 0; flags[1] = n; }
+}
+
 hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *window, int n_window, double scale, double repeat_penalty, int k,
-                                  double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st) {
+                                  double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st, void *ws) {
     if (V > 32768 || k < 1 || k > 64 || n_window > 1024) return hipErrorInvalidValue;
+    static const bool one_launch = getenv("LLAMAHIP_TOPK_ONE") != nullptr;          // measurement: round-2a single-workgroup kernel
+    if (ws && !one_launch) {
+        unsigned long long *keys = (unsigned long long *) ws, *gmax = keys + 32768;
+        uint32_t *badw = (uint32_t *) (gmax + 64);
+        hipLaunchKernelGGL(k_topk_keys, dim3((V + 1023) / 1024), dim3(1024), 0, st, logits, V, window, n_window, scale, repeat_penalty, keys, gmax, badw);
+        LH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_topk_select, dim3(1), dim3(1024), 0, st, V, k, keys, gmax, badw, out_score, out_id, flags);
+        LH_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(k_topk_candidates, dim3(1), dim3(1024), 0, st, logits, V, window, n_window, scale, repeat_penalty, k, out_score, out_id, flags);
     LH_LAUNCH_CHECK();
     return hipSuccess;

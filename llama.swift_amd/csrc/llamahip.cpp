@@ -1041,13 +1041,16 @@ int llamahip_eval_topk(llamahip_model *m, int32_t n_threads, int32_t n_past, con
     const double t0 = now_ms();
     int rc = eval_impl(m, n_threads, n_past, tokens, n_tokens, nullptr, nullptr, -1, nullptr, 0, nullptr, false, err, err_cap);   // logits stay on the device, no wait
     if (rc) return rc;
-    if (!m->d_topk) HIP_TRY(hipMalloc(&m->d_topk, 1024 * 4 + 64 * 8 + 64 * 4 + 8), LLAMAHIP_ERR_PREDICT);
+    if (!m->d_topk) {
+        HIP_TRY(hipMalloc(&m->d_topk, 8192 + TOPK_WS_BYTES), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(m->d_topk, 0, 8192 + TOPK_WS_BYTES), LLAMAHIP_ERR_PREDICT);
+    }
     int32_t *d_win = (int32_t *) m->d_topk;
     double *d_sc = (double *) ((char *) m->d_topk + 4096);
     int32_t *d_id = (int32_t *) ((char *) m->d_topk + 4096 + 512), *d_fl = d_id + 64;
     if (n_last > 0) HIP_TRY(hipMemcpyAsync(d_win, last_n_tokens, (size_t) n_last * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     const float *row = m->logits + (size_t) (n_tokens - 1) * V;
-    HIP_TRY(launch_topk_candidates(row, V, d_win, n_last, 1.0 / temp, repeat_penalty, k, d_sc, d_id, d_fl, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(launch_topk_candidates(row, V, d_win, n_last, 1.0 / temp, repeat_penalty, k, d_sc, d_id, d_fl, m->stream, (char *) m->d_topk + 8192), LLAMAHIP_ERR_PREDICT);
     struct { double sc[64]; int32_t id[64]; int32_t fl[2]; } h;
     HIP_TRY(hipMemcpyAsync(&h, d_sc, sizeof(h), hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
@@ -1408,12 +1411,13 @@ int llamahip_op_topk(const float *logits, int32_t n_vocab, const int32_t *last_n
     }
     float *d_l = nullptr; void *d_w = nullptr;
     HIP_TRY(hipMalloc((void **) &d_l, (size_t) n_vocab * 4), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipMalloc(&d_w, 4096 + 512 + 256 + 8), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMalloc(&d_w, 8192 + TOPK_WS_BYTES), LLAMAHIP_ERR_PREDICT);
+    if (hipMemset(d_w, 0, 8192 + TOPK_WS_BYTES) != hipSuccess) { (void) hipFree(d_l); (void) hipFree(d_w); set_err(err, err_cap, "llamahip_op_topk: memset failed"); return LLAMAHIP_ERR_PREDICT; }
     int32_t *d_win = (int32_t *) d_w; double *d_sc = (double *) ((char *) d_w + 4096); int32_t *d_id = (int32_t *) ((char *) d_w + 4096 + 512), *d_fl = d_id + 64;
     struct { double sc[64]; int32_t id[64]; int32_t fl[2]; } h;
     hipError_t e = hipMemcpy(d_l, logits, (size_t) n_vocab * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_last > 0) e = hipMemcpy(d_win, last_n_tokens, (size_t) n_last * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_topk_candidates(d_l, n_vocab, d_win, n_last, 1.0 / temp, repeat_penalty, top_k, d_sc, d_id, d_fl, nullptr);
+    if (e == hipSuccess) e = launch_topk_candidates(d_l, n_vocab, d_win, n_last, 1.0 / temp, repeat_penalty, top_k, d_sc, d_id, d_fl, nullptr, (char *) d_w + 8192);
     if (e == hipSuccess) e = hipMemcpy(&h, d_sc, sizeof(h), hipMemcpyDeviceToHost);
     (void) hipFree(d_l); (void) hipFree(d_w);
     HIP_TRY(e, LLAMAHIP_ERR_PREDICT);

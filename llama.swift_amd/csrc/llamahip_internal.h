@@ -137,7 +137,8 @@ hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long 
 hipError_t launch_advance(int32_t *state, hipStream_t st);
 // sampler front end (utils.cpp:345-395): the k best candidate scores of the last row of logits, on the device
 hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *window, int n_window, double scale, double repeat_penalty, int k,
-                                  double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st);
+                                  double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st, void *ws = nullptr);      // ws: TOPK_WS_BYTES zeroed once -> the two-launch variant
+constexpr size_t TOPK_WS_BYTES = 32768 * 8 + 64 * 8 + 64;
 hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st);
 
 }  // namespace lh
