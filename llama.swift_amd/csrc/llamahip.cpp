@@ -144,6 +144,11 @@ struct llamahip_model {
     // workspace (sized for ws_cap tokens)
     int ws_cap = 0;
     int32_t *d_tokens = nullptr;
+    // single-token evals through the C ABI: token, sampler window and candidate results live in ONE pinned, device-mapped host
+    // block that the kernels read / write directly (three ~4 us blit copies per sampled token otherwise)
+    struct HostIo { int32_t tok[16]; int32_t window[1024]; double sc[64]; int32_t id[64]; int32_t fl[2]; };
+    HostIo *h_io = nullptr, *d_io = nullptr;       // host pointer / its device alias
+    const int32_t *tok_src = nullptr;              // set by eval_impl around forward(): where the embedding kernel finds the token
     float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *qr = nullptr, *merged = nullptr, *gu = nullptr;
     float *tmp = nullptr;                // debug: un-fused residual operand
     float *logits = nullptr;             // [ws_cap][V] (all rows only in debug evals)
@@ -219,6 +224,7 @@ llamahip_model::~llamahip_model() {
     free_dev(d_out_tokens); free_dev(d_topk);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_sync); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_qat_A); free_dev(d_qat_d);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
+    if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
     for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
@@ -439,7 +445,7 @@ int forward_dense(llamahip_model *m, int n_threads, int n_past, int N, const flo
         HIP_TRY(hipMemcpyAsync(m->d_state, &pos, sizeof(pos), hipMemcpyHostToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
     if (m->first_stage) {
-        HIP_TRY(launch_embed_dense(m->d_tokens, m->tok_emb, hp.f16, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);     // .mm:558-561
+        HIP_TRY(launch_embed_dense(m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, hp.f16, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);     // .mm:558-561
     } else {
         HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
@@ -541,10 +547,10 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     if (use_qkvx && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (m->first_stage) {
         if (use_part) {
-            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_qkvx ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_qkvx ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);
             n_part_x = 1;
         } else
-        HIP_TRY(launch_embed((io && io->token) ? io->token : m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
+        HIP_TRY(launch_embed((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
     } else if (!x_first) {
         HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
@@ -907,6 +913,11 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipHostMalloc((void **) &m->h_fault, 64, hipHostMallocMapped), LLAMAHIP_ERR_LOAD);
         *m->h_fault = 0;
         HIP_TRY(hipHostGetDevicePointer((void **) &m->d_fault, m->h_fault, 0), LLAMAHIP_ERR_LOAD);
+        if (!getenv("LLAMAHIP_NO_HOST_IO")) {
+            HIP_TRY(hipHostMalloc((void **) &m->h_io, sizeof(llamahip_model::HostIo), hipHostMallocMapped), LLAMAHIP_ERR_LOAD);
+            memset(m->h_io, 0, sizeof(llamahip_model::HostIo));
+            HIP_TRY(hipHostGetDevicePointer((void **) &m->d_io, m->h_io, 0), LLAMAHIP_ERR_LOAD);
+        }
         // decode attention as one launch needs every workgroup of a head behind one L2: check the placement on this
         // device before relying on it (LLAMAHIP_NO_ATTN_X: keep the two launches)
         if (!getenv("LLAMAHIP_NO_ATTN_X") && H % 8 == 0 && xcd_selftest(H, (int) (d / H / 32) + (n_ctx + 31) / 32, m->stream)) {
@@ -994,14 +1005,18 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
     if (rc) return rc;
     rc = ensure_prompt_copies(m, N, err, err_cap);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    const bool tok_mapped = N == 1 && m->h_io != nullptr;          // (the stream is idle here: every entry point synchronises before it returns)
+    if (tok_mapped) m->h_io->tok[0] = tokens[0];
+    else HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     DumpSink sink;
     if (dump_layer >= 0 && dump && dump_sizes) {
         sink.dump = dump; sink.cap = dump_cap; sink.sizes = dump_sizes; sink.st = m->stream;
         for (int i = 0; i < 17; i++) dump_sizes[i] = 0;
     }
     const bool want_all = logits_all != nullptr;
+    m->tok_src = tok_mapped ? m->d_io->tok : nullptr;
     rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap);
+    m->tok_src = nullptr;
     if (rc) return rc;
     const size_t V = m->hp.n_vocab;
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
@@ -1048,12 +1063,17 @@ int llamahip_eval_topk(llamahip_model *m, int32_t n_threads, int32_t n_past, con
     int32_t *d_win = (int32_t *) m->d_topk;
     double *d_sc = (double *) ((char *) m->d_topk + 4096);
     int32_t *d_id = (int32_t *) ((char *) m->d_topk + 4096 + 512), *d_fl = d_id + 64;
-    if (n_last > 0) HIP_TRY(hipMemcpyAsync(d_win, last_n_tokens, (size_t) n_last * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    const bool mapped = m->h_io != nullptr;        // window in, candidates out through the pinned host block: no blit copies
+    if (mapped) {
+        if (n_last > 0) memcpy(m->h_io->window, last_n_tokens, (size_t) n_last * 4);
+        d_win = m->d_io->window; d_sc = m->d_io->sc; d_id = m->d_io->id; d_fl = m->d_io->fl;
+    } else if (n_last > 0) HIP_TRY(hipMemcpyAsync(d_win, last_n_tokens, (size_t) n_last * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     const float *row = m->logits + (size_t) (n_tokens - 1) * V;
     HIP_TRY(launch_topk_candidates(row, V, d_win, n_last, 1.0 / temp, repeat_penalty, k, d_sc, d_id, d_fl, m->stream, (char *) m->d_topk + 8192), LLAMAHIP_ERR_PREDICT);
     struct { double sc[64]; int32_t id[64]; int32_t fl[2]; } h;
-    HIP_TRY(hipMemcpyAsync(&h, d_sc, sizeof(h), hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
+    if (!mapped) HIP_TRY(hipMemcpyAsync(&h, d_sc, sizeof(h), hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    if (mapped) { memcpy(h.sc, m->h_io->sc, sizeof(h.sc)); memcpy(h.id, m->h_io->id, sizeof(h.id)); memcpy(h.fl, m->h_io->fl, sizeof(h.fl)); }
     if (n_tokens == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
     m->t_eval_ms += now_ms() - t0;
     if (h.fl[0] == 1) {
