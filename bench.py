@@ -429,6 +429,15 @@ def main():
     try:        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), committed under profiles/
         tj = json.load(open(os.path.join(ROOT, "profiles", "gemv_traffic.json")))
         traffic = tj["per_launch"]["w1|w3"]["traffic_bytes"] if args.model == "7B" else None
+        traffic_src = "profiles/gemv_traffic.json (separate rocprofv3 --pmc passes over the stand-alone probe launches, committed; not measured in this run)"
+        try:        # preferred: the same counters over the captured decode step itself (tools/pmc_decode_pass.sh)
+            dj = json.load(open(os.path.join(ROOT, "profiles", "decode_traffic.json")))
+            hit = [v for k, v in dj["per_launch"].items() if k.startswith("lh::k_gemv<4, 2, 4")]
+            if hit and args.model == "7B":
+                traffic = hit[0]["traffic_bytes"]
+                traffic_src = "profiles/decode_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the captured decode step, in situ; committed, not measured in this run)"
+        except Exception:
+            pass
     except Exception:
         pass
     if prof:
@@ -448,7 +457,7 @@ def main():
         roof.update({"kernel": f"{dom['kernel']} -- the {dom['name']} mat-vec as it runs in the captured decode step (norm prologue, SiLU*up -> Q4_0 epilogue); "
                                f"{dom['algorithmic_bytes'] * nl / gb * 100:.0f}% of the mat-vec bytes of a token",
                      "achieved": dom["GBps"], "frac": dom["frac"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "us_per_launch": dom["us"],
-                     "traffic": traffic, "traffic_source": "profiles/gemv_traffic.json (separate rocprofv3 --pmc passes, committed; not measured in this run)" if traffic else None,
+                     "traffic": traffic, "traffic_source": traffic_src if traffic else None,
                      "method": f"rocprofv3 --kernel-trace of the same decode loop in a child process ({prof['tokens']} tokens); every dispatch labelled by its position in the "
                                "token's launch sequence; average kernel duration",
                      "in_situ_per_launch": per,
