@@ -32,7 +32,10 @@ for c0 in range(0, 495, 9):
 dt = time.perf_counter() - t0
 print(f"prefill, 9-token chunks : {n_past} tokens in {dt * 1e3:8.1f} ms = {n_past / dt:8.1f} tok/s", flush=True)
 t0 = time.perf_counter(); lg = m.eval(toks[:P], 0); dt = time.perf_counter() - t0
-print(f"prefill, one {P} eval   : {P} tokens in {dt * 1e3:8.1f} ms = {P / dt:8.1f} tok/s", flush=True)
+print(f"prefill, one {P} eval   : {P} tokens in {dt * 1e3:8.1f} ms = {P / dt:8.1f} tok/s   (FIRST eval of 61+ rows on this handle: it allocates and builds "
+      f"the two prompt-only weight copies and the attention workspace)", flush=True)
+t0 = time.perf_counter(); lg = m.eval(toks[:P], 0); dt = time.perf_counter() - t0
+print(f"prefill, one {P} eval   : {P} tokens in {dt * 1e3:8.1f} ms = {P / dt:8.1f} tok/s   (again)", flush=True)
 tok = int(np.argmax(lg))
 w = m.decode_greedy(tok, P, 8)
 t0 = time.perf_counter()
