@@ -335,7 +335,7 @@ def prefill_2048(args, cfg, path):
                          "bound": "fp32 VALU issue: the reference's arithmetic needs 8 separately rounded fp32 FMA chains per Q4_0 block and "
                                   "output (ggml.c:1415-1466), 3.3e12 plain v_fma_f32 for this eval.  Only the 4-element integer sums of a chain "
                                   "run on the matrix cores (exact in fp16 -> fp32: v_mfma_f32_32x32x4_2b_f16, two chains per issue, "
-                                  "lh::k_gemm_mfma16), which keeps that pipe ~60% busy with K = 4 issues; the whole eval (attention, "
+                                  "lh::k_gemm_mfma16), which keeps that pipe 30% busy while the VALU is active 81% of the SIMD cycles (profiles/r02_i_prefill_pmc.txt); the whole eval (attention, "
                                   "norms, quantizers included) is divided by the peaks here"}}
 
 
