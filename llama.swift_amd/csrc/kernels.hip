@@ -2658,6 +2658,82 @@ k_attnq_pv(const float *__restrict__ S, const float *__restrict__ inv, const flo
 }
 
 // merged[n][h*128 + c] = part[0] + part[1] + ... in thread order.  grid (NB/2, H), 256 threads = 2 queries x 128 columns
+// The same V*P partial sums on the matrix cores (round 2).  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fmaf chain per
+// output -- D = fma(a1, b1, fma(a0, b0, C)), one rounding per product, subnormals kept (cdna_hip_programming.md, "Numerics" of the
+// f32 MFMAs) -- i.e. exactly acc = fma(v, p, acc) over two consecutive keys, which is what the chain of a (chunk, query, column)
+// is.  One wave = 64 queries x the head's 128 columns x ONE chunk of the nth-way key split: 8 accumulator tiles (128 registers),
+// per pair of keys 2 loads of probabilities (lane = query) and 4 of values (lane = column), 8 MFMAs = 512 cycles of the matrix
+// pipe at the fp32 FMA peak, and no VALU work but the soft_max scale.  A chunk with an odd number of keys is padded with a zero
+// pair at the FRONT: fma(0, 0, +0) = +0 leaves the chain's start unchanged (a trailing pad could turn a -0 sum into +0).
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
+k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ part,
+                int n_past, int N, int nb0, int NB, int d, int T, int nth) {
+    const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5, h = blockIdx.y, th = blockIdx.z;
+    const int q0 = blockIdx.x * 64;
+    const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
+    const int Tb = n_past + nb_end;
+    const int dc = (T + nth - 1) / nth;
+    const int t0 = dc * th;
+    const int t1 = min(min(t0 + dc, T), Tb);              // beyond Tb every P of this block is 0: fma(v, 0, acc) == acc
+    f32x16v D[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) D[a][b][r] = 0.0f;
+    const float iv0 = inv[(size_t) h * NB + q0 + i], iv1 = inv[(size_t) h * NB + q0 + 32 + i];
+    const int nk = t1 - t0;
+    // operands of PF pair-steps in flight: a step is 512 matrix-pipe cycles, a load round trip several times that
+    constexpr int PF = 4;
+    float pa0[PF], pa1[PF], pb0[PF], pb1[PF], pb2[PF], pb3[PF];
+    const int tstart = t0 - (nk > 0 ? (nk & 1) : 0);
+#define LH_PVLOAD(ST, TP)                                                                           \
+    {                                                                                               \
+        const int key_ = (TP) + kk;                                                                 \
+        const bool real_ = key_ >= t0 && key_ < t1;      /* (the front pad, and steps past the end) */ \
+        const int kc_ = min(max(key_, t0), max(t1 - 1, t0));                                        \
+        const float *sp_ = S + ((size_t) h * T + kc_) * NB + q0 + i;                                \
+        const float *vp_ = Vc + (size_t) kc_ * d + h * 128 + i;                                     \
+        const float s0_ = sp_[0], s1_ = sp_[32], v0_ = vp_[0], v1_ = vp_[32], v2_ = vp_[64], v3_ = vp_[96]; \
+        pa0[ST] = real_ ? s0_ * iv0 : 0.0f; pa1[ST] = real_ ? s1_ * iv1 : 0.0f;     /* soft_max's final scale (ggml.c:7036-7041) */ \
+        pb0[ST] = real_ ? v0_ : 0.0f; pb1[ST] = real_ ? v1_ : 0.0f; pb2[ST] = real_ ? v2_ : 0.0f; pb3[ST] = real_ ? v3_ : 0.0f; \
+    }
+    if (nk > 0) {
+#pragma unroll
+        for (int st = 0; st < PF; st++) LH_PVLOAD(st, tstart + 2 * st)
+        for (int tp = tstart; tp < t1; tp += 2 * PF) {
+#pragma unroll
+            for (int st = 0; st < PF; st++) {
+                if (tp + 2 * st < t1) {
+                    const float a0 = pa0[st], a1 = pa1[st], b0 = pb0[st], b1 = pb1[st], b2 = pb2[st], b3 = pb3[st];
+                    LH_PVLOAD(st, tp + 2 * (st + PF))
+                    D[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, D[0][0], 0, 0, 0);
+                    D[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, D[0][1], 0, 0, 0);
+                    D[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, D[0][2], 0, 0, 0);
+                    D[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, D[0][3], 0, 0, 0);
+                    D[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, D[1][0], 0, 0, 0);
+                    D[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, D[1][1], 0, 0, 0);
+                    D[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, D[1][2], 0, 0, 0);
+                    D[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, D[1][3], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef LH_PVLOAD
+    // part[th][h][nl][128]; D register r of tile (a, b): query q0 + 32 a + (r & 3) + 8 (r >> 2) + 4 kk, column 32 b + i
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int nl = q0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            float *o = part + (((size_t) th * gridDim.y + h) * NB + nl) * 128 + i;
+#pragma unroll
+            for (int b = 0; b < 4; b++) o[32 * b] = D[a][b][r];
+        }
+}
+
 __global__ void __launch_bounds__(256)
 k_attnq_merge(const float *__restrict__ part, float *__restrict__ merged, int N, int nb0, int NB, int d, int nth) {
     const int c = threadIdx.x & 127, nl = blockIdx.x * 2 + (threadIdx.x >> 7), h = blockIdx.y, H = gridDim.y;
@@ -4157,6 +4233,10 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
+            // V*P on the fp32 matrix cores (k_attnq_pv_mfma: bit-identical fmaf chains) unless LLAMAHIP_ATTNQ_PV_VALU asks for round 1's kernel
+            static const bool pv_valu = getenv("LLAMAHIP_ATTNQ_PV_VALU") != nullptr;
+            if (!pv_valu) hipLaunchKernelGGL(k_attnq_pv_mfma, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
+            else
             hipLaunchKernelGGL(k_attnq_pv, dim3(qb, H, 4 * nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_merge, dim3((nb + 1) / 2, H), dim3(256), 0, st, ws->part, merged, N, nb0, ws->NB, d, nth);
