@@ -2487,6 +2487,85 @@ k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float
     pmax[((size_t) h * KS + ks) * NB + nl] = mx;
 }
 
+// The same scores on the fp32 matrix cores (round 2, after k_attnq_scores_lds).  v_mfma_f32_16x16x4_f32 is bit-for-bit the k-ordered
+// fmaf chain fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C)))) per output: with A = query elements {l, l + 32, l + 64, l + 96} and
+// B = the same elements of a key it IS chain l of ggml_vec_dot_f32 (ggml.c:1223-1258) for a 16 x 16 tile of (query, key) pairs.  Lane
+// (m = lane % 16, kk = lane / 16) supplies element l + 32 kk of row m: the 32 operands a lane needs for the 32 chains are the 32
+// CONSECUTIVE floats [32 kk, 32 kk + 32) of its query / key row -- loaded straight into registers, no LDS, no scalar loads.  One wave =
+// 16 queries (registers, loaded once) against its key slice, 16 keys per step = 32 independent MFMAs (C = 0) + the reduction tree
+// (ggml.c:872-887) on the VALU, 31 additions per pair.  Result registers: lane holds key n = lane % 16, queries 4 kk + r.
+// 153 (LDS variant) -> 100 us per launch at 2 048 tokens, logits bit-identical; requesting the next step's key rows a step ahead
+// (+32 registers) measured 109 us: two waves per SIMD already cover the load.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
+                    int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
+    const int lane = threadIdx.x, m = lane & 15, kk = lane >> 4, h = blockIdx.y, ks = blockIdx.z;
+    const int nl0 = blockIdx.x * 16;
+    const int Tb = n_past + min(nb0 + nl0 + 16, N);                    // keys any query of this tile can see
+    const int per = (Tb + KS - 1) / KS, t0 = ks * per, t1 = min(Tb, t0 + per);
+    float mx[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    if (t0 < t1) {
+        float aq[32];
+        {
+            const int nq = min(nb0 + nl0 + m, N - 1);
+            const f32x4 *qp = (const f32x4 *) (qr + (size_t) nq * d + h * 128 + 32 * kk);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const f32x4 v = qp[j]; aq[4 * j] = v.x; aq[4 * j + 1] = v.y; aq[4 * j + 2] = v.z; aq[4 * j + 3] = v.w; }
+        }
+        int tq[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) tq[r] = n_past + min(nb0 + nl0 + 4 * kk + r, N - 1);      // last key query 4 kk + r sees
+        const f32x4v zero4 = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int tb = t0; tb < t1; tb += 16) {
+            float bk[32];
+            {
+                const f32x4 *kp = (const f32x4 *) (Kc + (size_t) min(tb + m, t1 - 1) * d + h * 128 + 32 * kk);
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const f32x4 v = kp[j]; bk[4 * j] = v.x; bk[4 * j + 1] = v.y; bk[4 * j + 2] = v.z; bk[4 * j + 3] = v.w; }
+            }
+            float r1[2][8][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                f32x4v D[16];
+#pragma unroll
+                for (int l = 0; l < 16; l++) D[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[16 * hf + l], bk[16 * hf + l], zero4, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) r1[hf][j][r] = D[j][r] + D[j + 8][r];
+            }
+            f32x4 out;
+            float scv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float u[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) u[j] = r1[0][j][r] + r1[1][j][r];
+                const float v0 = u[0] + u[4], v1 = u[1] + u[5], v2 = u[2] + u[6], v3 = u[3] + u[7];
+                scv[r] = ((v0 + v1) + (v2 + v3)) * kq_scale;
+            }
+            const int t = tb + m;                                       // this lane's key
+            if (t < t1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (t <= tq[r]) mx[r] = fmaxf(mx[r], scv[r]);
+                out.x = scv[0]; out.y = scv[1]; out.z = scv[2]; out.w = scv[3];
+                *(f32x4 *) (S + ((size_t) h * T + t) * NB + nl0 + 4 * kk) = out;
+            }
+        }
+    }
+    // running maximum of each query over this key slice: across the 16 lanes (keys) of a DPP row
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float v = mx[r];
+        v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
+        v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+        v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+        v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+        if (m == 0) pmax[((size_t) h * KS + ks) * NB + nl0 + 4 * kk + r] = v;
+    }
+}
+
 // The same scores with the K rows staged in LDS (round 2): a workgroup = 4 waves = 256 consecutive queries of one head; a
 // tile of 32 keys (16 KB) is fetched with coalesced vector loads (next tile in registers while this one is consumed,
 // two LDS buffers, one barrier per tile) and every lane reads the key's elements as LDS BROADCASTS (wave-uniform
@@ -4223,7 +4302,14 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             // scores: K rows through LDS broadcasts (k_attnq_scores_lds, 256 queries per workgroup) unless LLAMAHIP_ATTNQ_SCALAR
             // asks for round 1's scalar-cache variant; ~3 workgroups per CU: KS key slices
             static const bool scalar_k = getenv("LLAMAHIP_ATTNQ_SCALAR") != nullptr;
-            if (!scalar_k) {
+            static const bool lds_k = getenv("LLAMAHIP_ATTNQ_LDS") != nullptr;
+            if (!scalar_k && !lds_k) {
+                // scores on the fp32 matrix cores (k_attnq_scores_mfma): 16 queries per wave, ~4 waves per SIMD over key slices
+                const int qt = (nb + 15) / 16;
+                KS = (4096 + qt * H - 1) / (qt * H);
+                KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
+                hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
+            } else if (!scalar_k) {
                 const int qb4 = (nb + 255) / 256;
                 KS = (768 + qb4 * H - 1) / (qb4 * H);
                 KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
