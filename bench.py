@@ -122,7 +122,7 @@ def cpu_decode(path: str, n_threads: int, budget_s: float, n_ctx: int, want_toke
     import reflib
     kind = "reference" if reflib.have_ref() else "port"
     lib = reflib.RefLib() if kind == "reference" else reflib.OracleLib()
-    m = lib.load(path, n_ctx, 1)
+    m = lib.load(path, n_ctx, 0)          # 0: the loader derives the part count from n_embd (.mm:33-38): 13B = 2 files, 65B = 8
     prompt = PROMPT.copy()
     logits = m.eval(prompt, 0, n_threads)["logits"]
     tok, n_past, toks = int(np.argmax(logits)), len(prompt), []
