@@ -74,6 +74,18 @@ __device__ __forceinline__ uint16_t exp_math_bits(uint16_t h) {
     return f2h_bits((float) exp((double) h2f_bits(h)));
 }
 
+// the same granule for readers on ANY XCD (another launch of the overlapped decode schedule): one write-through (sc1) store
+__device__ __forceinline__ void store_tagged_agent(uint64_t *p, uint32_t bits, uint32_t tag) {
+    __hip_atomic_store(p, (uint64_t) bits | ((uint64_t) tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Tag of a granule = {epoch of the forward pass : 24 bits | slot : 8 bits}.  slot = 0 for the embedding row, il + 1 for everything layer
+// il (counted from the handle's first layer) produces; a residual-stream row is therefore tagged with the index of the layer that
+// CONSUMES it.  The host refuses the tagged schedules on handles with more than TAG_MAX_LAYERS layers; k_bump_epoch skips the epoch
+// whose 24 low bits are zero, so no tag ever equals the zero-filled state of a fresh buffer.
+constexpr int TAG_MAX_LAYERS = 250;
+__device__ __forceinline__ uint32_t make_tag(uint32_t epoch, int slot) { return (epoch << 8) | (uint32_t) slot; }
+__device__ __forceinline__ uint32_t next_epoch(uint32_t e) { e += 1u; if ((e & 0xFFFFFFu) == 0u) e += 1u; return e; }
+
 template <int Q>
 __device__ __forceinline__ float quad_bcast(float v) {           // lane Q of every quad (DPP quad_perm:[Q,Q,Q,Q])
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q | (Q << 2) | (Q << 4) | (Q << 6), 0xF, 0xF, true));
@@ -306,9 +318,11 @@ __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__res
 // mat-vec folds instead of reducing the row itself (PREP_NORMP).  One workgroup; same dequantization.
 __global__ void __launch_bounds__(256)
 k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb, float *__restrict__ x, int d,
-             f64x2 *__restrict__ part_out, uint32_t *__restrict__ epoch) {
+             f64x2 *__restrict__ part_out, uint32_t *__restrict__ epoch, uint64_t *__restrict__ xt) {
     __shared__ double red[32];
     const int tok = tokens[0];
+    // xt (overlapped decode schedule): the row also leaves as tagged granules, slot 0 of the epoch k_bump_epoch set before this launch
+    const uint32_t tag = xt ? make_tag(epoch[0], 0) : 0u;
     const uint8_t *row = emb + (size_t) tok * (d / 32) * 20;
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < d / 2; i += blockDim.x) {       // one byte = two elements
@@ -320,13 +334,21 @@ k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb
         const float v0 = (float) ((int) (q & 0xF) - 8) * dd, v1 = (float) ((int) (q >> 4) - 8) * dd;
         x[2 * i + 0] = v0;
         x[2 * i + 1] = v1;
+        if (xt) { store_tagged_agent(xt + 2 * i, __builtin_bit_cast(uint32_t, v0), tag); store_tagged_agent(xt + 2 * i + 1, __builtin_bit_cast(uint32_t, v1), tag); }
         s1 += (double) v0; s1 += (double) v1;
         s2 += (double) v0 * (double) v0; s2 += (double) v1 * (double) v1;
     }
     s1 = block_sum_d(s1, red, 0);
     s2 = block_sum_d(s2, red, 1);
     if (threadIdx.x == 0) part_out[0] = f64x2{ s1, s2 };
-    if (epoch && threadIdx.x == 0) epoch[0] += 1u;       // one forward pass = one epoch of the tagged hand-offs (k_qkv_attn)
+    if (epoch && !xt && threadIdx.x == 0) epoch[0] = next_epoch(epoch[0]);       // one forward pass = one epoch of the tagged hand-offs (k_qkv_attn)
+}
+
+// a residual-stream row that arrived behind a kernel boundary (pipeline stage input) re-published as tagged granules, slot 0
+__global__ void __launch_bounds__(256)
+k_tag_row(const float *__restrict__ x, int d, const uint32_t *__restrict__ epoch, uint64_t *__restrict__ xt) {
+    const uint32_t tag = make_tag(epoch[0], 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d; i += gridDim.x * blockDim.x) store_tagged_agent(xt + i, __builtin_bit_cast(uint32_t, x[i]), tag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -739,6 +761,13 @@ constexpr int SYNC_SHARDS = 8;      // words, 64 B apart: 8 shard counters | top
 enum { SYNC_NONE = 0, SYNC_WAIT = 1, SYNC_ARRIVE = 2 };
 // 8-byte granule {value, tag}: written with one 8-byte store, read with one 8-byte load that bypasses the L1 (sc1), so a
 // reader sees the value together with its tag or not at all.  The spin is bounded; running out raises the fault word.
+// one more look of a bounded poll: true = stop looking.  Running out raises the sticky fault word (results are invalid from there on);
+// a fault somebody else raised is noticed every 1024 looks, so that one lost hand-off does not make every later poll of the forward
+// pass wait out its own bound.
+__device__ __forceinline__ bool poll_give_up(int &spins, int limit, uint32_t *fault) {
+    if (++spins > limit) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return true; }
+    return (spins & 1023) == 0 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
 __device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, int nowait /* bit 0: pass at once (measurement), bit 1: no sleep between polls, bit 2: give up after 256 polls (fault-injection test) */) {
     uint64_t v;
     int spins = 0;
@@ -746,7 +775,7 @@ __device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, ui
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t) (v >> 32) == tag || (nowait & 1)) break;
         if (!(nowait & 2)) __builtin_amdgcn_s_sleep(1);
-        if (++spins > ((nowait & 4) ? (1 << 8) : (1 << 20))) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        if (poll_give_up(spins, (nowait & 4) ? (1 << 8) : (1 << 20), fault)) break;
     }
     return __builtin_bit_cast(float, (uint32_t) v);
 }
@@ -764,7 +793,11 @@ struct GemvArgs {
     const f64x2 *part_in; int npart; f64x2 *part_out;
     uint32_t *sync; int sync_blocks, sync_epoch;      // hand-off words, blocks of the producer role, 1-based epoch
     int lut_math;                                     // bit 0: evaluate SiLU instead of gathering it (verified at load time)
-    uint32_t *fault;                                  // PRE_QA_TAG: sticky fault word (a bounded poll that ran out)
+    uint32_t *fault;                                  // tagged operands: sticky fault word (a bounded poll that ran out)
+    // overlapped decode schedule (launch_gemv_ov): operands / results as tagged granules; `sync` -> the epoch word, slots as make_tag
+    const uint64_t *in_t;   int slot_in;              // PREP_NORM_TAG: the fp32 row [K]
+    const uint64_t *resid_t; int slot_resid;          // EPI_RESID_TAG: the residual row [M]
+    uint64_t *out_t;        int slot_out;             // EPI_RESID_TAG: y [M]; EPI_SILU_QAT: [block][9] (8 chain dwords + scale)
 };
 
 __device__ __forceinline__ void sync_arrive(uint32_t *sync, int blk, int nblocks, int epoch) {
@@ -803,7 +836,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     uint32_t *__restrict__ out_A = ga.out_A; float *__restrict__ out_d = ga.out_d;
     const f64x2 *__restrict__ part_in = ga.part_in; f64x2 *__restrict__ part_out = ga.part_out;
     // (EPI_STORE_TAG: the tag of this launch's output granules, read up front -- not a dependent load at the tail)
-    const uint32_t store_tag = (EPI == EPI_STORE_TAG || PRE == PRE_QA_TAG) ? ((__builtin_nontemporal_load(ga.sync) << 7) | (uint32_t) ga.sync_epoch) : 0u;
+    constexpr bool TAGGED = (EPI == EPI_STORE_TAG || PRE == PRE_QA_TAG || PRE == PREP_NORM_TAG || EPI == EPI_RESID_TAG || EPI == EPI_SILU_QAT);
+    const uint32_t epoch_ = TAGGED ? __builtin_nontemporal_load(ga.sync) : 0u;
+    const uint32_t store_tag = make_tag(epoch_, ga.sync_epoch + 1);        // EPI_STORE_TAG output / PRE_QA_TAG operand: layer ga.sync_epoch
+    const uint32_t tag_in = make_tag(epoch_, ga.slot_in), tag_resid = make_tag(epoch_, ga.slot_resid), tag_out = make_tag(epoch_, ga.slot_out);
     // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
     // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
     // index clamp -- their addresses are `loop base + immediate` instead of three VALU per chunk.
@@ -856,7 +892,8 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     // whole norm -> quantize pipeline stays in registers (no LDS staging of y, no one-thread-per-block
     // serial quantizer: the prologue is VALU work repeated by every workgroup, so its instruction
     // count matters as much as the mat-vec's).
-    constexpr bool NORMLIKE = (PRE == PREP_NORM || PRE == PREP_NORMP);
+    constexpr bool NORMTAG = (PRE == PREP_NORM_TAG);      // PREP_NORM on a row that arrives as tagged granules (gathered after phase 2)
+    constexpr bool NORMLIKE = (PRE == PREP_NORM || PRE == PREP_NORMP || NORMTAG);
     constexpr bool REGPRE = (PRE == PRE_QA || NORMLIKE || PRE == PREP_PLAIN);
     constexpr int MAXH = (NORMLIKE || PRE == PREP_PLAIN) ? PG : 1;   // half-block granules per thread
     constexpr int MAXQA = (PRE == PRE_QA) ? PG : 1, MAXQD = (PG + 7) / 8;    // QA granules per thread (da is 1/8 of A)
@@ -874,6 +911,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     f64x2 pp[PNP];
     const int npl = (npart + 63) >> 6;
     float resid_v = 0.0f;
+    uint64_t resid_g = 0;
     auto phase1 = [&]() {
     if ((NORMLIKE || PRE == PREP_PLAIN) && active) {
         const int ng = (nh + nt - 1) / nt;
@@ -884,7 +922,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
                 const int hi = min(tid + u * nt, nh - 1);
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
-                    xa[u][v] = ((const f32x4 *) in0)[hi * 4 + v];
+                    if (!NORMTAG) xa[u][v] = ((const f32x4 *) in0)[hi * 4 + v];
                     if (NORMLIKE) xb[u][v] = ((const f32x4 *) in1)[hi * 4 + v];
                 }
             } else {
@@ -903,6 +941,13 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         int lg0 = g;
         if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
         resid_v = resid[min(lg0 * 8 + (lane >> 3), M - 1)];
+    }
+    // (EPI_RESID_TAG: the residual granule is requested here as well -- its producer ran two launches back on this branch, so
+    //  it is normally there already; the epilogue re-polls only if the tag says otherwise: layer 0, whose row the other branch embeds)
+    if (EPI == EPI_RESID_TAG && active && (lane & 7) == 0) {
+        int lg0 = g;
+        if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
+        resid_g = __hip_atomic_load(ga.resid_t + min(lg0 * 8 + (lane >> 3), M - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (PRE == PRE_QA && active) {
         const int nqa = (nchunks * 16 + nt - 1) / nt, nqd = (nchunks * 2 + nt - 1) / nt;
@@ -930,6 +975,53 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (NORMTAG) {
+        // The row comes from the launch that runs BESIDE this one (the other branch of the overlapped decode schedule) as tagged
+        // granules.  This workgroup's first D weight chunks are in flight (phase 2).  Wave 0 watches 64 sample granules (the last
+        // of every K / 64 rows), sleeping between looks -- the producer's workgroups finish together, and pollers compete with its
+        // weight stream -- then every thread runs the tag-checked copy of its own half-blocks, which passes on its first or second
+        // round.  Correctness rests on the copy alone; the watch only keeps the polling traffic small.
+        const uint64_t *__restrict__ xt = ga.in_t;
+        const int give_up = (ga.lut_math & 0x1000) ? (1 << 8) : (1 << 20);      // (0x1000: fault-injection test)
+        if (wave == 0) {
+            const int stride = K >> 6;
+            int spins = 0;
+            for (;;) {
+                const bool ok = (uint32_t) (__hip_atomic_load(xt + lane * stride + stride - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag_in;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (give_up >> 2) || ((spins & 255) == 0 && __hip_atomic_load(ga.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) break;   // (the copy below raises the fault word if the row never comes)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MAXH; u++) {
+            const int hi = tid + u * nt;
+            if (active && hi < nh) {
+                uint64_t gv[16];
+                int spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        gv[i] = __hip_atomic_load(xt + hi * 16 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (uint32_t) (gv[i] >> 32) == tag_in;
+                    }
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (poll_give_up(spins, give_up, ga.fault)) break;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    xa[u][v] = f32x4{ __builtin_bit_cast(float, (uint32_t) gv[4 * v]), __builtin_bit_cast(float, (uint32_t) gv[4 * v + 1]),
+                                      __builtin_bit_cast(float, (uint32_t) gv[4 * v + 2]), __builtin_bit_cast(float, (uint32_t) gv[4 * v + 3]) };
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; v++) xa[u][v] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            }
+        }
+    }
+
     // ---- phase 3: prologue arithmetic while the weights stream in
     LH_STAMP(1);
     double *red = (double *) (ldsD + (nchunks + PADC) * 8);
@@ -953,11 +1045,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
             int spins = 0;
             for (;;) {
                 bool ok = true;
-                for (int gi = lane; gi < nd; gi += 64)
+                for (int gi = lane; gi < min(nd, K >> 5); gi += 64)
                     ok = ok && (uint32_t) (__hip_atomic_load(ta + gi * 9 + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == store_tag;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 18)) break;             // (the copy below raises the fault word if the data never comes)
+                if (++spins > ((ga.lut_math & 0x1000) ? (1 << 6) : (1 << 18)) || ((spins & 255) == 0 && __hip_atomic_load(ga.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) break;             // (the copy below raises the fault word if the data never comes; 0x1000: fault-injection test)
             }
         }
         __syncthreads();
@@ -972,14 +1064,17 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
                     if (active && gi < ntot) {
                         // granule of LDS dword gi = (chunk cc, chain kk, block j): the producer of block cc * 8 + j wrote its 8 chain dwords
                         // and its scale as 9 CONTIGUOUS granules (one 72-byte write-through burst per producer, not 9 scattered ones)
-                        const int src = gi < na ? (((gi >> 6) * 8 + (gi & 7)) * 9 + ((gi >> 3) & 7)) : ((gi - na) * 9 + 8);
-                        v[u] = __hip_atomic_load(ta + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && (uint32_t) (v[u] >> 32) == store_tag;
+                        const int blk_ = gi < na ? ((gi >> 6) * 8 + (gi & 7)) : (gi - na);
+                        const int src = gi < na ? (blk_ * 9 + ((gi >> 3) & 7)) : (blk_ * 9 + 8);
+                        if (blk_ < (K >> 5)) {                   // (blocks that pad K to a multiple of 256 have no producer: zero)
+                            v[u] = __hip_atomic_load(ta + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && (uint32_t) (v[u] >> 32) == store_tag;
+                        }
                     }
                 }
                 if (ok || nowait) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 20)) { __hip_atomic_store(ga.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                if (poll_give_up(spins, (ga.lut_math & 0x1000) ? (1 << 8) : (1 << 20), ga.fault)) break;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1181,7 +1276,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     int lg = g;
     if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
     const int m = lg * 8 + (lane >> 3);
-    if (EPI == EPI_SILU_QA) {
+    if (EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) {
         // 8 waves: waves 0-3 hold gate rows b*32 .. b*32+31, waves 4-7 the matching up rows (b = blockIdx.x)
         float *gu = (float *) red;                      // prologue scratch is free again
         if (!(ga.lut_math & 8)) __syncthreads();
@@ -1201,6 +1296,13 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
             const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
             const int b = blk, c = b >> 3, j = b & 7;
             const uint32_t dw = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+            if (EPI == EPI_SILU_QAT) {
+                // read by the w2 launch that runs beside this one (polling): 9 contiguous write-through granules {dword, tag} per
+                // Q4_0 block -- its 8 chain dwords, then its scale (the consumer watches the scales)
+                if (lane < 8) store_tagged_agent(ga.out_t + (b * 9 + kk), dw, tag_out);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the scale leaves after the dwords it announces)
+                if (lane == 0) store_tagged_agent(ga.out_t + (b * 9 + 8), __builtin_bit_cast(uint32_t, dd), tag_out);
+            } else
             if (SYNC == SYNC_ARRIVE) {       // write-through: the consumer role of this launch reads them on another XCD
                 if (lane < 8) __hip_atomic_store(out_A + (c * 8 + kk) * 8 + j, dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) __hip_atomic_store((uint32_t *) out_d + b, __builtin_bit_cast(uint32_t, dd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1218,11 +1320,18 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     } else {
         const bool live = valid && k == 0 && m < M;
         if (EPI == EPI_RESID) acc = acc + resid_v;
+        if (EPI == EPI_RESID_TAG) {
+            float rv = __builtin_bit_cast(float, (uint32_t) resid_g);
+            if (live && (uint32_t) (resid_g >> 32) != tag_resid) rv = poll_tagged(ga.resid_t + m, tag_resid, ga.fault, (ga.lut_math & 0x1000) ? 4 : 0);
+            acc = acc + rv;
+        }
         if (EPI == EPI_STORE_TAG) {                     // ga.sync -> the epoch word, ga.sync_epoch = layer (k_qkv_attn)
             if (live) store_tagged((uint64_t *) y + m, acc, store_tag ^ ((ga.lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test -- a tag nobody waits for)
+        } else if (EPI == EPI_RESID_TAG) {              // the row for the launches that run beside / after this one (+ plain, where somebody reads it behind a boundary)
+            if (live) { store_tagged_agent(ga.out_t + m, __builtin_bit_cast(uint32_t, acc), tag_out ^ ((ga.lut_math & 0x2000) ? 1u : 0u)); if (y) y[m] = acc; }      // (0x2000: fault-injection test)
         } else
         if (live) y[m] = acc;
-        if (EPI == EPI_RESID && part_out) {
+        if ((EPI == EPI_RESID || EPI == EPI_RESID_TAG) && part_out) {
             // this workgroup's share of the next norm's statistics (consumed by a PREP_NORMP prologue): sum y and
             // sum y^2 over its rows, in double (y^2 is exact there), folded in a fixed order
             const double yd = live ? (double) acc : 0.0;
@@ -1258,7 +1367,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
 
 
 template <int PRE, int EPI, int D, bool RING, int PG>
-__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256, EPI == EPI_SILU_QA ? 4 : 1)
+__global__ void __launch_bounds__((EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) ? 512 : 256, (EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) ? 4 : 1)
 k_gemv(const GemvArgs ga) {
     extern __shared__ double smem_d[];
     gemv_body<PRE, EPI, D, RING, PG, SYNC_NONE, false>(ga, blockIdx.x, blockDim.x >> 6, smem_d);
@@ -3198,7 +3307,7 @@ struct AttnXArgs {
     const float *qkv; int d, dh; const double *sincos_tab; float *Kc, *Vc, *sc; int n_ctx, nth; float kq_scale;
     float *merged; uint32_t *qa_A; float *qa_d; const uint16_t *T_exp; const int32_t *st; uint32_t *sync, *fault; int lut_math;
     // k_qkv_attn only: data-tagged hand-offs.  qkv2[3 d] / sc2[H][n_ctx] hold {fp32 bits, tag} 8-byte granules,
-    // tag = epoch[0] << 7 | layer: a reader polls the granule itself until the tag is this launch's
+    // tag = make_tag(epoch[0], layer + 1): a reader polls the granule itself until the tag is this launch's
     const uint64_t *qkv2; uint64_t *sc2; const uint32_t *epoch; int layer;
     uint64_t *qat_A, *qat_d;      // non-null: the wo mat-vec is a role of the same launch and takes the quantized row as tagged granules
 };
@@ -3250,7 +3359,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
             }
         };
         const int nowait = ((lut_math & 0x400) ? 1 : 0) | ((lut_math >> 8) & 2) | ((lut_math & 0x1000) ? 4 : 0);     // (measurement-only switches: 0x400 this hop does not wait, results invalid; 0x200 polls without sleep; 0x1000 fault-injection test)
-        const uint32_t tag = QKV_WAIT ? ((aa.epoch[0] << 7) | (uint32_t) aa.layer) : 0u;
+        const uint32_t tag = QKV_WAIT ? (make_tag(aa.epoch[0], aa.layer + 1)) : 0u;
         if (QKV_WAIT) load_keys();                              // in flight while the mat-vec workgroups finish
         if (tid < dh / 2) {
             const int e = 2 * tid;
@@ -3347,7 +3456,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
     const float *row = sc + (size_t) h * n_ctx;
     float mx = -INFINITY;
     if (QKV_WAIT) {
-        const uint32_t tag = (aa.epoch[0] << 7) | (uint32_t) aa.layer;
+        const uint32_t tag = make_tag(aa.epoch[0], aa.layer + 1);
         const int nowait = ((lut_math & 0x800) ? 1 : 0) | ((lut_math >> 8) & 2) | ((lut_math & 0x1000) ? 4 : 0);
         for (int t = tid; t < T; t += nt) { const float v = poll_tagged(aa.sc2 + (size_t) h * n_ctx + t, tag, fault, nowait); p[t] = v; mx = fmaxf(mx, v); }
     } else
@@ -3411,7 +3520,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
         if (QKV_WAIT && aa.qat_A) {
             // consumed by the wo role of this launch on all XCDs: 9 contiguous write-through granules {dword, tag} per Q4_0 block
             // (its 8 chain dwords, then its scale)
-            const uint32_t tagq = (aa.epoch[0] << 7) | (uint32_t) aa.layer;
+            const uint32_t tagq = make_tag(aa.epoch[0], aa.layer + 1);
             if (tid < 8) __hip_atomic_store(aa.qat_A + (b * 9 + kk), (uint64_t) dwq | ((uint64_t) tagq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid == 0) __hip_atomic_store(aa.qat_A + (b * 9 + 8), (uint64_t) __builtin_bit_cast(uint32_t, dd) | ((uint64_t) tagq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -3443,7 +3552,7 @@ k_dec_attn_x(const AttnXArgs aa) {
 // wq|wk|wv mat-vec AND the attention in one launch.  The seam is per head as well: head h's scores need only head h's
 // 3 dh output rows.  Blocks [0, gridA) are the mat-vec's workgroups (4 waves = 32 rows), PERMUTED so that the 3 dh / 32
 // workgroups that own head h's q, k and v rows sit on XCD h % 8 (block b: XCD b % 8, slot b / 8 -> (head of that XCD, part)):
-// they store their rows as tagged 8-byte granules {value, epoch << 7 | layer} (EPI_STORE_TAG) which the readers poll.  Blocks [gridA, ...) are the attention workgroups
+// they store their rows as tagged 8-byte granules {value, make_tag(epoch, layer + 1)} (EPI_STORE_TAG) which the readers poll.  Blocks [gridA, ...) are the attention workgroups
 // of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
@@ -3697,6 +3806,9 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
     LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
     LH_ATTR((k_gemv_pair<PREP_NORMP, 4, 4, 10, true>)); LH_ATTR((k_gemv_pair<PREP_NORM, 4, 4, 10, true>));
+    LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 16, false, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 8, true, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 10, true, 1>));
+    LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 16, true, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 22, true, 1>));
+    LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 16, false, 1>)); LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 8, true, 1>));
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
@@ -3705,6 +3817,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
     LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1, true>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1, true>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2, false>));
+    LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 4, 2, false>));
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -3761,8 +3874,13 @@ hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int
 
 size_t prep_lds_bytes(int K) { return 32 * sizeof(double) + ((size_t) K + K / 32 + 64) * sizeof(float); }
 
-hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch) {
-    hipLaunchKernelGGL(k_embed_part, dim3(1), dim3(256), 0, st, token, emb, x, d, (f64x2 *) part_out, epoch);
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch, uint64_t *xt) {
+    hipLaunchKernelGGL(k_embed_part, dim3(1), dim3(256), 0, st, token, emb, x, d, (f64x2 *) part_out, epoch, xt);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_tag_row(const float *x, int d, const uint32_t *epoch, uint64_t *xt, hipStream_t st) {
+    hipLaunchKernelGGL(k_tag_row, dim3((d + 1023) / 1024), dim3(256), 0, st, x, d, epoch, xt);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -4020,6 +4138,79 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
     if (pre == PREP_SILU_MUL && epi == EPI_RESID) return launch_gemv_t<PREP_SILU_MUL, EPI_RESID>(LH_ARGS);
 #undef LH_ARGS
     return hipErrorInvalidValue;
+}
+
+// ---- overlapped decode schedule (llamahip.cpp forward(), "two-branch"): the decode mat-vecs whose operands arrive and whose
+// results leave as tagged granules, so that a launch can start (dispatch its workgroups, put its first D weight chunks in flight)
+// while its producer is still running on the other branch of the captured graph.
+//   resid role (wo, w2): PRE_QA_TAG  [block][9] granules  ->  y + residual as tagged row (+ plain y, + norm partial sums on request)
+//   silu role  (w1|w3) : PREP_NORM_TAG tagged row         ->  SiLU(gate) * up quantized, [block][9] granules
+static int ov_depth(const char *env, int dflt) {
+    const char *e = getenv(env);
+    return e ? atoi(e) : dflt;
+}
+static int ov_resid_waves(const QMat &w) { return w.ngroups >= 1024 ? 4 : w.ngroups >= 512 ? 2 : 1; }
+static int ov_resid_depth(const QMat &w) {
+    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) return 0;            // whole row in flight
+    static const int ovr = ov_depth("LLAMAHIP_OV_DEPTH_RESID", 0);                        // measurement: 8 | 10 | 16 | 22
+    const int D = ovr ? ovr : pick_depth(w.nchunks, w.ngroups);
+    return (D == 8 || D == 10 || D == 16 || D == 22) ? D : -1;
+}
+static int ov_silu_depth(const QMat &w) {
+    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) return 0;
+    static const int ovr = ov_depth("LLAMAHIP_OV_DEPTH_SILU", 0);                         // measurement: 4 | 8
+    const int D = ovr ? ovr : pick_depth(w.nchunks, w.ngroups);
+    return (D == 4 || D == 8) ? D : -1;
+}
+bool gemv_ov_applies(const QMat &wo, const QMat &w13, const QMat &w2, int n_layers) {
+    if (n_layers < 1 || n_layers > TAG_MAX_LAYERS) return false;
+    for (const QMat *w : { &wo, &w2 }) {
+        if (w->gmapF8 || w->K % 32 != 0 || w->M != w->ngroups * 8 || ov_resid_depth(*w) < 0) return false;
+        if ((w->ngroups + ov_resid_waves(*w) - 1) / ov_resid_waves(*w) > NORM_PART_MAX) return false;
+    }
+    if (!w13.gmapF8 || w13.ngroups % 8 != 0 || w13.K / 16 > 512 || w13.K % 64 != 0 || w13.K < 64 || ov_silu_depth(w13) < 0) return false;
+    if (wo.M != w13.K || w2.M != w13.K || wo.K != w13.K || w2.K * 2 != w13.M) return false;
+    return true;
+}
+int gemv_ov_resid_parts(const QMat &w) { const int nw = ov_resid_waves(w); return (w.ngroups + nw - 1) / nw; }
+hipError_t launch_gemv_ov_resid(const QMat &w, const OvArgs &o, hipStream_t st) {
+    const int nw = ov_resid_waves(w), grid = (w.ngroups + nw - 1) / nw, D = ov_resid_depth(w);
+    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
+    lds = (lds + 15) & ~(size_t) 15;
+    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, (const uint32_t *) o.in_t, nullptr, nullptr, nullptr, w.K, o.y_plain, nullptr, o.T_silu, nullptr, nullptr,
+                    nullptr, 0, (f64x2 *) o.part_out, o.epoch, 0, o.layer, g_lut_math | o.test_bits, o.fault };
+    ga.resid_t = o.resid_t; ga.slot_resid = o.slot_resid; ga.out_t = o.out_t; ga.slot_out = o.slot_out;
+#define LH_GO(D_, RING) hipLaunchKernelGGL((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, D_, RING, 1>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D_) * 288 : 0), st, ga)
+    switch (D) {
+        case 0:  LH_GO(16, false); break;
+        case 8:  LH_GO(8, true); break;
+        case 10: LH_GO(10, true); break;
+        case 16: LH_GO(16, true); break;
+        case 22: LH_GO(22, true); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LH_GO
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_gemv_ov_silu(const QMat &w, const float *norm_w, const OvArgs &o, hipStream_t st) {
+    const int nw = 8, grid = w.ngroups / 8, D = ov_silu_depth(w);
+    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
+    lds = (lds + 15) & ~(size_t) 15;
+    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // 0: the reference's two-pass statistics
+    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, nullptr, norm_w, w.K, nullptr, nullptr, o.T_silu, nullptr, nullptr,
+                    nullptr, norm_mode == 0 ? -1 : 0, nullptr, o.epoch, 0, o.layer, g_lut_math | o.test_bits, o.fault };
+    ga.in_t = o.in_t; ga.slot_in = o.slot_in; ga.out_t = o.out_t; ga.slot_out = o.slot_out;
+#define LH_GO(D_, RING) hipLaunchKernelGGL((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, D_, RING, 1>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D_) * 288 : 0), st, ga)
+    switch (D) {
+        case 0: LH_GO(16, false); break;
+        case 4: LH_GO(4, true); break;
+        case 8: LH_GO(8, true); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LH_GO
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
 }
 
 template <int NC>
@@ -4463,7 +4654,9 @@ bool qkv_attn_fuses_wo(const QMat &wqkv, const QMat &wo) {
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           const QMat *wo, uint64_t *qat_A, uint64_t *qat_d, float *wo_y, const float *wo_resid, const NormPart *np_wo) {
+                           const QMat *wo, uint64_t *qat_A, uint64_t *qat_d, float *wo_y, const float *wo_resid, const NormPart *np_wo, const uint64_t *x_t) {
+    // x_t (overlapped decode schedule): the input row arrives as tagged granules (slot = layer) from the launch running beside this
+    // one, and the quantized attention output leaves as tagged granules (qat_A) for the wo launch that is already waiting
     const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // as launch_gemv
@@ -4481,9 +4674,10 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     static const int nosleep = (getenv("LLAMAHIP_POLL_SLEEP") && atoi(getenv("LLAMAHIP_POLL_SLEEP")) == 0) ? 0x200 : 0;     // measurement only
     // test only (tests/test_gpu_parity.py): the mat-vec role publishes a wrong tag and every poll gives up after 256 looks -> the
     // sticky fault word must come back as an error
-    static const int fault_test = getenv("LLAMAHIP_HANDOFF_FAULT_TEST") ? 0x1000 : 0;
-    const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
+    static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) < 2) ? 0x1000 : 0;     // (2: the wo launch of the overlapped schedule misbehaves instead)
+    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
                           (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
+    if (x_t) { ga.in_t = x_t; ga.slot_in = layer; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; }
     GemvArgs gw = ga;
     if (fuse_wo) {
         const NormPart npw = (np_wo && norm_mode >= 2) ? *np_wo : NormPart();
@@ -4492,8 +4686,16 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
                        nullptr, nullptr, nullptr, 0, (f64x2 *) npw.out, epoch, 0, layer, g_lut_math | nowait, fault };
     }
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep | fault_test,
-                           qkv2, sc2, epoch, layer, fuse_wo ? qat_A : nullptr, fuse_wo ? qat_d : nullptr };
+                           qkv2, sc2, epoch, layer, (fuse_wo || x_t) ? qat_A : nullptr, (fuse_wo || x_t) ? qat_d : nullptr };
     const int grid = gridA + H * (nsl + dh / 32) + (fuse_wo ? wo->ngroups / 4 : 0);
+    if (x_t) {
+        if (fuse_wo || !qat_A) return hipErrorInvalidValue;
+#define LH_GOT(D, PG) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG, false>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H)
+        if (variant == 1) LH_GOT(8, 1); else if (variant == 2) LH_GOT(10, 2); else if (variant == 3) LH_GOT(4, 2); else return hipErrorInvalidValue;
+#undef LH_GOT
+        LH_LAUNCH_CHECK();
+        return hipSuccess;
+    }
 #define LH_GOX(D, PG, WO) { if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); \
                             else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); }
     if (variant == 1 && fuse_wo) LH_GOX(8, 1, true) else if (variant == 1) LH_GOX(8, 1, false) else if (variant == 2) LH_GOX(10, 2, false) else if (variant == 3) LH_GOX(4, 2, false) else return hipErrorInvalidValue;
@@ -4502,7 +4704,7 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     return hipSuccess;
 }
 
-__global__ void k_bump_epoch(uint32_t *epoch) { epoch[0] += 1u; }
+__global__ void k_bump_epoch(uint32_t *epoch) { epoch[0] = next_epoch(epoch[0]); }
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st) {
     hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(1), 0, st, epoch);
     LH_LAUNCH_CHECK();

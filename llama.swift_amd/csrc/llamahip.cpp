@@ -176,6 +176,10 @@ struct llamahip_model {
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
     uint64_t *d_qat_A = nullptr, *d_qat_d = nullptr; // ... and the quantized attention output for the wo role: [Kp_d / 4] and [Kp_d / 32] granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
+    // overlapped ("two-branch") decode schedule: the residual stream and the FFN activation as tagged granules, the second branch
+    uint64_t *d_xt = nullptr, *d_x1t = nullptr, *d_qa2t = nullptr;   // [d], [d], [Kp_F / 32][9]
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
@@ -222,6 +226,10 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
+    free_dev(d_xt); free_dev(d_x1t); free_dev(d_qa2t);
+    if (ev_fork) (void) hipEventDestroy(ev_fork);
+    if (ev_join) (void) hipEventDestroy(ev_join);
+    if (stream2) (void) hipStreamDestroy(stream2);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_sync); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_qat_A); free_dev(d_qat_d);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
@@ -544,6 +552,66 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     if (use_pair) { m->pair_used = true; HIP_TRY(hipMemsetAsync(m->d_sync, 0, SYNC_CLEAR_BYTES, st), LLAMAHIP_ERR_PREDICT); }
     // decode: wq|wk|wv + attention as one launch with tagged hand-offs (k_qkv_attn); one forward pass = one epoch
     const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
+    // decode, overlapped ("two-branch") schedule: the four launches of a layer alternate between two branches of the captured graph
+    // (two streams when run eagerly) and hand their rows over as tagged granules, so that launch k + 1 is dispatched and has its first
+    // weight chunks in flight while launch k still runs (DESIGN.md "overlapped decode schedule").  Branch A (this stream): wq|wk|wv +
+    // attention, w1|w3.  Branch B: embedding | stage input, wo, w2, lm head.  Results are those of the one-branch schedule.
+    static const bool no_overlap = getenv("LLAMAHIP_NO_OVERLAP") != nullptr;
+    if (use_qkvx && !no_overlap && m->d_xt && m->stream2 && m->w13_interleaved &&
+        gemv_ov_applies(m->layers[0].wo, m->layers[0].w13, m->layers[0].w2, m->l1 - m->l0)) {
+        hipStream_t sb = m->stream2;
+        static const int test_bits = getenv("LLAMAHIP_HANDOFF_FAULT_TEST") ? atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) : 0;      // 2: the wo launch publishes a tag nobody waits for (test only)
+        HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
+        if (!m->first_stage && !x_first) HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipEventRecord(m->ev_fork, st), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipStreamWaitEvent(sb, m->ev_fork, 0), LLAMAHIP_ERR_PREDICT);
+        if (m->first_stage) {
+            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, sb, m->d_epoch, m->d_xt), LLAMAHIP_ERR_PREDICT);
+        } else {
+            HIP_TRY(launch_tag_row(x_first ? x_first : m->x, d, m->d_epoch, m->d_xt, sb), LLAMAHIP_ERR_PREDICT);
+        }
+        const int nl = m->l1 - m->l0;
+        for (int li = 0; li < nl; li++) {
+            const Layer &L = m->layers[li];
+            const size_t kv_at = ((size_t) m->cur_seq * nl + li) * C * d;
+            float *Kl = m->Kc + kv_at, *Vl = m->Vc + kv_at;
+            const bool last = li == nl - 1;
+            // A: wq|wk|wv + attention: row in <- xt (slot li), quantized attention output -> qat (slot li + 1)
+            HIP_TRY(launch_qkv_attn(L.qkv, nullptr, L.attention_norm, NormPart(), m->d_qkv2, m->d_sc2, m->d_epoch, li, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
+                                    m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st,
+                                    nullptr, m->d_qat_A, m->d_qat_d, nullptr, nullptr, nullptr, m->d_xt), LLAMAHIP_ERR_PREDICT);
+            // B: wo: qat -> x1t (slot li + 1), residual xt (slot li)
+            OvArgs ow;
+            ow.epoch = m->d_epoch; ow.fault = m->d_fault; ow.layer = li; ow.T_silu = m->T_silu;
+            ow.in_t = m->d_qat_A; ow.resid_t = m->d_xt; ow.slot_resid = li; ow.out_t = m->d_x1t; ow.slot_out = li + 1;
+            if (test_bits == 2) ow.test_bits = 0x2000;
+            else if (test_bits) ow.test_bits = 0x1000;
+            HIP_TRY(launch_gemv_ov_resid(L.wo, ow, sb), LLAMAHIP_ERR_PREDICT);
+            // A: w1|w3: x1t (slot li + 1) -> qa2t (slot li + 1)
+            OvArgs o13;
+            o13.epoch = m->d_epoch; o13.fault = m->d_fault; o13.layer = li; o13.T_silu = m->T_silu;
+            o13.in_t = m->d_x1t; o13.slot_in = li + 1; o13.out_t = m->d_qa2t; o13.slot_out = li + 1;
+            if (test_bits) o13.test_bits = 0x1000;
+            HIP_TRY(launch_gemv_ov_silu(L.w13, L.ffn_norm, o13, st), LLAMAHIP_ERR_PREDICT);
+            // B: w2: qa2t -> xt (slot li + 1 = the next layer's input), residual x1t; the last layer also leaves the row in plain form
+            // (lm head / stage output, both behind a kernel boundary on this branch) with its norm statistics
+            OvArgs o2;
+            o2.epoch = m->d_epoch; o2.fault = m->d_fault; o2.layer = li; o2.T_silu = m->T_silu;
+            o2.in_t = m->d_qa2t; o2.resid_t = m->d_x1t; o2.slot_resid = li + 1; o2.out_t = m->d_xt; o2.slot_out = li + 1;
+            if (test_bits) o2.test_bits = 0x1000;
+            if (last) { o2.y_plain = x_last ? x_last : m->x; if (m->last_stage) o2.part_out = m->npart_a; }
+            HIP_TRY(launch_gemv_ov_resid(L.w2, o2, sb), LLAMAHIP_ERR_PREDICT);
+        }
+        if (m->last_stage) {
+            NormPart np_out;
+            const int p2 = gemv_ov_resid_parts(m->layers[nl - 1].w2);
+            if (p2 > 0 && p2 <= NORM_PART_MAX) { np_out.in = m->npart_a; np_out.n_in = p2; }
+            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, nullptr, nullptr, sb, &np_out), LLAMAHIP_ERR_PREDICT);
+        }
+        HIP_TRY(hipEventRecord(m->ev_join, sb), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0), LLAMAHIP_ERR_PREDICT);
+        return 0;
+    }
     if (use_qkvx && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (m->first_stage) {
         if (use_part) {
@@ -695,7 +763,7 @@ int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
     uint32_t *word = m->d_sync + (SYNC_BYTES - 64) / 4;
     if (m->h_fault && *(volatile uint32_t *) m->h_fault) {
         *(volatile uint32_t *) m->h_fault = 0;
-        set_err(err, err_cap, "decode step: the in-launch hand-off of the attention kernel timed out (set LLAMAHIP_NO_ATTN_X=1 to use two launches)");
+        set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch, or between the overlapped decode launches) timed out; LLAMAHIP_NO_OVERLAP=1 / LLAMAHIP_NO_ATTN_X=1 select the schedules without them");
         return LLAMAHIP_ERR_PREDICT;
     }
     if (!m->pair_used) return 0;         // (the check is a device round trip: only when the hand-off was in play)
@@ -933,6 +1001,17 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemset(m->d_qat_d, 0, Kp_d / 32 * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
+            if (!getenv("LLAMAHIP_NO_OVERLAP")) {
+                HIP_TRY(hipMalloc((void **) &m->d_xt, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipMemset(m->d_xt, 0, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipMalloc((void **) &m->d_x1t, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipMemset(m->d_x1t, 0, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipMalloc((void **) &m->d_qa2t, Kp_F / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipMemset(m->d_qa2t, 0, Kp_F / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
+                HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
+            }
         }
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
@@ -1106,6 +1185,7 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
     if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t) N * d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     if (m->last_stage && logits_out) HIP_TRY(hipMemcpyAsync(logits_out, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    if (N == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;       // (single-token stage evals take the in-launch hand-offs too)
     m->n_evals++;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
@@ -1283,7 +1363,7 @@ int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     int32_t hs[2] = { 0, 0 };
     HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);       // steps may be in flight on any caller stream
-    HIP_TRY(hipMemcpy(hs, m->d_slot_state + 2 * seq, sizeof(hs), hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    { const int rc = check_sync_timeout(m, err, err_cap); if (rc) return rc; }     // a hand-off of one of those steps that timed out: their results are invalid    HIP_TRY(hipMemcpy(hs, m->d_slot_state + 2 * seq, sizeof(hs), hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
     if (n_past) *n_past = hs[0];
     const int n = std::min(std::min(hs[1], cap), m->hp.n_ctx);
     if (tokens && m->last_stage && n > 0)

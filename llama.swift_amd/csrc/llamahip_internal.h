@@ -10,8 +10,10 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
 // (PREP_NORMP: PREP_NORM with the row's {sum x, sum x^2} supplied by its producer -- k_gemv only, selected by launch_gemv)
-enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PRE_QA_TAG = 5 /* k_qkv_attn: QA handed over inside the launch as {dword, tag} granules */ };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4 /* k_qkv_attn: rows as {value, tag} granules */ };
+// (the *_TAG / *_QAT forms: the operand arrives / the result leaves as 8-byte {fp32 bits or dword, tag} granules that the consumer
+//  polls -- hand-offs inside k_qkv_attn, and between the overlapped decode launches of the two-branch schedule, see launch_gemv_ov)
+enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PRE_QA_TAG = 5, PREP_NORM_TAG = 6 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5, EPI_SILU_QAT = 6 };
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
 struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; };
 
@@ -92,7 +94,7 @@ hipError_t launch_gemv_pair(const QMat &w13, const QMat &w2, const float *x_in, 
                             uint32_t *qa2_A, float *qa2_d, float *y, const float *resid, const NormPart &np2,
                             const uint16_t *T_silu, uint32_t *sync, int epoch, hipStream_t st);
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
-hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr);
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr, uint64_t *xt = nullptr);
 enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_COUNT = 5 };
 extern long g_gemm_path_counts[GEMM_PATH_COUNT];     // launches per kernel family of launch_gemm (process-wide; tests)
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
@@ -131,8 +133,23 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
                            const QMat *wo = nullptr, uint64_t *qat_A = nullptr, uint64_t *qat_d = nullptr, float *wo_y = nullptr, const float *wo_resid = nullptr,
-                           const NormPart *np_wo = nullptr);
+                           const NormPart *np_wo = nullptr, const uint64_t *x_t = nullptr);
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
+// overlapped decode schedule: mat-vecs with tagged operands / results (kernels.hip "overlapped decode schedule")
+struct OvArgs {
+    uint32_t *epoch = nullptr, *fault = nullptr; int layer = 0;        // epoch word, sticky fault word, layer index on this handle
+    const uint64_t *in_t = nullptr; int slot_in = 0;                   // resid role: QA granules [block][9] (slot layer + 1); silu role: the fp32 row
+    const uint64_t *resid_t = nullptr; int slot_resid = 0;             // resid role: residual row
+    uint64_t *out_t = nullptr; int slot_out = 0;
+    float *y_plain = nullptr; double *part_out = nullptr;              // resid role: optional plain copy of the row / norm partial sums
+    const uint16_t *T_silu = nullptr;
+    int test_bits = 0;                                                 // 0x1000 / 0x2000: fault-injection tests
+};
+bool gemv_ov_applies(const QMat &wo, const QMat &w13, const QMat &w2, int n_layers);
+hipError_t launch_gemv_ov_resid(const QMat &w, const OvArgs &o, hipStream_t st);
+int gemv_ov_resid_parts(const QMat &w);                             // workgroups (= norm partial-sum pairs) of a resid-role launch
+hipError_t launch_gemv_ov_silu(const QMat &w13, const float *norm_w, const OvArgs &o, hipStream_t st);
+hipError_t launch_tag_row(const float *x, int d, const uint32_t *epoch, uint64_t *xt, hipStream_t st);
 hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st);
 hipError_t launch_advance(int32_t *state, hipStream_t st);
 // sampler front end (utils.cpp:345-395): the k best candidate scores of the last row of logits, on the device
