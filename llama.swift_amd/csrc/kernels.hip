@@ -83,6 +83,9 @@ __device__ __forceinline__ void store_tagged_agent(uint64_t *p, uint32_t bits, u
 // CONSUMES it.  The host refuses the tagged schedules on handles with more than TAG_MAX_LAYERS layers; k_bump_epoch skips the epoch
 // whose 24 low bits are zero, so no tag ever equals the zero-filled state of a fresh buffer.
 constexpr int TAG_MAX_LAYERS = 250;
+#ifndef LH_WATCH
+#define LH_WATCH 4          // granules a waiting workgroup looks at per poll (one lane each)
+#endif
 __device__ __forceinline__ uint32_t make_tag(uint32_t epoch, int slot) { return (epoch << 8) | (uint32_t) slot; }
 __device__ __forceinline__ uint32_t next_epoch(uint32_t e) { e += 1u; if ((e & 0xFFFFFFu) == 0u) e += 1u; return e; }
 
@@ -977,17 +980,17 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
 
     if (NORMTAG) {
         // The row comes from the launch that runs BESIDE this one (the other branch of the overlapped decode schedule) as tagged
-        // granules.  This workgroup's first D weight chunks are in flight (phase 2).  Wave 0 watches 64 sample granules (the last
-        // of every K / 64 rows), sleeping between looks -- the producer's workgroups finish together, and pollers compete with its
+        // granules.  This workgroup's first D weight chunks are in flight (phase 2).  Wave 0 watches LH_WATCH sample granules spread
+        // over the row, sleeping between looks -- the producer's workgroups finish together, and pollers compete with its
         // weight stream -- then every thread runs the tag-checked copy of its own half-blocks, which passes on its first or second
         // round.  Correctness rests on the copy alone; the watch only keeps the polling traffic small.
         const uint64_t *__restrict__ xt = ga.in_t;
         const int give_up = (ga.lut_math & 0x1000) ? (1 << 8) : (1 << 20);      // (0x1000: fault-injection test)
         if (wave == 0) {
-            const int stride = K >> 6;
             int spins = 0;
             for (;;) {
-                const bool ok = (uint32_t) (__hip_atomic_load(xt + lane * stride + stride - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag_in;
+                bool ok = true;
+                if (lane < LH_WATCH) ok = (uint32_t) (__hip_atomic_load(xt + ((2 * lane + 1) * K / (2 * LH_WATCH)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag_in;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (give_up >> 2) || ((spins & 255) == 0 && __hip_atomic_load(ga.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) break;   // (the copy below raises the fault word if the row never comes)
@@ -1041,12 +1044,14 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         // sleeping between looks; when they are all there the whole workgroup runs the tag-checked copy, which then passes
         // on its first or second round.
         if (wave == 0 && !nowait) {
-            const int nd = nchunks * 8;
+            // (a SAMPLE of the scale granules, LH_WATCH of them spread over the row: every look of every waiting workgroup is a line
+            //  fetched through the fabric next to the producer's weight stream -- 256 workgroups watching all 344 scales of the FFN
+            //  activation measured as 12 us on the producer)
+            const int nbl = K >> 5;
             int spins = 0;
             for (;;) {
                 bool ok = true;
-                for (int gi = lane; gi < min(nd, K >> 5); gi += 64)
-                    ok = ok && (uint32_t) (__hip_atomic_load(ta + gi * 9 + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == store_tag;
+                if (lane < LH_WATCH) ok = (uint32_t) (__hip_atomic_load(ta + (size_t) ((2 * lane + 1) * nbl / (2 * LH_WATCH)) * 9 + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == store_tag;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > ((ga.lut_math & 0x1000) ? (1 << 6) : (1 << 18)) || ((spins & 255) == 0 && __hip_atomic_load(ga.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) break;             // (the copy below raises the fault word if the data never comes; 0x1000: fault-injection test)

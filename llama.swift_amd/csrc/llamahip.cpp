@@ -1363,7 +1363,8 @@ int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     int32_t hs[2] = { 0, 0 };
     HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);       // steps may be in flight on any caller stream
-    { const int rc = check_sync_timeout(m, err, err_cap); if (rc) return rc; }     // a hand-off of one of those steps that timed out: their results are invalid    HIP_TRY(hipMemcpy(hs, m->d_slot_state + 2 * seq, sizeof(hs), hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    { const int rc = check_sync_timeout(m, err, err_cap); if (rc) return rc; }     // a hand-off of one of those steps that timed out: their results are invalid
+    HIP_TRY(hipMemcpy(hs, m->d_slot_state + 2 * seq, sizeof(hs), hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
     if (n_past) *n_past = hs[0];
     const int n = std::min(std::min(hs[1], cap), m->hp.n_ctx);
     if (tokens && m->last_stage && n > 0)

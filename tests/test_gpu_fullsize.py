@@ -1,0 +1,104 @@
+"""Full-depth parity of the other BASELINE.json configurations against the CPU path (the reference's own ggml.c build,
+oracle/_ref, when it travelled with the snapshot; else the standalone restatement):
+
+  configs[2]  LLaMA-7B, all 32 layers, a 2048-token prompt in ONE eval at n_ctx 2560 (the eval bench.py's prefill leg times)
+  configs[3]  LLaMA-13B, 40 layers, 2-part file (.mm:33-38, merged as .mm:312-495)
+  configs[4]  LLaMA-65B, 80 layers, 8-part file -- the model the 8-GPU pipeline shards
+
+Model files are synthetic (random Q4_0 weights of the exact shapes, written in the reference's file format by
+csrc/tools/make_synth_model) and shared with bench.py through LLAMAHIP_MODEL_DIR.  The 65B file is 40 GB: that test
+needs ~45 GB of /tmp and of host RAM and takes a few minutes; LLAMAHIP_SKIP_65B=1 skips it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import synth_tool
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def describe(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return f"shape {a.shape} vs {b.shape}"
+    bad = np.flatnonzero(a.ravel() != b.ravel())
+    return f"{bad.size}/{a.size} differ, first at {bad[:4]}, got {a.ravel()[bad[:3]]} want {b.ravel()[bad[:3]]}"
+
+
+def _model(preset: str) -> str:
+    d = os.environ.get("LLAMAHIP_MODEL_DIR", "/tmp/llamahip_models")
+    path = os.path.join(d, f"{preset}-seed20230312", "ggml-model-q4_0.bin")
+    if not os.path.exists(path + ".done"):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        synth_tool(path, preset=preset, seed=20230312)
+        open(path + ".done", "w").close()
+    return path
+
+
+def _cpu_lib():
+    import reflib
+    return reflib.RefLib() if reflib.have_ref() else reflib.OracleLib()
+
+
+def _decode_vs_cpu(L, path, n_ctx, n_prompt, n_gen, nth=8):
+    """prompt eval (last-row logits bit for bit), then n_gen greedy tokens: the device-resident loop against one CPU eval per
+    token, final logits bit for bit, and the same tokens once more through one host-driven llamahip_eval per token."""
+    cpu = _cpu_lib().load(path, n_ctx)          # (0 parts forced: the loader derives the part count from n_embd, .mm:33-38)
+    prompt = synth.synth_prompt(n_prompt, 32000, seed=3)
+    lg = cpu.eval(prompt, 0, nth)["logits"]
+    first, want, t = int(np.argmax(lg)), [], None
+    t = first
+    for i in range(n_gen):
+        lo = cpu.eval(np.array([t], np.int32), n_prompt + i, nth)["logits"]
+        t = int(np.argmax(lo)); want.append(t)
+    cpu.close()
+    with L.Model(path, n_ctx=n_ctx) as gm:
+        a = gm.eval(prompt, 0, nth)
+        assert same(a, lg), "prompt logits: " + describe(a, lg)
+        got, last = gm.decode_greedy(first, n_prompt, n_gen, nth, want_logits=True)
+        assert got.tolist() == want, (got.tolist(), want)
+        assert same(last, lo), "final logits: " + describe(last, lo)
+        t, got2 = first, []
+        for i in range(n_gen):
+            lg2 = gm.eval(np.array([t], np.int32), n_prompt + i, nth)
+            t = int(np.argmax(lg2)); got2.append(t)
+        assert got2 == want and same(lg2, lo)
+
+
+def test_13b_full_depth_vs_cpu_path(L):
+    """configs[3]: 40 layers, n_embd 5120, two-part file; 9-token prompt + 16 greedy tokens."""
+    _decode_vs_cpu(L, _model("13B"), 128, 9, 16)
+
+
+@pytest.mark.skipif(os.environ.get("LLAMAHIP_SKIP_65B") == "1", reason="LLAMAHIP_SKIP_65B=1")
+def test_65b_full_depth_vs_cpu_path(L):
+    """configs[4]'s model on one GPU: 80 layers, n_embd 8192, eight-part file; 9-token prompt + 4 greedy tokens."""
+    _decode_vs_cpu(L, _model("65B"), 64, 9, 4)
+
+
+def test_7b_full_depth_2048_token_prefill_vs_cpu_path(L):
+    """configs[2]: the 32-layer 2048-token single eval that bench.py's prefill leg times (matrix-core GEMMs, lane-per-query
+    attention), last-row logits bit for bit, then 3 decode tokens from that context."""
+    path = _model("7B")
+    prompt = synth.synth_prompt(2048, 32000, seed=5)
+    cpu = _cpu_lib().load(path, 2560)
+    lg = cpu.eval(prompt, 0, 8)["logits"]
+    t, want = int(np.argmax(lg)), []
+    first = t
+    for i in range(3):
+        lo = cpu.eval(np.array([t], np.int32), 2048 + i, 8)["logits"]
+        t = int(np.argmax(lo)); want.append(t)
+    cpu.close()
+    with L.Model(path, n_ctx=2560) as gm:
+        a = gm.eval(prompt, 0, 8)
+        assert same(a, lg), "last-row logits of the 2048-token eval: " + describe(a, lg)
+        got, last = gm.decode_greedy(first, 2048, 3, 8, want_logits=True)
+        assert got.tolist() == want and same(last, lo), (got.tolist(), want, describe(last, lo))

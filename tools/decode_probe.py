@@ -26,10 +26,11 @@ ap.add_argument("--at", default="8")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--n_ctx", type=int, default=512)
 ap.add_argument("--threads", type=int, default=8)
+ap.add_argument("--flags", type=int, default=int(os.environ.get("PROBE_FLAGS", "0")), help="LLAMAHIP_FLAG_* (1 = eager launches instead of hipGraph replay)")
 args = ap.parse_args()
 cfg = bench.MODELS[args.model]
 path = bench.model_path(args.model, cfg, 20230312)
-m = L.Model(path, n_ctx=args.n_ctx)
+m = L.Model(path, n_ctx=args.n_ctx, flags=args.flags)
 rng = np.random.default_rng(11)
 out = []
 for at in [int(x) for x in args.at.split(",")]:
