@@ -801,7 +801,13 @@ struct GemvArgs {
     const uint64_t *in_t;   int slot_in;              // PREP_NORM_TAG: the fp32 row [K]
     const uint64_t *resid_t; int slot_resid;          // EPI_RESID_TAG: the residual row [M]
     uint64_t *out_t;        int slot_out;             // EPI_RESID_TAG: y [M]; EPI_SILU_QAT: [block][9] (8 chain dwords + scale)
+    uint32_t *prog;                                   // decode: launch counter the L2 prefetcher follows (k_prefetch), or null
 };
+// the first workgroup of every weight-streaming launch of the decode step counts the launch in: the prefetcher reads how far the
+// step has come (one relaxed device-scope add per launch; nobody waits for it)
+__device__ __forceinline__ void count_launch(uint32_t *prog) {
+    if (prog && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ void sync_arrive(uint32_t *sync, int blk, int nblocks, int epoch) {
     // (the caller has drained its stores and passed a barrier; one lane)
@@ -1375,6 +1381,7 @@ template <int PRE, int EPI, int D, bool RING, int PG>
 __global__ void __launch_bounds__((EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) ? 512 : 256, (EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) ? 4 : 1)
 k_gemv(const GemvArgs ga) {
     extern __shared__ double smem_d[];
+    count_launch(ga.prog);
     gemv_body<PRE, EPI, D, RING, PG, SYNC_NONE, false>(ga, blockIdx.x, blockDim.x >> 6, smem_d);
 }
 
@@ -3565,6 +3572,7 @@ template <int PRE, int D, int PG, bool WO>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG == 1 ? 4 : 3)))
 k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int gridA, const int H) {
     extern __shared__ double smem_d[];
+    count_launch(ga.prog);
     int b = blockIdx.x;
     if (WO) {
         // the wo mat-vec of the layer: its 4-wave workgroups come FIRST (a multiple of 8 of them, so the XCD placement of the
@@ -3584,6 +3592,72 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int g
     }
     const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
     attn_x_body<true>(aa, h, y, smem_d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// L2 run-ahead prefetcher of the decode step.  Every launch boundary of the step is an all-to-all dependency, and while a launch
+// ramps up, runs its prologue / epilogue or walks the attention chain, HBM idles (DESIGN.md "decode: where the time goes").  What can
+// be done ahead of any dependency is fetching the NEXT launches' weights.  This kernel runs beside the whole decode loop on a second
+// stream (one wave per workgroup, a few registers, no LDS) and touches one dword per cache line of the weight tiles in launch order,
+// keeping at most `budget` bytes ahead of the launch that is running (count_launch): the 8 x 4 MiB of L2 are the run-ahead buffer.
+// A workgroup asks the hardware which XCD it runs on and fetches exactly the tiles the consumer workgroups of that XCD will read
+// (consumer workgroup b runs on XCD b % 8; k_qkv_attn places heads), because the L2s are per XCD.  Nothing waits for this kernel and
+// it writes nothing anybody reads: if a placement assumption is wrong, or it falls behind, only speed is lost.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_prefetch(const PfOp *__restrict__ ops, const int n_ops, const uint32_t *prog, const int n_tokens, const unsigned long long budget,
+           const int line, uint32_t *__restrict__ sink, const uint32_t never) {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int) (xcc & 7u), j = blockIdx.x >> 3, nj = max(1, (int) (gridDim.x >> 3)), lane = threadIdx.x;
+    const unsigned long long token_bytes = ops[n_ops - 1].cum_start + ops[n_ops - 1].bytes;
+    uint32_t acc = 0;
+    unsigned long long allowed = 0;            // absolute byte position (tokens x token_bytes + position in the token) fetching may reach
+    long waited = 0;
+    for (int t = 0; t < n_tokens; t++) {
+        for (int q = 0; q < n_ops; q++) {
+            const PfOp op = ops[q];
+            const int nblk = (op.ngroups + op.gpb - 1) / op.gpb;
+            // consumer workgroups of this op that run on this XCD
+            const int per_h = op.mode == 1 ? (nblk / op.hdiv) * op.ncb : 0;          // mode 1: blocks per head = (q, k, v) x (dh / 32)
+            const int cnt = op.mode == 1 ? (op.hdiv / op.ncb / 8) * per_h : (nblk - xcd + 7) / 8;
+            const unsigned long long base_abs = (unsigned long long) t * token_bytes + op.cum_start;
+            {   // fallen behind?  A launch that has already been followed by the next one needs no prefetching any more
+                const uint32_t c = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                allowed = (unsigned long long) (c / (unsigned) n_ops) * token_bytes + ops[c % (unsigned) n_ops].cum_start + budget;
+                if ((unsigned long long) t * (unsigned) n_ops + (unsigned) q + 1ull < (unsigned long long) c) continue;
+            }
+            for (int i = j; i < cnt; i += nj) {
+                int b;
+                if (op.mode == 1) {             // i -> (head of this XCD, matrix, part): gemv block mat * hdiv + h * ncb + sub
+                    const int jj = i / per_h, r = i % per_h, mat = r / op.ncb, sub = r % op.ncb;
+                    b = mat * op.hdiv + (xcd + 8 * jj) * op.ncb + sub;
+                } else b = xcd + 8 * i;
+                // throttle: stay within `budget` bytes of the end of the launch that is running
+                const unsigned long long pos = base_abs + op.bytes / (unsigned) cnt * (unsigned) i;
+                while (pos > allowed) {
+                    const uint32_t c = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    allowed = (unsigned long long) (c / (unsigned) n_ops) * token_bytes + ops[c % (unsigned) n_ops].cum_start + budget;
+                    if (pos <= allowed) break;
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++waited > (1L << 22)) return;            // (the decode loop stopped: nothing left to run ahead of)
+                }
+                const int g0 = b * op.gpb, ng = min(op.gpb, op.ngroups - g0);
+                if (ng <= 0) continue;
+                const uint8_t *p = op.base + (size_t) g0 * op.group_bytes;
+                const int nbytes = ng * (int) op.group_bytes;
+                // one dword per line, 8 wave-loads in flight
+                for (int off = lane * line; off < nbytes; off += 64 * line * 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int o = off + u * 64 * line;
+                        if (o < nbytes) acc ^= *(const uint32_t *) (p + o);
+                    }
+                }
+            }
+        }
+    }
+    if (acc == never && sink) sink[lane] = acc;          // (keeps the loads alive; `never` is a value the host picks at random)
 }
 
 // load-time self-test of the assumption above: out[b] = XCC_ID of workgroup b of a (H, Y) grid
@@ -3924,6 +3998,10 @@ hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_str
     return hipSuccess;
 }
 
+// decode: the launch counter of the forward pass being issued on this thread (set_decode_progress), or null
+static thread_local uint32_t *t_prog = nullptr;
+void set_decode_progress(uint32_t *prog) { t_prog = prog; }
+
 static int pick_waves(int ngroups) {
     static const int ovr = getenv("LLAMAHIP_WAVES") ? atoi(getenv("LLAMAHIP_WAVES")) : 0;      // tuning override (measurement only)
     if (ovr == 1 || ovr == 2 || ovr == 4) return ovr;
@@ -3972,8 +4050,9 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     if (PRE == PREP_SILU_MUL) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
-    const GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d,
-                          (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out, nullptr, 0, 0, g_lut_math };
+    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d,
+                    (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out, nullptr, 0, 0, g_lut_math };
+    ga.prog = t_prog;
 #define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, ga)
     if (np.out && grid > NORM_PART_MAX) return hipErrorInvalidValue;
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
@@ -4184,7 +4263,7 @@ hipError_t launch_gemv_ov_resid(const QMat &w, const OvArgs &o, hipStream_t st) 
     lds = (lds + 15) & ~(size_t) 15;
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, (const uint32_t *) o.in_t, nullptr, nullptr, nullptr, w.K, o.y_plain, nullptr, o.T_silu, nullptr, nullptr,
                     nullptr, 0, (f64x2 *) o.part_out, o.epoch, 0, o.layer, g_lut_math | o.test_bits, o.fault };
-    ga.resid_t = o.resid_t; ga.slot_resid = o.slot_resid; ga.out_t = o.out_t; ga.slot_out = o.slot_out;
+    ga.resid_t = o.resid_t; ga.slot_resid = o.slot_resid; ga.out_t = o.out_t; ga.slot_out = o.slot_out; ga.prog = t_prog;
 #define LH_GO(D_, RING) hipLaunchKernelGGL((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, D_, RING, 1>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D_) * 288 : 0), st, ga)
     switch (D) {
         case 0:  LH_GO(16, false); break;
@@ -4205,7 +4284,7 @@ hipError_t launch_gemv_ov_silu(const QMat &w, const float *norm_w, const OvArgs 
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // 0: the reference's two-pass statistics
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, nullptr, norm_w, w.K, nullptr, nullptr, o.T_silu, nullptr, nullptr,
                     nullptr, norm_mode == 0 ? -1 : 0, nullptr, o.epoch, 0, o.layer, g_lut_math | o.test_bits, o.fault };
-    ga.in_t = o.in_t; ga.slot_in = o.slot_in; ga.out_t = o.out_t; ga.slot_out = o.slot_out;
+    ga.in_t = o.in_t; ga.slot_in = o.slot_in; ga.out_t = o.out_t; ga.slot_out = o.slot_out; ga.prog = t_prog;
 #define LH_GO(D_, RING) hipLaunchKernelGGL((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, D_, RING, 1>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D_) * 288 : 0), st, ga)
     switch (D) {
         case 0: LH_GO(16, false); break;
@@ -4216,6 +4295,23 @@ hipError_t launch_gemv_ov_silu(const QMat &w, const float *norm_w, const OvArgs 
 #undef LH_GO
     LH_LAUNCH_CHECK();
     return hipSuccess;
+}
+
+hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, hipStream_t st) {
+    static const int line = getenv("LLAMAHIP_PF_LINE") ? atoi(getenv("LLAMAHIP_PF_LINE")) : 128;
+    nwg = std::max(8, nwg / 8 * 8);
+    hipLaunchKernelGGL(k_prefetch, dim3(nwg), dim3(64), 0, st, ops, n_ops, prog, n_tokens, (unsigned long long) budget, line, sink, 0x9e3779b9u);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+// row-groups per consumer workgroup of the decode launches, for the prefetcher's schedule (mirrors the launchers above)
+int gemv_groups_per_block(const QMat &w, int role) {        // role 0: norm prologue + store (wq|wk|wv, lm head), 1: QA + residual (wo, w2), 2: w1|w3
+    if (role == 2) return w.gmapF8 ? 8 : pick_waves(w.ngroups);
+    if (role == 1) { int pg = 0; const int nw = gemv_pick_nw_qa(w, &pg); return nw ? nw : 1; }
+    int nw = pick_waves(w.ngroups);
+    const int need = w.K / 16;
+    while (nw < 4 && need > nw * 64) nw *= 2;
+    return nw;
 }
 
 template <int NC>
@@ -4683,6 +4779,7 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
                           (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
     if (x_t) { ga.in_t = x_t; ga.slot_in = layer; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; }
+    ga.prog = t_prog;
     GemvArgs gw = ga;
     if (fuse_wo) {
         const NormPart npw = (np_wo && norm_mode >= 2) ? *np_wo : NormPart();

@@ -178,8 +178,12 @@ struct llamahip_model {
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
     // overlapped ("two-branch") decode schedule: the residual stream and the FFN activation as tagged granules, the second branch
     uint64_t *d_xt = nullptr, *d_x1t = nullptr, *d_qa2t = nullptr;   // [d], [d], [Kp_F / 32][9]
-    hipStream_t stream2 = nullptr;
+    hipStream_t stream2 = nullptr;       // second branch of that schedule / the stream the L2 prefetcher runs on
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // L2 run-ahead prefetcher of the decode step (k_prefetch): schedule, launch counter, tuning
+    PfOp *d_pf_ops = nullptr; int n_pf_ops = 0;
+    uint32_t *d_prog = nullptr, *d_pf_sink = nullptr;
+    size_t pf_budget = 0; int pf_wgs = 0;
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
@@ -226,7 +230,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    free_dev(d_xt); free_dev(d_x1t); free_dev(d_qa2t);
+    free_dev(d_xt); free_dev(d_x1t); free_dev(d_qa2t); free_dev(d_pf_ops); free_dev(d_prog); free_dev(d_pf_sink);
     if (ev_fork) (void) hipEventDestroy(ev_fork);
     if (ev_join) (void) hipEventDestroy(ev_join);
     if (stream2) (void) hipStreamDestroy(stream2);
@@ -556,7 +560,9 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     // (two streams when run eagerly) and hand their rows over as tagged granules, so that launch k + 1 is dispatched and has its first
     // weight chunks in flight while launch k still runs (DESIGN.md "overlapped decode schedule").  Branch A (this stream): wq|wk|wv +
     // attention, w1|w3.  Branch B: embedding | stage input, wo, w2, lm head.  Results are those of the one-branch schedule.
-    static const bool no_overlap = getenv("LLAMAHIP_NO_OVERLAP") != nullptr;
+    // decode launches count themselves in for the L2 prefetcher (harmless when none is running)
+    struct ProgGuard { ProgGuard(uint32_t *p) { set_decode_progress(p); } ~ProgGuard() { set_decode_progress(nullptr); } } prog_guard(fused ? m->d_prog : nullptr);
+    static const bool no_overlap = getenv("LLAMAHIP_OVERLAP") == nullptr;
     if (use_qkvx && !no_overlap && m->d_xt && m->stream2 && m->w13_interleaved &&
         gemv_ov_applies(m->layers[0].wo, m->layers[0].w13, m->layers[0].w2, m->l1 - m->l0)) {
         hipStream_t sb = m->stream2;
@@ -763,7 +769,7 @@ int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
     uint32_t *word = m->d_sync + (SYNC_BYTES - 64) / 4;
     if (m->h_fault && *(volatile uint32_t *) m->h_fault) {
         *(volatile uint32_t *) m->h_fault = 0;
-        set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch, or between the overlapped decode launches) timed out; LLAMAHIP_NO_OVERLAP=1 / LLAMAHIP_NO_ATTN_X=1 select the schedules without them");
+        set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch, or between the overlapped decode launches) timed out; LLAMAHIP_NO_ATTN_X=1 selects the attention launches without them (the overlapped schedule is opt-in: LLAMAHIP_OVERLAP)");
         return LLAMAHIP_ERR_PREDICT;
     }
     if (!m->pair_used) return 0;         // (the check is a device round trip: only when the hand-off was in play)
@@ -772,6 +778,29 @@ int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
     (void) hipMemset(word, 0, 4);
     set_err(err, err_cap, "decode step: in-launch hand-off between w1|w3 and w2 timed out (set LLAMAHIP_NO_PAIR=1 to use separate launches)");
     return LLAMAHIP_ERR_PREDICT;
+}
+
+// The L2 prefetcher runs beside the `n_tokens` decode steps about to be issued on m->stream: launched on the second stream once
+// the main stream has reached this point, joined back after the steps (it has nothing left to fetch by then and exits).
+static bool prefetch_enabled(const llamahip_model *m) {
+    static const bool off = getenv("LLAMAHIP_NO_PREFETCH") || getenv("LLAMAHIP_PAIR") || getenv("LLAMAHIP_WO_FUSE") || getenv("LLAMAHIP_OVERLAP");
+    return !off && m->d_pf_ops && m->d_prog && m->stream2 && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
+}
+int prefetch_begin(llamahip_model *m, int n_tokens, bool *running, char *err, size_t err_cap) {
+    *running = false;
+    if (!prefetch_enabled(m)) return 0;
+    HIP_TRY(hipMemsetAsync(m->d_prog, 0, 4, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipEventRecord(m->ev_fork, m->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(launch_prefetch(m->d_pf_ops, m->n_pf_ops, m->d_prog, n_tokens, m->pf_budget, m->pf_wgs, m->d_pf_sink, m->stream2), LLAMAHIP_ERR_PREDICT);
+    *running = true;
+    return 0;
+}
+int prefetch_end(llamahip_model *m, bool running, char *err, size_t err_cap) {
+    if (!running) return 0;
+    HIP_TRY(hipEventRecord(m->ev_join, m->stream2), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_join, 0), LLAMAHIP_ERR_PREDICT);
+    return 0;
 }
 
 int check_eval_args(llamahip_model *m, int n_past, const int32_t *tokens, int N, bool need_tokens, char *err, size_t err_cap) {
@@ -1001,17 +1030,43 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemset(m->d_qat_d, 0, Kp_d / 32 * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
-            if (!getenv("LLAMAHIP_NO_OVERLAP")) {
+            if (getenv("LLAMAHIP_OVERLAP")) {          // the overlapped two-branch schedule: opt-in (measured slower)
                 HIP_TRY(hipMalloc((void **) &m->d_xt, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
                 HIP_TRY(hipMemset(m->d_xt, 0, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
                 HIP_TRY(hipMalloc((void **) &m->d_x1t, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
                 HIP_TRY(hipMemset(m->d_x1t, 0, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
                 HIP_TRY(hipMalloc((void **) &m->d_qa2t, Kp_F / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
                 HIP_TRY(hipMemset(m->d_qa2t, 0, Kp_F / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
             }
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
+        if (!m->dense && m->l1 > m->l0 && !getenv("LLAMAHIP_NO_PREFETCH")) {
+            // the prefetcher's schedule: the weight matrices of one decode step in launch order, with the row-groups each consumer
+            // workgroup owns (what decides which XCD's L2 a tile belongs in)
+            std::vector<PfOp> ops;
+            unsigned long long cum = 0;
+            auto add = [&](const QMat &w, int role, int mode) {
+                PfOp o{};
+                o.base = w.tiles; o.group_bytes = (uint32_t) ((w.nchunks + 1) * TILE_BYTES); o.ngroups = w.ngroups;
+                o.gpb = std::max(1, gemv_groups_per_block(w, role)); o.mode = mode; o.hdiv = (int) (d / 32); o.ncb = (int) (dh / 32);
+                o.cum_start = cum; o.bytes = (unsigned long long) w.ngroups * o.group_bytes;
+                if (mode == 1 && (o.gpb != 4 || o.ncb < 1 || H % 8 != 0 || ((w.ngroups / 4) % o.hdiv) != 0)) o.mode = 0;
+                cum += o.bytes;
+                ops.push_back(o);
+            };
+            const bool headwise = m->d_attn_sync && qkv_attn_applies(m->layers[0].qkv, (int) d, (int) H, 8);
+            for (auto &L : m->layers) { add(L.qkv, 0, headwise ? 1 : 0); add(L.wo, 1, 0); add(L.w13, 2, 0); add(L.w2, 1, 0); }
+            if (m->last_stage) add(m->output, 0, 0);
+            m->n_pf_ops = (int) ops.size();
+            HIP_TRY(hipMalloc((void **) &m->d_pf_ops, ops.size() * sizeof(PfOp)), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemcpy(m->d_pf_ops, ops.data(), ops.size() * sizeof(PfOp), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_prog, 64), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_prog, 0, 64), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_pf_sink, 256), LLAMAHIP_ERR_LOAD);
+            m->pf_budget = (size_t) (getenv("LLAMAHIP_PF_BUDGET_MB") ? atof(getenv("LLAMAHIP_PF_BUDGET_MB")) : 16.0) * 1024 * 1024;
+            m->pf_wgs = getenv("LLAMAHIP_PF_WGS") ? atoi(getenv("LLAMAHIP_PF_WGS")) : 128;
         }
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
@@ -1094,9 +1149,12 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
     }
     const bool want_all = logits_all != nullptr;
     m->tok_src = tok_mapped ? m->d_io->tok : nullptr;
+    bool pf = false;
+    if (N == 1 && !sink.dump && !m->dense && (rc = prefetch_begin(m, 1, &pf, err, err_cap)) != 0) return rc;
     rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap);
     m->tok_src = nullptr;
     if (rc) return rc;
+    if ((rc = prefetch_end(m, pf, err, err_cap)) != 0) return rc;
     const size_t V = m->hp.n_vocab;
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     if (logits_all) HIP_TRY(hipMemcpyAsync(logits_all, m->logits, (size_t) N * V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
@@ -1237,8 +1295,14 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
             (void) hipGraphDestroy(graph);
             it = m->decode_graphs.emplace(gkey, exec).first;
         }
+        bool pf = false;
+        if (!m->dense && (rc = prefetch_begin(m, n_steps, &pf, err, err_cap)) != 0) return rc;
         for (int i = 0; i < n_steps; i++) HIP_TRY(hipGraphLaunch(it->second, m->stream), LLAMAHIP_ERR_PREDICT);
+        if ((rc = prefetch_end(m, pf, err, err_cap)) != 0) return rc;
     } else {
+        bool pf = false;
+        if (fusable && !m->dense && (rc = prefetch_begin(m, n_steps, &pf, err, err_cap)) != 0) return rc;
+        struct PfJoin { llamahip_model *m; bool *pf; ~PfJoin() { char e[8]; (void) prefetch_end(m, *pf, e, sizeof(e)); } } pf_join{ m, &pf };
         for (int i = 0; i < n_steps; i++) {
             rc = forward(m, n_threads, n_past + i, 1, nullptr, fusable, false, -1, nullptr, err, err_cap);
             if (rc) return rc;

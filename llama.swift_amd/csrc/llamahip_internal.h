@@ -135,6 +135,14 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
                            const QMat *wo = nullptr, uint64_t *qat_A = nullptr, uint64_t *qat_d = nullptr, float *wo_y = nullptr, const float *wo_resid = nullptr,
                            const NormPart *np_wo = nullptr, const uint64_t *x_t = nullptr);
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
+// L2 run-ahead prefetcher of the decode step (k_prefetch): the weight matrices of one token in launch order
+struct PfOp {
+    const uint8_t *base; uint32_t group_bytes; int32_t ngroups, gpb, mode, hdiv, ncb, pad;
+    unsigned long long cum_start, bytes;
+};
+void set_decode_progress(uint32_t *prog);                           // launch counter the decode launches issued on this thread bump (or null)
+hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, hipStream_t st);
+int gemv_groups_per_block(const QMat &w, int role);
 // overlapped decode schedule: mat-vecs with tagged operands / results (kernels.hip "overlapped decode schedule")
 struct OvArgs {
     uint32_t *epoch = nullptr, *fault = nullptr; int layer = 0;        // epoch word, sticky fault word, layer index on this handle
