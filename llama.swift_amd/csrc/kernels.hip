@@ -30,7 +30,7 @@
 //                  with RoPE + KV append / SiLU*up -> QA), k_gemm_rows (row-lane tiles, SGPR operands),
 //                  k_gemm_mfma (+ k_tiles_to_rows, k_tiles_to_mtiles, k_qa_to_qb)
 //   attention      k_rope_kv, k_attn (per row), k_attnq_* (lane = query), k_dec_scores, k_decn_scores (short
-//                  evals), k_dec_pv_blk (decode and short evals), k_dec_attn
+//                  evals), k_dec_pv_blk (decode and short evals), k_dec_attn_x, k_qkv_attn
 //   misc           k_argmax, k_advance, k_add
 //   launchers      init_kernel_attrs, launch_* (kernel selection rules live next to the launch)
 #include <hip/hip_runtime.h>
@@ -749,19 +749,6 @@ __device__ __forceinline__ float fold8(float acc) {
 #ifndef LH_GEMV_PAD
 #define LH_GEMV_PAD 1
 #endif
-// In-launch hand-off between two dependent mat-vecs of ONE launch (k_gemv_pair): the producer role's blocks end
-// with {write-through (sc1) stores of their outputs, every wave drains its stores, one agent-scope atomic on one of 8
-// shard counters -> the last block of a shard bumps the top counter -> the last shard publishes 8 "go" words}; the
-// consumer role's blocks put their first D weight chunks in flight, then ONE lane polls its go word (relaxed
-// agent-scope loads + s_sleep), takes one agent-scope acquire, and only then reads the producer's outputs.
-// Counters are zeroed once per token (memset node) and count monotonically over the layers: `epoch` = 1-based index
-// of the pair within the token.  Every block of the launch is resident at once (host-checked), so a waiting block
-// can never starve the block it waits for; the spin is bounded all the same (err word set, results invalid).
-// Measured with tools/pair_probe.hip (profiles/r02_pair_probe.txt): w1|w3 -> w2 in one launch saves 2.3 us of 23,
-// because w2 -- 512 waves, latency bound -- hides its ramp, its first chunks and the launch boundary under w1|w3;
-// for wo -> w1|w3 and w2 -> wq|wk|wv the hand-off costs what the boundary did, those stay separate launches.
-constexpr int SYNC_SHARDS = 8;      // words, 64 B apart: 8 shard counters | top counter | 8 go words | time-out word (SYNC_BYTES)
-enum { SYNC_NONE = 0, SYNC_WAIT = 1, SYNC_ARRIVE = 2 };
 // 8-byte granule {value, tag}: written with one 8-byte store, read with one 8-byte load that bypasses the L1 (sc1), so a
 // reader sees the value together with its tag or not at all.  The spin is bounded; running out raises the fault word.
 // one more look of a bounded poll: true = stop looking.  Running out raises the sticky fault word (results are invalid from there on);
@@ -809,32 +796,7 @@ __device__ __forceinline__ void count_launch(uint32_t *prog) {
     if (prog && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void sync_arrive(uint32_t *sync, int blk, int nblocks, int epoch) {
-    // (the caller has drained its stores and passed a barrier; one lane)
-    const int nsh = nblocks < SYNC_SHARDS ? nblocks : SYNC_SHARDS;
-    const int sh = blk % nsh, in_shard = (nblocks - sh + nsh - 1) / nsh;
-    const uint32_t old = __hip_atomic_fetch_add(sync + sh * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == (uint32_t) in_shard * (uint32_t) epoch) {
-        const uint32_t t = __hip_atomic_fetch_add(sync + SYNC_SHARDS * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t + 1 == (uint32_t) nsh * (uint32_t) epoch)
-            for (int i = 0; i < SYNC_SHARDS; i++) __hip_atomic_store(sync + (SYNC_SHARDS + 1 + i) * 16, (uint32_t) epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-__device__ __forceinline__ void sync_wait(uint32_t *sync, int blk, int epoch) {
-    // one lane; the caller follows with a barrier
-    uint32_t *go = sync + (SYNC_SHARDS + 1 + blk % SYNC_SHARDS) * 16;
-    unsigned spins = 0;
-    while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t) epoch) {
-        if (++spins > (1u << 21)) { __hip_atomic_store(sync + (2 * SYNC_SHARDS + 1) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // ~1 s: give up loudly
-        __builtin_amdgcn_s_sleep(8);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-//   SYNC : SYNC_NONE | SYNC_WAIT (consumer role of k_gemv_pair: weights first, then the hand-off, then the prologue's
-//          own loads) | SYNC_ARRIVE (producer role: write-through stores + arrival)
-//   PB   : the block has more waves than this role uses (`nw` active waves; the others only keep the barriers)
-template <int PRE, int EPI, int D, bool RING, int PG, int SYNC, bool PB>
+template <int PRE, int EPI, int D, bool RING, int PG>
 __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, const int nw, double *smem_d) {
     const uint8_t *__restrict__ wt = ga.wt;
     const int ngroups = ga.ngroups, nchunks = ga.nchunks, M = ga.M, gmapF8 = ga.gmapF8, K = ga.K, npart = ga.npart;
@@ -858,7 +820,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     // (LH_GEMV_SADDR, off: with a provably uniform wave index the row-group base lives in SGPRs and every
     //  weight load is `global_load ... v_off, s[base]` with a constant per-lane offset -- measured slower here)
     const int tid = threadIdx.x, lane = tid & 63, wave = LH_GEMV_SADDR ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
-    const bool active = !PB || wave < nw;
+    constexpr bool active = true;
     const int g = blk * nw + wave;
     const bool valid = active && g < ngroups;
     const uint8_t *wbase = wt + (size_t) (valid ? g : 0) * (nchunks + 1) * TILE_BYTES;
@@ -968,21 +930,13 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     };
     // ---- phase 2: put the first D weight chunks in flight (they do not depend on the activations).
     // The scheduling barriers pin the issue order phase 1 -> phase 2 -> phase 3.
-    // (SYNC_WAIT: the weights go first, the activations do not exist yet; their loads follow the hand-off and
-    //  retire behind weight loads that landed long before)
-    if (SYNC != SYNC_WAIT) phase1();
+    phase1();
     __builtin_amdgcn_sched_barrier(0);
     if (active) {
 #pragma unroll
         for (int i = 0; i < D; i++) LH_LOADW(i, i)
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (SYNC == SYNC_WAIT) {
-        if (tid == 0) sync_wait(ga.sync, blk, ga.sync_epoch);
-        __syncthreads();
-        phase1();
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
     if (NORMTAG) {
         // The row comes from the launch that runs BESIDE this one (the other branch of the overlapped decode schedule) as tagged
@@ -1313,20 +1267,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
                 if (lane < 8) store_tagged_agent(ga.out_t + (b * 9 + kk), dw, tag_out);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the scale leaves after the dwords it announces)
                 if (lane == 0) store_tagged_agent(ga.out_t + (b * 9 + 8), __builtin_bit_cast(uint32_t, dd), tag_out);
-            } else
-            if (SYNC == SYNC_ARRIVE) {       // write-through: the consumer role of this launch reads them on another XCD
-                if (lane < 8) __hip_atomic_store(out_A + (c * 8 + kk) * 8 + j, dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0) __hip_atomic_store((uint32_t *) out_d + b, __builtin_bit_cast(uint32_t, dd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (lane < 8) out_A[(c * 8 + kk) * 8 + j] = dw;
                 if (lane == 0) out_d[b] = dd;
             }
             if (y && lane < 32) y[b * 32 + i] = act;
-        }
-        if (SYNC == SYNC_ARRIVE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the arrival
-            __syncthreads();
-            if (tid == 0) sync_arrive(ga.sync, blk, ga.sync_blocks, ga.sync_epoch);
         }
     } else {
         const bool live = valid && k == 0 && m < M;
@@ -1382,18 +1327,7 @@ __global__ void __launch_bounds__((EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) ? 
 k_gemv(const GemvArgs ga) {
     extern __shared__ double smem_d[];
     count_launch(ga.prog);
-    gemv_body<PRE, EPI, D, RING, PG, SYNC_NONE, false>(ga, blockIdx.x, blockDim.x >> 6, smem_d);
-}
-
-// One launch, two dependent mat-vecs: blocks [0, gridA) run role A (w1|w3: norm prologue, SiLU*up -> Q4_0 epilogue,
-// arrival), blocks [gridA, gridA + gridB) role B (w2: weights in flight, hand-off, QA copy, mat-vec + residual)
-// on `nwB` of the block's 8 waves.  See the hand-off notes above gemv_body.
-template <int PREA, int DA, int PGB, int DB, bool RINGB>
-__global__ void __launch_bounds__(512, 4)
-k_gemv_pair(const GemvArgs a, const GemvArgs b, const int gridA, const int nwB) {
-    extern __shared__ double smem_d[];
-    if ((int) blockIdx.x < gridA) gemv_body<PREA, EPI_SILU_QA, DA, true, 1, SYNC_ARRIVE, false>(a, blockIdx.x, 8, smem_d);
-    else gemv_body<PRE_QA, EPI_RESID, DB, RINGB, PGB, SYNC_WAIT, true>(b, blockIdx.x - gridA, nwB, smem_d);
+    gemv_body<PRE, EPI, D, RING, PG>(ga, blockIdx.x, blockDim.x >> 6, smem_d);
 }
 
 // Prompt path on the decode tiles (runs when the handle has no row-lane copy): NC activation rows
@@ -3055,132 +2989,6 @@ k_decn_scores(const float *__restrict__ qr, int d, int dh, const float *__restri
     }
 }
 
-// Fused decode attention: one workgroup per (head, 32-column block), 1024 threads.  Every workgroup
-// of a head recomputes the head's RoPE'd q, the new K row and ALL scores (the four workgroups of a
-// head land on the same XCD -- linear id = h + H*cb, H a multiple of 8 -- so the repeated K reads are
-// L2 hits), then soft_max, its 32 columns of the nth-chunked V*P, the ordered combine and the Q4_0
-// quantization of one activation block.  One launch instead of two saves a kernel boundary and a
-// round trip of the scores through memory; arithmetic is identical to k_dec_scores + k_dec_pv_blk.
-// dynamic LDS: [32 doubles][dh q][dh k_new][n_ctx p][nth*32 partials]
-__global__ void __launch_bounds__(1024)
-k_dec_attn(const float *__restrict__ qkv, int d, int dh, const double *__restrict__ sincos_tab,
-           float *__restrict__ Kc, float *__restrict__ Vc, int n_ctx, int nth, float kq_scale,
-           float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
-           const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st) {
-    extern __shared__ double smem_d[];
-    double *red = smem_d;
-    float *qs = (float *) (smem_d + 32);
-    float *kn = qs + dh;
-    float *p = kn + dh;
-    float *part = p + n_ctx;
-    const int h = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const int n_past = st[0];
-    const int T = n_past + 1;
-    // ---- RoPE of q and of the new key (ggml.c:7076-7131); the cb == 0 workgroup appends K and V (.mm:586-611)
-    {
-        const double *tab = sincos_tab + (size_t) n_past * dh;
-        const float *q = qkv + h * dh, *kk = qkv + d + h * dh, *vv = qkv + 2 * d + h * dh;
-        if (tid < dh / 2) {
-            const int e = 2 * tid;
-            const double cs = tab[e], sn = tab[e + 1];
-            const double x0 = (double) q[e], x1 = (double) q[e + 1];
-            qs[e] = (float) (x0 * cs - x1 * sn);
-            qs[e + 1] = (float) (x0 * sn + x1 * cs);
-            const double k0 = (double) kk[e], k1 = (double) kk[e + 1];
-            const float r0 = (float) (k0 * cs - k1 * sn), r1 = (float) (k0 * sn + k1 * cs);
-            kn[e] = r0; kn[e + 1] = r1;
-            if (cb == 0) {
-                Kc[(size_t) n_past * d + h * dh + e] = r0;
-                Kc[(size_t) n_past * d + h * dh + e + 1] = r1;
-            }
-        } else if (cb == 0 && tid >= 64 && tid < 64 + dh) {
-            Vc[(size_t) n_past * d + h * dh + (tid - 64)] = vv[tid - 64];
-        }
-    }
-    __syncthreads();
-    // ---- scores: one half-wave per key, 4 keys in flight per half-wave (ggml.c:1223-1258, 872-887)
-    {
-        const int hw = tid >> 5, l = tid & 31, nhw = nt >> 5;
-        for (int tb = hw * 4; tb < T; tb += nhw * 4) {
-            float kv[4][8];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float *kr = Kc + (size_t) min(tb + u, n_past) * d + h * dh;
-#pragma unroll
-                for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int t = tb + u;
-                float s = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (i * 32 < dh) {
-                        const float kval = (t == n_past) ? kn[i * 32 + l] : kv[u][i];   // the row just appended is not visible through global memory yet
-                        s = fmaf(kval, qs[i * 32 + l], s);
-                    }
-                }
-                s = tree32_to_lane0(s);
-                if (l == 0 && t <= n_past) p[t] = s * kq_scale;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- soft_max (ggml.c:6982-7050)
-    float mx = -INFINITY;
-    for (int t = tid; t < T; t += nt) mx = fmaxf(mx, p[t]);
-    mx = block_max_f(mx, red, 0);
-    double sum = 0.0;
-    for (int t = tid; t < T; t += nt) {
-        const float e = h2f_bits(T_exp[f2h_bits(p[t] - mx)]);
-        p[t] = e;
-        sum += (double) e;
-    }
-    sum = block_sum_d(sum, red, 1);
-    const float inv = (float) (1.0 / sum);
-    for (int t = tid; t < T; t += nt) p[t] *= inv;
-    __syncthreads();
-    // ---- V*P for this workgroup's 32 columns, nth chunks (ggml.c:5619-5665); the new V row comes from qkv
-    const int c = tid & 31, sub = tid >> 5, nsub = nt >> 5;
-    const int dc = (T + nth - 1) / nth;
-    const int col = h * dh + cb * 32 + c;
-    const float *vcol = Vc + col;
-    const float vnew = qkv[2 * d + col];
-    for (int th = sub; th < nth; th += nsub) {
-        const int t0 = dc * th, t1 = min(t0 + dc, T);
-        float acc = 0.0f;
-        for (int tb = t0; tb < t1; tb += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = vcol[(size_t) min(tb + u, max(n_past - 1, 0)) * d];
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int t = tb + u;
-                const float pe = (t < t1) ? p[min(t, T - 1)] : 0.0f;              // fma(v, 0, acc) == acc
-                acc = fmaf(t == n_past ? vnew : v[u], pe, acc);
-            }
-        }
-        part[th * 32 + c] = acc;
-    }
-    __syncthreads();
-    if (tid < 32) {
-        float s = part[tid];
-        for (int th = 1; th < nth; th++) s += part[th * 32 + tid];          // thread order (ggml.c:5553-5577)
-        if (merged) merged[col] = s;
-        float amax = fabsf(s);
-        amax = max_lanes_0_31(amax);
-        const float dd = amax / 7.0f;
-        const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
-        const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
-        const int kk = tid & 7;
-        const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
-        const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
-        const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
-        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
-        if (tid == 0) qa_d[b] = dd;
-    }
-}
-
 // One workgroup per (head, 32-column block of the head): soft_max of the head's score row
 // (recomputed by each of the head's dh/32 workgroups -- exact in any order), the nth partial V*P sums
 // for its 32 columns (one sequential FMA chain per (chunk, column), all nth*32 chains in parallel),
@@ -3321,7 +3129,7 @@ struct AttnXArgs {
     // k_qkv_attn only: data-tagged hand-offs.  qkv2[3 d] / sc2[H][n_ctx] hold {fp32 bits, tag} 8-byte granules,
     // tag = make_tag(epoch[0], layer + 1): a reader polls the granule itself until the tag is this launch's
     const uint64_t *qkv2; uint64_t *sc2; const uint32_t *epoch; int layer;
-    uint64_t *qat_A, *qat_d;      // non-null: the wo mat-vec is a role of the same launch and takes the quantized row as tagged granules
+    uint64_t *qat_A;              // non-null (overlapped schedule): the quantized attention output leaves as [block][9] tagged granules for the wo launch
 };
 // role of workgroup (h, yy): yy < ncb: soft_max . V for column block yy; else scores for key slice yy - ncb.
 // QKV_WAIT (k_qkv_attn): the head's q / k / v rows come from mat-vec workgroups of the SAME launch as tagged granules
@@ -3568,26 +3376,17 @@ k_dec_attn_x(const AttnXArgs aa) {
 // of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
-template <int PRE, int D, int PG, bool WO>
+template <int PRE, int D, int PG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG == 1 ? 4 : 3)))
-k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int gridA, const int H) {
+k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
     extern __shared__ double smem_d[];
     count_launch(ga.prog);
-    int b = blockIdx.x;
-    if (WO) {
-        // the wo mat-vec of the layer: its 4-wave workgroups come FIRST (a multiple of 8 of them, so the XCD placement of the
-        // other roles is unchanged): dispatched at once, their weight rows stream in together with the first mat-vec's and sit
-        // in registers when the quantized attention output arrives as tagged granules from the soft_max . V workgroups.
-        // (They wait for HIGHER block indices, like the soft_max . V workgroups: few enough never to fill the chip.)
-        const int gridW = gw.ngroups / 4;
-        if (b < gridW) { gemv_body<PRE_QA_TAG, EPI_RESID, 16, false, 1, SYNC_NONE, false>(gw, b, 4, smem_d); return; }
-        b -= gridW;
-    }
+    const int b = blockIdx.x;
     if (b < gridA) {
         const int ncb = aa.dh / 32, wph = 3 * ncb;
         const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
         const int h = xcd + 8 * j;
-        gemv_body<PRE, EPI_STORE_TAG, D, true, PG, SYNC_NONE, false>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules
+        gemv_body<PRE, EPI_STORE_TAG, D, true, PG>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules
         return;
     }
     const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
@@ -3606,10 +3405,12 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const GemvArgs gw, const int g
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_prefetch(const PfOp *__restrict__ ops, const int n_ops, const uint32_t *prog, const int n_tokens, const unsigned long long budget,
-           const int line, uint32_t *__restrict__ sink, const uint32_t never) {
+           const int line, uint32_t *__restrict__ sink, const uint32_t never, const int xcc_of_wg0) {
+    // consumer workgroup b runs on the XCD with HW_REG_XCC_ID (xcc_of_wg0 + b) % 8: the round-robin restarts with every launch at
+    // an XCD that depends on the QUEUE (measured: tools/xcd_dispatch_probe.hip), so the host measures it on the consumers' stream
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const int xcd = (int) (xcc & 7u), j = blockIdx.x >> 3, nj = max(1, (int) (gridDim.x >> 3)), lane = threadIdx.x;
+    const int xcd = (int) ((xcc - (uint32_t) xcc_of_wg0) & 7u), j = blockIdx.x >> 3, nj = max(1, (int) (gridDim.x >> 3)), lane = threadIdx.x;
     const unsigned long long token_bytes = ops[n_ops - 1].cum_start + ops[n_ops - 1].bytes;
     uint32_t acc = 0;
     unsigned long long allowed = 0;            // absolute byte position (tokens x token_bytes + position in the token) fetching may reach
@@ -3884,7 +3685,6 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
     LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
     LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
-    LH_ATTR((k_gemv_pair<PREP_NORMP, 4, 4, 10, true>)); LH_ATTR((k_gemv_pair<PREP_NORM, 4, 4, 10, true>));
     LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 16, false, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 8, true, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 10, true, 1>));
     LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 16, true, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 22, true, 1>));
     LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 16, false, 1>)); LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 8, true, 1>));
@@ -3895,8 +3695,8 @@ hipError_t init_kernel_attrs() {
     LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
-    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1, true>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1, true>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2, false>));
-    LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 8, 1, false>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 10, 2, false>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 4, 2, false>));
+    LH_ATTR(k_attn); LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));
+    LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 4, 2>));
 #undef LH_ATTR
     return hipSuccess;
 }
@@ -4137,67 +3937,11 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
 #undef LH_PGARGS
 }
 
-// ---- w1|w3 and w2 of a layer in one launch (k_gemv_pair).  Applies to the shapes whose two roles use the kernel
-// variants instantiated below AND whose blocks are all resident at once; everything else keeps two launches.
 static size_t gemv_lds_bytes(const QMat &w, int depth_pad) {
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     lds = (lds + 15) & ~(size_t) 15;
     return lds + (LH_GEMV_PAD ? (size_t) depth_pad * 288 : 0);
 }
-static const void *pair_kernel(bool normp) {
-    return normp ? (const void *) k_gemv_pair<PREP_NORMP, 4, 4, 10, true> : (const void *) k_gemv_pair<PREP_NORM, 4, 4, 10, true>;
-}
-bool gemv_pair_applies(const QMat &w13, const QMat &w2) {
-    // OFF by default: in the real decode step the fused launch takes what the two launches took (7B: 22.6 us against
-    // 13.35 + 8.49 us of kernel time, 688.6 against 684.8 tokens/s; profiles/r02_b_pair_ab.txt) -- the hand-off costs what
-    // the boundary did, as MI355X_MICROARCH.md's price list says of every all-to-all seam.  LLAMAHIP_PAIR=1 enables it.
-    static const bool off = getenv("LLAMAHIP_PAIR") == nullptr || getenv("LLAMAHIP_NO_PAIR") != nullptr;
-    if (off || !w13.gmapF8 || w13.ngroups % 8 != 0 || w13.K / 16 > 512) return false;
-    if (w13.ngroups < 2048 || pick_depth(w13.nchunks, w13.ngroups) != 4) return false;       // role A: k_gemv<*, SILU_QA, 4, ring, 1>
-    int pg = 0;
-    const int nwB = gemv_pick_nw_qa(w2, &pg);
-    if (pg != 4 || nwB < 1 || nwB > 8 || w2.nchunks <= 16 || pick_depth(w2.nchunks, w2.ngroups) != 10) return false;   // role B: k_gemv<QA, RESID, 10, ring, 4>
-    const int gridA = w13.ngroups / 8, gridB = (w2.ngroups + nwB - 1) / nwB;
-    const size_t lds = std::max(gemv_lds_bytes(w13, 4), gemv_lds_bytes(w2, 10));
-    // Every block resident at once (occupancy API x CUs; SGPR use is far below the range where the API over-reports,
-    // MI355X_MICROARCH.md "Residency and cooperative launch").  Independently of that, a waiting role-B block cannot
-    // starve a role-A block: blocks are handed out in index order per XCD, role A has the lower indices and never
-    // waits for anything -- and the spin is bounded.
-    static int occ[2] = { -1, -1 }, ncu = 0;
-    static size_t occ_lds[2] = { 0, 0 };
-    for (int v = 0; v < 2; v++) {
-        if (occ[v] < 0 || occ_lds[v] != lds) {
-            int o = 0, dev = 0;
-            hipDeviceProp_t prop;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, pair_kernel(v == 1), 512, lds) != hipSuccess) o = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-            occ[v] = o; occ_lds[v] = lds; ncu = prop.multiProcessorCount;
-        }
-    }
-    const int per_cu = std::min(occ[0], occ[1]);
-    return per_cu >= 1 && (long) gridA + gridB <= (long) ncu * per_cu;
-}
-
-hipError_t launch_gemv_pair(const QMat &w13, const QMat &w2, const float *x_in, const float *norm_w, const NormPart &np13,
-                            uint32_t *qa2_A, float *qa2_d, float *y, const float *resid, const NormPart &np2,
-                            const uint16_t *T_silu, uint32_t *sync, int epoch, hipStream_t st) {
-    int pg = 0;
-    const int nwB = gemv_pick_nw_qa(w2, &pg);
-    const int gridA = w13.ngroups / 8, gridB = (w2.ngroups + nwB - 1) / nwB;
-    const size_t lds = std::max(gemv_lds_bytes(w13, 4), gemv_lds_bytes(w2, 10));
-    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;
-    const bool normp = norm_mode >= 2 && np13.in && np13.n_in > 0 && np13.n_in <= NORM_PART_MAX;
-    if (np2.out && gridB > NORM_PART_MAX) return hipErrorInvalidValue;
-    const GemvArgs a = { w13.tiles, w13.ngroups, w13.nchunks, w13.M, w13.gmapF8, nullptr, nullptr, x_in, norm_w, w13.K, nullptr, nullptr, T_silu,
-                         qa2_A, qa2_d, normp ? (const f64x2 *) np13.in : nullptr, normp ? np13.n_in : (norm_mode == 0 ? -1 : 0), nullptr, sync, gridA, epoch, g_lut_math };
-    const GemvArgs b = { w2.tiles, w2.ngroups, w2.nchunks, w2.M, w2.gmapF8, qa2_A, qa2_d, nullptr, nullptr, w2.K, y, resid, T_silu,
-                         nullptr, nullptr, nullptr, 0, norm_mode >= 2 ? (f64x2 *) np2.out : nullptr, sync, gridA, epoch, g_lut_math };
-    if (normp) hipLaunchKernelGGL((k_gemv_pair<PREP_NORMP, 4, 4, 10, true>), dim3(gridA + gridB), dim3(512), lds, st, a, b, gridA, nwB);
-    else       hipLaunchKernelGGL((k_gemv_pair<PREP_NORM, 4, 4, 10, true>), dim3(gridA + gridB), dim3(512), lds, st, a, b, gridA, nwB);
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu,
@@ -4297,10 +4041,22 @@ hipError_t launch_gemv_ov_silu(const QMat &w, const float *norm_w, const OvArgs 
     return hipSuccess;
 }
 
-hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, hipStream_t st) {
+// HW_REG_XCC_ID of workgroup 0 of a launch on `st` (-1: could not tell)
+int measure_xcc_of_wg0(hipStream_t st) {
+    uint32_t *d_out = nullptr, h = 0xffffffffu;
+    if (hipMalloc((void **) &d_out, 4) != hipSuccess) return -1;
+    bool ok = hipMemsetAsync(d_out, 0xff, 4, st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_xcd_selftest, dim3(1), dim3(64), 0, st, d_out);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h, d_out, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    }
+    (void) hipFree(d_out);
+    return ok && h < 8u ? (int) h : -1;
+}
+hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, int xcc_of_wg0, hipStream_t st) {
     static const int line = getenv("LLAMAHIP_PF_LINE") ? atoi(getenv("LLAMAHIP_PF_LINE")) : 128;
     nwg = std::max(8, nwg / 8 * 8);
-    hipLaunchKernelGGL(k_prefetch, dim3(nwg), dim3(64), 0, st, ops, n_ops, prog, n_tokens, (unsigned long long) budget, line, sink, 0x9e3779b9u);
+    hipLaunchKernelGGL(k_prefetch, dim3(nwg), dim3(64), 0, st, ops, n_ops, prog, n_tokens, (unsigned long long) budget, line, sink, 0x9e3779b9u, xcc_of_wg0);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -4699,16 +4455,8 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
         LH_LAUNCH_CHECK();
         return hipSuccess;
     }
-    // The single-launch variant (k_dec_attn) measured SLOWER on MI355X (13.3 us vs 4.9 + 5.7 us per layer at
-    // 7B, n_ctx 512: its 16-wave workgroups serialise four phases that the split version spreads over
-    // 8x more workgroups); it stays selectable for comparison only.
-    static const bool fused = getenv("LLAMAHIP_FUSED_ATTN") != nullptr;
-    if (fused) {
-        const size_t lds = 32 * sizeof(double) + ((size_t) 2 * dh + n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
-        hipLaunchKernelGGL(k_dec_attn, dim3(H, dh / 32), dim3(1024), lds, st, qkv, d, dh, tab, Kc, Vc, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state);
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
+    // (a variant with one 16-wave workgroup per (head, column block) doing scores and soft_max . V measured slower in round 1 --
+    //  13.3 us against 4.9 + 5.7 per layer at 7B, n_ctx 512 -- and was removed in round 3)
     const int nsl = (n_ctx + DEC_TS - 1) / DEC_TS;
     hipLaunchKernelGGL(k_dec_scores, dim3(H, nsl), dim3(256), 2 * dh * sizeof(float), st, qkv, d, dh, tab, Kc, Vc, sc, n_ctx, kq_scale, state);
     LH_LAUNCH_CHECK();
@@ -4743,31 +4491,20 @@ bool qkv_attn_applies(const QMat &w, int d, int H, int nth) {
     if (dh % 32 != 0 || dh > 256 || nth > 8 || w.gmapF8 || w.M != 3 * d || w.K != d || w.ngroups != 3 * d / 8) return false;
     return qkv_attn_variant(w) != 0;
 }
-// wo as a role of the same launch: the 7B shapes (whole 4096-wide rows in flight, no padding blocks)
-bool qkv_attn_fuses_wo(const QMat &wqkv, const QMat &wo) {
-    // OFF by default (LLAMAHIP_WO_FUSE=1 enables it): measured on the 7B decode step the launch with the wo role takes
-    // 21.5 us against 15.1 + 4.8 us as two launches (profiles/r02_g_wo_fuse_ab.txt) -- and 15.4 against 9.9 us even with
-    // every poll disabled: the 128 trailing workgroups only get their slots and their 10.5 MB of weights when the first
-    // mat-vec's stream ends, so nothing of wo's latency is hidden and its hand-off comes on top.
-    static const bool off = getenv("LLAMAHIP_WO_FUSE") == nullptr || getenv("LLAMAHIP_NO_WO_FUSE") != nullptr;
-    return !off && qkv_attn_variant(wqkv) == 1 && !wo.gmapF8 && wo.nchunks == 16 && wo.K % 256 == 0 && wo.ngroups % 32 == 0 && wo.ngroups < 1024 && wo.M == wo.ngroups * 8;
-}
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           const QMat *wo, uint64_t *qat_A, uint64_t *qat_d, float *wo_y, const float *wo_resid, const NormPart *np_wo, const uint64_t *x_t) {
-    // x_t (overlapped decode schedule): the input row arrives as tagged granules (slot = layer) from the launch running beside this
-    // one, and the quantized attention output leaves as tagged granules (qat_A) for the wo launch that is already waiting
+                           uint64_t *qat_A, const uint64_t *x_t) {
+    // x_t (overlapped decode schedule, opt-in): the input row arrives as tagged granules (slot = layer) from the launch running beside
+    // this one, and the quantized attention output leaves as tagged granules (qat_A) for the wo launch that is already waiting
     const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // as launch_gemv
     const bool normp = norm_mode >= 2 && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX;
     const int variant = qkv_attn_variant(w);
-    const bool fuse_wo = wo && qat_A && qat_d && qkv_attn_fuses_wo(w, *wo);
     const size_t lds_mv = gemv_lds_bytes(w, variant == 1 ? 8 : variant == 2 ? 10 : 4);
     const size_t lds_pv = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
-    size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
-    if (fuse_wo) lds = std::max(lds, gemv_lds_bytes(*wo, 0));
+    const size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
     // the mat-vec role writes tagged granules: y -> qkv2, sync -> the epoch word, sync_epoch = layer
     // measurement only, RESULTS ARE INVALID: LLAMAHIP_ATTN_NOWAIT=1 no poll waits, =2 only the soft_max . V role does not wait, =3 only the score role
     static const int nw_mode = getenv("LLAMAHIP_ATTN_NOWAIT") ? atoi(getenv("LLAMAHIP_ATTN_NOWAIT")) : 0;
@@ -4777,30 +4514,17 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     // sticky fault word must come back as an error
     static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) < 2) ? 0x1000 : 0;     // (2: the wo launch of the overlapped schedule misbehaves instead)
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
-                          (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
+                    (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
     if (x_t) { ga.in_t = x_t; ga.slot_in = layer; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; }
     ga.prog = t_prog;
-    GemvArgs gw = ga;
-    if (fuse_wo) {
-        const NormPart npw = (np_wo && norm_mode >= 2) ? *np_wo : NormPart();
-        if (npw.out && wo->ngroups / 4 > NORM_PART_MAX) return hipErrorInvalidValue;
-        gw = GemvArgs{ wo->tiles, wo->ngroups, wo->nchunks, wo->M, wo->gmapF8, (const uint32_t *) qat_A, (const float *) qat_d, nullptr, nullptr, wo->K, wo_y, wo_resid, T_silu,
-                       nullptr, nullptr, nullptr, 0, (f64x2 *) npw.out, epoch, 0, layer, g_lut_math | nowait, fault };
-    }
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep | fault_test,
-                           qkv2, sc2, epoch, layer, (fuse_wo || x_t) ? qat_A : nullptr, (fuse_wo || x_t) ? qat_d : nullptr };
-    const int grid = gridA + H * (nsl + dh / 32) + (fuse_wo ? wo->ngroups / 4 : 0);
-    if (x_t) {
-        if (fuse_wo || !qat_A) return hipErrorInvalidValue;
-#define LH_GOT(D, PG) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG, false>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H)
-        if (variant == 1) LH_GOT(8, 1); else if (variant == 2) LH_GOT(10, 2); else if (variant == 3) LH_GOT(4, 2); else return hipErrorInvalidValue;
-#undef LH_GOT
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
-#define LH_GOX(D, PG, WO) { if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); \
-                            else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG, WO>), dim3(grid), dim3(256), lds, st, ga, aa, gw, gridA, H); }
-    if (variant == 1 && fuse_wo) LH_GOX(8, 1, true) else if (variant == 1) LH_GOX(8, 1, false) else if (variant == 2) LH_GOX(10, 2, false) else if (variant == 3) LH_GOX(4, 2, false) else return hipErrorInvalidValue;
+                           qkv2, sc2, epoch, layer, x_t ? qat_A : nullptr };
+    const int grid = gridA + H * (nsl + dh / 32);
+    if (x_t && !qat_A) return hipErrorInvalidValue;
+#define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
+                        else if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
+                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); }
+    if (variant == 1) LH_GOX(8, 1) else if (variant == 2) LH_GOX(10, 2) else if (variant == 3) LH_GOX(4, 2) else return hipErrorInvalidValue;
 #undef LH_GOX
     LH_LAUNCH_CHECK();
     return hipSuccess;

@@ -170,11 +170,9 @@ struct llamahip_model {
     float *qa1_d = nullptr, *qa2_d = nullptr;
     bool w13_interleaved = false;
     bool prompt_copies = false;          // the row-lane / matrix-core copies of the layer matrices exist (ensure_prompt_copies)
-    bool pair_used = false;              // a fused w1|w3 + w2 launch ran since the time-out word was last read
-    uint32_t *d_sync = nullptr;          // in-launch hand-off words of the fused w1|w3 + w2 launch (k_gemv_pair), SYNC_BYTES
     uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
-    uint64_t *d_qat_A = nullptr, *d_qat_d = nullptr; // ... and the quantized attention output for the wo role: [Kp_d / 4] and [Kp_d / 32] granules
+    uint64_t *d_qat_A = nullptr;         // ... and the quantized attention output for the wo launch of the overlapped schedule: [Kp_d / 32][9] granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
     // overlapped ("two-branch") decode schedule: the residual stream and the FFN activation as tagged granules, the second branch
     uint64_t *d_xt = nullptr, *d_x1t = nullptr, *d_qa2t = nullptr;   // [d], [d], [Kp_F / 32][9]
@@ -183,7 +181,7 @@ struct llamahip_model {
     // L2 run-ahead prefetcher of the decode step (k_prefetch): schedule, launch counter, tuning
     PfOp *d_pf_ops = nullptr; int n_pf_ops = 0;
     uint32_t *d_prog = nullptr, *d_pf_sink = nullptr;
-    size_t pf_budget = 0; int pf_wgs = 0;
+    size_t pf_budget = 0; int pf_wgs = 0, pf_xcc0 = -1;     // pf_xcc0: the XCD workgroup 0 of a launch on `stream` lands on
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
@@ -234,7 +232,7 @@ llamahip_model::~llamahip_model() {
     if (ev_fork) (void) hipEventDestroy(ev_fork);
     if (ev_join) (void) hipEventDestroy(ev_join);
     if (stream2) (void) hipStreamDestroy(stream2);
-    free_dev(npart_a); free_dev(npart_b); free_dev(d_sync); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_qat_A); free_dev(d_qat_d);
+    free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_qat_A);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
@@ -550,10 +548,6 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     static const bool no_norm_part = getenv("LLAMAHIP_NORM_MODE") && atoi(getenv("LLAMAHIP_NORM_MODE")) < 2;
     const bool use_part = fused && m->w13_interleaved && !no_norm_part;
     int n_part_x = 0;                                       // pairs in npart_a valid for the row currently in x (0: none)
-    // decode: w1|w3 and w2 of a layer share one launch where the shapes allow (k_gemv_pair); its hand-off counters
-    // run monotonically over the layers of a token and are cleared here, once per token
-    const bool use_pair = fused && m->w13_interleaved && m->l1 > m->l0 && gemv_pair_applies(m->layers[0].w13, m->layers[0].w2);
-    if (use_pair) { m->pair_used = true; HIP_TRY(hipMemsetAsync(m->d_sync, 0, SYNC_CLEAR_BYTES, st), LLAMAHIP_ERR_PREDICT); }
     // decode: wq|wk|wv + attention as one launch with tagged hand-offs (k_qkv_attn); one forward pass = one epoch
     const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
     // decode, overlapped ("two-branch") schedule: the four launches of a layer alternate between two branches of the captured graph
@@ -584,8 +578,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             const bool last = li == nl - 1;
             // A: wq|wk|wv + attention: row in <- xt (slot li), quantized attention output -> qat (slot li + 1)
             HIP_TRY(launch_qkv_attn(L.qkv, nullptr, L.attention_norm, NormPart(), m->d_qkv2, m->d_sc2, m->d_epoch, li, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
-                                    m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st,
-                                    nullptr, m->d_qat_A, m->d_qat_d, nullptr, nullptr, nullptr, m->d_xt), LLAMAHIP_ERR_PREDICT);
+                                    m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st, m->d_qat_A, m->d_xt), LLAMAHIP_ERR_PREDICT);
             // B: wo: qat -> x1t (slot li + 1), residual xt (slot li)
             OvArgs ow;
             ow.epoch = m->d_epoch; ow.fault = m->d_fault; ow.layer = li; ow.T_silu = m->T_silu;
@@ -641,9 +634,8 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             const float *xa = (il == m->l0 && x_first) ? x_first : m->x;      // residual stream into this layer
             float *xo = (il == m->l1 - 1 && x_last) ? x_last : m->x;           // ... and out of it
             NormPart np_qkv, np_wo, np_w13, np_w2;
-            const bool fuse_wo = use_qkvx && qkv_attn_fuses_wo(L.qkv, L.wo);
             if (use_part) {
-                const int pw = fuse_wo ? L.wo.ngroups / 4 : gemv_resid_parts(L.wo), p2 = gemv_resid_parts(L.w2);
+                const int pw = gemv_resid_parts(L.wo), p2 = gemv_resid_parts(L.w2);
                 if (n_part_x > 0) { np_qkv.in = m->npart_a; np_qkv.n_in = n_part_x; }
                 if (pw > 0 && pw <= NORM_PART_MAX) { np_wo.out = m->npart_b; np_w13.in = m->npart_b; np_w13.n_in = pw; }
                 n_part_x = 0;
@@ -651,17 +643,13 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             }
             if (use_qkvx) {
                 HIP_TRY(launch_qkv_attn(L.qkv, xa, L.attention_norm, np_qkv, m->d_qkv2, m->d_sc2, m->d_epoch, il - m->l0, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
-                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st,
-                                        fuse_wo ? &L.wo : nullptr, m->d_qat_A, m->d_qat_d, m->x1, xa, &np_wo), LLAMAHIP_ERR_PREDICT);
+                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st), LLAMAHIP_ERR_PREDICT);
             } else {
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
             }
-            if (!fuse_wo)
             HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo), LLAMAHIP_ERR_PREDICT);
-            if (use_pair) {
-                HIP_TRY(launch_gemv_pair(L.w13, L.w2, m->x1, L.ffn_norm, np_w13, m->qa2_A, m->qa2_d, xo, m->x1, np_w2, m->T_silu, m->d_sync, il - m->l0 + 1, st), LLAMAHIP_ERR_PREDICT);
-            } else if (m->w13_interleaved) {
+            if (m->w13_interleaved) {
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, st, &np_w13), LLAMAHIP_ERR_PREDICT);
                 HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, nullptr, nullptr, st, &np_w2), LLAMAHIP_ERR_PREDICT);
             } else {
@@ -762,29 +750,22 @@ dump_fail:
     return LLAMAHIP_ERR_PREDICT;
 }
 
-// The in-launch hand-off of k_gemv_pair bounds its spin; a time-out leaves a sticky word (results are invalid then).
+// Every tagged hand-off is a bounded poll; one that runs out raises the sticky fault word (results are invalid then).
 // Read after the stream has been synchronised.
 int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
-    uint32_t w = 0;
-    uint32_t *word = m->d_sync + (SYNC_BYTES - 64) / 4;
     if (m->h_fault && *(volatile uint32_t *) m->h_fault) {
         *(volatile uint32_t *) m->h_fault = 0;
         set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch, or between the overlapped decode launches) timed out; LLAMAHIP_NO_ATTN_X=1 selects the attention launches without them (the overlapped schedule is opt-in: LLAMAHIP_OVERLAP)");
         return LLAMAHIP_ERR_PREDICT;
     }
-    if (!m->pair_used) return 0;         // (the check is a device round trip: only when the hand-off was in play)
-    m->pair_used = false;
-    if (!m->d_sync || hipMemcpy(&w, word, 4, hipMemcpyDeviceToHost) != hipSuccess || w == 0) return 0;
-    (void) hipMemset(word, 0, 4);
-    set_err(err, err_cap, "decode step: in-launch hand-off between w1|w3 and w2 timed out (set LLAMAHIP_NO_PAIR=1 to use separate launches)");
-    return LLAMAHIP_ERR_PREDICT;
+    return 0;
 }
 
 // The L2 prefetcher runs beside the `n_tokens` decode steps about to be issued on m->stream: launched on the second stream once
 // the main stream has reached this point, joined back after the steps (it has nothing left to fetch by then and exits).
 static bool prefetch_enabled(const llamahip_model *m) {
-    static const bool off = getenv("LLAMAHIP_NO_PREFETCH") || getenv("LLAMAHIP_PAIR") || getenv("LLAMAHIP_WO_FUSE") || getenv("LLAMAHIP_OVERLAP");
-    return !off && m->d_pf_ops && m->d_prog && m->stream2 && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
+    static const bool off = getenv("LLAMAHIP_NO_PREFETCH") || getenv("LLAMAHIP_OVERLAP");
+    return !off && m->d_pf_ops && m->d_prog && m->stream2 && m->pf_xcc0 >= 0 && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
 }
 int prefetch_begin(llamahip_model *m, int n_tokens, bool *running, char *err, size_t err_cap) {
     *running = false;
@@ -792,7 +773,7 @@ int prefetch_begin(llamahip_model *m, int n_tokens, bool *running, char *err, si
     HIP_TRY(hipMemsetAsync(m->d_prog, 0, 4, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipEventRecord(m->ev_fork, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(launch_prefetch(m->d_pf_ops, m->n_pf_ops, m->d_prog, n_tokens, m->pf_budget, m->pf_wgs, m->d_pf_sink, m->stream2), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(launch_prefetch(m->d_pf_ops, m->n_pf_ops, m->d_prog, n_tokens, m->pf_budget, m->pf_wgs, m->d_pf_sink, m->pf_xcc0, m->stream2), LLAMAHIP_ERR_PREDICT);
     *running = true;
     return 0;
 }
@@ -1005,8 +986,6 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipMemset(m->d_state, 0, 2 * sizeof(int32_t)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->sc, (size_t) H * n_ctx * 4), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->part, (size_t) H * 64 * dh * 4), LLAMAHIP_ERR_LOAD);
-        HIP_TRY(hipMalloc((void **) &m->d_sync, SYNC_BYTES), LLAMAHIP_ERR_LOAD);
-        HIP_TRY(hipMemset(m->d_sync, 0, SYNC_BYTES), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipHostMalloc((void **) &m->h_fault, 64, hipHostMallocMapped), LLAMAHIP_ERR_LOAD);
         *m->h_fault = 0;
         HIP_TRY(hipHostGetDevicePointer((void **) &m->d_fault, m->h_fault, 0), LLAMAHIP_ERR_LOAD);
@@ -1026,8 +1005,6 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemset(m->d_sc2, 0, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_qat_A, Kp_d / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_qat_A, 0, Kp_d / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMalloc((void **) &m->d_qat_d, Kp_d / 32 * 8), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMemset(m->d_qat_d, 0, Kp_d / 32 * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
             if (getenv("LLAMAHIP_OVERLAP")) {          // the overlapped two-branch schedule: opt-in (measured slower)
@@ -1067,6 +1044,7 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMalloc((void **) &m->d_pf_sink, 256), LLAMAHIP_ERR_LOAD);
             m->pf_budget = (size_t) (getenv("LLAMAHIP_PF_BUDGET_MB") ? atof(getenv("LLAMAHIP_PF_BUDGET_MB")) : 16.0) * 1024 * 1024;
             m->pf_wgs = getenv("LLAMAHIP_PF_WGS") ? atoi(getenv("LLAMAHIP_PF_WGS")) : 128;
+            m->pf_xcc0 = getenv("LLAMAHIP_PF_XCC0") ? atoi(getenv("LLAMAHIP_PF_XCC0")) : measure_xcc_of_wg0(m->stream);
         }
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);

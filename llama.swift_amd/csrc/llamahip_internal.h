@@ -85,14 +85,6 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
                        const NormPart *np = nullptr);
-// w1|w3 and w2 of a decode step in ONE launch with an in-launch hand-off (k_gemv_pair); `sync` = SYNC_BYTES of
-// device memory zeroed once per token, `epoch` = 1-based index of the pair within the token
-constexpr int SYNC_BYTES = (2 * 8 + 2) * 64;           // the last 64 B hold the sticky time-out word
-constexpr int SYNC_CLEAR_BYTES = (2 * 8 + 1) * 64;     // what the per-token memset clears
-bool gemv_pair_applies(const QMat &w13, const QMat &w2);
-hipError_t launch_gemv_pair(const QMat &w13, const QMat &w2, const float *x_in, const float *norm_w, const NormPart &np13,
-                            uint32_t *qa2_A, float *qa2_d, float *y, const float *resid, const NormPart &np2,
-                            const uint16_t *T_silu, uint32_t *sync, int epoch, hipStream_t st);
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
 hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr, uint64_t *xt = nullptr);
 enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_COUNT = 5 };
@@ -128,12 +120,10 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
 bool xcd_selftest(int H, int Y, hipStream_t st);
 // wq|wk|wv mat-vec + decode attention as one launch (k_qkv_attn); xsync / fault as launch_dec_attn
 bool qkv_attn_applies(const QMat &w, int d, int H, int nth);
-bool qkv_attn_fuses_wo(const QMat &wqkv, const QMat &wo);          // ... and the wo mat-vec as a further role (qat_A / qat_d: tagged QA granules)
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           const QMat *wo = nullptr, uint64_t *qat_A = nullptr, uint64_t *qat_d = nullptr, float *wo_y = nullptr, const float *wo_resid = nullptr,
-                           const NormPart *np_wo = nullptr, const uint64_t *x_t = nullptr);
+                           uint64_t *qat_A = nullptr, const uint64_t *x_t = nullptr);      // x_t / qat_A: tagged row in / tagged QA out (overlapped schedule)
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
 // L2 run-ahead prefetcher of the decode step (k_prefetch): the weight matrices of one token in launch order
 struct PfOp {
@@ -141,7 +131,8 @@ struct PfOp {
     unsigned long long cum_start, bytes;
 };
 void set_decode_progress(uint32_t *prog);                           // launch counter the decode launches issued on this thread bump (or null)
-hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, hipStream_t st);
+hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, int xcc_of_wg0, hipStream_t st);
+int measure_xcc_of_wg0(hipStream_t st);                             // HW_REG_XCC_ID of workgroup 0 of launches on `st` (the XCD round-robin's start is per queue), or -1
 int gemv_groups_per_block(const QMat &w, int role);
 // overlapped decode schedule: mat-vecs with tagged operands / results (kernels.hip "overlapped decode schedule")
 struct OvArgs {
