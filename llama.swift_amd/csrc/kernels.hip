@@ -3376,9 +3376,46 @@ k_dec_attn_x(const AttnXArgs aa) {
 // of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
+// L2 warm-up of the NEXT launches' weights by the mat-vec workgroups of k_qkv_attn, on their way out.  While the attention roles of
+// the launch walk their dependent chain (scores -> soft_max -> V*P: about 6 us at 7B), HBM idles and these workgroups are done.
+// Workgroup b of this launch and workgroup b' of the next launch of the same stream run on the same XCD when b = b' (mod 8) (the
+// round-robin restarts with every launch, at an XCD fixed per queue: tools/xcd_dispatch_probe.hip), and what one launch leaves in an
+// XCD's L2 is still there for the next (tools/l2_prefetch_probe.hip: a 64 KiB region read in 0.7 us instead of 2.7).  So each
+// mat-vec workgroup touches one dword per 128-byte line of the leading tiles of the row-groups that consumer workgroups of ITS
+// residue class will stream: all of wo, the first tiles of w1|w3.  It writes nothing and nobody waits for it: a wrong guess about
+// placement costs speed, never a result.
+struct PfTarget { const uint8_t *base; uint32_t group_bytes; int32_t ngroups, gpb, tiles; };       // tiles: leading tiles of every row-group (0: nothing)
+struct PfTail { PfTarget t[2]; uint32_t *sink; uint32_t never; };
+__device__ __forceinline__ void prefetch_tail(const PfTail &pf, const int b, const int nmates) {
+    const int x = b & 7, j = b >> 3, tid = threadIdx.x;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const PfTarget t = pf.t[q];
+        if (t.tiles <= 0) continue;
+        const int nblk = (t.ngroups + t.gpb - 1) / t.gpb, cnt = (nblk - x + 7) / 8;
+        const int lines_g = t.tiles * (TILE_BYTES / 128);                  // lines per row-group
+        for (int i = j; i < cnt; i += nmates) {
+            const int g0 = (x + 8 * i) * t.gpb, ng = min(t.gpb, t.ngroups - g0);
+            const int total = ng * lines_g;
+            for (int l0 = 0; l0 < total; l0 += 256 * 4) {
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int l = min(l0 + u * 256 + tid, total - 1), g = g0 + l / lines_g, o = (l % lines_g) * 128;
+                    v[u] = *(const __attribute__((address_space(1))) uint32_t *) (uintptr_t) (t.base + (size_t) g * t.group_bytes + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc ^= v[u];
+            }
+        }
+    }
+    if (acc == pf.never && pf.sink) pf.sink[tid] = acc;            // (keeps the loads alive)
+}
+
 template <int PRE, int D, int PG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG == 1 ? 4 : 3)))
-k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
+k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H, const PfTail pf) {
     extern __shared__ double smem_d[];
     count_launch(ga.prog);
     const int b = blockIdx.x;
@@ -3387,6 +3424,7 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) 
         const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
         const int h = xcd + 8 * j;
         gemv_body<PRE, EPI_STORE_TAG, D, true, PG>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules
+        prefetch_tail(pf, b, gridA >> 3);
         return;
     }
     const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
@@ -3405,7 +3443,8 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_prefetch(const PfOp *__restrict__ ops, const int n_ops, const uint32_t *prog, const int n_tokens, const unsigned long long budget,
-           const int line, uint32_t *__restrict__ sink, const uint32_t never, const int xcc_of_wg0) {
+           const int line, uint32_t *__restrict__ sink, const uint32_t never, const int xcc_of_wg0, const int mode, const int nap) {
+    // mode (measurement): 0 normal | 1 follow the launch counter but fetch nothing | 2 fetch everything, never look at the counter
     // consumer workgroup b runs on the XCD with HW_REG_XCC_ID (xcc_of_wg0 + b) % 8: the round-robin restarts with every launch at
     // an XCD that depends on the QUEUE (measured: tools/xcd_dispatch_probe.hip), so the host measures it on the consumers' stream
     uint32_t xcc;
@@ -3423,7 +3462,7 @@ k_prefetch(const PfOp *__restrict__ ops, const int n_ops, const uint32_t *prog, 
             const int per_h = op.mode == 1 ? (nblk / op.hdiv) * op.ncb : 0;          // mode 1: blocks per head = (q, k, v) x (dh / 32)
             const int cnt = op.mode == 1 ? (op.hdiv / op.ncb / 8) * per_h : (nblk - xcd + 7) / 8;
             const unsigned long long base_abs = (unsigned long long) t * token_bytes + op.cum_start;
-            {   // fallen behind?  A launch that has already been followed by the next one needs no prefetching any more
+            if (mode != 2) {   // fallen behind?  A launch that has already been followed by the next one needs no prefetching any more
                 const uint32_t c = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 allowed = (unsigned long long) (c / (unsigned) n_ops) * token_bytes + ops[c % (unsigned) n_ops].cum_start + budget;
                 if ((unsigned long long) t * (unsigned) n_ops + (unsigned) q + 1ull < (unsigned long long) c) continue;
@@ -3436,24 +3475,26 @@ k_prefetch(const PfOp *__restrict__ ops, const int n_ops, const uint32_t *prog, 
                 } else b = xcd + 8 * i;
                 // throttle: stay within `budget` bytes of the end of the launch that is running
                 const unsigned long long pos = base_abs + op.bytes / (unsigned) cnt * (unsigned) i;
-                while (pos > allowed) {
+                while (mode != 2 && pos > allowed) {
                     const uint32_t c = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     allowed = (unsigned long long) (c / (unsigned) n_ops) * token_bytes + ops[c % (unsigned) n_ops].cum_start + budget;
                     if (pos <= allowed) break;
-                    __builtin_amdgcn_s_sleep(32);
+                    for (int z = 0; z < nap; z++) __builtin_amdgcn_s_sleep(32);
                     if (++waited > (1L << 22)) return;            // (the decode loop stopped: nothing left to run ahead of)
                 }
+                if (mode == 1) continue;
                 const int g0 = b * op.gpb, ng = min(op.gpb, op.ngroups - g0);
                 if (ng <= 0) continue;
                 const uint8_t *p = op.base + (size_t) g0 * op.group_bytes;
                 const int nbytes = ng * (int) op.group_bytes;
-                // one dword per line, 8 wave-loads in flight
-                for (int off = lane * line; off < nbytes; off += 64 * line * 8) {
+                // one dword per line, 16 wave-loads in flight.  Branch-free (offsets past the end are clamped to the last line): a
+                // predicated load compiles to a branch with a full vmcnt(0) wait behind it, i.e. ONE load in flight per wave.
+                for (int off = lane * line; off < nbytes; off += 64 * line * 16) {
+                    uint32_t v[16];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int o = off + u * 64 * line;
-                        if (o < nbytes) acc ^= *(const uint32_t *) (p + o);
-                    }
+                    for (int u = 0; u < 16; u++) v[u] = *(const __attribute__((address_space(1))) uint32_t *) (uintptr_t) (p + min(off + u * 64 * line, nbytes - 4));
+#pragma unroll
+                    for (int u = 0; u < 16; u++) acc ^= v[u];
                 }
             }
         }
@@ -4055,8 +4096,10 @@ int measure_xcc_of_wg0(hipStream_t st) {
 }
 hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, int xcc_of_wg0, hipStream_t st) {
     static const int line = getenv("LLAMAHIP_PF_LINE") ? atoi(getenv("LLAMAHIP_PF_LINE")) : 128;
+    static const int mode = getenv("LLAMAHIP_PF_MODE") ? atoi(getenv("LLAMAHIP_PF_MODE")) : 0;          // measurement only
+    static const int nap = getenv("LLAMAHIP_PF_NAP") ? atoi(getenv("LLAMAHIP_PF_NAP")) : 1;             // poll interval in units of s_sleep(32)
     nwg = std::max(8, nwg / 8 * 8);
-    hipLaunchKernelGGL(k_prefetch, dim3(nwg), dim3(64), 0, st, ops, n_ops, prog, n_tokens, (unsigned long long) budget, line, sink, 0x9e3779b9u, xcc_of_wg0);
+    hipLaunchKernelGGL(k_prefetch, dim3(nwg), dim3(64), 0, st, ops, n_ops, prog, n_tokens, (unsigned long long) budget, line, sink, 0x9e3779b9u, xcc_of_wg0, mode, nap);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -4494,7 +4537,7 @@ bool qkv_attn_applies(const QMat &w, int d, int H, int nth) {
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           uint64_t *qat_A, const uint64_t *x_t) {
+                           uint64_t *qat_A, const uint64_t *x_t, const QMat *pf_wo, const QMat *pf_w13, uint32_t *pf_sink) {
     // x_t (overlapped decode schedule, opt-in): the input row arrives as tagged granules (slot = layer) from the launch running beside
     // this one, and the quantized attention output leaves as tagged granules (qat_A) for the wo launch that is already waiting
     const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
@@ -4521,9 +4564,16 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
                            qkv2, sc2, epoch, layer, x_t ? qat_A : nullptr };
     const int grid = gridA + H * (nsl + dh / 32);
     if (x_t && !qat_A) return hipErrorInvalidValue;
-#define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
-                        else if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
-                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); }
+    // L2 warm-up targets of the mat-vec workgroups' exit (prefetch_tail): all of wo, the leading tiles of w1|w3
+    PfTail pf{};
+    static const int pf_wo_tiles = getenv("LLAMAHIP_PF_WO_TILES") ? atoi(getenv("LLAMAHIP_PF_WO_TILES")) : 1 << 20;       // tuning (measurement): tiles per row-group
+    static const int pf_w13_tiles = getenv("LLAMAHIP_PF_W13_TILES") ? atoi(getenv("LLAMAHIP_PF_W13_TILES")) : 3;
+    if (pf_sink && pf_wo && pf_wo_tiles > 0) pf.t[0] = PfTarget{ pf_wo->tiles, (uint32_t) ((pf_wo->nchunks + 1) * TILE_BYTES), pf_wo->ngroups, std::max(1, gemv_groups_per_block(*pf_wo, 1)), std::min(pf_wo_tiles, pf_wo->nchunks) };
+    if (pf_sink && pf_w13 && pf_w13_tiles > 0) pf.t[1] = PfTarget{ pf_w13->tiles, (uint32_t) ((pf_w13->nchunks + 1) * TILE_BYTES), pf_w13->ngroups, std::max(1, gemv_groups_per_block(*pf_w13, 2)), std::min(pf_w13_tiles, pf_w13->nchunks) };
+    pf.sink = pf_sink; pf.never = 0x9e3779b9u;
+#define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, pf); \
+                        else if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, pf); \
+                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, pf); }
     if (variant == 1) LH_GOX(8, 1) else if (variant == 2) LH_GOX(10, 2) else if (variant == 3) LH_GOX(4, 2) else return hipErrorInvalidValue;
 #undef LH_GOX
     LH_LAUNCH_CHECK();

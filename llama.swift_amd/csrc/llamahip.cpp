@@ -550,6 +550,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     int n_part_x = 0;                                       // pairs in npart_a valid for the row currently in x (0: none)
     // decode: wq|wk|wv + attention as one launch with tagged hand-offs (k_qkv_attn); one forward pass = one epoch
     const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
+    static const bool tail_pf = getenv("LLAMAHIP_NO_TAIL_PREFETCH") == nullptr;       // the mat-vec workgroups of k_qkv_attn warm the L2 for wo / w1|w3 on their way out
     // decode, overlapped ("two-branch") schedule: the four launches of a layer alternate between two branches of the captured graph
     // (two streams when run eagerly) and hand their rows over as tagged granules, so that launch k + 1 is dispatched and has its first
     // weight chunks in flight while launch k still runs (DESIGN.md "overlapped decode schedule").  Branch A (this stream): wq|wk|wv +
@@ -643,7 +644,8 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             }
             if (use_qkvx) {
                 HIP_TRY(launch_qkv_attn(L.qkv, xa, L.attention_norm, np_qkv, m->d_qkv2, m->d_sc2, m->d_epoch, il - m->l0, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
-                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st), LLAMAHIP_ERR_PREDICT);
+                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st, nullptr, nullptr,
+                                        tail_pf ? &L.wo : nullptr, tail_pf ? &L.w13 : nullptr, m->d_pf_sink), LLAMAHIP_ERR_PREDICT);
             } else {
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
@@ -764,7 +766,7 @@ int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
 // The L2 prefetcher runs beside the `n_tokens` decode steps about to be issued on m->stream: launched on the second stream once
 // the main stream has reached this point, joined back after the steps (it has nothing left to fetch by then and exits).
 static bool prefetch_enabled(const llamahip_model *m) {
-    static const bool off = getenv("LLAMAHIP_NO_PREFETCH") || getenv("LLAMAHIP_OVERLAP");
+    static const bool off = getenv("LLAMAHIP_PREFETCH") == nullptr || getenv("LLAMAHIP_OVERLAP");
     return !off && m->d_pf_ops && m->d_prog && m->stream2 && m->pf_xcc0 >= 0 && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
 }
 int prefetch_begin(llamahip_model *m, int n_tokens, bool *running, char *err, size_t err_cap) {
@@ -1019,7 +1021,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
-        if (!m->dense && m->l1 > m->l0 && !getenv("LLAMAHIP_NO_PREFETCH")) {
+        HIP_TRY(hipMalloc((void **) &m->d_pf_sink, 4096), LLAMAHIP_ERR_LOAD);
+        if (!m->dense && m->l1 > m->l0 && getenv("LLAMAHIP_PREFETCH")) {          // the stand-alone L2 prefetcher beside the decode loop: opt-in (measured slower)
             // the prefetcher's schedule: the weight matrices of one decode step in launch order, with the row-groups each consumer
             // workgroup owns (what decides which XCD's L2 a tile belongs in)
             std::vector<PfOp> ops;
@@ -1041,7 +1044,6 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemcpy(m->d_pf_ops, ops.data(), ops.size() * sizeof(PfOp), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_prog, 64), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_prog, 0, 64), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMalloc((void **) &m->d_pf_sink, 256), LLAMAHIP_ERR_LOAD);
             m->pf_budget = (size_t) (getenv("LLAMAHIP_PF_BUDGET_MB") ? atof(getenv("LLAMAHIP_PF_BUDGET_MB")) : 16.0) * 1024 * 1024;
             m->pf_wgs = getenv("LLAMAHIP_PF_WGS") ? atoi(getenv("LLAMAHIP_PF_WGS")) : 128;
             m->pf_xcc0 = getenv("LLAMAHIP_PF_XCC0") ? atoi(getenv("LLAMAHIP_PF_XCC0")) : measure_xcc_of_wg0(m->stream);

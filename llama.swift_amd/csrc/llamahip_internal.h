@@ -123,7 +123,8 @@ bool qkv_attn_applies(const QMat &w, int d, int H, int nth);
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           uint64_t *qat_A = nullptr, const uint64_t *x_t = nullptr);      // x_t / qat_A: tagged row in / tagged QA out (overlapped schedule)
+                           uint64_t *qat_A = nullptr, const uint64_t *x_t = nullptr,       // x_t / qat_A: tagged row in / tagged QA out (overlapped schedule)
+                           const QMat *pf_wo = nullptr, const QMat *pf_w13 = nullptr, uint32_t *pf_sink = nullptr);   // L2 warm-up of the next launches' weights (prefetch_tail)
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
 // L2 run-ahead prefetcher of the decode step (k_prefetch): the weight matrices of one token in launch order
 struct PfOp {
