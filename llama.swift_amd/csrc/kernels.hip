@@ -80,9 +80,8 @@ __device__ __forceinline__ void store_tagged_agent(uint64_t *p, uint32_t bits, u
 }
 // Tag of a granule = {epoch of the forward pass : 24 bits | slot : 8 bits}.  slot = 0 for the embedding row, il + 1 for everything layer
 // il (counted from the handle's first layer) produces; a residual-stream row is therefore tagged with the index of the layer that
-// CONSUMES it.  The host refuses the tagged schedules on handles with more than TAG_MAX_LAYERS layers; k_bump_epoch skips the epoch
+// CONSUMES it.  The host refuses the tagged hand-offs on handles with more than TAG_MAX_LAYERS layers (llamahip_internal.h); k_bump_epoch skips the epoch
 // whose 24 low bits are zero, so no tag ever equals the zero-filled state of a fresh buffer.
-constexpr int TAG_MAX_LAYERS = 250;
 #ifndef LH_WATCH
 #define LH_WATCH 4          // granules a waiting workgroup looks at per poll (one lane each)
 #endif
@@ -784,18 +783,11 @@ struct GemvArgs {
     uint32_t *sync; int sync_blocks, sync_epoch;      // hand-off words, blocks of the producer role, 1-based epoch
     int lut_math;                                     // bit 0: evaluate SiLU instead of gathering it (verified at load time)
     uint32_t *fault;                                  // tagged operands: sticky fault word (a bounded poll that ran out)
-    // overlapped decode schedule (launch_gemv_ov): operands / results as tagged granules; `sync` -> the epoch word, slots as make_tag
-    const uint64_t *in_t;   int slot_in;              // PREP_NORM_TAG: the fp32 row [K]
-    const uint64_t *resid_t; int slot_resid;          // EPI_RESID_TAG: the residual row [M]
-    uint64_t *out_t;        int slot_out;             // EPI_RESID_TAG: y [M]; EPI_SILU_QAT: [block][9] (8 chain dwords + scale)
-    uint32_t *prog;                                   // decode: launch counter the L2 prefetcher follows (k_prefetch), or null
+    // residual-stream rows handed between pipeline stages through a device-side mailbox: tagged granules; `sync` -> the epoch word
+    const uint64_t *in_t;   int slot_in;              // PREP_NORM_TAG: the fp32 row [K] arrives tagged
+    const uint64_t *resid_t; int slot_resid;          // EPI_RESID_TAG: the residual row [M] arrives tagged (null: plain `resid`)
+    uint64_t *out_t;        int slot_out;             // EPI_RESID_TAG: y [M] also leaves tagged (null: plain `y` only)
 };
-// the first workgroup of every weight-streaming launch of the decode step counts the launch in: the prefetcher reads how far the
-// step has come (one relaxed device-scope add per launch; nobody waits for it)
-__device__ __forceinline__ void count_launch(uint32_t *prog) {
-    if (prog && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int PRE, int EPI, int D, bool RING, int PG>
 __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, const int nw, double *smem_d) {
     const uint8_t *__restrict__ wt = ga.wt;
@@ -807,9 +799,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     uint32_t *__restrict__ out_A = ga.out_A; float *__restrict__ out_d = ga.out_d;
     const f64x2 *__restrict__ part_in = ga.part_in; f64x2 *__restrict__ part_out = ga.part_out;
     // (EPI_STORE_TAG: the tag of this launch's output granules, read up front -- not a dependent load at the tail)
-    constexpr bool TAGGED = (EPI == EPI_STORE_TAG || PRE == PRE_QA_TAG || PRE == PREP_NORM_TAG || EPI == EPI_RESID_TAG || EPI == EPI_SILU_QAT);
+    constexpr bool TAGGED = (EPI == EPI_STORE_TAG || PRE == PREP_NORM_TAG || EPI == EPI_RESID_TAG);
     const uint32_t epoch_ = TAGGED ? __builtin_nontemporal_load(ga.sync) : 0u;
-    const uint32_t store_tag = make_tag(epoch_, ga.sync_epoch + 1);        // EPI_STORE_TAG output / PRE_QA_TAG operand: layer ga.sync_epoch
+    const uint32_t store_tag = make_tag(epoch_, ga.sync_epoch + 1);        // EPI_STORE_TAG output of layer ga.sync_epoch
     const uint32_t tag_in = make_tag(epoch_, ga.slot_in), tag_resid = make_tag(epoch_, ga.slot_resid), tag_out = make_tag(epoch_, ga.slot_out);
     // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
     // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
@@ -992,63 +984,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         if (i < PADC * 64) ldsA[nchunks * 64 + i] = 0u;
         else ldsD[nchunks * 8 + (i - PADC * 64)] = 0.0f;
     }
-    if (PRE == PRE_QA_TAG) {
-        // the quantized activation row comes from workgroups of the SAME launch (other XCDs) as tagged 8-byte granules
-        // {dword, tag}: qa_A -> nchunks * 64 of them, qa_d -> nchunks * 8.  Every thread polls its own granules, four
-        // loads in flight per round; the weights of this workgroup are already on their way (phase 2).
-        const uint64_t *ta = (const uint64_t *) qa_A;            // [block][9] granules: 8 chain dwords + the scale
-        const int na = nchunks * 64, ntot = na + nchunks * 8;
-        const bool nowait = (ga.lut_math & 0x100) != 0;              // (measurement-only switch, results invalid)
-        // Throttle: 128 workgroups polling 9 KB each through the fabric would compete with the mat-vec that is still streaming
-        // (measured: the launch got SLOWER).  Only wave 0 watches the scale granules (1 KB, the last thing a producer writes),
-        // sleeping between looks; when they are all there the whole workgroup runs the tag-checked copy, which then passes
-        // on its first or second round.
-        if (wave == 0 && !nowait) {
-            // (a SAMPLE of the scale granules, LH_WATCH of them spread over the row: every look of every waiting workgroup is a line
-            //  fetched through the fabric next to the producer's weight stream -- 256 workgroups watching all 344 scales of the FFN
-            //  activation measured as 12 us on the producer)
-            const int nbl = K >> 5;
-            int spins = 0;
-            for (;;) {
-                bool ok = true;
-                if (lane < LH_WATCH) ok = (uint32_t) (__hip_atomic_load(ta + (size_t) ((2 * lane + 1) * nbl / (2 * LH_WATCH)) * 9 + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == store_tag;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > ((ga.lut_math & 0x1000) ? (1 << 6) : (1 << 18)) || ((spins & 255) == 0 && __hip_atomic_load(ga.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) break;             // (the copy below raises the fault word if the data never comes; 0x1000: fault-injection test)
-            }
-        }
-        __syncthreads();
-        for (int base = 0; base < ntot; base += nt * 4) {
-            uint64_t v[4] = { 0, 0, 0, 0 };
-            int spins = 0;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int gi = base + tid + u * nt;
-                    if (active && gi < ntot) {
-                        // granule of LDS dword gi = (chunk cc, chain kk, block j): the producer of block cc * 8 + j wrote its 8 chain dwords
-                        // and its scale as 9 CONTIGUOUS granules (one 72-byte write-through burst per producer, not 9 scattered ones)
-                        const int blk_ = gi < na ? ((gi >> 6) * 8 + (gi & 7)) : (gi - na);
-                        const int src = gi < na ? (blk_ * 9 + ((gi >> 3) & 7)) : (blk_ * 9 + 8);
-                        if (blk_ < (K >> 5)) {                   // (blocks that pad K to a multiple of 256 have no producer: zero)
-                            v[u] = __hip_atomic_load(ta + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && (uint32_t) (v[u] >> 32) == store_tag;
-                        }
-                    }
-                }
-                if (ok || nowait) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (poll_give_up(spins, (ga.lut_math & 0x1000) ? (1 << 8) : (1 << 20), ga.fault)) break;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int gi = base + tid + u * nt;
-                if (active && gi < ntot) { if (gi < na) ldsA[gi] = (uint32_t) v[u]; else ldsD[gi - na] = __builtin_bit_cast(float, (uint32_t) v[u]); }
-            }
-        }
-        __syncthreads();
-    } else if (PRE == PRE_QA) {
+    if (PRE == PRE_QA) {
 #pragma unroll
         for (int u = 0; u < MAXQA; u++) { const int gi = tid + u * nt; if (active && gi < nchunks * 16) ((u32x4 *) ldsA)[gi] = qg[u]; }
 #pragma unroll
@@ -1241,7 +1177,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     int lg = g;
     if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
     const int m = lg * 8 + (lane >> 3);
-    if (EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) {
+    if (EPI == EPI_SILU_QA) {
         // 8 waves: waves 0-3 hold gate rows b*32 .. b*32+31, waves 4-7 the matching up rows (b = blockIdx.x)
         float *gu = (float *) red;                      // prologue scratch is free again
         if (!(ga.lut_math & 8)) __syncthreads();
@@ -1261,13 +1197,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
             const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
             const int b = blk, c = b >> 3, j = b & 7;
             const uint32_t dw = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
-            if (EPI == EPI_SILU_QAT) {
-                // read by the w2 launch that runs beside this one (polling): 9 contiguous write-through granules {dword, tag} per
-                // Q4_0 block -- its 8 chain dwords, then its scale (the consumer watches the scales)
-                if (lane < 8) store_tagged_agent(ga.out_t + (b * 9 + kk), dw, tag_out);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the scale leaves after the dwords it announces)
-                if (lane == 0) store_tagged_agent(ga.out_t + (b * 9 + 8), __builtin_bit_cast(uint32_t, dd), tag_out);
-            } else {
+            {
                 if (lane < 8) out_A[(c * 8 + kk) * 8 + j] = dw;
                 if (lane == 0) out_d[b] = dd;
             }
@@ -1323,10 +1253,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
 
 
 template <int PRE, int EPI, int D, bool RING, int PG>
-__global__ void __launch_bounds__((EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) ? 512 : 256, (EPI == EPI_SILU_QA || EPI == EPI_SILU_QAT) ? 4 : 1)
+__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256, EPI == EPI_SILU_QA ? 4 : 1)
 k_gemv(const GemvArgs ga) {
     extern __shared__ double smem_d[];
-    count_launch(ga.prog);
     gemv_body<PRE, EPI, D, RING, PG>(ga, blockIdx.x, blockDim.x >> 6, smem_d);
 }
 
@@ -3129,7 +3058,6 @@ struct AttnXArgs {
     // k_qkv_attn only: data-tagged hand-offs.  qkv2[3 d] / sc2[H][n_ctx] hold {fp32 bits, tag} 8-byte granules,
     // tag = make_tag(epoch[0], layer + 1): a reader polls the granule itself until the tag is this launch's
     const uint64_t *qkv2; uint64_t *sc2; const uint32_t *epoch; int layer;
-    uint64_t *qat_A;              // non-null (overlapped schedule): the quantized attention output leaves as [block][9] tagged granules for the wo launch
 };
 // role of workgroup (h, yy): yy < ncb: soft_max . V for column block yy; else scores for key slice yy - ncb.
 // QKV_WAIT (k_qkv_attn): the head's q / k / v rows come from mat-vec workgroups of the SAME launch as tagged granules
@@ -3337,16 +3265,8 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
         const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
         const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
         const uint32_t dwq = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
-        if (QKV_WAIT && aa.qat_A) {
-            // consumed by the wo role of this launch on all XCDs: 9 contiguous write-through granules {dword, tag} per Q4_0 block
-            // (its 8 chain dwords, then its scale)
-            const uint32_t tagq = make_tag(aa.epoch[0], aa.layer + 1);
-            if (tid < 8) __hip_atomic_store(aa.qat_A + (b * 9 + kk), (uint64_t) dwq | ((uint64_t) tagq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0) __hip_atomic_store(aa.qat_A + (b * 9 + 8), (uint64_t) __builtin_bit_cast(uint32_t, dd) | ((uint64_t) tagq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
         if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = dwq;
         if (tid == 0) qa_d[b] = dd;
-        }
     }
     // the last soft_max . V workgroup of the head to get here clears the counters for the next launch (every one of them
     // has passed the poll, every score workgroup has arrived: nobody touches them again in this launch)
@@ -3376,130 +3296,20 @@ k_dec_attn_x(const AttnXArgs aa) {
 // of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
-// L2 warm-up of the NEXT launches' weights by the mat-vec workgroups of k_qkv_attn, on their way out.  While the attention roles of
-// the launch walk their dependent chain (scores -> soft_max -> V*P: about 6 us at 7B), HBM idles and these workgroups are done.
-// Workgroup b of this launch and workgroup b' of the next launch of the same stream run on the same XCD when b = b' (mod 8) (the
-// round-robin restarts with every launch, at an XCD fixed per queue: tools/xcd_dispatch_probe.hip), and what one launch leaves in an
-// XCD's L2 is still there for the next (tools/l2_prefetch_probe.hip: a 64 KiB region read in 0.7 us instead of 2.7).  So each
-// mat-vec workgroup touches one dword per 128-byte line of the leading tiles of the row-groups that consumer workgroups of ITS
-// residue class will stream: all of wo, the first tiles of w1|w3.  It writes nothing and nobody waits for it: a wrong guess about
-// placement costs speed, never a result.
-struct PfTarget { const uint8_t *base; uint32_t group_bytes; int32_t ngroups, gpb, tiles; };       // tiles: leading tiles of every row-group (0: nothing)
-struct PfTail { PfTarget t[2]; uint32_t *sink; uint32_t never; };
-__device__ __forceinline__ void prefetch_tail(const PfTail &pf, const int b, const int nmates) {
-    const int x = b & 7, j = b >> 3, tid = threadIdx.x;
-    uint32_t acc = 0;
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const PfTarget t = pf.t[q];
-        if (t.tiles <= 0) continue;
-        const int nblk = (t.ngroups + t.gpb - 1) / t.gpb, cnt = (nblk - x + 7) / 8;
-        const int lines_g = t.tiles * (TILE_BYTES / 128);                  // lines per row-group
-        for (int i = j; i < cnt; i += nmates) {
-            const int g0 = (x + 8 * i) * t.gpb, ng = min(t.gpb, t.ngroups - g0);
-            const int total = ng * lines_g;
-            for (int l0 = 0; l0 < total; l0 += 256 * 4) {
-                uint32_t v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int l = min(l0 + u * 256 + tid, total - 1), g = g0 + l / lines_g, o = (l % lines_g) * 128;
-                    v[u] = *(const __attribute__((address_space(1))) uint32_t *) (uintptr_t) (t.base + (size_t) g * t.group_bytes + o);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) acc ^= v[u];
-            }
-        }
-    }
-    if (acc == pf.never && pf.sink) pf.sink[tid] = acc;            // (keeps the loads alive)
-}
-
 template <int PRE, int D, int PG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG == 1 ? 4 : 3)))
-k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H, const PfTail pf) {
+k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
     extern __shared__ double smem_d[];
-    count_launch(ga.prog);
     const int b = blockIdx.x;
     if (b < gridA) {
         const int ncb = aa.dh / 32, wph = 3 * ncb;
         const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
         const int h = xcd + 8 * j;
         gemv_body<PRE, EPI_STORE_TAG, D, true, PG>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules
-        prefetch_tail(pf, b, gridA >> 3);
         return;
     }
     const int a = b - gridA, h = a % H, y = a / H;            // y < dh / 32: soft_max . V (their V prefetch starts with the mat-vec), then the score slices
     attn_x_body<true>(aa, h, y, smem_d);
-}
-
-// ------------------------------------------------------------------------------------------------
-// L2 run-ahead prefetcher of the decode step.  Every launch boundary of the step is an all-to-all dependency, and while a launch
-// ramps up, runs its prologue / epilogue or walks the attention chain, HBM idles (DESIGN.md "decode: where the time goes").  What can
-// be done ahead of any dependency is fetching the NEXT launches' weights.  This kernel runs beside the whole decode loop on a second
-// stream (one wave per workgroup, a few registers, no LDS) and touches one dword per cache line of the weight tiles in launch order,
-// keeping at most `budget` bytes ahead of the launch that is running (count_launch): the 8 x 4 MiB of L2 are the run-ahead buffer.
-// A workgroup asks the hardware which XCD it runs on and fetches exactly the tiles the consumer workgroups of that XCD will read
-// (consumer workgroup b runs on XCD b % 8; k_qkv_attn places heads), because the L2s are per XCD.  Nothing waits for this kernel and
-// it writes nothing anybody reads: if a placement assumption is wrong, or it falls behind, only speed is lost.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-k_prefetch(const PfOp *__restrict__ ops, const int n_ops, const uint32_t *prog, const int n_tokens, const unsigned long long budget,
-           const int line, uint32_t *__restrict__ sink, const uint32_t never, const int xcc_of_wg0, const int mode, const int nap) {
-    // mode (measurement): 0 normal | 1 follow the launch counter but fetch nothing | 2 fetch everything, never look at the counter
-    // consumer workgroup b runs on the XCD with HW_REG_XCC_ID (xcc_of_wg0 + b) % 8: the round-robin restarts with every launch at
-    // an XCD that depends on the QUEUE (measured: tools/xcd_dispatch_probe.hip), so the host measures it on the consumers' stream
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const int xcd = (int) ((xcc - (uint32_t) xcc_of_wg0) & 7u), j = blockIdx.x >> 3, nj = max(1, (int) (gridDim.x >> 3)), lane = threadIdx.x;
-    const unsigned long long token_bytes = ops[n_ops - 1].cum_start + ops[n_ops - 1].bytes;
-    uint32_t acc = 0;
-    unsigned long long allowed = 0;            // absolute byte position (tokens x token_bytes + position in the token) fetching may reach
-    long waited = 0;
-    for (int t = 0; t < n_tokens; t++) {
-        for (int q = 0; q < n_ops; q++) {
-            const PfOp op = ops[q];
-            const int nblk = (op.ngroups + op.gpb - 1) / op.gpb;
-            // consumer workgroups of this op that run on this XCD
-            const int per_h = op.mode == 1 ? (nblk / op.hdiv) * op.ncb : 0;          // mode 1: blocks per head = (q, k, v) x (dh / 32)
-            const int cnt = op.mode == 1 ? (op.hdiv / op.ncb / 8) * per_h : (nblk - xcd + 7) / 8;
-            const unsigned long long base_abs = (unsigned long long) t * token_bytes + op.cum_start;
-            if (mode != 2) {   // fallen behind?  A launch that has already been followed by the next one needs no prefetching any more
-                const uint32_t c = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                allowed = (unsigned long long) (c / (unsigned) n_ops) * token_bytes + ops[c % (unsigned) n_ops].cum_start + budget;
-                if ((unsigned long long) t * (unsigned) n_ops + (unsigned) q + 1ull < (unsigned long long) c) continue;
-            }
-            for (int i = j; i < cnt; i += nj) {
-                int b;
-                if (op.mode == 1) {             // i -> (head of this XCD, matrix, part): gemv block mat * hdiv + h * ncb + sub
-                    const int jj = i / per_h, r = i % per_h, mat = r / op.ncb, sub = r % op.ncb;
-                    b = mat * op.hdiv + (xcd + 8 * jj) * op.ncb + sub;
-                } else b = xcd + 8 * i;
-                // throttle: stay within `budget` bytes of the end of the launch that is running
-                const unsigned long long pos = base_abs + op.bytes / (unsigned) cnt * (unsigned) i;
-                while (mode != 2 && pos > allowed) {
-                    const uint32_t c = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    allowed = (unsigned long long) (c / (unsigned) n_ops) * token_bytes + ops[c % (unsigned) n_ops].cum_start + budget;
-                    if (pos <= allowed) break;
-                    for (int z = 0; z < nap; z++) __builtin_amdgcn_s_sleep(32);
-                    if (++waited > (1L << 22)) return;            // (the decode loop stopped: nothing left to run ahead of)
-                }
-                if (mode == 1) continue;
-                const int g0 = b * op.gpb, ng = min(op.gpb, op.ngroups - g0);
-                if (ng <= 0) continue;
-                const uint8_t *p = op.base + (size_t) g0 * op.group_bytes;
-                const int nbytes = ng * (int) op.group_bytes;
-                // one dword per line, 16 wave-loads in flight.  Branch-free (offsets past the end are clamped to the last line): a
-                // predicated load compiles to a branch with a full vmcnt(0) wait behind it, i.e. ONE load in flight per wave.
-                for (int off = lane * line; off < nbytes; off += 64 * line * 16) {
-                    uint32_t v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) v[u] = *(const __attribute__((address_space(1))) uint32_t *) (uintptr_t) (p + min(off + u * 64 * line, nbytes - 4));
-#pragma unroll
-                    for (int u = 0; u < 16; u++) acc ^= v[u];
-                }
-            }
-        }
-    }
-    if (acc == never && sink) sink[lane] = acc;          // (keeps the loads alive; `never` is a value the host picks at random)
 }
 
 // load-time self-test of the assumption above: out[b] = XCC_ID of workgroup b of a (H, Y) grid
@@ -3726,9 +3536,6 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
     LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
     LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
-    LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 16, false, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 8, true, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 10, true, 1>));
-    LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 16, true, 1>)); LH_ATTR((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, 22, true, 1>));
-    LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 16, false, 1>)); LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, 8, true, 1>));
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
@@ -3839,10 +3646,6 @@ hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_str
     return hipSuccess;
 }
 
-// decode: the launch counter of the forward pass being issued on this thread (set_decode_progress), or null
-static thread_local uint32_t *t_prog = nullptr;
-void set_decode_progress(uint32_t *prog) { t_prog = prog; }
-
 static int pick_waves(int ngroups) {
     static const int ovr = getenv("LLAMAHIP_WAVES") ? atoi(getenv("LLAMAHIP_WAVES")) : 0;      // tuning override (measurement only)
     if (ovr == 1 || ovr == 2 || ovr == 4) return ovr;
@@ -3893,7 +3696,6 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
     lds = (lds + 15) & ~(size_t) 15;
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d,
                     (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out, nullptr, 0, 0, g_lut_math };
-    ga.prog = t_prog;
 #define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, ga)
     if (np.out && grid > NORM_PART_MAX) return hipErrorInvalidValue;
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
@@ -4007,110 +3809,6 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
     if (pre == PREP_SILU_MUL && epi == EPI_RESID) return launch_gemv_t<PREP_SILU_MUL, EPI_RESID>(LH_ARGS);
 #undef LH_ARGS
     return hipErrorInvalidValue;
-}
-
-// ---- overlapped decode schedule (llamahip.cpp forward(), "two-branch"): the decode mat-vecs whose operands arrive and whose
-// results leave as tagged granules, so that a launch can start (dispatch its workgroups, put its first D weight chunks in flight)
-// while its producer is still running on the other branch of the captured graph.
-//   resid role (wo, w2): PRE_QA_TAG  [block][9] granules  ->  y + residual as tagged row (+ plain y, + norm partial sums on request)
-//   silu role  (w1|w3) : PREP_NORM_TAG tagged row         ->  SiLU(gate) * up quantized, [block][9] granules
-static int ov_depth(const char *env, int dflt) {
-    const char *e = getenv(env);
-    return e ? atoi(e) : dflt;
-}
-static int ov_resid_waves(const QMat &w) { return w.ngroups >= 1024 ? 4 : w.ngroups >= 512 ? 2 : 1; }
-static int ov_resid_depth(const QMat &w) {
-    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) return 0;            // whole row in flight
-    static const int ovr = ov_depth("LLAMAHIP_OV_DEPTH_RESID", 0);                        // measurement: 8 | 10 | 16 | 22
-    const int D = ovr ? ovr : pick_depth(w.nchunks, w.ngroups);
-    return (D == 8 || D == 10 || D == 16 || D == 22) ? D : -1;
-}
-static int ov_silu_depth(const QMat &w) {
-    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) return 0;
-    static const int ovr = ov_depth("LLAMAHIP_OV_DEPTH_SILU", 0);                         // measurement: 4 | 8
-    const int D = ovr ? ovr : pick_depth(w.nchunks, w.ngroups);
-    return (D == 4 || D == 8) ? D : -1;
-}
-bool gemv_ov_applies(const QMat &wo, const QMat &w13, const QMat &w2, int n_layers) {
-    if (n_layers < 1 || n_layers > TAG_MAX_LAYERS) return false;
-    for (const QMat *w : { &wo, &w2 }) {
-        if (w->gmapF8 || w->K % 32 != 0 || w->M != w->ngroups * 8 || ov_resid_depth(*w) < 0) return false;
-        if ((w->ngroups + ov_resid_waves(*w) - 1) / ov_resid_waves(*w) > NORM_PART_MAX) return false;
-    }
-    if (!w13.gmapF8 || w13.ngroups % 8 != 0 || w13.K / 16 > 512 || w13.K % 64 != 0 || w13.K < 64 || ov_silu_depth(w13) < 0) return false;
-    if (wo.M != w13.K || w2.M != w13.K || wo.K != w13.K || w2.K * 2 != w13.M) return false;
-    return true;
-}
-int gemv_ov_resid_parts(const QMat &w) { const int nw = ov_resid_waves(w); return (w.ngroups + nw - 1) / nw; }
-hipError_t launch_gemv_ov_resid(const QMat &w, const OvArgs &o, hipStream_t st) {
-    const int nw = ov_resid_waves(w), grid = (w.ngroups + nw - 1) / nw, D = ov_resid_depth(w);
-    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
-    lds = (lds + 15) & ~(size_t) 15;
-    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, (const uint32_t *) o.in_t, nullptr, nullptr, nullptr, w.K, o.y_plain, nullptr, o.T_silu, nullptr, nullptr,
-                    nullptr, 0, (f64x2 *) o.part_out, o.epoch, 0, o.layer, g_lut_math | o.test_bits, o.fault };
-    ga.resid_t = o.resid_t; ga.slot_resid = o.slot_resid; ga.out_t = o.out_t; ga.slot_out = o.slot_out; ga.prog = t_prog;
-#define LH_GO(D_, RING) hipLaunchKernelGGL((k_gemv<PRE_QA_TAG, EPI_RESID_TAG, D_, RING, 1>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D_) * 288 : 0), st, ga)
-    switch (D) {
-        case 0:  LH_GO(16, false); break;
-        case 8:  LH_GO(8, true); break;
-        case 10: LH_GO(10, true); break;
-        case 16: LH_GO(16, true); break;
-        case 22: LH_GO(22, true); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef LH_GO
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-hipError_t launch_gemv_ov_silu(const QMat &w, const float *norm_w, const OvArgs &o, hipStream_t st) {
-    const int nw = 8, grid = w.ngroups / 8, D = ov_silu_depth(w);
-    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
-    lds = (lds + 15) & ~(size_t) 15;
-    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // 0: the reference's two-pass statistics
-    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, nullptr, norm_w, w.K, nullptr, nullptr, o.T_silu, nullptr, nullptr,
-                    nullptr, norm_mode == 0 ? -1 : 0, nullptr, o.epoch, 0, o.layer, g_lut_math | o.test_bits, o.fault };
-    ga.in_t = o.in_t; ga.slot_in = o.slot_in; ga.out_t = o.out_t; ga.slot_out = o.slot_out; ga.prog = t_prog;
-#define LH_GO(D_, RING) hipLaunchKernelGGL((k_gemv<PREP_NORM_TAG, EPI_SILU_QAT, D_, RING, 1>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D_) * 288 : 0), st, ga)
-    switch (D) {
-        case 0: LH_GO(16, false); break;
-        case 4: LH_GO(4, true); break;
-        case 8: LH_GO(8, true); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef LH_GO
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-// HW_REG_XCC_ID of workgroup 0 of a launch on `st` (-1: could not tell)
-int measure_xcc_of_wg0(hipStream_t st) {
-    uint32_t *d_out = nullptr, h = 0xffffffffu;
-    if (hipMalloc((void **) &d_out, 4) != hipSuccess) return -1;
-    bool ok = hipMemsetAsync(d_out, 0xff, 4, st) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(k_xcd_selftest, dim3(1), dim3(64), 0, st, d_out);
-        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h, d_out, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-    }
-    (void) hipFree(d_out);
-    return ok && h < 8u ? (int) h : -1;
-}
-hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, int xcc_of_wg0, hipStream_t st) {
-    static const int line = getenv("LLAMAHIP_PF_LINE") ? atoi(getenv("LLAMAHIP_PF_LINE")) : 128;
-    static const int mode = getenv("LLAMAHIP_PF_MODE") ? atoi(getenv("LLAMAHIP_PF_MODE")) : 0;          // measurement only
-    static const int nap = getenv("LLAMAHIP_PF_NAP") ? atoi(getenv("LLAMAHIP_PF_NAP")) : 1;             // poll interval in units of s_sleep(32)
-    nwg = std::max(8, nwg / 8 * 8);
-    hipLaunchKernelGGL(k_prefetch, dim3(nwg), dim3(64), 0, st, ops, n_ops, prog, n_tokens, (unsigned long long) budget, line, sink, 0x9e3779b9u, xcc_of_wg0, mode, nap);
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-// row-groups per consumer workgroup of the decode launches, for the prefetcher's schedule (mirrors the launchers above)
-int gemv_groups_per_block(const QMat &w, int role) {        // role 0: norm prologue + store (wq|wk|wv, lm head), 1: QA + residual (wo, w2), 2: w1|w3
-    if (role == 2) return w.gmapF8 ? 8 : pick_waves(w.ngroups);
-    if (role == 1) { int pg = 0; const int nw = gemv_pick_nw_qa(w, &pg); return nw ? nw : 1; }
-    int nw = pick_waves(w.ngroups);
-    const int need = w.K / 16;
-    while (nw < 4 && need > nw * 64) nw *= 2;
-    return nw;
 }
 
 template <int NC>
@@ -4537,9 +4235,8 @@ bool qkv_attn_applies(const QMat &w, int d, int H, int nth) {
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           uint64_t *qat_A, const uint64_t *x_t, const QMat *pf_wo, const QMat *pf_w13, uint32_t *pf_sink) {
-    // x_t (overlapped decode schedule, opt-in): the input row arrives as tagged granules (slot = layer) from the launch running beside
-    // this one, and the quantized attention output leaves as tagged granules (qat_A) for the wo launch that is already waiting
+                           const uint64_t *x_t) {
+    // x_t (first layer of a pipeline stage fed through a device-side mailbox): the input row arrives as tagged granules, slot 0
     const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // as launch_gemv
@@ -4558,22 +4255,13 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) < 2) ? 0x1000 : 0;     // (2: the wo launch of the overlapped schedule misbehaves instead)
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
                     (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
-    if (x_t) { ga.in_t = x_t; ga.slot_in = layer; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; }
-    ga.prog = t_prog;
+    if (x_t) { ga.in_t = x_t; ga.slot_in = 0; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; }
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep | fault_test,
-                           qkv2, sc2, epoch, layer, x_t ? qat_A : nullptr };
+                           qkv2, sc2, epoch, layer };
     const int grid = gridA + H * (nsl + dh / 32);
-    if (x_t && !qat_A) return hipErrorInvalidValue;
-    // L2 warm-up targets of the mat-vec workgroups' exit (prefetch_tail): all of wo, the leading tiles of w1|w3
-    PfTail pf{};
-    static const int pf_wo_tiles = getenv("LLAMAHIP_PF_WO_TILES") ? atoi(getenv("LLAMAHIP_PF_WO_TILES")) : 1 << 20;       // tuning (measurement): tiles per row-group
-    static const int pf_w13_tiles = getenv("LLAMAHIP_PF_W13_TILES") ? atoi(getenv("LLAMAHIP_PF_W13_TILES")) : 3;
-    if (pf_sink && pf_wo && pf_wo_tiles > 0) pf.t[0] = PfTarget{ pf_wo->tiles, (uint32_t) ((pf_wo->nchunks + 1) * TILE_BYTES), pf_wo->ngroups, std::max(1, gemv_groups_per_block(*pf_wo, 1)), std::min(pf_wo_tiles, pf_wo->nchunks) };
-    if (pf_sink && pf_w13 && pf_w13_tiles > 0) pf.t[1] = PfTarget{ pf_w13->tiles, (uint32_t) ((pf_w13->nchunks + 1) * TILE_BYTES), pf_w13->ngroups, std::max(1, gemv_groups_per_block(*pf_w13, 2)), std::min(pf_w13_tiles, pf_w13->nchunks) };
-    pf.sink = pf_sink; pf.never = 0x9e3779b9u;
-#define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, pf); \
-                        else if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, pf); \
-                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, pf); }
+#define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
+                        else if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
+                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); }
     if (variant == 1) LH_GOX(8, 1) else if (variant == 2) LH_GOX(10, 2) else if (variant == 3) LH_GOX(4, 2) else return hipErrorInvalidValue;
 #undef LH_GOX
     LH_LAUNCH_CHECK();

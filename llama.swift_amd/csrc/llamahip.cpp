@@ -172,16 +172,7 @@ struct llamahip_model {
     bool prompt_copies = false;          // the row-lane / matrix-core copies of the layer matrices exist (ensure_prompt_copies)
     uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
-    uint64_t *d_qat_A = nullptr;         // ... and the quantized attention output for the wo launch of the overlapped schedule: [Kp_d / 32][9] granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
-    // overlapped ("two-branch") decode schedule: the residual stream and the FFN activation as tagged granules, the second branch
-    uint64_t *d_xt = nullptr, *d_x1t = nullptr, *d_qa2t = nullptr;   // [d], [d], [Kp_F / 32][9]
-    hipStream_t stream2 = nullptr;       // second branch of that schedule / the stream the L2 prefetcher runs on
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // L2 run-ahead prefetcher of the decode step (k_prefetch): schedule, launch counter, tuning
-    PfOp *d_pf_ops = nullptr; int n_pf_ops = 0;
-    uint32_t *d_prog = nullptr, *d_pf_sink = nullptr;
-    size_t pf_budget = 0; int pf_wgs = 0, pf_xcc0 = -1;     // pf_xcc0: the XCD workgroup 0 of a launch on `stream` lands on
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
@@ -228,11 +219,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    free_dev(d_xt); free_dev(d_x1t); free_dev(d_qa2t); free_dev(d_pf_ops); free_dev(d_prog); free_dev(d_pf_sink);
-    if (ev_fork) (void) hipEventDestroy(ev_fork);
-    if (ev_join) (void) hipEventDestroy(ev_join);
-    if (stream2) (void) hipStreamDestroy(stream2);
-    free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_qat_A);
+    free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
@@ -549,69 +536,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     const bool use_part = fused && m->w13_interleaved && !no_norm_part;
     int n_part_x = 0;                                       // pairs in npart_a valid for the row currently in x (0: none)
     // decode: wq|wk|wv + attention as one launch with tagged hand-offs (k_qkv_attn); one forward pass = one epoch
-    const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
-    static const bool tail_pf = getenv("LLAMAHIP_NO_TAIL_PREFETCH") == nullptr;       // the mat-vec workgroups of k_qkv_attn warm the L2 for wo / w1|w3 on their way out
-    // decode, overlapped ("two-branch") schedule: the four launches of a layer alternate between two branches of the captured graph
-    // (two streams when run eagerly) and hand their rows over as tagged granules, so that launch k + 1 is dispatched and has its first
-    // weight chunks in flight while launch k still runs (DESIGN.md "overlapped decode schedule").  Branch A (this stream): wq|wk|wv +
-    // attention, w1|w3.  Branch B: embedding | stage input, wo, w2, lm head.  Results are those of the one-branch schedule.
-    // decode launches count themselves in for the L2 prefetcher (harmless when none is running)
-    struct ProgGuard { ProgGuard(uint32_t *p) { set_decode_progress(p); } ~ProgGuard() { set_decode_progress(nullptr); } } prog_guard(fused ? m->d_prog : nullptr);
-    static const bool no_overlap = getenv("LLAMAHIP_OVERLAP") == nullptr;
-    if (use_qkvx && !no_overlap && m->d_xt && m->stream2 && m->w13_interleaved &&
-        gemv_ov_applies(m->layers[0].wo, m->layers[0].w13, m->layers[0].w2, m->l1 - m->l0)) {
-        hipStream_t sb = m->stream2;
-        static const int test_bits = getenv("LLAMAHIP_HANDOFF_FAULT_TEST") ? atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) : 0;      // 2: the wo launch publishes a tag nobody waits for (test only)
-        HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
-        if (!m->first_stage && !x_first) HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
-        HIP_TRY(hipEventRecord(m->ev_fork, st), LLAMAHIP_ERR_PREDICT);
-        HIP_TRY(hipStreamWaitEvent(sb, m->ev_fork, 0), LLAMAHIP_ERR_PREDICT);
-        if (m->first_stage) {
-            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, sb, m->d_epoch, m->d_xt), LLAMAHIP_ERR_PREDICT);
-        } else {
-            HIP_TRY(launch_tag_row(x_first ? x_first : m->x, d, m->d_epoch, m->d_xt, sb), LLAMAHIP_ERR_PREDICT);
-        }
-        const int nl = m->l1 - m->l0;
-        for (int li = 0; li < nl; li++) {
-            const Layer &L = m->layers[li];
-            const size_t kv_at = ((size_t) m->cur_seq * nl + li) * C * d;
-            float *Kl = m->Kc + kv_at, *Vl = m->Vc + kv_at;
-            const bool last = li == nl - 1;
-            // A: wq|wk|wv + attention: row in <- xt (slot li), quantized attention output -> qat (slot li + 1)
-            HIP_TRY(launch_qkv_attn(L.qkv, nullptr, L.attention_norm, NormPart(), m->d_qkv2, m->d_sc2, m->d_epoch, li, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
-                                    m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st, m->d_qat_A, m->d_xt), LLAMAHIP_ERR_PREDICT);
-            // B: wo: qat -> x1t (slot li + 1), residual xt (slot li)
-            OvArgs ow;
-            ow.epoch = m->d_epoch; ow.fault = m->d_fault; ow.layer = li; ow.T_silu = m->T_silu;
-            ow.in_t = m->d_qat_A; ow.resid_t = m->d_xt; ow.slot_resid = li; ow.out_t = m->d_x1t; ow.slot_out = li + 1;
-            if (test_bits == 2) ow.test_bits = 0x2000;
-            else if (test_bits) ow.test_bits = 0x1000;
-            HIP_TRY(launch_gemv_ov_resid(L.wo, ow, sb), LLAMAHIP_ERR_PREDICT);
-            // A: w1|w3: x1t (slot li + 1) -> qa2t (slot li + 1)
-            OvArgs o13;
-            o13.epoch = m->d_epoch; o13.fault = m->d_fault; o13.layer = li; o13.T_silu = m->T_silu;
-            o13.in_t = m->d_x1t; o13.slot_in = li + 1; o13.out_t = m->d_qa2t; o13.slot_out = li + 1;
-            if (test_bits) o13.test_bits = 0x1000;
-            HIP_TRY(launch_gemv_ov_silu(L.w13, L.ffn_norm, o13, st), LLAMAHIP_ERR_PREDICT);
-            // B: w2: qa2t -> xt (slot li + 1 = the next layer's input), residual x1t; the last layer also leaves the row in plain form
-            // (lm head / stage output, both behind a kernel boundary on this branch) with its norm statistics
-            OvArgs o2;
-            o2.epoch = m->d_epoch; o2.fault = m->d_fault; o2.layer = li; o2.T_silu = m->T_silu;
-            o2.in_t = m->d_qa2t; o2.resid_t = m->d_x1t; o2.slot_resid = li + 1; o2.out_t = m->d_xt; o2.slot_out = li + 1;
-            if (test_bits) o2.test_bits = 0x1000;
-            if (last) { o2.y_plain = x_last ? x_last : m->x; if (m->last_stage) o2.part_out = m->npart_a; }
-            HIP_TRY(launch_gemv_ov_resid(L.w2, o2, sb), LLAMAHIP_ERR_PREDICT);
-        }
-        if (m->last_stage) {
-            NormPart np_out;
-            const int p2 = gemv_ov_resid_parts(m->layers[nl - 1].w2);
-            if (p2 > 0 && p2 <= NORM_PART_MAX) { np_out.in = m->npart_a; np_out.n_in = p2; }
-            HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, nullptr, nullptr, sb, &np_out), LLAMAHIP_ERR_PREDICT);
-        }
-        HIP_TRY(hipEventRecord(m->ev_join, sb), LLAMAHIP_ERR_PREDICT);
-        HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0), LLAMAHIP_ERR_PREDICT);
-        return 0;
-    }
+    const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
     if (use_qkvx && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (m->first_stage) {
         if (use_part) {
@@ -644,8 +569,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             }
             if (use_qkvx) {
                 HIP_TRY(launch_qkv_attn(L.qkv, xa, L.attention_norm, np_qkv, m->d_qkv2, m->d_sc2, m->d_epoch, il - m->l0, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
-                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st, nullptr, nullptr,
-                                        tail_pf ? &L.wo : nullptr, tail_pf ? &L.w13 : nullptr, m->d_pf_sink), LLAMAHIP_ERR_PREDICT);
+                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st), LLAMAHIP_ERR_PREDICT);
             } else {
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
@@ -760,29 +684,6 @@ int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
         set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch, or between the overlapped decode launches) timed out; LLAMAHIP_NO_ATTN_X=1 selects the attention launches without them (the overlapped schedule is opt-in: LLAMAHIP_OVERLAP)");
         return LLAMAHIP_ERR_PREDICT;
     }
-    return 0;
-}
-
-// The L2 prefetcher runs beside the `n_tokens` decode steps about to be issued on m->stream: launched on the second stream once
-// the main stream has reached this point, joined back after the steps (it has nothing left to fetch by then and exits).
-static bool prefetch_enabled(const llamahip_model *m) {
-    static const bool off = getenv("LLAMAHIP_PREFETCH") == nullptr || getenv("LLAMAHIP_OVERLAP");
-    return !off && m->d_pf_ops && m->d_prog && m->stream2 && m->pf_xcc0 >= 0 && !(m->flags & LLAMAHIP_FLAG_UNFUSED);
-}
-int prefetch_begin(llamahip_model *m, int n_tokens, bool *running, char *err, size_t err_cap) {
-    *running = false;
-    if (!prefetch_enabled(m)) return 0;
-    HIP_TRY(hipMemsetAsync(m->d_prog, 0, 4, m->stream), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipEventRecord(m->ev_fork, m->stream), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(launch_prefetch(m->d_pf_ops, m->n_pf_ops, m->d_prog, n_tokens, m->pf_budget, m->pf_wgs, m->d_pf_sink, m->pf_xcc0, m->stream2), LLAMAHIP_ERR_PREDICT);
-    *running = true;
-    return 0;
-}
-int prefetch_end(llamahip_model *m, bool running, char *err, size_t err_cap) {
-    if (!running) return 0;
-    HIP_TRY(hipEventRecord(m->ev_join, m->stream2), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_join, 0), LLAMAHIP_ERR_PREDICT);
     return 0;
 }
 
@@ -1005,48 +906,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemset(m->d_qkv2, 0, (size_t) 3 * d * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_sc2, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_sc2, 0, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMalloc((void **) &m->d_qat_A, Kp_d / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMemset(m->d_qat_A, 0, Kp_d / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
-            if (getenv("LLAMAHIP_OVERLAP")) {          // the overlapped two-branch schedule: opt-in (measured slower)
-                HIP_TRY(hipMalloc((void **) &m->d_xt, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipMemset(m->d_xt, 0, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipMalloc((void **) &m->d_x1t, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipMemset(m->d_x1t, 0, (size_t) d * 8), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipMalloc((void **) &m->d_qa2t, Kp_F / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
-                HIP_TRY(hipMemset(m->d_qa2t, 0, Kp_F / 32 * 9 * 8), LLAMAHIP_ERR_LOAD);
-            }
-        }
-        HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking), LLAMAHIP_ERR_LOAD);
-        HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
-        HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
-        HIP_TRY(hipMalloc((void **) &m->d_pf_sink, 4096), LLAMAHIP_ERR_LOAD);
-        if (!m->dense && m->l1 > m->l0 && getenv("LLAMAHIP_PREFETCH")) {          // the stand-alone L2 prefetcher beside the decode loop: opt-in (measured slower)
-            // the prefetcher's schedule: the weight matrices of one decode step in launch order, with the row-groups each consumer
-            // workgroup owns (what decides which XCD's L2 a tile belongs in)
-            std::vector<PfOp> ops;
-            unsigned long long cum = 0;
-            auto add = [&](const QMat &w, int role, int mode) {
-                PfOp o{};
-                o.base = w.tiles; o.group_bytes = (uint32_t) ((w.nchunks + 1) * TILE_BYTES); o.ngroups = w.ngroups;
-                o.gpb = std::max(1, gemv_groups_per_block(w, role)); o.mode = mode; o.hdiv = (int) (d / 32); o.ncb = (int) (dh / 32);
-                o.cum_start = cum; o.bytes = (unsigned long long) w.ngroups * o.group_bytes;
-                if (mode == 1 && (o.gpb != 4 || o.ncb < 1 || H % 8 != 0 || ((w.ngroups / 4) % o.hdiv) != 0)) o.mode = 0;
-                cum += o.bytes;
-                ops.push_back(o);
-            };
-            const bool headwise = m->d_attn_sync && qkv_attn_applies(m->layers[0].qkv, (int) d, (int) H, 8);
-            for (auto &L : m->layers) { add(L.qkv, 0, headwise ? 1 : 0); add(L.wo, 1, 0); add(L.w13, 2, 0); add(L.w2, 1, 0); }
-            if (m->last_stage) add(m->output, 0, 0);
-            m->n_pf_ops = (int) ops.size();
-            HIP_TRY(hipMalloc((void **) &m->d_pf_ops, ops.size() * sizeof(PfOp)), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMemcpy(m->d_pf_ops, ops.data(), ops.size() * sizeof(PfOp), hipMemcpyHostToDevice), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMalloc((void **) &m->d_prog, 64), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMemset(m->d_prog, 0, 64), LLAMAHIP_ERR_LOAD);
-            m->pf_budget = (size_t) (getenv("LLAMAHIP_PF_BUDGET_MB") ? atof(getenv("LLAMAHIP_PF_BUDGET_MB")) : 16.0) * 1024 * 1024;
-            m->pf_wgs = getenv("LLAMAHIP_PF_WGS") ? atoi(getenv("LLAMAHIP_PF_WGS")) : 128;
-            m->pf_xcc0 = getenv("LLAMAHIP_PF_XCC0") ? atoi(getenv("LLAMAHIP_PF_XCC0")) : measure_xcc_of_wg0(m->stream);
         }
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
@@ -1129,12 +990,9 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
     }
     const bool want_all = logits_all != nullptr;
     m->tok_src = tok_mapped ? m->d_io->tok : nullptr;
-    bool pf = false;
-    if (N == 1 && !sink.dump && !m->dense && (rc = prefetch_begin(m, 1, &pf, err, err_cap)) != 0) return rc;
     rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap);
     m->tok_src = nullptr;
     if (rc) return rc;
-    if ((rc = prefetch_end(m, pf, err, err_cap)) != 0) return rc;
     const size_t V = m->hp.n_vocab;
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     if (logits_all) HIP_TRY(hipMemcpyAsync(logits_all, m->logits, (size_t) N * V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
@@ -1275,14 +1133,8 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
             (void) hipGraphDestroy(graph);
             it = m->decode_graphs.emplace(gkey, exec).first;
         }
-        bool pf = false;
-        if (!m->dense && (rc = prefetch_begin(m, n_steps, &pf, err, err_cap)) != 0) return rc;
         for (int i = 0; i < n_steps; i++) HIP_TRY(hipGraphLaunch(it->second, m->stream), LLAMAHIP_ERR_PREDICT);
-        if ((rc = prefetch_end(m, pf, err, err_cap)) != 0) return rc;
     } else {
-        bool pf = false;
-        if (fusable && !m->dense && (rc = prefetch_begin(m, n_steps, &pf, err, err_cap)) != 0) return rc;
-        struct PfJoin { llamahip_model *m; bool *pf; ~PfJoin() { char e[8]; (void) prefetch_end(m, *pf, e, sizeof(e)); } } pf_join{ m, &pf };
         for (int i = 0; i < n_steps; i++) {
             rc = forward(m, n_threads, n_past + i, 1, nullptr, fusable, false, -1, nullptr, err, err_cap);
             if (rc) return rc;

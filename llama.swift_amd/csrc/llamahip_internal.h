@@ -10,10 +10,10 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
 // (PREP_NORMP: PREP_NORM with the row's {sum x, sum x^2} supplied by its producer -- k_gemv only, selected by launch_gemv)
-// (the *_TAG / *_QAT forms: the operand arrives / the result leaves as 8-byte {fp32 bits or dword, tag} granules that the consumer
-//  polls -- hand-offs inside k_qkv_attn, and between the overlapped decode launches of the two-branch schedule, see launch_gemv_ov)
-enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PRE_QA_TAG = 5, PREP_NORM_TAG = 6 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5, EPI_SILU_QAT = 6 };
+// (the *_TAG forms: the operand arrives / the result leaves as 8-byte {fp32 bits, tag} granules that the consumer polls -- the
+//  hand-offs inside k_qkv_attn, and the residual-stream row between pipeline stages through a device-side mailbox)
+enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PREP_NORM_TAG = 6 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5 };
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
 struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; };
 
@@ -119,36 +119,14 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
                            uint32_t *xsync = nullptr, uint32_t *fault = nullptr);     // xsync: H * 32 zeroed dwords -> single-launch k_dec_attn_x
 bool xcd_selftest(int H, int Y, hipStream_t st);
 // wq|wk|wv mat-vec + decode attention as one launch (k_qkv_attn); xsync / fault as launch_dec_attn
+constexpr int TAG_MAX_LAYERS = 250;                                 // hand-off tags carry the layer index in 8 bits (kernels.hip make_tag)
 bool qkv_attn_applies(const QMat &w, int d, int H, int nth);
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           uint64_t *qat_A = nullptr, const uint64_t *x_t = nullptr,       // x_t / qat_A: tagged row in / tagged QA out (overlapped schedule)
-                           const QMat *pf_wo = nullptr, const QMat *pf_w13 = nullptr, uint32_t *pf_sink = nullptr);   // L2 warm-up of the next launches' weights (prefetch_tail)
+                           const uint64_t *x_t = nullptr);      // x_t: the row arrives as tagged granules (pipeline mailbox)
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
-// L2 run-ahead prefetcher of the decode step (k_prefetch): the weight matrices of one token in launch order
-struct PfOp {
-    const uint8_t *base; uint32_t group_bytes; int32_t ngroups, gpb, mode, hdiv, ncb, pad;
-    unsigned long long cum_start, bytes;
-};
-void set_decode_progress(uint32_t *prog);                           // launch counter the decode launches issued on this thread bump (or null)
-hipError_t launch_prefetch(const PfOp *ops, int n_ops, const uint32_t *prog, int n_tokens, size_t budget, int nwg, uint32_t *sink, int xcc_of_wg0, hipStream_t st);
-int measure_xcc_of_wg0(hipStream_t st);                             // HW_REG_XCC_ID of workgroup 0 of launches on `st` (the XCD round-robin's start is per queue), or -1
-int gemv_groups_per_block(const QMat &w, int role);
-// overlapped decode schedule: mat-vecs with tagged operands / results (kernels.hip "overlapped decode schedule")
-struct OvArgs {
-    uint32_t *epoch = nullptr, *fault = nullptr; int layer = 0;        // epoch word, sticky fault word, layer index on this handle
-    const uint64_t *in_t = nullptr; int slot_in = 0;                   // resid role: QA granules [block][9] (slot layer + 1); silu role: the fp32 row
-    const uint64_t *resid_t = nullptr; int slot_resid = 0;             // resid role: residual row
-    uint64_t *out_t = nullptr; int slot_out = 0;
-    float *y_plain = nullptr; double *part_out = nullptr;              // resid role: optional plain copy of the row / norm partial sums
-    const uint16_t *T_silu = nullptr;
-    int test_bits = 0;                                                 // 0x1000 / 0x2000: fault-injection tests
-};
-bool gemv_ov_applies(const QMat &wo, const QMat &w13, const QMat &w2, int n_layers);
-hipError_t launch_gemv_ov_resid(const QMat &w, const OvArgs &o, hipStream_t st);
-int gemv_ov_resid_parts(const QMat &w);                             // workgroups (= norm partial-sum pairs) of a resid-role launch
-hipError_t launch_gemv_ov_silu(const QMat &w13, const float *norm_w, const OvArgs &o, hipStream_t st);
+// a residual-stream row re-published as tagged granules, slot 0 of the current epoch (pipeline mailbox tests, single-GPU stage chains)
 hipError_t launch_tag_row(const float *x, int d, const uint32_t *epoch, uint64_t *xt, hipStream_t st);
 hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st);
 hipError_t launch_advance(int32_t *state, hipStream_t st);

@@ -234,15 +234,12 @@ def test_matrix_core_prompt_gemm_forced_on_small_models():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("switch", ["LLAMAHIP_OVERLAP", "LLAMAHIP_NO_PREFETCH", "LLAMAHIP_NO_QKV_ATTN", "LLAMAHIP_NO_ATTN_X"])
+@pytest.mark.parametrize("switch", ["LLAMAHIP_NO_QKV_ATTN", "LLAMAHIP_NO_ATTN_X"])
 def test_decode_attention_fallback_paths(switch):
     """The decode step runs wq|wk|wv + attention as one launch with in-launch hand-offs (k_qkv_attn) where the shapes allow;
     the paths it replaces stay in the library for every other shape: the single-launch attention with per-head counters
     (k_dec_attn_x: LLAMAHIP_NO_QKV_ATTN=1) and the two-launch attention (LLAMAHIP_NO_ATTN_X=1).  The switches are read once
-    per process, hence the subprocess; same parity tests, same oracle.  LLAMAHIP_OVERLAP=1: the overlapped two-branch schedule
-    (the four launches of a layer on two graph branches, rows handed over as tagged granules; opt-in, measured slower) instead of
-    the default four launches behind kernel boundaries.  LLAMAHIP_NO_PREFETCH=1: without the L2 run-ahead prefetcher beside the
-    decode loop (which changes no result: it writes nothing)."""
+    per process, hence the subprocess; same parity tests, same oracle."""
     import subprocess
     import sys
     env = dict(os.environ, **{switch: "1"})
@@ -252,12 +249,10 @@ def test_decode_attention_fallback_paths(switch):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("who", ["1", "2"])
-def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b, who):
+def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b):
     """The tagged hand-offs of the decode step are bounded polls; one that runs out raises a sticky fault word in
     pinned host memory and the next synchronisation returns PredictionFailed.  LLAMAHIP_HANDOFF_FAULT_TEST=1 makes the
-    mat-vec role of k_qkv_attn publish a tag nobody waits for, =2 the wo launch of the overlapped schedule (its consumers run
-    on the other branch of the graph), and shortens the polls (read once per process: subprocess)."""
+    mat-vec role of k_qkv_attn publish a tag nobody waits for and shortens the polls (read once per process: subprocess)."""
     import subprocess
     import sys
     code = (
@@ -273,9 +268,7 @@ def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b, who):
         "    print('ERR', e.code, str(e)); print('SECONDS', time.time() - t0)\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LLAMAHIP_HANDOFF_FAULT_TEST=who, PYTHONPATH=root)
-    if who == "2":
-        env["LLAMAHIP_OVERLAP"] = "1"
+    env = dict(os.environ, LLAMAHIP_HANDOFF_FAULT_TEST="1", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code, model7b], env=env, capture_output=True, text=True, cwd=root, timeout=300)
     assert "ERR -1001" in r.stdout and "hand-off" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert float(r.stdout.split("SECONDS")[1].split()[0]) < 30.0, r.stdout
