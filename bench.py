@@ -238,6 +238,45 @@ def insitu_profile(args, cfg):
     return prof, None if prof else "no decode token sequence found in the kernel trace"
 
 
+def insitu_traffic(args, cfg):
+    """HBM bytes per launch of the decode step's kernels, measured in THIS run: two rocprofv3 children over a short decode loop, one
+    with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE (separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes).
+    gfx950: FETCH_SIZE reports half the bytes of a wide streaming read -> traffic = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB.
+    Returns ({kernel name prefix: bytes per launch}, None) or (None, reason)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        outdir = tempfile.mkdtemp(prefix="llamahip_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--insitu-child", "--model", args.model, "--n_ctx", str(args.n_ctx),
+               "--steps", "16", "--warmup", str(args.warmup), "--threads", str(args.threads), "--seed", str(args.seed)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+        except Exception as e:
+            shutil.rmtree(outdir, ignore_errors=True)
+            return None, repr(e)
+        files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            shutil.rmtree(outdir, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} rc={r.returncode}: {r.stderr[-200:]}"
+        acc = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") != counter:
+                    continue
+                k = row["Kernel_Name"]
+                k = (k[:k.index("(")] if "(" in k else k).replace("void ", "")
+                acc.setdefault(k, []).append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            if len(v) >= 16:                         # the decode loop's launches (a layer's kernels run >= 16 x n_layer times)
+                res.setdefault(k, {})[counter] = sum(v) / len(v) * 1024.0
+        shutil.rmtree(outdir, ignore_errors=True)
+    out = {k: 2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for k, v in res.items() if "FETCH_SIZE" in v}
+    return (out, None) if out else (None, "no decode launches in the counter files")
+
+
 # ------------------------------------------------------------------------------------------------ the single-GPU run
 def run_single(args, cfg, path):
     import llama_swift_amd as L
@@ -271,6 +310,15 @@ def run_single(args, cfg, path):
         tk = int(np.argmax(lg)); pcie_toks.append(tk)
     dt_pcie = time.perf_counter() - t1
     pcie_same = pcie_toks == [int(x) for x in out[:n_pcie]]
+    # configs[1] is a 512-token generation: whatever --steps the caller passed, time the full context once more (8 prompt + 8 warm-up
+    # + 496 generated tokens fill n_ctx 512); its tokens must continue the timed run's
+    full = None
+    n_full = args.n_ctx - len(prompt) - args.warmup
+    if n_full > steps:
+        t3 = time.perf_counter()
+        out_full = m.decode_greedy(tok, len(prompt) + args.warmup, n_full, args.threads)
+        dt_full = time.perf_counter() - t3
+        full = {"steps": n_full, "seconds": dt_full, "tokens": out_full, "same_prefix": [int(x) for x in out_full[:steps]] == [int(x) for x in out]}
     # stand-alone probe of the mat-vec kernel (PRE_QA / STORE variant, back-to-back launches cycling over the layers):
     # kept as a secondary figure -- this variant never runs in the decode step
     shapes = []
@@ -306,7 +354,7 @@ def run_single(args, cfg, path):
         return last
     res = dict(steps=steps, dt=dt, t_load=t_load, value_pcie=n_pcie / dt_pcie, pcie_same=pcie_same, shapes=shapes,
                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, prefill=prefill, first=first, gpu_trace=gpu_trace,
-               n_past0=n_past, gpu_logits_at=gpu_logits_at, model=m)
+               n_past0=n_past, gpu_logits_at=gpu_logits_at, model=m, full=full)
     return res
 
 
@@ -426,7 +474,9 @@ def main():
             "end_to_end_frac": e2e_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "probe_back_to_back": probe}
     traffic = None
-    try:        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), committed under profiles/
+    traffic_src = None
+    pmc, pmc_err = (None, "skipped") if args.no_insitu else insitu_traffic(args, cfg)
+    try:        # fallback only: figures committed under profiles/ (labelled as such in the output)
         tj = json.load(open(os.path.join(ROOT, "profiles", "gemv_traffic.json")))
         traffic = tj["per_launch"]["w1|w3"]["traffic_bytes"] if args.model == "7B" else None
         traffic_src = "profiles/gemv_traffic.json (separate rocprofv3 --pmc passes over the stand-alone probe launches, committed; not measured in this run)"
@@ -440,6 +490,8 @@ def main():
             pass
     except Exception:
         pass
+    traffic_committed = traffic
+    traffic = None
     if prof:
         per = []
         gb = gu = 0.0
@@ -454,10 +506,33 @@ def main():
             mult = 1 if role == "output" else nl
             gb += b * mult; gu += us * mult
         dom = max(per, key=lambda p: p["algorithmic_bytes"] * (1 if p["name"] == "output" else nl))
+        # HBM traffic of every launch, measured by the PMC passes of this run (kernel names are matched by their template prefix)
+        if pmc:
+            for p_ in per:
+                kn = (p_["kernel"] or "")
+                hit = [v for k, v in pmc.items() if kn and (k == kn or k.startswith(kn) or kn.startswith(k))]
+                if hit:
+                    p_["traffic_bytes"] = hit[0]
+                    p_["traffic_over_algorithmic"] = hit[0] / p_["algorithmic_bytes"]
+            traffic = dom.get("traffic_bytes")
+            traffic_src = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE children of this run (separate passes, --kernel-trace only; 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), 16 decode steps"
+        # the launch that takes the most GPU time per token: k_qkv_attn -- the wq|wk|wv mat-vec AND the layer's attention; its bytes are
+        # the mat-vec's plus the K and V rows it reads at the mean position of the profiled window (2 (t + 1) d fp32) and the two rows it appends
+        by_time = max(per, key=lambda p: p["us"] * (1 if p["name"] == "output" else nl))
+        t_prof = len(PROMPT) + max(args.warmup, 1) + min(args.steps, 96) // 2
+        dbt = dict(by_time)
+        if "+attention" in by_time["name"]:
+            kvb = 2 * (t_prof + 1) * cfg["n_embd"] * 4 + 2 * cfg["n_embd"] * 4
+            dbt.update({"kv_bytes_at_mean_position": kvb, "mean_position": t_prof, "algorithmic_bytes": by_time["algorithmic_bytes"] + kvb,
+                        "GBps": (by_time["algorithmic_bytes"] + kvb) / by_time["us"] / 1e3, "frac": (by_time["algorithmic_bytes"] + kvb) / by_time["us"] / 1e3 / HBM_PEAK_GBPS})
+            dbt.pop("note", None)
+        dbt["share_of_gpu_time"] = by_time["us"] * (1 if by_time["name"] == "output" else nl) / prof["us"].get("token_span", float("nan"))
+        roof["dominant_by_time"] = dbt
         roof.update({"kernel": f"{dom['kernel']} -- the {dom['name']} mat-vec as it runs in the captured decode step (norm prologue, SiLU*up -> Q4_0 epilogue); "
                                f"{dom['algorithmic_bytes'] * nl / gb * 100:.0f}% of the mat-vec bytes of a token",
                      "achieved": dom["GBps"], "frac": dom["frac"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "us_per_launch": dom["us"],
                      "traffic": traffic, "traffic_source": traffic_src if traffic else None,
+                     "traffic_committed": traffic_committed, "traffic_error": None if traffic else pmc_err,
                      "method": f"rocprofv3 --kernel-trace of the same decode loop in a child process ({prof['tokens']} tokens); every dispatch labelled by its position in the "
                                "token's launch sequence; average kernel duration",
                      "in_situ_per_launch": per,
@@ -467,7 +542,7 @@ def main():
         dom = max(r["shapes"], key=lambda s: s["algo_bytes"] * (1 if s["name"] == "output" else nl))
         roof.update({"kernel": "lh::k_gemv PRE_QA / STORE PROBE VARIANT on w1|w3 (the in-situ profile was unavailable: " + str(prof_err) + ")",
                      "achieved": dom["GBps"], "frac": dom["GBps"] / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": dom["algo_bytes"],
-                     "us_per_launch": dom["us_per_launch"], "traffic": traffic, "method": "HIP events over back-to-back launches (probe variant, not in situ)"})
+                     "us_per_launch": dom["us_per_launch"], "traffic": None, "traffic_committed": traffic_committed, "method": "HIP events over back-to-back launches (probe variant, not in situ)"})
 
     result = {
         "metric": "decode tokens/sec LLaMA-7B Q4_0 @1 GPU; % HBM-roofline on Q4_0 GEMV",
@@ -483,6 +558,16 @@ def main():
         "roofline": roof,
         "parity": parity,
     }
+    if r.get("full"):
+        fc = r["full"]
+        fb = token_bytes(cfg, len(PROMPT) + args.warmup + fc["steps"] // 2)
+        fms = fc["seconds"] * 1e3 / fc["steps"]
+        result["full_context"] = {"workload": f"configs[1]: {fc['steps']} generated tokens to context {args.n_ctx} (8 prompt + {args.warmup} warm-up before them)",
+                                  "steps": fc["steps"], "tokens_per_s": fc["steps"] / fc["seconds"], "ms_per_step": fms,
+                                  "end_to_end_frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "tokens_continue_the_timed_run": fc["same_prefix"]}
+    elif r["steps"] >= args.n_ctx - len(PROMPT) - args.warmup:
+        result["full_context"] = {"workload": "the timed run IS configs[1]: it fills the context", "steps": r["steps"], "tokens_per_s": tps, "ms_per_step": ms_step,
+                                  "end_to_end_frac": roof["end_to_end_frac"]}
     if cpu_base is not None:
         result["cpu_baseline"] = cpu_base
     result["prefill"] = r["prefill"]

@@ -48,10 +48,18 @@ def _cpu_lib():
     return reflib.RefLib() if reflib.have_ref() else reflib.OracleLib()
 
 
+def _cpu_load(path, n_ctx, nth):
+    """The CPU path as the bridge drives it: load, then the 4-token eval that sizes its per-token scratch (.mm:820-822) -- without it
+    the reference's fixed 512 MiB eval buffer (.mm:529-547) overflows on 65B-sized or 2048-token evals."""
+    cpu = _cpu_lib().load(path, n_ctx)          # (0 parts forced: the loader derives the part count from n_embd, .mm:33-38)
+    cpu.eval(np.array([0, 1, 2, 3], np.int32), 0, nth)
+    return cpu
+
+
 def _decode_vs_cpu(L, path, n_ctx, n_prompt, n_gen, nth=8):
     """prompt eval (last-row logits bit for bit), then n_gen greedy tokens: the device-resident loop against one CPU eval per
     token, final logits bit for bit, and the same tokens once more through one host-driven llamahip_eval per token."""
-    cpu = _cpu_lib().load(path, n_ctx)          # (0 parts forced: the loader derives the part count from n_embd, .mm:33-38)
+    cpu = _cpu_load(path, n_ctx, nth)
     prompt = synth.synth_prompt(n_prompt, 32000, seed=3)
     lg = cpu.eval(prompt, 0, nth)["logits"]
     first, want, t = int(np.argmax(lg)), [], None
@@ -89,7 +97,7 @@ def test_7b_full_depth_2048_token_prefill_vs_cpu_path(L):
     attention), last-row logits bit for bit, then 3 decode tokens from that context."""
     path = _model("7B")
     prompt = synth.synth_prompt(2048, 32000, seed=5)
-    cpu = _cpu_lib().load(path, 2560)
+    cpu = _cpu_load(path, 2560, 8)
     lg = cpu.eval(prompt, 0, 8)["logits"]
     t, want = int(np.argmax(lg)), []
     first = t
