@@ -9,7 +9,10 @@
 // the single-part file of the same seed).
 //
 //   make_synth_model --out PATH [--preset 7B|13B|30B|65B] [--n_vocab V --n_embd D --n_mult M --n_head H
-//                    --n_layer L] [--parts P] [--seed S] [--sigma X] [--threads T]
+//                    --n_layer L] [--parts P] [--seed S] [--sigma X] [--threads T] [--emb_offset C]
+//   --emb_offset C : embedding row r gets the constant C * (r % 4) / 2 added to every element (rows whose mean is 0, small, near and
+//                    well above sigma / sqrt(3): the norm prologue of the decode kernels switches from the one-pass second moment to the
+//                    reference's two-pass form when the mean dominates -- tests need rows on both sides of that threshold)
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -43,17 +46,18 @@ struct Args {
     std::string out;
     int n_vocab = 32000, n_embd = 4096, n_mult = 256, n_head = 32, n_layer = 32, parts = 0, threads = 0;
     uint64_t seed = 20230312;
-    float sigma = 0.02f;
+    float sigma = 0.02f, emb_offset = 0.0f;
 };
 
 // quantize one row slice [col0, col0+n) of tensor `tkey` row `row` to Q4_0 blocks
-static void quant_row(uint64_t tkey, int64_t row, int64_t ncols_total, int64_t col0, int64_t n, float sigma, uint8_t *dst) {
+static void quant_row(uint64_t tkey, int64_t row, int64_t ncols_total, int64_t col0, int64_t n, float sigma, uint8_t *dst, float offset = 0.0f) {
+    const float dc = offset * (float) (row & 3) * 0.5f;
     float v[32];
     for (int64_t b = 0; b < n / 32; b++) {
         float amax = 0.0f;
         for (int l = 0; l < 32; l++) {
             const int64_t col = col0 + b * 32 + l;
-            v[l] = sigma * gauss(tkey ^ splitmix64((uint64_t) (row * ncols_total + col)));
+            v[l] = sigma * gauss(tkey ^ splitmix64((uint64_t) (row * ncols_total + col))) + dc;
             amax = fmaxf(amax, fabsf(v[l]));
         }
         const float d = amax / 7.0f;
@@ -94,7 +98,7 @@ static void write_q4(FILE *f, const Args &a, const std::string &name, int64_t ro
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++)
         th.emplace_back([&, t]() {
-            for (int64_t r = t; r < nr; r += T) quant_row(tkey, r0 + r, cols, c0, nc, a.sigma, buf.data() + r * row_bytes);
+            for (int64_t r = t; r < nr; r += T) quant_row(tkey, r0 + r, cols, c0, nc, a.sigma, buf.data() + r * row_bytes, name.find("tok_embeddings") != std::string::npos ? a.emb_offset : 0.0f);
         });
     for (auto &x : th) x.join();
     fwrite(buf.data(), 1, buf.size(), f);
@@ -133,6 +137,7 @@ int main(int argc, char **argv) {
         else if (k == "--parts") a.parts = atoi(val());
         else if (k == "--seed") a.seed = strtoull(val(), nullptr, 10);
         else if (k == "--sigma") a.sigma = (float) atof(val());
+        else if (k == "--emb_offset") a.emb_offset = (float) atof(val());
         else if (k == "--threads") a.threads = atoi(val());
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }

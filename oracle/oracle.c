@@ -476,9 +476,19 @@ void orc_kv(const orc_model *m, int il, int n_pos, float *out_k, float *out_v) {
 /* ------------------------------------------------------------------------------------------- */
 /* forward pass (LlamaPredictOperation.mm:510-735)                                             */
 /* ------------------------------------------------------------------------------------------- */
+/* OpenMP threads of the loops whose iterations are independent (rows of a mat-mul, (head, query) pairs of the attention): the
+ * reference's n_threads only enters the ARITHMETIC through the V*P key split below, so the worker count of these loops is free.
+ * ORC_OMP_THREADS overrides it (full-size tests: a 2048-token eval of the 32-layer model on all host cores). */
+static int omp_workers(int nth) {
+    static int ovr = -1;
+    if (ovr < 0) { const char *e = getenv("ORC_OMP_THREADS"); ovr = e ? atoi(e) : 0; }
+    return ovr > 0 ? ovr : nth;
+}
+
 static void matmul_q4(const orc_tensor *w, const uint8_t *qa, float *y, int N, int nth) {
     const int M = w->ne1, K = w->ne0;
     const size_t rb = (size_t) (K / QK) * BLK;
+    nth = omp_workers(nth);
 #pragma omp parallel for num_threads(nth) schedule(static)
     for (int mrow = 0; mrow < M; mrow++)
         for (int n = 0; n < N; n++)
@@ -549,7 +559,7 @@ static int eval_range(orc_model *m, int n_threads, int n_past, const int32_t *to
         DUMP(5, q, Nd);
 
         /* KQ[h][n][t] = K[t,h,:] . Q[n,h,:]  (.mm:614; ggml.c:5579-5618) then scale, mask, softmax */
-#pragma omp parallel for num_threads(nth) collapse(2) schedule(static)
+#pragma omp parallel for num_threads(omp_workers(nth)) collapse(2) schedule(static)
         for (int h = 0; h < H; h++)
             for (int n = 0; n < N; n++) {
                 float *row = kq + ((size_t) h * N + n) * T;
@@ -569,9 +579,13 @@ static int eval_range(orc_model *m, int n_threads, int n_past, const int32_t *to
          * (ggml.c:5553-5577).  The split therefore is part of the numerics.                     */
         {
             const int dc = (T + nth - 1) / nth;
+            const int nwk = omp_workers(nth);
+            float *part_all = (float *) malloc((size_t) nwk * nth * dh * 4);      /* one set of n_threads buffers per OpenMP worker */
+#pragma omp parallel for num_threads(nwk) collapse(2) schedule(static)
             for (int h = 0; h < H; h++)
                 for (int n = 0; n < N; n++) {
                     const float *P = kq + ((size_t) h * N + n) * T;
+                    float *part = part_all + (size_t) omp_get_thread_num() * nth * dh;
                     memset(part, 0, (size_t) nth * dh * 4);
                     for (int th = 0; th < nth; th++) {
                         const int t0 = dc * th, t1 = (t0 + dc < T) ? t0 + dc : T;
@@ -588,6 +602,7 @@ static int eval_range(orc_model *m, int n_threads, int n_past, const int32_t *to
                         out[c] = s;
                     }
                 }
+            free(part_all);
         }
         DUMP(7, kqv, Nd);
         for (int n = 0; n < N; n++)                                               /* .mm:641-646 */

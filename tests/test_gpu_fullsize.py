@@ -94,10 +94,17 @@ def test_65b_full_depth_vs_cpu_path(L):
 
 def test_7b_full_depth_2048_token_prefill_vs_cpu_path(L):
     """configs[2]: the 32-layer 2048-token single eval that bench.py's prefill leg times (matrix-core GEMMs, lane-per-query
-    attention), last-row logits bit for bit, then 3 decode tokens from that context."""
+    attention), last-row logits bit for bit, then 3 decode tokens from that context.  The CPU side is the standalone restatement
+    (oracle/oracle.c, pinned against the reference build by tests/test_oracle_vs_ref.py): the reference's own llama_eval cannot take
+    2048 tokens in one call -- its scratch buffer is sized from a 4-token eval and the attention scores grow with N^2 (.mm:529-547,
+    727-729), which is why the bridge feeds prompts 8 tokens at a time -- and a chunked evaluation is a different computation (the
+    V*P key split depends on the keys of the eval, ggml.c:5619-5665).  The restatement's row / (head, query) loops run on all host
+    cores (ORC_OMP_THREADS; n_threads = 8 stays the arithmetic's parameter)."""
+    import reflib
+    os.environ.setdefault("ORC_OMP_THREADS", str(min(os.cpu_count() or 8, 64)))
     path = _model("7B")
     prompt = synth.synth_prompt(2048, 32000, seed=5)
-    cpu = _cpu_load(path, 2560, 8)
+    cpu = reflib.OracleLib().load(path, 2560)
     lg = cpu.eval(prompt, 0, 8)["logits"]
     t, want = int(np.argmax(lg)), []
     first = t

@@ -249,6 +249,54 @@ def test_decode_attention_fallback_paths(switch):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("shape", ["small", "7b_width"])
+def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape):
+    """The decode kernels' norm prologue computes the second moment in one pass (S2 - mean * S1, from the producer's partial sums)
+    and switches to the reference's two-pass form (ggml.c:5355-5381) when the mean dominates (K mean^2 > S2 / 4).  Random weights
+    have mean ~ 0, so this model's embedding rows carry a constant: row r gets 0.0115 * (r % 4) / 2 added -- means of 0, 0.29, 0.58
+    and 0.86 sigma / ... i.e. rows well inside the fast branch, rows within 3 % of the threshold on either side (r % 4 == 2) and rows
+    well inside the two-pass branch; the residual stream keeps the offset through the layers, so every norm of the step sees it.
+    Single-token evals (both norm-fused mat-vecs, the lm head) and the captured greedy loop, against the oracle."""
+    kw = dict(n_vocab=64, n_embd=256, n_mult=64, n_head=2, n_layer=2) if shape == "small" else dict(n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2)
+    path = synth_tool(tmp_path / "dc.bin", seed=5, emb_offset=0.0115, **kw)
+    om = oracle.load(path, 64)
+    with L.Model(path, n_ctx=64) as gm:
+        toks = [1, 2, 3, 6, 7, 10, 5, 4, 14, 11]           # residues 1, 2, 3, 2, 3, 2, 1, 0, 2, 3
+        for pos, t in enumerate(toks):
+            a, b = gm.eval(np.array([t], np.int32), pos, 8), om.eval(np.array([t], np.int32), pos, 8)["logits"]
+            assert same(a, b), (shape, pos, t, describe(a, b))
+        t, want = int(np.argmax(b)), []
+        first = t
+        for i in range(12):
+            lo = om.eval(np.array([t], np.int32), len(toks) + i, 8)["logits"]
+            t = int(np.argmax(lo)); want.append(t)
+        got, last = gm.decode_greedy(first, len(toks), 12, 8, want_logits=True)
+        assert got.tolist() == want and same(last, lo), (shape, got.tolist(), want)
+        # a prompt chunk as well (the prompt path's norm is the reference's two-pass form throughout)
+        pr = np.array(toks[:9], np.int32)
+        a, b = gm.eval(pr, 0, 8), om.eval(pr, 0, 8)["logits"]
+        assert same(a, b), describe(a, b)
+    om.close()
+
+
+@pytest.mark.parametrize("env", [{"LLAMAHIP_NO_LUT_MATH": "1"}, {"LLAMAHIP_NORM_MODE": "0"}, {"LLAMAHIP_NORM_MODE": "1"},
+                                 {"LLAMAHIP_NO_HOST_IO": "1", "LLAMAHIP_HOST_SAMPLER": "1"},
+                                 {"LLAMAHIP_MFMA_I8": "1", "LLAMAHIP_MFMA_MIN": "32"}])
+def test_production_fallbacks_and_selectable_variants(env):
+    """Arithmetic that ships in libllamahip.so but that the default configuration of this box never selects:
+    NO_LUT_MATH -- the SiLU / exp fp16 tables GATHERED (ggml.c:1956-1963, 7024-7036) instead of evaluated, what a device whose
+    double-precision exp failed the exhaustive load-time check would run; NORM_MODE 0 / 1 -- the reference's two-pass statistics /
+    the one-pass statistics reduced inside every prologue instead of handed over by the producer; NO_HOST_IO + HOST_SAMPLER -- blit
+    copies and the host-side candidate selection; MFMA_I8 -- the int8 matrix-core prompt GEMM of round 1.  Switches are read once
+    per process, hence the subprocess; same parity tests, same oracle."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "dc_offset or thread_splits or tiny_model_golden or wider_models or prompt_continuation or runner_event or topk_candidates"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b):
     """The tagged hand-offs of the decode step are bounded polls; one that runs out raises a sticky fault word in
     pinned host memory and the next synchronisation returns PredictionFailed.  LLAMAHIP_HANDOFF_FAULT_TEST=1 makes the
