@@ -187,6 +187,25 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
 int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_t *tokens, int32_t cap,
                          char *err, size_t err_cap);
 
+/* Device-side mailboxes between pipeline stages: instead of the caller moving hidden_out -> hidden_in (and token_out -> token_in)
+ * between stages with a collective per token, the LAST kernel of a stage step stores the residual-stream row (.mm:563-564, 687-690)
+ * straight into the NEXT stage's inbox -- memory of the next stage's process / GPU, peer-mapped through HIP IPC (xGMI stores between
+ * GPUs) -- as 8-byte {fp32 bits, tag} granules, and the FIRST kernel of the next stage's step polls them; the last stage's pick
+ * kernel stores the token into the first stage's token inbox the same way.  The tag is the sequence position, which every stage
+ * knows: no host call, no RCCL launch and no stream ordering between stages per token; every poll is bounded (a lost neighbour
+ * surfaces as LLAMAHIP_ERR_PREDICT from the next llamahip_stage_trace).
+ *   llamahip_stage_mailbox         creates (once) slot `seq`'s inboxes -- n_embd granules on every stage but the first, one token
+ *                                  granule on the first stage of a multi-stage pipeline -- and returns their device pointers
+ *                                  (same-process neighbours) and / or 64-byte hipIpcMemHandle_t's (other processes); outputs may be NULL.
+ *   llamahip_stage_mailbox_connect gives the slot the NEXT stage's hidden inbox (every stage but the last) and / or the first stage's
+ *                                  token inbox (last stage), each as an IPC handle or as a raw device pointer.
+ * A slot with an inbox / a connected peer takes NULL for llamahip_stage_bind's hidden_in / hidden_out; on the first stage token_in
+ * still carries the FIRST token (bind publishes it to the inbox), later tokens arrive through the mailbox. */
+int llamahip_stage_mailbox(llamahip_model *m, int32_t seq, void **hidden_inbox, void **token_inbox,
+                           void *hidden_handle64, void *token_handle64, char *err, size_t err_cap);
+int llamahip_stage_mailbox_connect(llamahip_model *m, int32_t seq, const void *next_hidden_handle64, void *next_hidden_ptr,
+                                   const void *token_handle64, void *token_ptr, char *err, size_t err_cap);
+
 /* Select which of the handle's n_seq KV caches subsequent evals read and write (default 0). */
 int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap);
 

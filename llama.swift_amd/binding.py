@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
     L.llamahip_stage_bind.argtypes = [vp, i32, i32, vp, vp, vp, vp, cp, sz]
     L.llamahip_stage_step.argtypes = [vp, i32, i32, vp, cp, sz]
     L.llamahip_stage_trace.argtypes = [vp, i32, vp, vp, i32, cp, sz]
+    L.llamahip_stage_mailbox.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vp, vp, cp, sz]
+    L.llamahip_stage_mailbox_connect.argtypes = [vp, i32, vp, vp, vp, vp, cp, sz]
     L.llamahip_quantize_file.argtypes = [cp, cp, i32, cp, sz]
     L.llamahip_kv_read.argtypes = [vp, i32, i32, vp, vp, cp, sz]
     L.llamahip_set_seq.argtypes = [vp, i32, cp, sz]
@@ -283,6 +285,22 @@ class Model:
         err = C.create_string_buffer(1024)
         _check(lib().llamahip_stage_bind(self._h, seq, n_past, C.c_void_p(token_in), C.c_void_p(hidden_in), C.c_void_p(hidden_out),
                                          C.c_void_p(token_out), err, len(err)), err)
+
+    def stage_mailbox(self, seq: int):
+        """Create (once) slot `seq`'s device-side inboxes.  Returns (hidden_ptr, token_ptr, hidden_handle, token_handle): device
+        addresses (0 where the stage has no such inbox) for same-process neighbours, 64-byte IPC handles (bytes) for other processes."""
+        hp, tp = C.c_void_p(0), C.c_void_p(0)
+        hh, th = C.create_string_buffer(64), C.create_string_buffer(64)
+        err = C.create_string_buffer(1024)
+        _check(lib().llamahip_stage_mailbox(self._h, seq, C.byref(hp), C.byref(tp), hh, th, err, len(err)), err)
+        return (hp.value or 0), (tp.value or 0), (hh.raw if hp.value else None), (th.raw if tp.value else None)
+
+    def stage_mailbox_connect(self, seq: int, next_hidden_handle: bytes = None, next_hidden_ptr: int = 0, token_handle: bytes = None, token_ptr: int = 0):
+        """Give slot `seq` the next stage's hidden inbox and / or (last stage) the first stage's token inbox: an IPC handle (bytes) or a
+        device address each."""
+        err = C.create_string_buffer(1024)
+        _check(lib().llamahip_stage_mailbox_connect(self._h, seq, next_hidden_handle, C.c_void_p(next_hidden_ptr or None),
+                                                    token_handle, C.c_void_p(token_ptr or None), err, len(err)), err)
 
     def stage_step(self, seq: int, n_threads: int = 8, stream: int = 0):
         """Enqueue one token step of this stage on `stream` (hipStream_t address, 0 = the null stream); asynchronous."""

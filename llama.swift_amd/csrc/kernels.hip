@@ -78,6 +78,20 @@ __device__ __forceinline__ uint16_t exp_math_bits(uint16_t h) {
 __device__ __forceinline__ void store_tagged_agent(uint64_t *p, uint32_t bits, uint32_t tag) {
     __hip_atomic_store(p, (uint64_t) bits | ((uint64_t) tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one more look of a bounded poll: true = stop looking.  Running out raises the sticky fault word (results are invalid from there on);
+// a fault somebody else raised is noticed every 1024 looks, so that one lost hand-off does not make every later poll of the forward
+// pass wait out its own bound.
+__device__ __forceinline__ bool poll_give_up(int &spins, int limit, uint32_t *fault) {
+    if (++spins > limit) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return true; }
+    return (spins & 1023) == 0 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
+// the granule of a pipeline MAILBOX: the producer may be another device (peer-mapped memory, xGMI) -> system scope both ways
+__device__ __forceinline__ void store_tagged_sys(uint64_t *p, uint32_t bits, uint32_t tag) {
+    __hip_atomic_store(p, (uint64_t) bits | ((uint64_t) tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint64_t load_granule_sys(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // Tag of a granule = {epoch of the forward pass : 24 bits | slot : 8 bits}.  slot = 0 for the embedding row, il + 1 for everything layer
 // il (counted from the handle's first layer) produces; a residual-stream row is therefore tagged with the index of the layer that
 // CONSUMES it.  The host refuses the tagged hand-offs on handles with more than TAG_MAX_LAYERS layers (llamahip_internal.h); k_bump_epoch skips the epoch
@@ -320,9 +334,29 @@ __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__res
 // mat-vec folds instead of reducing the row itself (PREP_NORMP).  One workgroup; same dequantization.
 __global__ void __launch_bounds__(256)
 k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb, float *__restrict__ x, int d,
-             f64x2 *__restrict__ part_out, uint32_t *__restrict__ epoch, uint64_t *__restrict__ xt) {
+             f64x2 *__restrict__ part_out, uint32_t *__restrict__ epoch, uint64_t *__restrict__ xt,
+             const uint64_t *token_mb, const int32_t *__restrict__ st, uint32_t *fault, int n_vocab) {
     __shared__ double red[32];
-    const int tok = tokens[0];
+    __shared__ int tok_s;
+    // token_mb (first stage of a pipeline with device-side mailboxes): the token arrives as one tagged granule from the last stage's
+    // pick kernel (tag: the position it is for, st[0] + 1); one thread polls, bounded
+    if (token_mb) {
+        if (threadIdx.x == 0) {
+            const uint32_t want = make_tag((uint32_t) st[0] + 1u, 0);
+            int spins = 0;
+            uint64_t g;
+            for (;;) {
+                g = load_granule_sys(token_mb);
+                if ((uint32_t) (g >> 32) == want) break;
+                __builtin_amdgcn_s_sleep(16);
+                if (poll_give_up(spins, 1 << 27, fault)) break;
+            }
+            const uint32_t t = (uint32_t) g;
+            tok_s = t < (uint32_t) n_vocab ? (int) t : 0;        // (a poll that ran out: the fault word is up, keep the gather in bounds)
+        }
+        __syncthreads();
+    }
+    const int tok = token_mb ? tok_s : tokens[0];
     // xt (overlapped decode schedule): the row also leaves as tagged granules, slot 0 of the epoch k_bump_epoch set before this launch
     const uint32_t tag = xt ? make_tag(epoch[0], 0) : 0u;
     const uint8_t *row = emb + (size_t) tok * (d / 32) * 20;
@@ -750,13 +784,6 @@ __device__ __forceinline__ float fold8(float acc) {
 #endif
 // 8-byte granule {value, tag}: written with one 8-byte store, read with one 8-byte load that bypasses the L1 (sc1), so a
 // reader sees the value together with its tag or not at all.  The spin is bounded; running out raises the fault word.
-// one more look of a bounded poll: true = stop looking.  Running out raises the sticky fault word (results are invalid from there on);
-// a fault somebody else raised is noticed every 1024 looks, so that one lost hand-off does not make every later poll of the forward
-// pass wait out its own bound.
-__device__ __forceinline__ bool poll_give_up(int &spins, int limit, uint32_t *fault) {
-    if (++spins > limit) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return true; }
-    return (spins & 1023) == 0 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-}
 __device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, int nowait /* bit 0: pass at once (measurement), bit 1: no sleep between polls, bit 2: give up after 256 polls (fault-injection test) */) {
     uint64_t v;
     int spins = 0;
@@ -787,6 +814,8 @@ struct GemvArgs {
     const uint64_t *in_t;   int slot_in;              // PREP_NORM_TAG: the fp32 row [K] arrives tagged
     const uint64_t *resid_t; int slot_resid;          // EPI_RESID_TAG: the residual row [M] arrives tagged (null: plain `resid`)
     uint64_t *out_t;        int slot_out;             // EPI_RESID_TAG: y [M] also leaves tagged (null: plain `y` only)
+    const int32_t *pos_w;                             // mailbox tags are made from the sequence position, *pos_w + 1, not from the epoch (null: epoch)
+    int patience;                                     // mailbox polls wait for ANOTHER process / device: their bounds are shifted left by this
 };
 template <int PRE, int EPI, int D, bool RING, int PG>
 __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, const int nw, double *smem_d) {
@@ -802,7 +831,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     constexpr bool TAGGED = (EPI == EPI_STORE_TAG || PRE == PREP_NORM_TAG || EPI == EPI_RESID_TAG);
     const uint32_t epoch_ = TAGGED ? __builtin_nontemporal_load(ga.sync) : 0u;
     const uint32_t store_tag = make_tag(epoch_, ga.sync_epoch + 1);        // EPI_STORE_TAG output of layer ga.sync_epoch
-    const uint32_t tag_in = make_tag(epoch_, ga.slot_in), tag_resid = make_tag(epoch_, ga.slot_resid), tag_out = make_tag(epoch_, ga.slot_out);
+    // (mailbox rows between pipeline stages: the tag is the sequence position both sides know, st[0] + 1 -- the stages' epochs differ)
+    const uint32_t mb_epoch_ = ((PRE == PREP_NORM_TAG || EPI == EPI_RESID_TAG) && ga.pos_w) ? (uint32_t) __builtin_nontemporal_load(ga.pos_w) + 1u : epoch_;
+    const uint32_t tag_in = make_tag(mb_epoch_, ga.slot_in), tag_resid = make_tag(mb_epoch_, ga.slot_resid), tag_out = make_tag(mb_epoch_, ga.slot_out);
     // RING kernels: LDS holds D chunks more than the row has.  The ring's tail and its one-chunk-ahead
     // operand fetch run past the end (against the zero tile), and with zeroed padding those reads need no
     // index clamp -- their addresses are `loop base + immediate` instead of three VALU per chunk.
@@ -900,17 +931,17 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     }
     // the residual operand of the epilogue is fetched here too, not at the end of the kernel where it
     // would add a memory round trip to every wave's critical path
-    if (EPI == EPI_RESID && active) {
+    if ((EPI == EPI_RESID || (EPI == EPI_RESID_TAG && !ga.resid_t)) && active) {
         int lg0 = g;
         if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
         resid_v = resid[min(lg0 * 8 + (lane >> 3), M - 1)];
     }
-    // (EPI_RESID_TAG: the residual granule is requested here as well -- its producer ran two launches back on this branch, so
-    //  it is normally there already; the epilogue re-polls only if the tag says otherwise: layer 0, whose row the other branch embeds)
-    if (EPI == EPI_RESID_TAG && active && (lane & 7) == 0) {
+    // (EPI_RESID_TAG with a mailbox residual: the granule is requested here as well -- the launch before this one gathered the same
+    //  row, so it is there; the epilogue re-polls only if the tag says otherwise)
+    if (EPI == EPI_RESID_TAG && ga.resid_t && active && (lane & 7) == 0) {
         int lg0 = g;
         if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
-        resid_g = __hip_atomic_load(ga.resid_t + min(lg0 * 8 + (lane >> 3), M - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        resid_g = load_granule_sys(ga.resid_t + min(lg0 * 8 + (lane >> 3), M - 1));
     }
     if (PRE == PRE_QA && active) {
         const int nqa = (nchunks * 16 + nt - 1) / nt, nqd = (nchunks * 2 + nt - 1) / nt;
@@ -937,12 +968,12 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         // weight stream -- then every thread runs the tag-checked copy of its own half-blocks, which passes on its first or second
         // round.  Correctness rests on the copy alone; the watch only keeps the polling traffic small.
         const uint64_t *__restrict__ xt = ga.in_t;
-        const int give_up = (ga.lut_math & 0x1000) ? (1 << 8) : (1 << 20);      // (0x1000: fault-injection test)
+        const int give_up = (ga.lut_math & 0x1000) ? (1 << 8) : ((1 << 20) << ga.patience);      // (0x1000: fault-injection test)
         if (wave == 0) {
             int spins = 0;
             for (;;) {
                 bool ok = true;
-                if (lane < LH_WATCH) ok = (uint32_t) (__hip_atomic_load(xt + ((2 * lane + 1) * K / (2 * LH_WATCH)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag_in;
+                if (lane < LH_WATCH) ok = (uint32_t) (load_granule_sys(xt + ((2 * lane + 1) * K / (2 * LH_WATCH))) >> 32) == tag_in;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (give_up >> 2) || ((spins & 255) == 0 && __hip_atomic_load(ga.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) break;   // (the copy below raises the fault word if the row never comes)
@@ -959,7 +990,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
                     bool ok = true;
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        gv[i] = __hip_atomic_load(xt + hi * 16 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gv[i] = load_granule_sys(xt + hi * 16 + i);
                         ok = ok && (uint32_t) (gv[i] >> 32) == tag_in;
                     }
                     if (ok) break;
@@ -1207,14 +1238,30 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
         const bool live = valid && k == 0 && m < M;
         if (EPI == EPI_RESID) acc = acc + resid_v;
         if (EPI == EPI_RESID_TAG) {
-            float rv = __builtin_bit_cast(float, (uint32_t) resid_g);
-            if (live && (uint32_t) (resid_g >> 32) != tag_resid) rv = poll_tagged(ga.resid_t + m, tag_resid, ga.fault, (ga.lut_math & 0x1000) ? 4 : 0);
+            float rv = resid_v;
+            if (ga.resid_t) {
+                rv = __builtin_bit_cast(float, (uint32_t) resid_g);
+                if (live && (uint32_t) (resid_g >> 32) != tag_resid) {
+                    int spins = 0;
+                    uint64_t gq;
+                    for (;;) {
+                        gq = load_granule_sys(ga.resid_t + m);
+                        if ((uint32_t) (gq >> 32) == tag_resid) break;
+                        __builtin_amdgcn_s_sleep(4);
+                        if (poll_give_up(spins, (ga.lut_math & 0x1000) ? (1 << 8) : ((1 << 20) << ga.patience), ga.fault)) break;
+                    }
+                    rv = __builtin_bit_cast(float, (uint32_t) gq);
+                }
+            }
             acc = acc + rv;
         }
         if (EPI == EPI_STORE_TAG) {                     // ga.sync -> the epoch word, ga.sync_epoch = layer (k_qkv_attn)
             if (live) store_tagged((uint64_t *) y + m, acc, store_tag ^ ((ga.lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test -- a tag nobody waits for)
-        } else if (EPI == EPI_RESID_TAG) {              // the row for the launches that run beside / after this one (+ plain, where somebody reads it behind a boundary)
-            if (live) { store_tagged_agent(ga.out_t + m, __builtin_bit_cast(uint32_t, acc), tag_out ^ ((ga.lut_math & 0x2000) ? 1u : 0u)); if (y) y[m] = acc; }      // (0x2000: fault-injection test)
+        } else if (EPI == EPI_RESID_TAG) {              // the row leaves for the next pipeline stage's mailbox (and / or plain)
+            if (live) {
+                if (ga.out_t) store_tagged_sys(ga.out_t + m, __builtin_bit_cast(uint32_t, acc), tag_out ^ ((ga.lut_math & 0x2000) ? 1u : 0u));      // (0x2000: fault-injection test)
+                if (y) y[m] = acc;
+            }
         } else
         if (live) y[m] = acc;
         if ((EPI == EPI_RESID || EPI == EPI_RESID_TAG) && part_out) {
@@ -3340,7 +3387,7 @@ __device__ __forceinline__ void argmax_dpp(float &v, int &i) {
 }
 __global__ void __launch_bounds__(1024)
 k_argmax(const float *__restrict__ logits, int V, int32_t *__restrict__ out, int out_idx,
-         int32_t *__restrict__ next_token, int32_t *__restrict__ st) {
+         int32_t *__restrict__ next_token, int32_t *__restrict__ st, uint64_t *token_mb) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -3377,6 +3424,8 @@ k_argmax(const float *__restrict__ logits, int V, int32_t *__restrict__ out, int
         const int r = i == 0x7fffffff ? 0 : i;
         out[st ? st[1] : out_idx] = r;
         if (next_token) *next_token = r;
+        // (pipeline mailbox: the pick is the token of the NEXT position -- tagged with it -- stored into the first stage's memory)
+        if (token_mb && st) store_tagged_sys(token_mb, (uint32_t) r, make_tag((uint32_t) st[0] + 2u, 0));
         if (st) { st[0] += 1; st[1] += 1; }
     }
 }
@@ -3536,6 +3585,7 @@ hipError_t init_kernel_attrs() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
     LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
     LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
+    LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 1); LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 2); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 4); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 12);
 #undef LH_ATTR_G1
 #undef LH_ATTR_G
 #define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
@@ -3601,8 +3651,9 @@ hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int
 
 size_t prep_lds_bytes(int K) { return 32 * sizeof(double) + ((size_t) K + K / 32 + 64) * sizeof(float); }
 
-hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch, uint64_t *xt) {
-    hipLaunchKernelGGL(k_embed_part, dim3(1), dim3(256), 0, st, token, emb, x, d, (f64x2 *) part_out, epoch, xt);
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch, uint64_t *xt,
+                             const uint64_t *token_mb, const int32_t *state, uint32_t *fault, int n_vocab) {
+    hipLaunchKernelGGL(k_embed_part, dim3(1), dim3(256), 0, st, token, emb, x, d, (f64x2 *) part_out, epoch, xt, token_mb, state, fault, n_vocab);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3689,13 +3740,17 @@ template <int PRE, int EPI, int PG>
 static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, const float *qa_d,
                                  const float *in0, const float *in1, float *y, const float *resid,
                                  const uint16_t *T_silu,
-                                 uint32_t *out_A, float *out_d, const NormPart &np, hipStream_t st) {
+                                 uint32_t *out_A, float *out_d, const NormPart &np, hipStream_t st, const MailboxIO *mb = nullptr) {
     const int grid = (w.ngroups + nw - 1) / nw;
     size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
     if (PRE == PREP_SILU_MUL) lds += prep_lds_bytes(w.K);      // only the LDS-staged prologues need y scratch
     lds = (lds + 15) & ~(size_t) 15;
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, in0, in1, w.K, y, resid, T_silu, out_A, out_d,
                     (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out, nullptr, 0, 0, g_lut_math };
+    if (mb) {       // a row of a pipeline mailbox on one side of this launch
+        ga.in_t = mb->in_t; ga.resid_t = mb->resid_t; ga.out_t = mb->out_t; ga.slot_in = ga.slot_resid = ga.slot_out = 0;
+        ga.pos_w = mb->pos_w; ga.patience = 7; ga.fault = mb->fault; ga.sync = mb->epoch; ga.lut_math |= mb->test_bits;
+    }
 #define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, ga)
     if (np.out && grid > NORM_PART_MAX) return hipErrorInvalidValue;
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
@@ -3751,8 +3806,8 @@ template <int PRE, int EPI>
 static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float *qa_d,
                                 const float *in0, const float *in1, float *y, const float *resid,
                                 const uint16_t *T_silu,
-                                uint32_t *out_A, float *out_d, const NormPart &np, hipStream_t st) {
-#define LH_PGARGS w, nw, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, np, st
+                                uint32_t *out_A, float *out_d, const NormPart &np, hipStream_t st, const MailboxIO *mb = nullptr) {
+#define LH_PGARGS w, nw, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, np, st, mb
     if constexpr (EPI == EPI_SILU_QA) {
         // 8 waves = 4 gate row-groups + the 4 matching up row-groups (interleaved layout)
         const int nw = 8;
@@ -3767,6 +3822,7 @@ static hipError_t launch_gemv_t(const QMat &w, const uint32_t *qa_A, const float
         if constexpr (PRE == PRE_QA) {
             int pg = 0;
             nw = gemv_pick_nw_qa(w, &pg);
+            if (np.out && (w.ngroups + std::max(nw, 1) - 1) / std::max(nw, 1) > NORM_PART_MAX) return hipErrorInvalidValue;
             if (pg == 4) return launch_gemv_pg<PRE, EPI, 4>(LH_PGARGS);
             if (pg == 12) return launch_gemv_pg<PRE, EPI, 12>(LH_PGARGS);
         } else {
@@ -3788,7 +3844,7 @@ static size_t gemv_lds_bytes(const QMat &w, int depth_pad) {
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu,
-                       uint32_t *out_A, float *out_d, hipStream_t st, const NormPart *npp) {
+                       uint32_t *out_A, float *out_d, hipStream_t st, const NormPart *npp, const MailboxIO *mb) {
     // LLAMAHIP_NORM_MODE (measurement only): 0 = the reference's two-pass statistics in the prologue, 1 = one-pass
     // statistics in the prologue, 2 (default) = statistics handed over by the producer where the caller offers them
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;
@@ -3796,6 +3852,11 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
     if (norm_mode < 2) np = NormPart();
     if (pre == PREP_NORM && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX) pre = PREP_NORMP;
     else { np.in = nullptr; np.n_in = norm_mode == 0 ? -1 : 0; }
+    // pipeline mailbox on one side of the launch: the row arrives tagged (first layer's wq|wk|wv; its wo takes the residual from
+    // the same granules) or leaves tagged (last layer's w2)
+    if (mb && mb->in_t && (pre == PREP_NORM || pre == PREP_NORMP) && epi == EPI_STORE) return launch_gemv_t<PREP_NORM_TAG, EPI_STORE>(w, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, np, st, mb);
+    if (mb && (mb->resid_t || mb->out_t) && pre == PRE_QA && epi == EPI_RESID) return launch_gemv_t<PRE_QA, EPI_RESID_TAG>(w, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, np, st, mb);
+    if (mb) return hipErrorInvalidValue;
 #define LH_ARGS w, qa_A, qa_d, in0, in1, y, resid, T_silu, out_A, out_d, np, st
     // only the (prologue, epilogue) pairs the forward pass uses are instantiated
     if (pre == PRE_QA && epi == EPI_STORE)        return launch_gemv_t<PRE_QA, EPI_STORE>(LH_ARGS);
@@ -4235,7 +4296,8 @@ bool qkv_attn_applies(const QMat &w, int d, int H, int nth) {
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           const uint64_t *x_t) {
+                           const MailboxIO *mb) {
+    const uint64_t *x_t = mb ? mb->in_t : nullptr;
     // x_t (first layer of a pipeline stage fed through a device-side mailbox): the input row arrives as tagged granules, slot 0
     const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
@@ -4255,7 +4317,7 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) < 2) ? 0x1000 : 0;     // (2: the wo launch of the overlapped schedule misbehaves instead)
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
                     (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
-    if (x_t) { ga.in_t = x_t; ga.slot_in = 0; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; }
+    if (x_t) { ga.in_t = x_t; ga.slot_in = 0; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; ga.pos_w = mb->pos_w; ga.patience = 7; ga.lut_math |= mb->test_bits; }
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep | fault_test,
                            qkv2, sc2, epoch, layer };
     const int grid = gridA + H * (nsl + dh / 32);
@@ -4415,8 +4477,8 @@ hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *win
     return hipSuccess;
 }
 
-hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st) {
-    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, V, out, out_idx, next_token, state);
+hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st, uint64_t *token_mb) {
+    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, V, out, out_idx, next_token, state, token_mb);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -184,6 +184,10 @@ struct llamahip_model {
     struct StageSlot {
         int32_t *token_in = nullptr, *token_out = nullptr;     // caller-owned device buffers
         const float *hidden_in = nullptr; float *hidden_out = nullptr;
+        // device-side mailboxes (llamahip_stage_mailbox / _connect): this slot's inboxes (owned) and the neighbours' (peer-mapped)
+        uint64_t *inbox_hidden = nullptr, *inbox_token = nullptr;     // [n_embd] granules (stages after the first) / 1 granule (first stage)
+        uint64_t *peer_hidden = nullptr, *peer_token = nullptr;       // the next stage's hidden inbox / the first stage's token inbox
+        bool peer_hidden_ipc = false, peer_token_ipc = false;         // opened with hipIpcOpenMemHandle (closed with the handle)
         bool bound = false;
         int next_pos = 0;                                       // host mirror of the device position (bounds check)
         std::map<int, hipGraphExec_t> graphs;                   // keyed by nth
@@ -224,7 +228,12 @@ llamahip_model::~llamahip_model() {
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
     for (auto &kv : decode_graphs) (void) hipGraphExecDestroy(kv.second);
-    for (auto &sl : slots) for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
+    for (auto &sl : slots) {
+        for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
+        if (sl.peer_hidden && sl.peer_hidden_ipc) (void) hipIpcCloseMemHandle(sl.peer_hidden);
+        if (sl.peer_token && sl.peer_token_ipc) (void) hipIpcCloseMemHandle(sl.peer_token);
+        free_dev(sl.inbox_hidden); free_dev(sl.inbox_token);
+    }
     free_dev(d_slot_state); free_dev(d_slot_trace);
     free_dev(attn_ws.S); free_dev(attn_ws.pmax); free_dev(attn_ws.inv); free_dev(attn_ws.part);
     if (stream) (void) hipStreamDestroy(stream);
@@ -502,6 +511,10 @@ struct StepIO {
     int32_t *state = nullptr;
     const float *x_first = nullptr;
     float *x_last = nullptr;
+    // device-side mailboxes instead of x_first / x_last / token (tagged granules, see MailboxIO)
+    const uint64_t *mb_in = nullptr;
+    uint64_t *mb_out = nullptr;
+    const uint64_t *mb_token = nullptr;
 };
 int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool state_on_device,
             bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap, const StepIO *io = nullptr) {
@@ -538,15 +551,23 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     // decode: wq|wk|wv + attention as one launch with tagged hand-offs (k_qkv_attn); one forward pass = one epoch
     const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
     if (use_qkvx && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
+    if (io && fused && io->mb_token && m->first_stage && !use_part) { set_err(err, err_cap, "pipeline mailboxes need the default norm-statistics mode (LLAMAHIP_NORM_MODE unset)"); return LLAMAHIP_ERR_PREDICT; }
     if (m->first_stage) {
         if (use_part) {
-            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_qkvx ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_qkvx ? m->d_epoch : nullptr, nullptr,
+                                      (io && fused) ? io->mb_token : nullptr, state, m->d_fault, hp.n_vocab), LLAMAHIP_ERR_PREDICT);
             n_part_x = 1;
         } else
         HIP_TRY(launch_embed((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, N, st), LLAMAHIP_ERR_PREDICT);      // .mm:558-561
-    } else if (!x_first) {
+    } else if (!x_first && !(io && fused && io->mb_in)) {
         HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t) N * d * 4, hipMemcpyDeviceToDevice, st), LLAMAHIP_ERR_PREDICT);
     }
+    // pipeline mailboxes (fused single-token steps only): the first layer's row arrives / the last layer's row leaves as tagged granules
+    static const int mb_test = getenv("LLAMAHIP_HANDOFF_FAULT_TEST") ? atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) : 0;      // 3: the last layer publishes a tag nobody waits for (test only)
+    MailboxIO mb_first, mb_last;
+    const bool has_mb_in = io && fused && io->mb_in && m->l1 > m->l0, has_mb_out = io && fused && io->mb_out && m->l1 > m->l0;
+    if (has_mb_in) { mb_first.in_t = io->mb_in; mb_first.resid_t = io->mb_in; mb_first.pos_w = state; mb_first.epoch = m->d_epoch; mb_first.fault = m->d_fault; mb_first.test_bits = mb_test ? 0x1000 : 0; }
+    if (has_mb_out) { mb_last.out_t = io->mb_out; mb_last.pos_w = state; mb_last.epoch = m->d_epoch; mb_last.fault = m->d_fault; mb_last.test_bits = mb_test == 3 ? 0x2000 : 0; }
 
     for (int il = m->l0; il < m->l1; il++) {
         const Layer &L = m->layers[il - m->l0];
@@ -567,18 +588,22 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
                 n_part_x = 0;
                 if (p2 > 0 && p2 <= NORM_PART_MAX) { np_w2.out = m->npart_a; n_part_x = p2; }
             }
+            // (mailboxes: the first layer reads its row -- norm input and residual operand -- from the tagged inbox, the last layer's w2
+            //  stores its row into the next stage's inbox; everything in between is the usual schedule)
+            const MailboxIO *mbi = (has_mb_in && il == m->l0) ? &mb_first : nullptr, *mbo = (has_mb_out && il == m->l1 - 1) ? &mb_last : nullptr;
             if (use_qkvx) {
                 HIP_TRY(launch_qkv_attn(L.qkv, xa, L.attention_norm, np_qkv, m->d_qkv2, m->d_sc2, m->d_epoch, il - m->l0, d, H, C, nth, m->sincos, Kl, Vl, nullptr,
-                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st), LLAMAHIP_ERR_PREDICT);
+                                        m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st, mbi), LLAMAHIP_ERR_PREDICT);
             } else {
-            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv, mbi), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
             }
-            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo, mbi), LLAMAHIP_ERR_PREDICT);
             if (m->w13_interleaved) {
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, st, &np_w13), LLAMAHIP_ERR_PREDICT);
-                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, xo, m->x1, m->T_silu, nullptr, nullptr, st, &np_w2), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, mbo ? nullptr : xo, m->x1, m->T_silu, nullptr, nullptr, st, &np_w2, mbo), LLAMAHIP_ERR_PREDICT);
             } else {
+                if (mbo) { set_err(err, err_cap, "pipeline mailboxes need the interleaved w1|w3 layout"); return LLAMAHIP_ERR_PREDICT; }
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x1, L.ffn_norm, m->gu, nullptr, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
                 HIP_TRY(launch_gemv(L.w2, PREP_SILU_MUL, EPI_RESID, nullptr, nullptr, m->gu, m->gu + F, xo, m->x1, m->T_silu, nullptr, nullptr, st), LLAMAHIP_ERR_PREDICT);
             }
@@ -906,9 +931,9 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemset(m->d_qkv2, 0, (size_t) 3 * d * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_sc2, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_sc2, 0, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
-            HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
         }
+        HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->npart_a, 0, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
@@ -1161,8 +1186,12 @@ int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
     if (n_past < 0 || n_past >= m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (1) > n_ctx (%d)", n_past, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
     if ((m->flags & LLAMAHIP_FLAG_UNFUSED) || m->dense) { set_err(err, err_cap, "llamahip_stage_step needs the fused Q4_0 decode schedule (LLAMAHIP_FLAG_UNFUSED handle or f16 / f32 model): use llamahip_eval_stage"); return LLAMAHIP_ERR_PREDICT; }
     if (m->first_stage && !token_in) { set_err(err, err_cap, "stage [%d,%d) is the first stage: token_in is required", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
-    if (!m->first_stage && !hidden_in) { set_err(err, err_cap, "stage [%d,%d) needs hidden_in", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
-    if (!m->last_stage && !hidden_out) { set_err(err, err_cap, "stage [%d,%d) needs hidden_out", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
+    {   // (a slot with device-side mailboxes needs no hidden_in / hidden_out buffers: llamahip_stage_mailbox / _connect)
+        const bool has_slot = seq < (int32_t) m->slots.size();
+        const bool mb_in = has_slot && m->slots[seq].inbox_hidden, mb_out = has_slot && m->slots[seq].peer_hidden;
+        if (!m->first_stage && !hidden_in && !mb_in) { set_err(err, err_cap, "stage [%d,%d) needs hidden_in", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
+        if (!m->last_stage && !hidden_out && !mb_out) { set_err(err, err_cap, "stage [%d,%d) needs hidden_out", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
+    }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     int rc = ensure_workspace(m, 1, err, err_cap);
     if (rc) return rc;
@@ -1184,6 +1213,100 @@ int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
     sl.next_pos = n_past;
     const int32_t hs[2] = { n_past, 0 };
     HIP_TRY(hipMemcpy(m->d_slot_state + 2 * seq, hs, sizeof(hs), hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
+    // mailboxes: stale rows of an earlier binding must not match; the first stage's first token is the caller's (token_in), published
+    // to its own token inbox with the tag of the position it is for
+    if (sl.inbox_hidden) HIP_TRY(hipMemset(sl.inbox_hidden, 0, (size_t) m->hp.n_embd * 8), LLAMAHIP_ERR_PREDICT);
+    if (sl.inbox_token) {
+        int32_t tok = 0;
+        HIP_TRY(hipMemcpy(&tok, token_in, 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+        const uint64_t g = (uint64_t) (uint32_t) tok | ((uint64_t) ((((uint32_t) n_past + 1u) << 8) | 0u) << 32);      // make_tag(n_past + 1, 0)
+        HIP_TRY(hipMemcpy(sl.inbox_token, &g, 8, hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
+    }
+    return LLAMAHIP_OK;
+}
+
+namespace {
+int ensure_slots(llamahip_model *m, char *err, size_t err_cap) {
+    if (!m->d_slot_state) {
+        HIP_TRY(hipMalloc((void **) &m->d_slot_state, (size_t) m->n_seq * 2 * sizeof(int32_t)), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMalloc((void **) &m->d_slot_trace, (size_t) m->n_seq * m->hp.n_ctx * sizeof(int32_t)), LLAMAHIP_ERR_PREDICT);
+        m->slots.resize(m->n_seq);
+    }
+    return 0;
+}
+int drop_slot_graphs(llamahip_model *m, int seq, char *err, size_t err_cap) {
+    auto &sl = m->slots[seq];
+    HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);
+    for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
+    sl.graphs.clear();
+    return 0;
+}
+}  // namespace
+
+// ---- device-side mailboxes between pipeline stages (include/llamahip.h) -------------------------
+int llamahip_stage_mailbox(llamahip_model *m, int32_t seq, void **hidden_inbox, void **token_inbox,
+                           void *hidden_handle64, void *token_handle64, char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    if (m->host_only || m->dense || (m->flags & LLAMAHIP_FLAG_UNFUSED) || !m->w13_interleaved || m->l1 <= m->l0) {
+        set_err(err, err_cap, "pipeline mailboxes need a Q4_0 stage handle with layers and the fused decode schedule"); return LLAMAHIP_ERR_PREDICT; }
+    if (seq < 0 || seq >= m->n_seq) { set_err(err, err_cap, "sequence slot %d out of range [0, %d)", seq, m->n_seq); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    int rc = ensure_slots(m, err, err_cap);
+    if (rc) return rc;
+    auto &sl = m->slots[seq];
+    if (!m->first_stage && !sl.inbox_hidden) {
+        if ((rc = drop_slot_graphs(m, seq, err, err_cap)) != 0) return rc;
+        HIP_TRY(hipMalloc((void **) &sl.inbox_hidden, (size_t) m->hp.n_embd * 8), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(sl.inbox_hidden, 0, (size_t) m->hp.n_embd * 8), LLAMAHIP_ERR_PREDICT);
+    }
+    if (m->first_stage && !m->last_stage && !sl.inbox_token) {
+        if ((rc = drop_slot_graphs(m, seq, err, err_cap)) != 0) return rc;
+        HIP_TRY(hipMalloc((void **) &sl.inbox_token, 64), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(sl.inbox_token, 0, 64), LLAMAHIP_ERR_PREDICT);
+    }
+    if (hidden_inbox) *hidden_inbox = sl.inbox_hidden;
+    if (token_inbox) *token_inbox = sl.inbox_token;
+    if (hidden_handle64 && sl.inbox_hidden) {
+        hipIpcMemHandle_t h;
+        HIP_TRY(hipIpcGetMemHandle(&h, sl.inbox_hidden), LLAMAHIP_ERR_PREDICT);
+        static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+        memcpy(hidden_handle64, &h, 64);
+    }
+    if (token_handle64 && sl.inbox_token) {
+        hipIpcMemHandle_t h;
+        HIP_TRY(hipIpcGetMemHandle(&h, sl.inbox_token), LLAMAHIP_ERR_PREDICT);
+        memcpy(token_handle64, &h, 64);
+    }
+    return LLAMAHIP_OK;
+}
+
+int llamahip_stage_mailbox_connect(llamahip_model *m, int32_t seq, const void *next_hidden_handle64, void *next_hidden_ptr,
+                                   const void *token_handle64, void *token_ptr, char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    if (m->host_only || m->dense || (m->flags & LLAMAHIP_FLAG_UNFUSED) || !m->w13_interleaved || m->l1 <= m->l0) {
+        set_err(err, err_cap, "pipeline mailboxes need a Q4_0 stage handle with layers and the fused decode schedule"); return LLAMAHIP_ERR_PREDICT; }
+    if (seq < 0 || seq >= m->n_seq) { set_err(err, err_cap, "sequence slot %d out of range [0, %d)", seq, m->n_seq); return LLAMAHIP_ERR_PREDICT; }
+    if ((next_hidden_handle64 || next_hidden_ptr) && m->last_stage) { set_err(err, err_cap, "the last stage has no next stage to hand its row to"); return LLAMAHIP_ERR_PREDICT; }
+    if ((token_handle64 || token_ptr) && (!m->last_stage || m->first_stage)) { set_err(err, err_cap, "only the last stage of a multi-stage pipeline feeds the token back"); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    int rc = ensure_slots(m, err, err_cap);
+    if (rc) return rc;
+    if ((rc = drop_slot_graphs(m, seq, err, err_cap)) != 0) return rc;
+    auto &sl = m->slots[seq];
+    auto open = [&](const void *h64, void *raw, uint64_t **dst, bool *ipc) -> int {
+        if (!h64 && !raw) return 0;
+        if (*dst && *ipc) (void) hipIpcCloseMemHandle(*dst);
+        *dst = nullptr; *ipc = false;
+        if (raw) { *dst = (uint64_t *) raw; return 0; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, h64, 64);
+        void *p = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), LLAMAHIP_ERR_PREDICT);
+        *dst = (uint64_t *) p; *ipc = true;
+        return 0;
+    };
+    if ((rc = open(next_hidden_handle64, next_hidden_ptr, &sl.peer_hidden, &sl.peer_hidden_ipc)) != 0) return rc;
+    if ((rc = open(token_handle64, token_ptr, &sl.peer_token, &sl.peer_token_ipc)) != 0) return rc;
     return LLAMAHIP_OK;
 }
 
@@ -1196,6 +1319,11 @@ int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, size_t e
     io.token = sl.token_in; io.state = state;
     io.x_first = m->first_stage ? nullptr : sl.hidden_in;
     io.x_last = m->last_stage ? nullptr : sl.hidden_out;
+    io.mb_in = m->first_stage ? nullptr : sl.inbox_hidden;
+    io.mb_out = m->last_stage ? nullptr : sl.peer_hidden;
+    io.mb_token = m->first_stage ? sl.inbox_token : nullptr;
+    if (io.mb_in) io.x_first = nullptr;
+    if (io.mb_out) io.x_last = nullptr;
     const int save_seq = m->cur_seq;
     m->cur_seq = seq;
     int rc = forward(m, nth, 0, 1, sl.hidden_in, true, false, -1, nullptr, err, err_cap, &io);
@@ -1206,7 +1334,7 @@ int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, size_t e
         HIP_TRY(hipMemcpyAsync(sl.hidden_out, m->x, d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     if (m->last_stage) {
         // greedy pick on the device: trace[step] = token; token_out (if any) = token; position advances
-        HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_slot_trace + (size_t) seq * m->hp.n_ctx, 0, sl.token_out, state, m->stream), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_slot_trace + (size_t) seq * m->hp.n_ctx, 0, sl.token_out, state, m->stream, sl.peer_token), LLAMAHIP_ERR_PREDICT);
     } else {
         HIP_TRY(launch_advance(state, m->stream), LLAMAHIP_ERR_PREDICT);
     }

@@ -80,13 +80,24 @@ hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_str
 // row itself.  n_in <= NORM_PART_MAX.
 constexpr int NORM_PART_MAX = 512;
 struct NormPart { const double *in = nullptr; int n_in = 0; double *out = nullptr; };
+// Pipeline mailbox on one side of a decode launch: the residual-stream row as tagged 8-byte granules in memory the NEIGHBOUR stage
+// reads / writes (peer-mapped).  Tags are made from the sequence position (*pos_w + 1), which both stages know.
+struct MailboxIO {
+    const uint64_t *in_t = nullptr;      // the row the first layer's wq|wk|wv launch normalises arrives here ...
+    const uint64_t *resid_t = nullptr;   // ... and the same granules are the residual operand of the first layer's wo launch
+    uint64_t *out_t = nullptr;           // the last layer's w2 launch stores its row here (the next stage's inbox)
+    const int32_t *pos_w = nullptr;      // device word holding the position (the slot's st[0])
+    uint32_t *epoch = nullptr, *fault = nullptr;
+    int test_bits = 0;                   // 0x1000 short polls, 0x2000 wrong tag on out_t (fault-injection tests)
+};
 int gemv_resid_parts(const QMat &w);
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
-                       const NormPart *np = nullptr);
+                       const NormPart *np = nullptr, const MailboxIO *mb = nullptr);
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
-hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr, uint64_t *xt = nullptr);
+hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr, uint64_t *xt = nullptr,
+                             const uint64_t *token_mb = nullptr, const int32_t *state = nullptr, uint32_t *fault = nullptr, int n_vocab = 0);      // token_mb: the token arrives as a mailbox granule
 enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_COUNT = 5 };
 extern long g_gemm_path_counts[GEMM_PATH_COUNT];     // launches per kernel family of launch_gemm (process-wide; tests)
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
@@ -124,7 +135,7 @@ bool qkv_attn_applies(const QMat &w, int d, int H, int nth);
 hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, const NormPart &np, uint64_t *qkv2, uint64_t *sc2, uint32_t *epoch, int layer,
                            int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_silu, const uint16_t *T_exp, const int32_t *state, uint32_t *fault, hipStream_t st,
-                           const uint64_t *x_t = nullptr);      // x_t: the row arrives as tagged granules (pipeline mailbox)
+                           const MailboxIO *mb = nullptr);      // mb->in_t: the row arrives as tagged granules (pipeline mailbox)
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
 // a residual-stream row re-published as tagged granules, slot 0 of the current epoch (pipeline mailbox tests, single-GPU stage chains)
 hipError_t launch_tag_row(const float *x, int d, const uint32_t *epoch, uint64_t *xt, hipStream_t st);
@@ -134,6 +145,6 @@ hipError_t launch_advance(int32_t *state, hipStream_t st);
 hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *window, int n_window, double scale, double repeat_penalty, int k,
                                   double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st, void *ws = nullptr);      // ws: TOPK_WS_BYTES zeroed once -> the two-launch variant
 constexpr size_t TOPK_WS_BYTES = 32768 * 8 + 64 * 8 + 64;
-hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st);
+hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st, uint64_t *token_mb = nullptr);
 
 }  // namespace lh

@@ -361,3 +361,195 @@ def test_stream_ordered_two_stages_on_one_gpu(L, tmp_path):
         b.stage_bind(0, 0, token_in=tok[0].data_ptr())
     for m in (whole, a, b):
         m.close()
+
+
+# ------------------------------------------------------------------------------------------------ device-side mailboxes
+def _mailbox_model(tmp_path, shape):
+    """small: the separate wq|wk|wv + attention launches (k_gemv PREP_NORM_TAG); 7b_width: k_qkv_attn's tagged prologue."""
+    from conftest import synth_tool
+    if shape == "small":
+        hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=4)
+        path = str(tmp_path / "m.bin")
+        synth.write_model(path, hp, synth.random_tensors(hp, seed=9))
+        return path, hp.n_vocab, hp.n_embd, 4
+    path = synth_tool(tmp_path / "w.bin", seed=12, n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=3)
+    return path, 512, 4096, 3
+
+
+def _prompt_through_stages(torch, a, b, prompts, n_embd):
+    firsts = []
+    for s, p in enumerate(prompts):
+        h = torch.empty(len(p) * n_embd, dtype=torch.float32, device="cuda")
+        a.set_seq(s); b.set_seq(s)
+        a.eval_stage(0, tokens=p, hidden_out=h.data_ptr())
+        lg = b.eval_stage(0, n_tokens=len(p), hidden_in=h.data_ptr(), want_logits=True)
+        firsts.append(int(np.argmax(lg)))
+    torch.cuda.synchronize()
+    return firsts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["small", "7b_width"])
+def test_device_side_mailboxes_two_stages_two_streams(L, tmp_path, shape):
+    """Two stage handles in one process hand the residual-stream row and the token over through device-side mailboxes (tagged
+    granules stored by the last kernel of a stage step, polled by the first kernel of the neighbour's): no shared hidden / token
+    buffers, no ordering between the two streams -- stage B's steps are enqueued BEFORE stage A's, so its kernels really wait.
+    Tokens must be those of the whole model's greedy loop."""
+    import torch
+    path, n_vocab, n_embd, n_layer = _mailbox_model(tmp_path, shape)
+    a = L.Model(path, n_ctx=64, layer_begin=0, layer_end=1, n_seq=2)
+    b = L.Model(path, n_ctx=64, layer_begin=1, layer_end=n_layer, n_seq=2)
+    whole = L.Model(path, n_ctx=64)
+    prompts = [synth.synth_prompt(9, n_vocab, seed=1), synth.synth_prompt(6, n_vocab, seed=2)]
+    firsts = _prompt_through_stages(torch, a, b, prompts, n_embd)
+    tok = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(2)]
+    for s in range(2):
+        _, a_tok, _, _ = a.stage_mailbox(s)                       # stage A: token inbox
+        b_hid, _, _, _ = b.stage_mailbox(s)                       # stage B: hidden inbox
+        assert a_tok and b_hid
+        a.stage_mailbox_connect(s, next_hidden_ptr=b_hid)
+        b.stage_mailbox_connect(s, token_ptr=a_tok)
+        tok[s].fill_(firsts[s])
+        torch.cuda.synchronize()
+        a.stage_bind(s, len(prompts[s]), token_in=tok[s].data_ptr())            # no hidden_out: the mailbox
+        b.stage_bind(s, len(prompts[s]))                                          # no hidden_in, no token_out
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    n_steps = 7
+    for _ in range(n_steps):
+        for s in (1, 0):
+            b.stage_step(s, 8, sb.cuda_stream)                   # the consumer first: it polls until A's row arrives
+            a.stage_step(s, 8, sa.cuda_stream)
+    for s in range(2):
+        n, pos, got = b.stage_trace(s, n_steps)
+        assert (n, pos) == (n_steps, len(prompts[s]) + n_steps)
+        assert a.stage_trace(s, 0)[:2] == (n_steps, len(prompts[s]) + n_steps)
+        want = whole.decode_greedy(firsts[s], len(prompts[s]), n_steps, 8)
+        assert got.tolist() == want.tolist(), f"{shape}: sequence {s}: {got.tolist()} vs {want.tolist()}"
+    # re-binding at an earlier position: stale rows of the first run must not be taken for new ones
+    for s in range(2):
+        tok[s].fill_(firsts[s]); torch.cuda.synchronize()
+        a.stage_bind(s, len(prompts[s]), token_in=tok[s].data_ptr())
+        b.stage_bind(s, len(prompts[s]))
+    for _ in range(3):
+        for s in (0, 1):
+            b.stage_step(s, 8, sb.cuda_stream)
+            a.stage_step(s, 8, sa.cuda_stream)
+    for s in range(2):
+        n, pos, got = b.stage_trace(s, 3)
+        assert got.tolist() == whole.decode_greedy(firsts[s], len(prompts[s]), 3, 8).tolist()
+    for m in (whole, a, b):
+        m.close()
+
+
+_MAILBOX_PEER = r"""
+import os, sys, json, numpy as np
+root = sys.argv[1]; sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import torch
+import llama_swift_amd as L
+import synth
+path, n_layer, n_steps = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+b = L.Model(path, n_ctx=64, layer_begin=1, layer_end=n_layer, n_seq=1)
+b_hid, _, hh, _ = b.stage_mailbox(0)
+print(json.dumps({"hidden_handle": hh.hex()}), flush=True)
+msg = json.loads(sys.stdin.readline())                          # the first stage's token inbox + the prompt's hidden rows
+b.stage_mailbox_connect(0, token_handle=bytes.fromhex(msg["token_handle"]))
+hid = torch.tensor(msg["hidden"], dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()
+lg = b.eval_stage(0, n_tokens=msg["n_prompt"], hidden_in=hid.data_ptr(), want_logits=True)
+first = int(np.argmax(lg))
+print(json.dumps({"first": first}), flush=True)
+sys.stdin.readline()                                            # "go": the first stage is bound
+b.stage_bind(0, msg["n_prompt"])
+for _ in range(n_steps):
+    b.stage_step(0, 8, 0)
+try:
+    n, pos, got = b.stage_trace(0, n_steps)
+    print(json.dumps({"n": n, "pos": pos, "tokens": [int(t) for t in got]}), flush=True)
+except L.LlamaHipError as e:
+    print(json.dumps({"error": str(e), "code": e.code}), flush=True)
+b.close()
+"""
+
+
+@pytest.mark.gpu
+def test_device_side_mailboxes_two_processes_over_hip_ipc(L, tmp_path):
+    """The same hand-off between two PROCESSES on one GPU: each stage's inbox is exported as a hipIpcMemHandle_t and opened by its
+    neighbour -- what the stages of the 8-GPU pipeline do at bootstrap (the handles travel over the process group once; no collective
+    per token after that).  The second stage runs in a child process; tokens must be those of the whole model."""
+    import subprocess
+    import sys
+    import json
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=4)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=9))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_steps = 6
+    child = subprocess.Popen([sys.executable, "-c", _MAILBOX_PEER, root, path, "4", str(n_steps)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    try:
+        a = L.Model(path, n_ctx=64, layer_begin=0, layer_end=1, n_seq=1)
+        whole = L.Model(path, n_ctx=64)
+        prompt = synth.synth_prompt(9, hp.n_vocab, seed=1)
+        import torch
+        h = torch.empty(len(prompt) * hp.n_embd, dtype=torch.float32, device="cuda")
+        a.eval_stage(0, tokens=prompt, hidden_out=h.data_ptr())          # the prompt's residual rows after layer 0
+        torch.cuda.synchronize()
+        hid = h.cpu().numpy()
+        _, a_tok, _, th = a.stage_mailbox(0)
+        peer = json.loads(child.stdout.readline())
+        a.stage_mailbox_connect(0, next_hidden_handle=bytes.fromhex(peer["hidden_handle"]))
+        child.stdin.write(json.dumps({"token_handle": th.hex(), "hidden": [float(x) for x in hid], "n_prompt": len(prompt)}) + "\n"); child.stdin.flush()
+        first = json.loads(child.stdout.readline())["first"]
+        assert first == int(np.argmax(whole.eval(prompt, 0, 8)))
+        tokbuf = torch.full((1,), first, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        a.stage_bind(0, len(prompt), token_in=tokbuf.data_ptr())
+        child.stdin.write("go\n"); child.stdin.flush()
+        for _ in range(n_steps):
+            a.stage_step(0, 8, 0)
+        res = json.loads(child.stdout.readline())
+        assert "error" not in res, res
+        assert a.stage_trace(0, 0)[:2] == (n_steps, len(prompt) + n_steps)
+        want = whole.decode_greedy(first, len(prompt), n_steps, 8)
+        assert res["tokens"] == want.tolist(), (res, want.tolist())
+        a.close(); whole.close()
+    finally:
+        try:
+            child.stdin.close()
+        except Exception:
+            pass
+        child.wait(timeout=120)
+        err = child.stderr.read()
+        assert child.returncode == 0, err[-2000:]
+
+
+@pytest.mark.gpu
+def test_device_side_mailbox_lost_row_is_an_error_not_a_hang(tmp_path):
+    """A row that never arrives (LLAMAHIP_HANDOFF_FAULT_TEST=3: the producing stage publishes a tag nobody waits for, polls shortened)
+    raises the consumer's sticky fault word; llamahip_stage_trace returns PredictionFailed."""
+    import subprocess
+    import sys
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=4)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=9))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time, numpy as np, torch\n"
+        "import llama_swift_amd as L\n"
+        "p = sys.argv[1]\n"
+        "a = L.Model(p, n_ctx=64, layer_begin=0, layer_end=1); b = L.Model(p, n_ctx=64, layer_begin=1, layer_end=4)\n"
+        "_, a_tok, _, _ = a.stage_mailbox(0); b_hid, _, _, _ = b.stage_mailbox(0)\n"
+        "a.stage_mailbox_connect(0, next_hidden_ptr=b_hid); b.stage_mailbox_connect(0, token_ptr=a_tok)\n"
+        "tok = torch.ones(1, dtype=torch.int32, device='cuda'); torch.cuda.synchronize()\n"
+        "a.stage_bind(0, 0, token_in=tok.data_ptr()); b.stage_bind(0, 0)\n"
+        "t0 = time.time()\n"
+        "a.stage_step(0, 8, 0); b.stage_step(0, 8, 0)\n"
+        "try:\n"
+        "    b.stage_trace(0, 1); print('NO ERROR')\n"
+        "except L.LlamaHipError as e:\n"
+        "    print('ERR', e.code, str(e)); print('SECONDS', time.time() - t0)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, LLAMAHIP_HANDOFF_FAULT_TEST="3", PYTHONPATH=root),
+                       capture_output=True, text=True, cwd=root, timeout=300)
+    assert "ERR -1001" in r.stdout and "hand-off" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert float(r.stdout.split("SECONDS")[1].split()[0]) < 30.0, r.stdout
