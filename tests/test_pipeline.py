@@ -423,6 +423,7 @@ def test_device_side_mailboxes_two_stages_two_streams(L, tmp_path, shape):
         n, pos, got = b.stage_trace(s, n_steps)
         assert (n, pos) == (n_steps, len(prompts[s]) + n_steps)
         assert a.stage_trace(s, 0)[:2] == (n_steps, len(prompts[s]) + n_steps)
+        assert int(np.argmax(whole.eval(prompts[s], 0, 8))) == firsts[s]
         want = whole.decode_greedy(firsts[s], len(prompts[s]), n_steps, 8)
         assert got.tolist() == want.tolist(), f"{shape}: sequence {s}: {got.tolist()} vs {want.tolist()}"
     # re-binding at an earlier position: stale rows of the first run must not be taken for new ones
@@ -436,6 +437,7 @@ def test_device_side_mailboxes_two_stages_two_streams(L, tmp_path, shape):
             a.stage_step(s, 8, sa.cuda_stream)
     for s in range(2):
         n, pos, got = b.stage_trace(s, 3)
+        whole.eval(prompts[s], 0, 8)
         assert got.tolist() == whole.decode_greedy(firsts[s], len(prompts[s]), 3, 8).tolist()
     for m in (whole, a, b):
         m.close()
@@ -510,6 +512,7 @@ def test_device_side_mailboxes_two_processes_over_hip_ipc(L, tmp_path):
         res = json.loads(child.stdout.readline())
         assert "error" not in res, res
         assert a.stage_trace(0, 0)[:2] == (n_steps, len(prompt) + n_steps)
+        whole.eval(prompt, 0, 8)
         want = whole.decode_greedy(first, len(prompt), n_steps, 8)
         assert res["tokens"] == want.tolist(), (res, want.tolist())
         a.close(); whole.close()
