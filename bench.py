@@ -417,7 +417,7 @@ def main():
         # a point-to-point kernel waiting for its peer can never sit in front of unrelated work
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         from llama_swift_amd import pipeline
-        return pipeline.bench_main(args, cfg, model_path, log)
+        return pipeline.bench_main(args, cfg, model_path, log, MODELS)
 
     import torch
     if not torch.cuda.is_available():

@@ -149,9 +149,33 @@ class HipStage:
             want_logits=self.is_last, n_threads=self.n_threads)
         return logits if self.is_last else out
 
+    # --- device-side mailboxes (no collective per token) ---
+    def setup_mailboxes(self, dist, rank: int, world: int, n_seq: int) -> None:
+        """Bootstrap, once: every stage creates its inboxes, the 64-byte IPC handles travel over the process group (ONE object
+        all-gather), every stage opens its successor's hidden inbox and the last stage the first stage's token inbox.  From then on
+        a token step is `step(seq)` alone: the row and the token move between the GPUs inside the kernels (include/llamahip.h)."""
+        mine = []
+        for s in range(n_seq):
+            _, _, hh, th = self.model.stage_mailbox(s)
+            mine.append((hh, th))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        for s in range(n_seq):
+            nxt_h = everyone[rank + 1][s][0] if rank + 1 < world else None
+            tok_h = everyone[0][s][1] if (rank == world - 1 and world > 1) else None
+            self.model.stage_mailbox_connect(s, next_hidden_handle=nxt_h, token_handle=tok_h)
+        self.mailboxes = True
+
     # --- stream-ordered steps ---
     def bind(self, seq, n_past, first_token):
         torch = self._torch
+        if getattr(self, "mailboxes", False):
+            if not hasattr(self, "tok_in"):
+                self.tok_in = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.model.n_seq)]
+            self.tok_in[seq].fill_(int(first_token))
+            torch.cuda.current_stream().synchronize()
+            self.model.stage_bind(seq, n_past, token_in=self.tok_in[seq].data_ptr() if self.is_first else 0)
+            return
         if not hasattr(self, "tok_in"):
             S, dev = self.model.n_seq, self.device
             self.tok_in = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(S)]
@@ -269,6 +293,15 @@ def pipeline_decode(stage: Stage, rank: int, world: int, dist, n_seq: int, round
     reap(0)
 
 
+def mailbox_decode(stage: Stage, n_seq: int, rounds: int, seqs: Optional[Sequence[int]] = None) -> None:
+    """The decode loop with device-side mailboxes: `rounds` token steps for each sequence, enqueued back to back on the current
+    stream.  No receive, no send, no ordering with the other ranks on the host or on a communicator: a stage's first kernel polls
+    its inbox, its last kernel stores into the neighbour's (every poll is bounded; a lost neighbour surfaces from stage.trace)."""
+    for _ in range(rounds):
+        for s in (seqs if seqs is not None else range(n_seq)):
+            stage.step(s)
+
+
 def gather_traces(stage: Stage, rank: int, world: int, dist, torch, n_seq: int, cap: int):
     """Tokens picked since bind, [n_seq][cap] on every rank (the last stage owns them)."""
     out = np.zeros((n_seq, cap), np.int32)
@@ -284,7 +317,29 @@ def gather_traces(stage: Stage, rank: int, world: int, dist, torch, n_seq: int, 
     return out, pos
 
 
-def bench_main(args, cfg, model_path_fn, log):
+def _cpu_trace(path: str, prompt: np.ndarray, n_tokens: int, n_ctx: int, budget_s: float):
+    """Greedy tokens of the CPU path (the reference's ggml.c build when it travelled with the snapshot, else the restatement) for one
+    prompt: the parity gate of the multi-GPU line.  Bounded by `budget_s` seconds of decoding."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import reflib
+    kind = "reference" if reflib.have_ref() else "port"
+    lib = reflib.RefLib() if kind == "reference" else reflib.OracleLib()
+    m = lib.load(path, n_ctx, 0)
+    m.eval(np.array([0, 1, 2, 3], np.int32), 0, 8)            # the bridge's scratch-sizing eval (.mm:820-822)
+    lg = m.eval(prompt, 0, 8)["logits"]
+    t, toks, n_past = int(np.argmax(lg)), [], len(prompt)
+    first = t
+    t0 = time.time()
+    while len(toks) < n_tokens and time.time() - t0 < budget_s:
+        lg = m.eval(np.array([t], np.int32), n_past, 8)["logits"]
+        t = int(np.argmax(lg)); toks.append(t); n_past += 1
+    m.close()
+    return kind, first, toks
+
+
+def bench_main(args, cfg, model_path_fn, log, models=None):
     """`bench.py --gpus N` for N > 1 (launched by torch.distributed.run, one rank per GPU)."""
     import torch
     import torch.distributed as dist
@@ -307,91 +362,167 @@ def bench_main(args, cfg, model_path_fn, log):
     # caller forever: every schedule call below runs under run_guarded (transport error -> PipelineError, silence ->
     # exit code 3 after `limit` seconds), and the whole bench under one more timer of the same length
     limit = float(os.environ.get("LLAMAHIP_PIPE_WATCHDOG_S", "900"))
+    headline = {}                                # rank 0: the finished JSON line of the headline model (printed by whoever ends the run)
+
+    def _emit_and_exit(code):
+        if rank == 0 and headline:
+            os.dup2(saved_stdout, 1)
+            os.write(1, (json.dumps(headline) + "\n").encode())
+        os._exit(code)
 
     def _abort():
         os.write(2, f"[bench] rank {rank}/{world}: no result after {limit:.0f} s -- PredictionFailed ({ERR_PREDICT}), aborting\n".encode())
-        os._exit(3)
+        _emit_and_exit(0 if headline else 3)     # (a stuck EXTRA leg must not cost the headline line that is already measured)
 
     watchdog = threading.Timer(limit, _abort)
     watchdog.daemon = True
     watchdog.start()
-    guard = lambda fn, what: run_guarded(fn, rank, world, limit, what)
+    guard = lambda fn, what: run_guarded(fn, rank, world, limit, what, on_timeout=(lambda msg: _emit_and_exit(0)) if headline else None)
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
     fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]   # forward edges by sender parity
     sync_schedule = os.environ.get("LLAMAHIP_PIPELINE_SYNC", "0") == "1"
-    if rank == 0:
-        path = model_path_fn(args.model, cfg, args.seed)
-    dist.barrier()
-    path = model_path_fn(args.model, cfg, args.seed)
+    want_mailbox = os.environ.get("LLAMAHIP_PIPE_MAILBOX", "1") != "0" and not sync_schedule and world > 1
 
-    # sequences in flight: two per stage (weak scaling).  With exactly one per stage every stage waits out
-    # the hand-off latency of its predecessor on every step; a second one keeps a ready item queued.
-    S = world * max(1, int(os.environ.get("LLAMAHIP_PIPE_SEQS_PER_STAGE", "2"))) if world > 1 else 1
-    stage = HipStage(path, args.n_ctx, rank, world, S, cfg["n_layer"], local, args.threads)
-    rng = np.random.default_rng(1234)
-    prompts = [np.concatenate([[1], rng.integers(3, cfg["n_vocab"], 7)]).astype(np.int32) for _ in range(S)]
-    steps = min(args.steps, args.n_ctx - 8 - args.warmup - 1)
-    # prompt round (8 tokens per sequence): host-synchronous schedule, untimed
-    if sync_schedule:
-        toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + args.warmup, token_group), "pipeline_rounds (prompt + warm-up)")
-        last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
-        dist.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        toks2, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group), "pipeline_rounds (timed decode)")
-        dist.barrier(); torch.cuda.synchronize()
-    else:
-        toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt)")
-        for s in range(S):
-            stage.bind(s, n_past[s], int(toks[s, -1]))
-        lane = torch.cuda.Stream()               # the decode loop's own stream: receives, stage steps and sends are ordered on it
+    def run_model(model_name, mcfg, steps_req, warmup, parity_tokens):
+        if rank == 0:
+            model_path_fn(model_name, mcfg, args.seed)
+        dist.barrier()
+        path = model_path_fn(model_name, mcfg, args.seed)
+        # sequences in flight: two per stage (weak scaling).  With exactly one per stage every stage waits out
+        # the hand-off latency of its predecessor on every step; a second one keeps a ready item queued.
+        S = world * max(1, int(os.environ.get("LLAMAHIP_PIPE_SEQS_PER_STAGE", "2"))) if world > 1 else 1
+        stage = HipStage(path, args.n_ctx, rank, world, S, mcfg["n_layer"], local, args.threads)
+        rng = np.random.default_rng(1234)
+        prompts = [np.concatenate([[1], rng.integers(3, mcfg["n_vocab"], 7)]).astype(np.int32) for _ in range(S)]
+        n_single = 16                                          # single-stream latency leg: tokens of sequence 0 alone
+        steps = max(1, min(steps_req, args.n_ctx - 8 - warmup - 1 - n_single))
+        hand_off = "RCCL point-to-point per token (torch.distributed isend / recv, stream-ordered)"
+        if sync_schedule:
+            toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + warmup, token_group), "pipeline_rounds (prompt + warm-up)")
+            last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks2, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group), "pipeline_rounds (timed decode)")
+            dist.barrier(); torch.cuda.synchronize()
+            dt_loc = time.perf_counter() - t0
+            firsts = [int(toks[s, 0]) for s in range(S)]
+            traces = np.concatenate([toks[:, 1:], toks2], axis=1)
+            single = None
+        else:
+            toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt)")
+            firsts = [int(toks[s, -1]) for s in range(S)]
+            mailbox = False
+            if want_mailbox:
+                # device-side mailboxes: one object all-gather of IPC handles now, no collective per token afterwards.  Every rank
+                # must take the same branch: agree on the outcome.
+                ok = 1
+                try:
+                    stage.setup_mailboxes(dist, rank, world, S)
+                except Exception as e:                          # e.g. IPC not permitted on this box
+                    log(f"[bench] rank {rank}: mailboxes unavailable ({type(e).__name__}: {e}); RCCL hand-off")
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local}")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                mailbox = int(flag.item()) == 1
+                if not mailbox:
+                    stage.mailboxes = False
+            if mailbox:
+                hand_off = "device-side mailboxes: position-tagged granules stored into the next stage's memory (HIP IPC / xGMI) by the last kernel of a stage step, polled by the first kernel of the next; no collective and no host call per token"
+            for s in range(S):
+                stage.bind(s, n_past[s], firsts[s])
+            lane = torch.cuda.Stream()               # the decode loop's own stream
 
-        def decode(n):
-            with torch.cuda.stream(lane):
-                pipeline_decode(stage, rank, world, dist, S, n, fwd_groups, token_group)
-            torch.cuda.synchronize()
-        guard(lambda: decode(args.warmup), "pipeline_decode (warm-up)")                                # untimed; captures the graphs
-        dist.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        guard(lambda: decode(steps), "pipeline_decode (timed)")
-        dist.barrier(); torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
-    # roofline of this rank's dominant mat-vec (w1|w3) on ITS layers: the stand-alone probe variant of the kernel
-    # (PRE_QA / STORE, back-to-back launches over the stage's layers, HIP events) -- the in-situ rocprofv3 labelling of
-    # bench.py's single-GPU line needs a profiler child per rank and is not attempted under torchrun
-    roof = None
-    try:
-        r = stage.model.bench_gemv(2, -1, 1, 10)
-        roof = {"bound": "hbm", "kernel": "lh::k_gemv PRE_QA / STORE probe variant on w1|w3 of rank 0's layers (not in situ)", "achieved": r["GBps"], "peak": 8000.0,
-                "unit": "GB/s", "frac": r["GBps"] / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": r["algo_bytes"], "us_per_launch": r["us_per_launch"],
-                "per_stage_weight_bytes": stage.model.stats()["weight_bytes_device"]}
-    except Exception as e:                       # measurement extras never cost the headline line
-        roof = {"error": repr(e)}
+            def decode(n, seqs=None):
+                with torch.cuda.stream(lane):
+                    if mailbox:
+                        mailbox_decode(stage, S, n, seqs)
+                    else:
+                        pipeline_decode(stage, rank, world, dist, S if seqs is None else len(seqs), n, fwd_groups, token_group)
+                torch.cuda.synchronize()
+            guard(lambda: decode(warmup), "decode (warm-up)")                                # untimed; captures the graphs
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            guard(lambda: decode(steps), "decode (timed)")
+            dist.barrier(); torch.cuda.synchronize()
+            dt_loc = time.perf_counter() - t0
+            # single-stream latency, measured: sequence 0 alone through all stages
+            single = None
+            if world > 1:
+                dist.barrier(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                guard(lambda: decode(n_single, [0]), "decode (single stream)")
+                dist.barrier(); torch.cuda.synchronize()
+                ds = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=f"cuda:{local}")
+                dist.all_reduce(ds, op=dist.ReduceOp.MAX)
+                single = {"tokens": n_single, "ms_per_token": float(ds.item()) * 1e3 / n_single, "tokens_per_s": n_single / float(ds.item()),
+                          "note": "sequence 0 alone: one token at a time through every stage (the latency a single user sees)"}
+            traces, _pos = guard(lambda: gather_traces(stage, rank, world, dist, torch, S, warmup + steps + (n_single if world > 1 else 0)), "gather_traces")
+        dt = torch.tensor([dt_loc], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        # parity gate: sequence 0's prompt pick and first generated tokens against the CPU path (rank 0 computes it, bounded)
+        parity = {"checked": False}
+        if rank == 0 and parity_tokens > 0:
+            try:
+                kind, cfirst, ctoks = _cpu_trace(path, prompts[0], parity_tokens, args.n_ctx, float(os.environ.get("LLAMAHIP_PIPE_PARITY_S", "30")))
+                got = [int(t) for t in traces[0][:len(ctoks)]]
+                parity = {"checked": True, "against": f"{kind} CPU path, 8 threads, sequence 0", "prompt_pick_identical": cfirst == firsts[0],
+                          "tokens_compared": len(ctoks), "identical": cfirst == firsts[0] and got == ctoks,
+                          "first_divergence": next((i for i, (x, y) in enumerate(zip(got, ctoks)) if x != y), None)}
+            except Exception as e:                              # the checker must never take the measurement down
+                parity = {"checked": False, "error": repr(e)}
+        roof = None
+        try:
+            r = stage.model.bench_gemv(2, -1, 1, 10)
+            roof = {"bound": "hbm", "kernel": "lh::k_gemv PRE_QA / STORE probe variant on w1|w3 of rank 0's layers (stand-alone, not in situ)", "achieved": r["GBps"], "peak": 8000.0,
+                    "unit": "GB/s", "frac": r["GBps"] / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": r["algo_bytes"], "us_per_launch": r["us_per_launch"],
+                    "per_stage_weight_bytes": stage.model.stats()["weight_bytes_device"]}
+        except Exception as e:                       # measurement extras never cost the headline line
+            roof = {"error": repr(e)}
+        stage.model.close()
+        return dict(S=S, steps=steps, dt=dt, parity=parity, roof=roof, single=single, hand_off=hand_off, n_layer=mcfg["n_layer"])
+
+    r = run_model(args.model, cfg, args.steps, args.warmup, 8)
     if rank == 0:
-        total = S * steps
-        print(json.dumps({
-            "metric": f"decode tokens/sec LLaMA-{args.model} Q4_0 @{world} GPUs (layer pipeline, {S} sequences in flight); % HBM-roofline on Q4_0 GEMV",
-            "value": total / dt, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        total = r["S"] * r["steps"]
+        headline.update({
+            "metric": f"decode tokens/sec LLaMA-{args.model} Q4_0 @{world} GPUs (layer pipeline, {r['S']} sequences in flight); % HBM-roofline on Q4_0 GEMV",
+            "value": total / r["dt"], "unit": "tokens/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
+            "ms_per_step": r["dt"] * 1e3 / r["steps"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "q4_0 x q4_0 -> int32 block sums, fp32 scales/accumulate",
             "data": "synthetic (random-init weights in the reference file format, synthetic token ids)",
             "config": {"workload": f"LLaMA-{args.model} Q4_0 greedy decode, {world}-stage layer pipeline "
-                                   f"({cfg['n_layer']} layers / {world}), {S} independent sequences in flight, n_ctx {args.n_ctx}; "
+                                   f"({r['n_layer']} layers / {world}), {r['S']} independent sequences in flight, n_ctx {args.n_ctx}; "
                                    f"a step = one token for every sequence",
-                       "parallelism": f"pp{world} (RCCL p2p hand-off of the fp32 residual stream)",
-                       "sequences": S, "tokens_timed": total},
-            "roofline": roof,
+                       "parallelism": f"pp{world}", "hand_off": r["hand_off"],
+                       "sequences": r["S"], "tokens_timed": total},
+            "roofline": r["roof"],
+            "parity": r["parity"],
             "cpu_baseline": None,
             "cpu_baseline_note": "timed at N = 1 only (bench.py --gpus 1)",
-            "single_stream_tokens_per_s_estimate": steps / dt,
+            "single_stream": r["single"],
             "schedule": "host-synchronous" if sync_schedule else "stream-ordered (hipGraph stage steps, device-side greedy pick)",
-        }), flush=True)
+        })
+    # BASELINE.json configs[4]: the 65B model is what the 8-GPU pipeline is for.  A bounded extra leg (32 timed steps), reported next to
+    # the headline; whatever happens to it, the headline line above is printed.
+    if models and args.model != "65B" and os.environ.get("LLAMAHIP_BENCH_65B", "1") != "0" and "65B" in models:
+        try:
+            r65 = run_model("65B", models["65B"], 32, 4, 4)
+            if rank == 0:
+                t65 = r65["S"] * r65["steps"]
+                headline["config4_65B"] = {"workload": f"LLaMA-65B Q4_0, {r65['n_layer']} layers over {world} stages, {r65['S']} sequences in flight",
+                                           "tokens_per_s": t65 / r65["dt"], "ms_per_step": r65["dt"] * 1e3 / r65["steps"], "steps": r65["steps"],
+                                           "parity": r65["parity"], "single_stream": r65["single"], "hand_off": r65["hand_off"], "roofline": r65["roof"]}
+        except BaseException as e:                   # (SystemExit from a guard included: the headline survives)
+            if rank == 0:
+                headline["config4_65B"] = {"error": repr(e)}
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(headline), flush=True)
     watchdog.cancel()
     os.dup2(2, 1)                                # communicator teardown may print as well
     dist.destroy_process_group()
