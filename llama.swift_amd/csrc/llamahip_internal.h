@@ -59,6 +59,7 @@ hipError_t launch_quantize_q41_offline(const void *src, int f16, uint8_t *dst, l
 hipError_t launch_embed_dense(const int32_t *tokens, const void *emb, int wtype, float *x, int d, int N, hipStream_t st);
 
 hipError_t init_kernel_attrs();
+size_t prep_lds_bytes(int K);                                       // dynamic LDS of the LDS-staged activation preparation (prep.hip)
 // exhaustive check (all 65 536 entries) that the device's double-precision formulas reproduce the host-built SiLU /
 // exp tables; enables the gather-free paths of the decode kernels when they do (g_lut_math)
 extern int g_lut_math;

@@ -1,0 +1,1302 @@
+// prompt_gemm.hip -- the Q4_0 x Q4_0 mat-mul for MULTI-ROW evals (prompt chunks), bit-exact with ggml_compute_forward_mul_mat_q4_0_f32
+// (ggml.c:5987-6285, vec_dot :1415-1466): k_gemm_lds (decode tiles, QA in LDS), k_gemm_skinny (2..60 rows, epilogues with RoPE + KV append /
+// SiLU*up -> Q4_0), k_gemm_rows (row-lane tiles), k_gemm_mfma / k_gemm_mfma16 (integer sums on the matrix cores), the tile converters,
+// and launch_gemm with its kernel selection rules.  Conventions and layouts: decode.hip / DESIGN.md.
+#include "kcommon.hip.h"
+
+namespace lh {
+
+// Prompt path on the decode tiles (runs when the handle has no row-lane copy): NC activation rows
+// share every weight tile; their operands for one chunk (NC x 288 B) are staged once per workgroup in
+// LDS (double-buffered, one barrier per chunk) and shared by its 4 waves.  (Round 1's first variant
+// read them through the texture path instead: 64 vector loads per chunk per wave, 1.8x slower.)
+//   ncols <= NC: columns past ncols are clamped duplicates whose results are not stored.
+template <int NC, int EPI>
+__global__ void __launch_bounds__(256)
+k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
+           const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols,
+           float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    __shared__ u32x4 sA[2][NC * 16];          // [buf][col][chain k][2 x u32x4]  = [col][64 dwords]
+    __shared__ f32x4 sD[2][NC * 2];           // [buf][col][8 floats]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+    const int g = min((int) (blockIdx.x * nw + wave), ngroups - 1);
+    const bool valid = (int) (blockIdx.x * nw + wave) < ngroups;
+    const uint8_t *wbase = wt + (size_t) g * (nchunks + 1) * TILE_BYTES;
+    const int k = lane & 7;
+    const long strideA = (long) nchunks * 16, strideD = (long) nchunks * 2;      // in 16-byte granules
+    const int soff = 1024 + ((lane >> 3) * 8 + (lane & 3) * 2) * 4;
+    constexpr int GA = (NC * 16 + 255) / 256, GD = 1;                             // granules per thread per chunk
+    float accs[NC];
+#pragma unroll
+    for (int n = 0; n < NC; n++) accs[n] = 0.0f;
+
+    constexpr int RD = 4;                     // weight ring depth
+    u32x4 wq[RD];
+    f32x2 ws[RD];
+#pragma unroll
+    for (int i = 0; i < RD; i++) {
+        const uint8_t *tp = wbase + (size_t) min(i, nchunks) * TILE_BYTES;
+        wq[i] = __builtin_nontemporal_load((const u32x4 *) (tp + lane * 16));
+        ws[i] = __builtin_nontemporal_load((const f32x2 *) (tp + soff));
+    }
+    // QA granule (col n, piece p) of chunk c lives at qa_A4[n * strideA + c * 16 + p]
+    u32x4 ga[GA];
+    f32x4 gd[GD];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < GA; u++) {
+            const int gi = min(tid + u * nt, NC * 16 - 1), n = min(gi >> 4, ncols - 1), pce = gi & 15;
+            ga[u] = ((const u32x4 *) qa_A)[n * strideA + (long) c * 16 + pce];
+        }
+        const int gj = min(tid, NC * 2 - 1), n = min(gj >> 1, ncols - 1);
+        gd[0] = ((const f32x4 *) qa_d)[n * strideD + (long) c * 2 + (gj & 1)];
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < GA; u++) { const int gi = tid + u * nt; if (gi < NC * 16) sA[buf][gi] = ga[u]; }
+        if (tid < NC * 2) sD[buf][tid] = gd[0];
+    };
+    fetch(0);
+    stash(0);
+    for (int c0 = 0; c0 < nchunks; c0 += RD) {
+#pragma unroll
+        for (int i = 0; i < RD; i++) {
+            const int c = c0 + i;                        // chunks past the row end read the zero tile: no effect
+            __syncthreads();
+            const int buf = c & 1;
+            if (c + 1 < nchunks) fetch(c + 1);
+            const u32x4 w = wq[i];
+            const f32x2 sw = ws[i];
+            {
+                const uint8_t *tp = wbase + (size_t) min(c + RD, nchunks) * TILE_BYTES;
+                wq[i] = __builtin_nontemporal_load((const u32x4 *) (tp + lane * 16));
+                ws[i] = __builtin_nontemporal_load((const f32x2 *) (tp + soff));
+            }
+            if (c < nchunks) {
+                const uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
+                const float s0 = quad_bcast<0>(sw.x), s1 = quad_bcast<1>(sw.x), s2 = quad_bcast<2>(sw.x), s3 = quad_bcast<3>(sw.x);
+                const float s4 = quad_bcast<0>(sw.y), s5 = quad_bcast<1>(sw.y), s6 = quad_bcast<2>(sw.y), s7 = quad_bcast<3>(sw.y);
+#pragma unroll
+                for (int n = 0; n < NC; n++) {
+                    const u32x4 a0 = sA[buf][n * 16 + k * 2], a1 = sA[buf][n * 16 + k * 2 + 1];
+                    const f32x4 d0 = sD[buf][n * 2], d1 = sD[buf][n * 2 + 1];
+                    float acc = accs[n];
+#define LH_STEPN(SW, WD, AD, DA) { const float sc_ = (SW) * (DA); const int p_ = __builtin_amdgcn_sdot8((int) (WD), (int) (AD), 0, true); acc = fmaf(sc_, (float) p_, acc); }
+                    LH_STEPN(s0, w0, a0.x, d0.x) LH_STEPN(s1, w0, a0.y, d0.y)
+                    LH_STEPN(s2, w1, a0.z, d0.z) LH_STEPN(s3, w1, a0.w, d0.w)
+                    LH_STEPN(s4, w2, a1.x, d1.x) LH_STEPN(s5, w2, a1.y, d1.y)
+                    LH_STEPN(s6, w3, a1.z, d1.z) LH_STEPN(s7, w3, a1.w, d1.w)
+#undef LH_STEPN
+                    accs[n] = acc;
+                }
+            }
+            if (c + 1 < nchunks) stash((c + 1) & 1);
+        }
+    }
+    int lg = g;
+    if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+    const int m = lg * 8 + (lane >> 3);
+#pragma unroll
+    for (int n = 0; n < NC; n++) {
+        float acc = fold8(accs[n]);
+        if (valid && k == 0 && m < M && n < ncols) {
+            if (EPI == EPI_RESID) acc = acc + resid[(size_t) n * resid_stride + m];
+            y[(size_t) n * y_stride + m] = acc;
+        }
+    }
+}
+
+// Short prompt chunks (2 <= N <= ~32 columns; the reference feeds prompts n_batch = 8 tokens at a time): the
+// decode kernel's work distribution -- lane = (row, chain), weights streamed once per wave through a
+// register ring -- with NC activation columns per wave.  The row-per-lane kernel below needs 64 rows per
+// wave, which leaves a 4096-row matrix with 64 waves per column and makes every column re-read the
+// weights from L2; here a 4096-row matrix is 512 / RG waves per column GROUP and the weights are read once
+// per group.  The QA operands of the workgroup's NC columns are staged whole in LDS before the main loop
+// (no barriers inside it); the weight ring is put in flight before the staging so the two latencies
+// overlap.  Same arithmetic and order as k_gemv.  What bounds this kernel is VALU issue and LDS read
+// bandwidth together (a 16-byte broadcast read still delivers 1 KiB per wave), so:
+//   * a wave owns RG row-groups (lane = row r of each, chain k): every activation read serves RG rows;
+//   * the d_w * d_a products are computed once per quad lane (lane t of a quad holds the weight scales of
+//     blocks t and t + 4 -- the tile's scale layout -- and reads the two matching activation scales with
+//     one 4-byte LDS read each), and the FMA takes them through the DPP quad broadcast of v_fmac_f32_dpp:
+//     8 dots + 4 packed subtractions + 2 products + 8 FMAs = 22 VALU per (lane, chunk, column), not 28.
+//     The DPP form is written as inline assembly (the compiler keeps v_mov_dpp + v_fmac); its one hazard
+//     -- a VALU write of the DPP source needs two wait states before the read -- is padded inside.
+//   grid: XCD-aware, blockIdx -> (row-block of 4 * RG row-groups, column group), column groups of a row-block on one XCD
+//   dynamic LDS: [NC][(nchunks + 4) * 64] dwords A, then [NC][(nchunks + 4) * 8] floats d (4 zeroed padding chunks per column)
+// two independent chains interleaved (a dependent v_fmac issues ~1.7x slower than an independent one)
+#define LH_FMAC8_DPP2(ACC0, PLO0, PHI0, A01, A23, A45, A67, ACC1, PLO1, PHI1, B01, B23, B45, B67)  \
+    asm("s_nop 1\n\t"                                                                              \
+        "v_fmac_f32_dpp %0, %2, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %14 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %16 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %12, %17 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %13, %18 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
+        "v_fmac_f32_dpp %1, %13, %19 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"            \
+        "v_fmac_f32_dpp %1, %13, %20 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_fmac_f32_dpp %0, %3, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"            \
+        "v_fmac_f32_dpp %1, %13, %21 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"                \
+        : "+v"(ACC0), "+v"(ACC1)                                                                   \
+        : "v"(PLO0), "v"(PHI0), "v"((A01).x), "v"((A01).y), "v"((A23).x), "v"((A23).y),            \
+          "v"((A45).x), "v"((A45).y), "v"((A67).x), "v"((A67).y),                                  \
+          "v"(PLO1), "v"(PHI1), "v"((B01).x), "v"((B01).y), "v"((B23).x), "v"((B23).y),            \
+          "v"((B45).x), "v"((B45).y), "v"((B67).x), "v"((B67).y))
+
+//   EPI_ROPE_KV (the wq|wk|wv matrix): the epilogue is k_rope_kv -- outputs 2i, 2i+1 of a row sit in lanes 8
+//         apart of one DPP row, so the pair is rotated in place (double arithmetic, host-built cos/sin table)
+//         and q goes to qr, k and v straight into the cache rows n_past + column: no fp32 qkv round trip,
+//         no RoPE launch
+//   EPI_SILU_QA (the interleaved w1|w3 matrix only, RG = 1): 8 waves per workgroup = 32 gate rows + the same 32
+//         up rows; wave n of the workgroup then turns column n's 64 outputs into silu_lut(gate) * up
+//         (ggml.c:1956-1963, .mm:678-680) and quantizes them as one Q4_0 activation block (ggml.c:456-523)
+//         of the w2 mat-mul's operand: out_A / out_d, row strides out_strideA dwords / out_strideD floats
+//         (no fp32 round trip, no preparation launch in between)
+template <int NC, int RG, int EPI>
+__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256)
+k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
+              const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
+              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride,
+              const uint16_t *__restrict__ T_silu, uint32_t *__restrict__ out_A, float *__restrict__ out_d,
+              long out_strideA, long out_strideD, RopeKvArgs ra) {
+    constexpr int D = 4;
+    constexpr int NW = EPI == EPI_SILU_QA ? 8 : 4, NT = NW * 64;
+    static_assert(EPI != EPI_SILU_QA || RG == 1, "the fused FFN epilogue pairs one gate wave with one up wave");
+    extern __shared__ double smem_d[];
+    // every column's operand is padded with D zeroed chunks: the ring tail and the one-step-ahead operand
+    // fetch run past the row end (against the zero tile) without an index clamp (see k_gemv)
+    const int npad = nchunks + D;
+    u32x4 *sA = (u32x4 *) smem_d;                            // [NC][npad * 16]
+    f32x4 *sD = (f32x4 *) (sA + (size_t) NC * npad * 16);    // [NC][npad * 2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3, cg = q % ncg, wgi = (q / ncg) * 8 + xcd;
+    const int g0 = (wgi * NW + wave) * RG;                    // first of this wave's RG consecutive row-groups
+    const int n0 = cg * NC;
+    const int k = lane & 7, t = lane & 3;
+    const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + t * 2) * 4u;
+    uint32_t vw_ = voff_w, vs_ = voff_s;                     // (see k_gemv: SGPR base + per-lane offset addressing)
+#define LH_OPAQUE_OFFSETS() { vw_ = voff_w; vs_ = voff_s; asm volatile("" : "+v"(vw_), "+v"(vs_)); }
+    const uint8_t *wbase[RG];
+#pragma unroll
+    for (int rg = 0; rg < RG; rg++) wbase[rg] = wt + (size_t) min(g0 + rg, ngroups - 1) * (nchunks + 1) * TILE_BYTES;
+
+    u32x4 wq[RG][D];
+    f32x2 ws[RG][D];
+#define LH_LOADW(SLOT, CH)                                                                         \
+    _Pragma("unroll")                                                                              \
+    for (int rg = 0; rg < RG; rg++) {                                                              \
+        const uint8_t *tp_ = wbase[rg] + (size_t) min((CH), nchunks) * TILE_BYTES;                 \
+        wq[rg][SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + (size_t) vw_));           \
+        ws[rg][SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + (size_t) vs_));           \
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) { LH_LOADW(i, i) }
+    __builtin_amdgcn_sched_barrier(0);
+    // stage the NC columns' operands (columns past ncols are clamped duplicates, never stored);
+    // 8 loads per thread in flight per pass: a pass is one L2 round trip
+    {
+        constexpr int LB = 8;
+        const int perA = nchunks * 16, perD = nchunks * 2;     // QA row strides in 16-byte granules
+        const int totA = NC * perA, totD = NC * perD;
+        for (int base = tid; base < totA; base += NT * LB) {
+            u32x4 v[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int i = min(base + u * NT, totA - 1), n = i / perA, r = i - n * perA;
+                v[u] = ((const u32x4 *) qa_A)[(long) min(n0 + n, ncols - 1) * perA + r];
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int i = base + u * NT, n = i / perA, r = i - n * perA;
+                if (i < totA) sA[n * npad * 16 + r] = v[u];
+            }
+        }
+        for (int base = tid; base < totD; base += NT * LB) {
+            f32x4 v[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int i = min(base + u * NT, totD - 1), n = i / perD, r = i - n * perD;
+                v[u] = ((const f32x4 *) qa_d)[(long) min(n0 + n, ncols - 1) * perD + r];
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int i = base + u * NT, n = i / perD, r = i - n * perD;
+                if (i < totD) sD[n * npad * 2 + r] = v[u];
+            }
+        }
+        for (int i = tid; i < NC * D * 18; i += NT) {         // zero the padding chunks
+            const int n = i / (D * 18), r = i - n * (D * 18);
+            if (r < D * 16) sA[(n * npad + nchunks) * 16 + r] = u32x4{ 0u, 0u, 0u, 0u };
+            else sD[(n * npad + nchunks) * 2 + (r - D * 16)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        }
+    }
+    // The staging loops have run-time trip counts, after which the compiler's waitcnt pass no longer knows
+    // how old the ring loads are and would put a vmcnt(0) at the top of the single-block main loop, i.e. in
+    // EVERY iteration (no prefetch left).  Draining explicitly here makes the loop's entry state exact, and
+    // the waits inside become the counted vmcnt(2 * RG * (D - 1)) of the back edge.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), nothing else
+    __syncthreads();
+
+    const float *sDf = (const float *) sD;
+    float accs[RG][NC];
+#pragma unroll
+    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+        for (int n = 0; n < NC; n++) accs[rg][n] = 0.0f;
+    // LDS operands of step (slot, column) are fetched one step ahead into the other half of a two-entry
+    // register buffer (D * NC steps per loop trip is even, so the parity is a compile-time constant)
+    u32x4 la0[2], la1[2];
+    float ldl[2], ldh[2];
+#define LH_LDSLOAD(BUF, N, CH)                                                                     \
+    {                                                                                              \
+        const u32x4 *pa_ = sA + ((N) * npad + (CH)) * 16 + k * 2;                                  \
+        la0[BUF] = pa_[0]; la1[BUF] = pa_[1];                                                      \
+        const float *pd_ = sDf + ((N) * npad + (CH)) * 8 + t;                                      \
+        ldl[BUF] = pd_[0]; ldh[BUF] = pd_[4];                                                      \
+    }
+#define LH_CONSUME(SLOT, CH)                                                                       \
+    {                                                                                              \
+        _Pragma("unroll")                                                                          \
+        for (int n = 0; n < NC; n++) {                                                             \
+            const int pb_ = ((SLOT) * NC + n) & 1;                                                 \
+            const u32x4 a0 = la0[pb_], a1 = la1[pb_];                                              \
+            const float dlo_ = ldl[pb_], dhi_ = ldh[pb_];                                          \
+            if (n + 1 < NC) LH_LDSLOAD(pb_ ^ 1, n + 1, (CH))                                       \
+            else LH_LDSLOAD(pb_ ^ 1, 0, (CH) + 1)                                                  \
+            __builtin_amdgcn_sched_barrier(0);     /* reads for the next step go out before this step's arithmetic */ \
+            float plo_[RG], phi_[RG];                                                              \
+            f32x2 q01_[RG], q23_[RG], q45_[RG], q67_[RG];                                          \
+            _Pragma("unroll")                                                                      \
+            for (int rg = 0; rg < RG; rg++) {                                                      \
+                const u32x4 w = wq[rg][SLOT];                                                      \
+                plo_[rg] = ws[rg][SLOT].x * dlo_; phi_[rg] = ws[rg][SLOT].y * dhi_;                \
+                const int i0_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.x, 0x4B400000, true);   \
+                const int i1_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.y, 0x4B400000, true);   \
+                const int i2_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.z, 0x4B400000, true);   \
+                const int i3_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.w, 0x4B400000, true);   \
+                const int i4_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.x, 0x4B400000, true);   \
+                const int i5_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.y, 0x4B400000, true);   \
+                const int i6_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.z, 0x4B400000, true);   \
+                const int i7_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.w, 0x4B400000, true);   \
+                const f32x2 mg_ = { 12582912.0f, 12582912.0f };                                    \
+                q01_[rg] = f32x2{ __builtin_bit_cast(float, i0_), __builtin_bit_cast(float, i1_) } - mg_; \
+                q23_[rg] = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
+                q45_[rg] = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
+                q67_[rg] = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
+            }                                                                                      \
+            if (RG == 2) {                                                                         \
+                LH_FMAC8_DPP2(accs[0][n], plo_[0], phi_[0], q01_[0], q23_[0], q45_[0], q67_[0],    \
+                              accs[RG - 1][n], plo_[RG - 1], phi_[RG - 1], q01_[RG - 1], q23_[RG - 1], q45_[RG - 1], q67_[RG - 1]); \
+            } else {                                                                               \
+                LH_FMAC8_DPP(accs[0][n], plo_[0], phi_[0], q01_[0], q23_[0], q45_[0], q67_[0]);    \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    }
+    LH_LDSLOAD(0, 0, 0)
+    // straight-line ring body (see k_gemv): chunks past the row end read the zero tile (scale 0)
+    for (int c0 = 0; c0 < nchunks; c0 += D) {
+        LH_OPAQUE_OFFSETS()
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            LH_CONSUME(i, c0 + i)
+            LH_LOADW(i, c0 + D + i)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef LH_CONSUME
+#undef LH_LDSLOAD
+#undef LH_LOADW
+#undef LH_OPAQUE_OFFSETS
+
+    if (EPI == EPI_SILU_QA) {
+        // waves 0-3 hold gate rows wgi*32 .. +31, waves 4-7 the matching up rows
+        float *gu = (float *) smem_d;                          // [NC][64]; the operand staging area is free again
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float acc = fold8(accs[0][n]);
+            if (k == 0) gu[n * 64 + wave * 8 + (lane >> 3)] = acc;
+        }
+        __syncthreads();
+        if (wave < NC && n0 + wave < ncols && wgi * 8 < ngroups) {
+            const int i = lane & 31;
+            const float act = h2f_bits(T_silu[f2h_bits(gu[wave * 64 + i])]) * gu[wave * 64 + 32 + i];
+            const float amax = max_lanes_0_31(fabsf(act));
+            const float dd = amax / 7.0f;
+            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+            const uint32_t nib = (uint32_t) ((int) __builtin_rintf(act * id)) & 0xF;       // signed nibble of (q - 8)
+            const int kk = lane & 7;
+            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+            const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+            const int bb = wgi, c = bb >> 3, j = bb & 7;
+            uint32_t *oA = out_A + (size_t) (n0 + wave) * out_strideA;
+            float *oD = out_d + (size_t) (n0 + wave) * out_strideD;
+            if (lane < 8) oA[(c * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+            if (lane == 0) oD[bb] = dd;
+        }
+        return;
+    }
+#pragma unroll
+    for (int rg = 0; rg < RG; rg++) {
+        const int g = g0 + rg;
+        int lg = g;
+        if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
+        const int m = lg * 8 + (lane >> 3);
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            float acc = fold8(accs[rg][n]);
+            if (EPI == EPI_ROPE_KV) {
+                // (ggml.c:7076-7131, .mm:586-611; see k_rope_kv) rows m, m^1 = lanes 8 apart; m is even iff the lane's row is
+                const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
+                if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
+                    const int which = m / ra.d, c = m - which * ra.d, pos = ra.n_past + n0 + n;
+                    if (which == 2) {
+                        ra.Vc[(size_t) pos * ra.d + c] = acc;
+                    } else {
+                        const int pe = (c % ra.dh) & ~1;
+                        const double cs = ra.tab[(size_t) pos * ra.dh + pe], sn = ra.tab[(size_t) pos * ra.dh + pe + 1];
+                        const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
+                        const float val = (c & 1) ? (float) (x0 * sn + x1 * cs) : (float) (x0 * cs - x1 * sn);
+                        if (which == 0) ra.qr[(size_t) (n0 + n) * ra.d + c] = val;
+                        else ra.Kc[(size_t) pos * ra.d + c] = val;
+                    }
+                }
+                continue;
+            }
+            if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
+                if (EPI == EPI_RESID) acc = acc + resid[(size_t) (n0 + n) * resid_stride + m];
+                y[(size_t) (n0 + n) * y_stride + m] = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prompt path, row-per-lane: second resident copy of a matrix in ROW-LANE tiles.
+//   tile (row-block R of 64 rows, chunk c) = 10240 B; a row-block is nchunks + 1 tiles, the last all-zero:
+//     vector k = 0..7 : [64 lanes x 16 B]  lane = row: chain k of the row's 8 blocks (same 4 dwords a
+//                       decode tile holds for lane (r, k))
+//     vector 8, 9     : [64 lanes x 16 B]  the row's block scales s0..s3 | s4..s7
+// A wave owns 64 rows x NC activation columns; every lane runs all 8 chains of ITS row, so the
+// activation operand (column n, chunk c: 64 dwords + 8 scales) is the same for the whole wave: it is
+// fetched with scalar loads and fed to v_dot8_i32_i4 / v_mul_f32 as an SGPR operand -- no LDS, no
+// barriers, no cross-lane traffic, and the d_w*d_a product is shared by the 8 chains of a block
+// (25 VALU instructions per row x block x column instead of 32).  Same arithmetic, same order.
+// ------------------------------------------------------------------------------------------------
+constexpr int ROWTILE_BYTES = 10240;
+
+// decode tiles -> row-lane tiles (load time).  One thread per (row-block, chunk, vector, lane).
+__global__ void k_tiles_to_rows(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ rows,
+                                int ngroups, int nchunks, int nrb, int gmapF8) {
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long) nrb * (nchunks + 1) * 10 * 64;
+    if (gid >= total) return;
+    const int lane = (int) (gid & 63);
+    const long t = gid >> 6;
+    const int v = (int) (t % 10);
+    const int c = (int) ((t / 10) % (nchunks + 1));      // c == nchunks: the all-zero tile closing the row-block
+    const int rb = (int) (t / 10 / (nchunks + 1));
+    const int m = rb * 64 + lane, lg = m >> 3, r = m & 7;
+    u32x4 out = { 0u, 0u, 0u, 0u };
+    if (lg < ngroups && c < nchunks) {
+        int tg = lg;
+        if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
+        const uint8_t *tp = tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
+        if (v < 8) {
+            out = *(const u32x4 *) (tp + (r * 8 + v) * 16);
+        } else {
+            const uint32_t *sp = (const uint32_t *) (tp + 1024 + r * 32);     // stored [s0,s4,s1,s5,s2,s6,s3,s7]
+            const int o = (v - 8);
+            out = u32x4{ sp[0 + o], sp[2 + o], sp[4 + o], sp[6 + o] };
+        }
+    }
+    *(u32x4 *) (rows + ((size_t) rb * (nchunks + 1) + c) * ROWTILE_BYTES + v * 1024 + lane * 16) = out;
+}
+
+//   DB  : double-buffer the weight chunk in registers (next chunk in flight during the arithmetic);
+//         without it the wave stalls on every chunk and the other waves of the SIMD cover -- fewer
+//         registers, more waves
+//   WPE : occupancy target (waves per SIMD) the register allocator must honour
+template <int NC, int EPI, bool DB, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE)))
+k_gemm_rows(const uint8_t *__restrict__ wr, int nrb, int nchunks, int M,
+            const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
+            float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    // XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD its own
+    // row-blocks (rb % 8) and walk the column groups of one row-block back to back, so the weight
+    // tiles a column group streams are still in that XCD's L2 for the next one
+    // (one wave per workgroup: grouping 4 row-blocks of the same columns into a workgroup, to share the
+    // scalar-cache lines of the operand, measured 3 % slower)
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    const int cg = q % ncg, rb = (q / ncg) * 8 + xcd;
+    if (rb >= nrb) return;
+    const int lane = threadIdx.x;
+    const int n0 = cg * NC;
+    const uint8_t *wbase = wr + (size_t) rb * (nchunks + 1) * ROWTILE_BYTES + lane * 16;
+    const long strideA = (long) nchunks * 64, strideD = (long) nchunks * 8;      // per column, in dwords / floats
+    float acc[NC][8];
+#pragma unroll
+    for (int n = 0; n < NC; n++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[n][k] = 0.0f;
+
+// one chunk (registers WQ[8], scales SA/SB) against the NC columns at activation chunk CA
+#define LH_ROWS_CONSUME(WQ, SA, SB, CA)                                                                        \
+    {                                                                                                          \
+        const float sw_[8] = { (SA).x, (SA).y, (SA).z, (SA).w, (SB).x, (SB).y, (SB).z, (SB).w };               \
+        _Pragma("unroll") for (int n = 0; n < NC; n++) {                                                       \
+            const int col_ = min(n0 + n, ncols - 1);           /* wave-uniform: scalar loads below */          \
+            const uint32_t *Ap_ = qa_A + col_ * strideA + (long) (CA) * 64;                                    \
+            const float *Dp_ = qa_d + col_ * strideD + (long) (CA) * 8;                                        \
+            _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                    \
+                const float sc_ = sw_[j] * Dp_[j];                                                             \
+                _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                \
+                    const uint32_t wd_ = (j >> 1) == 0 ? (WQ)[k].x : (j >> 1) == 1 ? (WQ)[k].y : (j >> 1) == 2 ? (WQ)[k].z : (WQ)[k].w; \
+                    /* int -> float without v_cvt: accumulate onto the bit pattern of 1.5 * 2^23 (ulp 1), so the  */ \
+                    /* result IS the float 12582912 + isum; subtracting the constant is exact and pairs up as   */ \
+                    /* v_pk_add_f32 (|isum| <= 8 * 7 * 8 * 8 never leaves the binade)                           */ \
+                    const int p_ = __builtin_amdgcn_sdot8((int) wd_, (int) Ap_[k * 8 + j], 0x4B400000, true);  \
+                    acc[n][k] = fmaf(sc_, __builtin_bit_cast(float, p_) - 12582912.0f, acc[n][k]);             \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+#define LH_ROWS_LOAD(WQ, SA, SB, CH)                                                                           \
+    {                                                                                                          \
+        const uint8_t *tp_ = wbase + (size_t) (CH) * ROWTILE_BYTES;                                            \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) (WQ)[k] = __builtin_nontemporal_load((const u32x4 *) (tp_ + k * 1024)); \
+        (SA) = __builtin_nontemporal_load((const f32x4 *) (tp_ + 8192));                                       \
+        (SB) = __builtin_nontemporal_load((const f32x4 *) (tp_ + 9216));                                       \
+    }
+    if constexpr (NC >= 2 && DB) {
+        // column groups: accumulators take the registers (8 * NC) and one chunk of arithmetic
+        // (>= 1000 VALU instructions) covers the next chunk's load latency: double buffer
+        u32x4 w[8], wn[8];
+        f32x4 s0, s1, s0n, s1n;
+        LH_ROWS_LOAD(wn, s0n, s1n, 0)
+        for (int c = 0; c < nchunks; c++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = wn[k];
+            s0 = s0n; s1 = s1n;
+            LH_ROWS_LOAD(wn, s0n, s1n, min(c + 1, nchunks - 1))
+            LH_ROWS_CONSUME(w, s0, s1, c)
+        }
+    } else if constexpr (NC >= 2) {
+        u32x4 w[8];
+        f32x4 s0, s1;
+        for (int c = 0; c < nchunks; c++) {
+            LH_ROWS_LOAD(w, s0, s1, c)
+            LH_ROWS_CONSUME(w, s0, s1, c)
+        }
+    } else {
+        // single columns (short prompts: the reference feeds 9 tokens at a time): the wave is alone on
+        // its SIMD and walks K serially, so nothing may sit on its critical path but the arithmetic:
+        //   * weights: a ring of RD chunks with RD - 1 in flight.  Straight-line body (no branch around loads,
+        //     see k_gemv): chunks past the row end are the zero tile closing the row-block (scale 0);
+        //   * the column's whole operand (K + K/8 bytes) is copied to LDS once and read back with broadcast
+        //     ds_reads one block pair ahead -- scalar loads per chunk cannot be prefetched (a chunk's operand
+        //     is 72 of the ~100 SGPRs) and cost this kernel a scalar-cache round trip per chunk.
+        extern __shared__ __attribute__((aligned(16))) uint32_t lds_op[];   // [nchunks * 64] A dwords | [nchunks * 8] da
+        {
+            const int col = min(n0, ncols - 1);
+            const u32x4 *ga = (const u32x4 *) (qa_A + col * strideA);
+            const f32x4 *gd = (const f32x4 *) (qa_d + col * strideD);
+            for (int i = lane; i < nchunks * 16; i += 64) ((u32x4 *) lds_op)[i] = ga[i];
+            for (int i = lane; i < nchunks * 2; i += 64) ((f32x4 *) (lds_op + nchunks * 64))[i] = gd[i];
+        }
+        constexpr int RD = 3;                                     // 3 x 40 VGPRs; a 4th slot spills
+        u32x4 w[RD][8];
+        f32x4 s0[RD], s1[RD];
+#pragma unroll
+        for (int i = 0; i < RD; i++) LH_ROWS_LOAD(w[i], s0[i], s1[i], min(i, nchunks))
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        const float *lds_d = (const float *) (lds_op + nchunks * 64);
+        for (int c0 = 0; c0 < nchunks; c0 += RD) {
+#pragma unroll
+            for (int i = 0; i < RD; i++) {
+                const int c = c0 + i, ca = min(c, nchunks - 1);
+                const float sw[8] = { s0[i].x, s0[i].y, s0[i].z, s0[i].w, s1[i].x, s1[i].y, s1[i].z, s1[i].w };
+                const f32x4 d0 = *(const f32x4 *) (lds_d + ca * 8), d1 = *(const f32x4 *) (lds_d + ca * 8 + 4);
+                const float da[8] = { d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w };
+#pragma unroll
+                for (int h = 0; h < 2; h++) {                     // blocks 4h .. 4h + 3 of every chain: 8 ds_read_b128
+                    u32x4 a[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a[k] = *(const u32x4 *) (lds_op + ca * 64 + k * 8 + 4 * h);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const int j = 4 * h + jj;
+                        const float sc = sw[j] * da[j];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t wd = (j >> 1) == 0 ? w[i][k].x : (j >> 1) == 1 ? w[i][k].y : (j >> 1) == 2 ? w[i][k].z : w[i][k].w;
+                            const uint32_t ad = jj == 0 ? a[k].x : jj == 1 ? a[k].y : jj == 2 ? a[k].z : a[k].w;
+                            const int p = __builtin_amdgcn_sdot8((int) wd, (int) ad, 0x4B400000, true);
+                            acc[0][k] = fmaf(sc, __builtin_bit_cast(float, p) - 12582912.0f, acc[0][k]);
+                        }
+                        if (jj & 1) __builtin_amdgcn_sched_barrier(0);      // bound the live temporaries
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                LH_ROWS_LOAD(w[i], s0[i], s1[i], min(c + RD, nchunks))
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#undef LH_ROWS_CONSUME
+#undef LH_ROWS_LOAD
+    const int m = rb * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < NC; n++) {
+        // the reference's lane fold: ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7))  (ggml.c:872-887 tree)
+        float r = ((acc[n][0] + acc[n][4]) + (acc[n][2] + acc[n][6])) + ((acc[n][1] + acc[n][5]) + (acc[n][3] + acc[n][7]));
+        if (m < M && n0 + n < ncols) {
+            if (EPI == EPI_RESID) r = r + resid[(size_t) (n0 + n) * resid_stride + m];
+            y[(size_t) (n0 + n) * y_stride + m] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prompt path on the matrix cores, still bit-exact.
+// The reference needs, per output and Q4_0 block, EIGHT separate 4-element integer sums (one per
+// lane of its AVX accumulator), each scaled and FMA-accumulated on its own chain -- an MFMA sums
+// over its whole K.  So the activation operand is MASKED: v_mfma_i32_32x32x32_i8 (K = 32 = one
+// block) is issued once per chain with every byte of B zeroed except that chain's 4 elements; the
+// product is that chain's exact integer sum for a 32 x 32 tile of outputs.  7/8 of the MACs multiply
+// zeros, which the matrix pipe has to spare, and the VALU is left with what cannot be avoided: the
+// conversion and the scaled FMA, both packed (v_pk_add_f32 / v_pk_fma_f32), 16 outputs per lane.
+//   * A = weights as int8 = signed nibble << 4 (two VALU per 8 nibbles); the x16 is undone for free
+//     by accumulating onto the bit pattern of 1.5 * 2^19 (ulp 1/16): D IS the float 786432 + isum.
+//   * d_w * d_a: 16 products per lane and block, shared by the 8 chains.
+// Third resident copy of a matrix ("mtiles"): tile (row-block of 32, quad of 4 blocks) = 2560 B:
+//   [j 0..3][lane 0..63][8 B]  lane = m + 32 * kg (kg = K-half: elements 16kg..16kg+15 of block 4q+j);
+//                              dword 0 = signed nibbles of (k = 0..3, p = 0,1), dword 1 = k = 4..7,
+//                              nibble index 2 * (k & 3) + p  <->  element 2k + p + 16kg
+//   [j][32 rows] fp32 scales
+// Activation operand "QB" (k_qa_to_qb): per column [block][kg][16 int8] in the matching K order:
+//   dword t = (k >> 2) * 2 + p, byte k & 3.
+// Workgroup = 4 waves = 64 rows x 64 columns, operands of one quad staged in LDS (double-buffered).
+// ------------------------------------------------------------------------------------------------
+constexpr int MTILE_BYTES = 2560;
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x16v __attribute__((ext_vector_type(16)));
+
+// decode tiles -> mtiles (load time).  One thread per (row-block, quad, j, lane) for the nibbles,
+// plus the scales.
+__global__ void k_tiles_to_mtiles(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ mt,
+                                  int ngroups, int nchunks, int nrb32, int gmapF8) {
+    const int nq = nchunks * 2;
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long) nrb32 * nq * 4 * 64;
+    if (gid >= total) return;
+    const int lane = (int) (gid & 63), j = (int) ((gid >> 6) & 3);
+    const long t = gid >> 8;
+    const int q = (int) (t % nq), rb = (int) (t / nq);
+    const int m = lane & 31, kg = lane >> 5;
+    const int row = rb * 32 + m, lg = row >> 3, r = row & 7;
+    const int b = q * 4 + j, c = b >> 3, jj = b & 7, i = jj >> 1, half = jj & 1;
+    uint32_t x0 = 0, x1 = 0;
+    float d = 0.0f;
+    if (lg < ngroups) {
+        int tg = lg;
+        if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
+        const uint8_t *tp = tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t dw = ((const uint32_t *) (tp + (r * 8 + k) * 16))[i];       // chain k, blocks (2i, 2i+1)
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {
+                const uint32_t nib = (dw >> (8 * (2 * kg + pp) + 4 * half)) & 0xF;        // element 2k + pp + 16kg, already signed
+                if (k < 4) x0 |= nib << (4 * (2 * k + pp)); else x1 |= nib << (4 * (2 * (k - 4) + pp));
+            }
+        }
+        // scales of a row are stored [s0,s4,s1,s5,s2,s6,s3,s7]
+        d = ((const float *) (tp + 1024 + r * 32))[(jj & 3) * 2 + (jj >> 2)];
+    }
+    uint8_t *o = mt + ((size_t) rb * nq + q) * MTILE_BYTES;
+    ((uint32_t *) (o + j * 512 + lane * 8))[0] = x0;
+    ((uint32_t *) (o + j * 512 + lane * 8))[1] = x1;
+    if (kg == 0) ((float *) (o + 2048))[j * 32 + m] = d;
+}
+
+// QA (chain-major signed nibbles) -> QB (int8, MFMA K order).  One thread per (column, block, kg).
+__global__ void k_qa_to_qb(const uint32_t *__restrict__ qa_A, uint8_t *__restrict__ qb, int nchunks, int N) {
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int nbp = nchunks * 8;                           // blocks per column incl. padding
+    const long total = (long) N * nbp * 2;
+    if (gid >= total) return;
+    const int kg = (int) (gid & 1);
+    const long t = gid >> 1;
+    const int b = (int) (t % nbp), n = (int) (t / nbp);
+    const int c = b >> 3, jj = b & 7;
+    const uint32_t *src = qa_A + (size_t) n * nchunks * 64 + c * 64 + jj;
+    uint32_t out[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t dw = src[k * 8];
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+            const int nib = (int) ((dw >> (8 * (2 * kg + pp) + 4 * (jj & 1))) & 0xF);
+            const uint32_t v = (uint32_t) ((nib ^ 8) - 8) & 0xFF;                           // sign-extend 4 -> 8 bits
+            out[(k >> 2) * 2 + pp] |= v << (8 * (k & 3));
+        }
+    }
+    *(u32x4 *) (qb + ((size_t) n * nbp + b) * 32 + kg * 16) = u32x4{ out[0], out[1], out[2], out[3] };
+}
+
+//   FAST (LLAMAHIP_FLAG_FAST_PREFILL, opt-in, NOT the reference's arithmetic): one unmasked MFMA per Q4_0 block -- the
+//        whole 32-element integer sum -- and ONE fp32 FMA chain per output instead of eight: 8x fewer MFMAs, conversions
+//        and FMAs.  Sums are re-associated (the 8 lane partials of _mm256_madd_epi16 are added as integers before the
+//        scale), so logits agree with the exact path only to rounding and the next activation quantization can flip
+//        codes; never used for parity claims.
+template <int EPI, bool FAST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
+            const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
+            float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    constexpr int BSTRIDE = 144;                            // 128 B of a column's quad + 16 B pad: conflict-free b128 reads
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][2][MTILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t sB[2][64 * BSTRIDE];
+    __shared__ __attribute__((aligned(16))) float sDa[2][64 * 4];
+    // XCD-aware: a row-pair's column tiles run back to back on one XCD (its weights stay in that L2)
+    const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
+    const int ct = qq % nct, rp = (qq / nct) * 8 + xcd;
+    if (rp * 2 >= nrb32) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave & 1, wc = wave >> 1;
+    const int n0 = ct * 64;
+    const int nbp = nq * 4;
+    const long strideD = (long) nq * 4;                    // floats per column in qa_d
+
+    // ---- global -> registers -> LDS staging of one quad
+    u32x4 gw[2], gb[2];
+    f32x4 gd;
+    auto fetch = [&](int q) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int g = tid + u * 256;                   // 320 granules of weights (2 tiles x 160)
+            const int tile = min(g / 160, 1), off = (g % 160) * 16;
+            const int rb = min(rp * 2 + tile, nrb32 - 1);
+            gw[u] = *(const u32x4 *) (mt + ((size_t) rb * nq + q) * MTILE_BYTES + off);
+            const int col = min(n0 + (g >> 3), ncols - 1), part = g & 7;     // 512 granules of activations
+            gb[u] = *(const u32x4 *) (qb + ((size_t) col * nbp + q * 4) * 32 + part * 16);
+        }
+        gd = *(const f32x4 *) (qa_d + (size_t) min(n0 + (tid & 63), ncols - 1) * strideD + q * 4);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int g = tid + u * 256;
+            if (g < 320) *(u32x4 *) (&sW[buf][g / 160][(g % 160) * 16]) = gw[u];
+            *(u32x4 *) (&sB[buf][(g >> 3) * BSTRIDE + (g & 7) * 16]) = gb[u];
+        }
+        if (tid < 64) *(f32x4 *) (&sDa[buf][tid * 4]) = gd;
+    };
+
+    constexpr int NCH = FAST ? 1 : 8;
+    f32x2 acc[NCH][8];                                      // [chain][pair of adjacent C/D registers]
+#pragma unroll
+    for (int k = 0; k < NCH; k++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[k][r] = f32x2{ 0.0f, 0.0f };
+    i32x16v cm;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cm[r] = 0x49400000;       // 1.5 * 2^19: ulp 1/16
+
+    const bool second_tile_real = rp * 2 + 1 < nrb32;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int q = 0; q < nq; q++) {
+        const int buf = q & 1;
+        if (q + 1 < nq) fetch(q + 1);
+        const uint8_t *wt_ = sW[buf][wr];
+        const uint8_t *bt_ = &sB[buf][(wc * 32 + (lane & 31)) * BSTRIDE + (lane >> 5) * 16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x0 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[0];
+            const uint32_t x1 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[1];
+            const i32x4v A = { (int) ((x0 << 4) & 0xF0F0F0F0u), (int) (x0 & 0xF0F0F0F0u), (int) ((x1 << 4) & 0xF0F0F0F0u), (int) (x1 & 0xF0F0F0F0u) };
+            const u32x4 B = *(const u32x4 *) (bt_ + j * 32);
+            const float da = sDa[buf][(wc * 32 + (lane & 31)) * 4 + j];
+            f32x2 sc[8];
+            const f32x2 da2 = { da, da };
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 dw = *(const f32x4 *) (wt_ + 2048 + (j * 32 + 8 * g + 4 * (lane >> 5)) * 4);
+                sc[2 * g + 0] = f32x2{ dw.x, dw.y } * da2;
+                sc[2 * g + 1] = f32x2{ dw.z, dw.w } * da2;
+            }
+            if constexpr (FAST) {
+                const i32x4v Bi = { (int) B.x, (int) B.y, (int) B.z, (int) B.w };
+                const i32x16v Df = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bi, cm, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int d0 = Df[2 * r], d1 = Df[2 * r + 1];
+                    const f32x2 qv = f32x2{ __builtin_bit_cast(float, d0), __builtin_bit_cast(float, d1) } - f32x2{ 786432.0f, 786432.0f };
+                    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[0][r]) : "v"(sc[r]), "v"(qv));
+                }
+                continue;
+            }
+            // chain k: B with every byte but that chain's 4 elements zeroed.  Two MFMAs stay in flight
+            // ahead of the packed conversion + FMA of a chain.  Left alone, the scheduler issues all 32
+            // MFMAs of a quad first and spills their 512 result registers, so the order is pinned with
+            // empty volatile asms (they keep their program order): "use" all 16 accumulators of chain k,
+            // then "define" the operand of chain k + 2.
+            if constexpr (!FAST) {
+            i32x16v D[2];
+#define LH_MFMA(K, PIN)                                                                            \
+            {                                                                                      \
+                const uint32_t mask_ = 0xFFu << (8 * ((K) & 3));                                   \
+                i32x4v Bk_ = { 0, 0, 0, 0 };                                                       \
+                if ((K) < 4) { Bk_.x = (int) (B.x & mask_); Bk_.y = (int) (B.y & mask_); }         \
+                else         { Bk_.z = (int) (B.z & mask_); Bk_.w = (int) (B.w & mask_); }         \
+                if (PIN) { if ((K) < 4) asm volatile("" : "+v"(Bk_.x)); else asm volatile("" : "+v"(Bk_.z)); } \
+                D[(K) % 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bk_, cm, 0, 0, 0);           \
+            }
+            LH_MFMA(0, true)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k + 1 < 8) LH_MFMA(k + 1, true)             // in flight behind the consumption of chain k
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    // (scalar copies: __builtin_bit_cast on a vector ELEMENT reads element 0)
+                    const int d0 = D[k % 2][2 * r], d1 = D[k % 2][2 * r + 1];
+                    const f32x2 qv = f32x2{ __builtin_bit_cast(float, d0), __builtin_bit_cast(float, d1) } - f32x2{ 786432.0f, 786432.0f };
+                    // in-place packed FMA (tied operand): left to the register allocator, the 128 accumulators
+                    // come out of the loop body in other registers than they went in (~100 copies per block)
+                    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r]) : "v"(sc[r]), "v"(qv));
+                }
+                asm volatile("" :: "v"(acc[k][0]), "v"(acc[k][1]), "v"(acc[k][2]), "v"(acc[k][3]),
+                             "v"(acc[k][4]), "v"(acc[k][5]), "v"(acc[k][6]), "v"(acc[k][7]));
+            }
+            }
+#undef LH_MFMA
+        }
+        if (q + 1 < nq) stash(buf ^ 1);
+        __syncthreads();
+    }
+    (void) second_tile_real;
+    // ---- fold the 8 chains (ggml.c:872-887 tree) and store: lane = column, 16 rows (C/D layout)
+    const int n = n0 + wc * 32 + (lane & 31);
+    const int mb = (rp * 2 + wr) * 32 + 4 * (lane >> 5);
+    if (n < ncols && rp * 2 + wr < nrb32) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+#define LH_A(K) ((r & 1) ? acc[(K) % NCH][r >> 1].y : acc[(K) % NCH][r >> 1].x)
+            float v = FAST ? LH_A(0) : ((LH_A(0) + LH_A(4)) + (LH_A(2) + LH_A(6))) + ((LH_A(1) + LH_A(5)) + (LH_A(3) + LH_A(7)));
+#undef LH_A
+            if (m < M) {
+                if (EPI == EPI_RESID) v = v + resid[(size_t) n * resid_stride + m];
+                y[(size_t) n * y_stride + m] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same exact product on v_mfma_f32_32x32x4_2b_f16: K = 4 is exactly one chain of a Q4_0 block (the 4 elements
+// {2k, 2k+1, 16+2k, 17+2k} that one lane of the reference's _mm256_madd_epi16 sums), the instruction carries TWO
+// independent 32 x 32 x 4 products ("blocks" = lane halves on the operand side, result registers 0-15 / 16-31 --
+// checked on the hardware, tools/mfma_layout_probe.hip), so one issue returns two chains' sums for a 32 x 32 tile:
+//   * nothing is masked (the int8 kernel above issues one 32 x 32 x 32 MFMA per chain with 7/8 of its operand zeroed);
+//   * the sums arrive as FLOATS (small integers are exact in fp16 operands and fp32 accumulation), so the
+//     integer -> float conversion of the int8 kernel (one packed subtraction per pair of outputs, as many VALU issues
+//     as the FMAs themselves) disappears: what is left per output and chain is the one FMA the reference defines.
+// Matrix-pipe time per Q4_0 block and 32 x 32 tile is the same (4 issues of 16 passes = 8 of 8), VALU work drops from
+// ~190 to ~110 instructions.
+// Weight copy "mt16" (same size as the int8 tiles, replaces them): tile (row-block of 32, quad of 4 blocks) = 2560 B:
+//   [j 0..3][lane 0..63][8 B]   lane = m + 32 * g: the 16 nibbles of chains {g, 2 + g, 4 + g, 6 + g} of block 4q + j, row m,
+//                               BIASED (q = n + 8, 0..15) and placed so that `(x >> 4s) & 0x000F000F | 0x64006400` is the
+//                               fp16 pair (1024 + q_lo, 1024 + q_hi): dword 0 serves issues 0, 1 (chains g, 2 + g), dword 1
+//                               issues 2, 3; within a dword s = 0: (e0, e1) of the even issue, s = 1: (e2, e3), s = 2, 3: odd issue
+//   [j][32 rows] fp32 scales
+// Activation operand "QB16" (k_qa_to_qb16): per column [block][g][issue 0..3][4 fp16] = 64 B, exact integers -8..7.
+// Workgroup = 4 waves = 64 rows x 64 columns, operands of one quad staged in LDS (double-buffered), as above.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef float f32x32v __attribute__((ext_vector_type(32)));
+
+__global__ void k_tiles_to_mt16(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ mt,
+                                int ngroups, int nchunks, int nrb32, int gmapF8) {
+    const int nq = nchunks * 2;
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long) nrb32 * nq * 4 * 64;
+    if (gid >= total) return;
+    const int lane = (int) (gid & 63), j = (int) ((gid >> 6) & 3);
+    const long t = gid >> 8;
+    const int q = (int) (t % nq), rb = (int) (t / nq);
+    const int m = lane & 31, g = lane >> 5;
+    const int row = rb * 32 + m, lg = row >> 3, r = row & 7;
+    const int b = q * 4 + j, c = b >> 3, jj = b & 7, i = jj >> 1, half = jj & 1;
+    uint32_t x[2] = { 0x88888888u ^ 0x88888888u, 0u };     // biased zero is 8: padding rows get q = 8 everywhere below
+    x[0] = 0x88888888u; x[1] = 0x88888888u;
+    float d = 0.0f;
+    if (lg < ngroups) {
+        int tg = lg;
+        if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
+        const uint8_t *tp = tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
+        x[0] = x[1] = 0u;
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const int kc = 2 * ii + g;
+            const uint32_t dw = ((const uint32_t *) (tp + (r * 8 + kc) * 16))[i];       // chain kc, blocks (2i, 2i+1): byte p = element e_p
+            uint32_t e[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; pp++) e[pp] = (((dw >> (8 * pp + 4 * half)) & 0xFu) ^ 8u);     // signed nibble -> biased q
+            const int sh = (ii & 1) * 8;
+            x[ii >> 1] |= (e[0] << sh) | (e[1] << (16 + sh)) | (e[2] << (4 + sh)) | (e[3] << (20 + sh));
+        }
+        d = ((const float *) (tp + 1024 + r * 32))[(jj & 3) * 2 + (jj >> 2)];
+    }
+    uint8_t *o = mt + ((size_t) rb * nq + q) * MTILE_BYTES;
+    ((uint32_t *) (o + j * 512 + lane * 8))[0] = x[0];
+    ((uint32_t *) (o + j * 512 + lane * 8))[1] = x[1];
+    if (g == 0) ((float *) (o + 2048))[j * 32 + m] = d;
+}
+
+// QA (chain-major signed nibbles) -> QB16.  One thread per (column, block, chain).
+__global__ void k_qa_to_qb16(const uint32_t *__restrict__ qa_A, uint8_t *__restrict__ qb, int nchunks, int N) {
+    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int nbp = nchunks * 8;
+    const long total = (long) N * nbp * 8;
+    if (gid >= total) return;
+    const int kc = (int) (gid & 7);
+    const long t = gid >> 3;
+    const int b = (int) (t % nbp), n = (int) (t / nbp);
+    const int c = b >> 3, jj = b & 7;
+    const uint32_t dw = qa_A[(size_t) n * nchunks * 64 + c * 64 + kc * 8 + jj];
+    h4v v;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+        const int nib = (int) ((dw >> (8 * pp + 4 * (jj & 1))) & 0xF);
+        v[pp] = (_Float16) (float) ((nib ^ 8) - 8);
+    }
+    const int g = kc & 1, ii = kc >> 1;
+    *(h4v *) (qb + ((size_t) n * nbp + b) * 64 + g * 32 + ii * 8) = v;
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gemm_mfma16(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
+              const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
+              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
+    constexpr int CS = 272;                                 // 256 B of a column's quad + 16 B pad: conflict-free b128 reads
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][2][MTILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t sB[2][64 * CS];
+    __shared__ __attribute__((aligned(16))) float sDa[2][64 * 4];
+    const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
+    const int ct = qq % nct, rp = (qq / nct) * 8 + xcd;
+    if (rp * 2 >= nrb32) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave & 1, wc = wave >> 1;
+    const int n0 = ct * 64;
+    const int nbp = nq * 4;
+    const long strideD = (long) nq * 4;
+
+    u32x4 gw[2], gb[4];
+    f32x4 gd;
+    auto fetch = [&](int q) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int g = tid + u * 256;                   // 320 granules of weights (2 tiles x 160)
+            const int tile = min(g / 160, 1), off = (g % 160) * 16;
+            const int rb = min(rp * 2 + tile, nrb32 - 1);
+            gw[u] = *(const u32x4 *) (mt + ((size_t) rb * nq + q) * MTILE_BYTES + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = tid + u * 256;                   // 1024 granules of activations: 64 columns x 16
+            const int col = min(n0 + (g >> 4), ncols - 1), part = g & 15;
+            gb[u] = *(const u32x4 *) (qb + ((size_t) col * nbp + q * 4) * 64 + part * 16);
+        }
+        gd = *(const f32x4 *) (qa_d + (size_t) min(n0 + (tid & 63), ncols - 1) * strideD + q * 4);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int g = tid + u * 256;
+            if (g < 320) *(u32x4 *) (&sW[buf][g / 160][(g % 160) * 16]) = gw[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = tid + u * 256;
+            *(u32x4 *) (&sB[buf][(g >> 4) * CS + (g & 15) * 16]) = gb[u];
+        }
+        if (tid < 64) *(f32x4 *) (&sDa[buf][tid * 4]) = gd;
+    };
+
+    f32x2 acc[8][8];                                        // [chain][pair of adjacent C/D registers]
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[k][r] = f32x2{ 0.0f, 0.0f };
+    f32x32v zero32;
+#pragma unroll
+    for (int r = 0; r < 32; r++) zero32[r] = 0.0f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int q = 0; q < nq; q++) {
+        const int buf = q & 1;
+        if (q + 1 < nq) fetch(q + 1);
+        const uint8_t *wt_ = sW[buf][wr];
+        const uint8_t *bt_ = &sB[buf][(wc * 32 + (lane & 31)) * CS + (lane >> 5) * 32];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x0 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[0];
+            const uint32_t x1 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[1];
+            const u32x4 B0 = *(const u32x4 *) (bt_ + j * 64), B1 = *(const u32x4 *) (bt_ + j * 64 + 16);      // issues 0,1 | 2,3
+            const float da = sDa[buf][(wc * 32 + (lane & 31)) * 4 + j];
+            f32x2 sc[8];
+            const f32x2 da2 = { da, da };
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 dw = *(const f32x4 *) (wt_ + 2048 + (j * 32 + 8 * g + 4 * (lane >> 5)) * 4);
+                sc[2 * g + 0] = f32x2{ dw.x, dw.y } * da2;
+                sc[2 * g + 1] = f32x2{ dw.z, dw.w } * da2;
+            }
+            // Two waves per SIMD (256 registers each: 128 accumulators + one result set + operands + the next quad's
+            // staging): while one wave's issue is in the matrix pipe the other runs its FMA chains.  Measured alternatives,
+            // one wave per SIMD owning the whole file with two or four result sets in flight: 334 ms against 236 ms for
+            // 2048 tokens of the 7B -- the in-order wave stalls on every MFMA result, and above 256 registers the compiler
+            // parks results in AGPRs (+128 v_accvgpr_read per block).
+            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+            const h2v bias = { (_Float16) 1032.0f, (_Float16) 1032.0f };
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const uint32_t xs = (ii < 2 ? x0 : x1) >> ((ii & 1) * 8);
+                uint32_t p0, p1;                                // biased nibbles -> fp16 1024 + q (exact), then - 1032
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(p0) : "v"(xs), "v"(0x000F000Fu), "v"(0x64006400u));
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(p1) : "v"(xs >> 4), "v"(0x000F000Fu), "v"(0x64006400u));
+                const h2v a01 = __builtin_bit_cast(h2v, p0) - bias, a23 = __builtin_bit_cast(h2v, p1) - bias;
+                const h4v A = { a01.x, a01.y, a23.x, a23.y };
+                const u32x4 Bq = ii < 2 ? B0 : B1;
+                struct { uint32_t a, b; } bw = { (ii & 1) ? Bq.z : Bq.x, (ii & 1) ? Bq.w : Bq.y };
+                const f32x32v D = __builtin_amdgcn_mfma_f32_32x32x4f16(A, __builtin_bit_cast(h4v, bw), zero32, 0, 0, 0);
+                // The FMA chains are volatile asm so that they stay in this order with one result set live (written as plain
+                // C++ the compiler sinks them below later MFMAs and spills 2 KB per lane).  The MFMA -> VALU read needs software
+                // wait states which the compiler only inserts for instructions it can see: the first FMA of the issue is a
+                // visible one, and its result is a (dummy) input of the first asm FMA, which orders every asm FMA after it.
+                const float first = __builtin_fmaf(sc[0].x, D[0], acc[2 * ii][0].x);
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {
+                    const int k = 2 * ii + hb;                 // result registers 16 hb .. 16 hb + 15 = chain k (lane halves carried chains 2 ii, 2 ii + 1)
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const float d0 = D[16 * hb + 2 * r], d1 = D[16 * hb + 2 * r + 1];
+                        // (two plain FMAs issue faster than one packed one: tools/mfma_rate_probe.hip)
+                        if (hb == 0 && r == 0) {
+                            acc[k][r].x = first;
+                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r].y) : "v"(sc[r].y), "v"(d1), "v"(first));
+                        } else {
+                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r].x) : "v"(sc[r].x), "v"(d0));
+                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r].y) : "v"(sc[r].y), "v"(d1));
+                        }
+                    }
+                }
+            }
+        }
+        if (q + 1 < nq) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- fold the 8 chains (ggml.c:872-887 tree) and store: lane = column, 16 rows (C/D layout)
+    const int n = n0 + wc * 32 + (lane & 31);
+    const int mb = (rp * 2 + wr) * 32 + 4 * (lane >> 5);
+    if (n < ncols && rp * 2 + wr < nrb32) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+#define LH_A(K) ((r & 1) ? acc[K][r >> 1].y : acc[K][r >> 1].x)
+            float v = ((LH_A(0) + LH_A(4)) + (LH_A(2) + LH_A(6))) + ((LH_A(1) + LH_A(5)) + (LH_A(3) + LH_A(7)));
+#undef LH_A
+            if (m < M) {
+                if (EPI == EPI_RESID) v = v + resid[(size_t) n * resid_stride + m];
+                y[(size_t) n * y_stride + m] = v;
+            }
+        }
+    }
+}
+
+
+template <int NC>
+static hipError_t launch_gemm_lds_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols,
+                                    float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const int nw = 4;
+    const int grid = (w.ngroups + nw - 1) / nw;
+    if (epi == EPI_RESID)
+        hipLaunchKernelGGL((k_gemm_lds<NC, EPI_RESID>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, y, y_stride, resid, resid_stride);
+    else
+        hipLaunchKernelGGL((k_gemm_lds<NC, EPI_STORE>), dim3(grid), dim3(nw * 64), 0, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, y, y_stride, resid, resid_stride);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int NC, int RG>
+static hipError_t launch_gemm_skinny_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg,
+                                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const int nwg = (w.ngroups + 4 * RG - 1) / (4 * RG);
+    const int grid = ((nwg + 7) / 8) * ncg * 8;
+    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
+    if (epi == EPI_RESID)
+        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_RESID>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
+                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, RopeKvArgs{});
+    else
+        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_STORE>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
+                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, RopeKvArgs{});
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int NC>
+static hipError_t launch_gemm_skinny_silu_t(const QMat &w, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg,
+                                            const uint16_t *T_silu, uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
+    const int nwg = (w.ngroups + 7) / 8;
+    const int grid = ((nwg + 7) / 8) * ncg * 8;
+    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
+    hipLaunchKernelGGL((k_gemm_skinny<NC, 1, EPI_SILU_QA>), dim3(grid), dim3(512), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg,
+                       (float *) nullptr, 0L, (const float *) nullptr, 0L, T_silu, out_A, out_d, out_strideA, out_strideD, RopeKvArgs{});
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int NC>
+static hipError_t launch_gemm_skinny_rope_t(const QMat &w, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg, const RopeKvArgs &ra, hipStream_t st) {
+    const int nwg = (w.ngroups + 3) / 4;
+    const int grid = ((nwg + 7) / 8) * ncg * 8;
+    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
+    hipLaunchKernelGGL((k_gemm_skinny<NC, 1, EPI_ROPE_KV>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg,
+                       (float *) nullptr, 0L, (const float *) nullptr, 0L, (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, ra);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+static int skinny_max_rows() {
+    // measured crossover against the row-per-lane kernel at 7B shapes: +25 % at 33 rows, +7 % at 56, -1 % at 63
+    static const int v = getenv("LLAMAHIP_SKINNY_MAX") ? atoi(getenv("LLAMAHIP_SKINNY_MAX")) : 60;
+    return v;
+}
+// column-group width of k_gemm_skinny for N rows: the widest (<= 4) that still leaves ~1500 waves, balanced
+static int skinny_pick_nc(const QMat &w, int N) {
+    static const int skinny_nc = getenv("LLAMAHIP_SKINNY_NC") ? atoi(getenv("LLAMAHIP_SKINNY_NC")) : 0;
+    int nc = 4;
+    while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
+    if (nc > N) nc = N;
+    if (skinny_nc >= 1 && skinny_nc <= 5) nc = skinny_nc;
+    while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
+    const int ncg = (N + nc - 1) / nc;
+    return (N + ncg - 1) / ncg;                            // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
+}
+
+// Short evals, wq|wk|wv: mat-mul + RoPE + KV append in one launch (k_gemm_skinny<EPI_ROPE_KV>)
+bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
+    static const bool off = getenv("LLAMAHIP_NO_SKINNY_ROPE") != nullptr;      // measurement
+    return !off && N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
+}
+hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
+    const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
+    switch (nc) {
+    case 5:  return launch_gemm_skinny_rope_t<5>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    case 4:  return launch_gemm_skinny_rope_t<4>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    case 3:  return launch_gemm_skinny_rope_t<3>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    case 2:  return launch_gemm_skinny_rope_t<2>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    default: return launch_gemm_skinny_rope_t<1>(wqkv, qa_A, qa_d, N, ncg, ra, st);
+    }
+}
+
+// Short evals on the interleaved w1|w3 matrix: mat-mul + SiLU * up + Q4_0 quantization of the result in one
+// launch (k_gemm_skinny<EPI_SILU_QA>).  false = not applicable (row count, layout): use the separate steps.
+bool gemm_silu_qa_applies(const QMat &w13, int N) {
+    static const bool off = getenv("LLAMAHIP_NO_SKINNY_SILU") != nullptr;      // measurement
+    return !off && N >= 2 && N <= skinny_max_rows() && w13.gmapF8 != 0 && w13.ngroups % 8 == 0;
+}
+hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
+                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
+    const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
+    switch (nc) {
+    case 5:  return launch_gemm_skinny_silu_t<5>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    case 3:  return launch_gemm_skinny_silu_t<3>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    case 2:  return launch_gemm_skinny_silu_t<2>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    default: return launch_gemm_skinny_silu_t<1>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
+    }
+}
+
+template <int NC, bool DB, int WPE>
+static hipError_t launch_gemm_rows_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols,
+                                     float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const int ncg = (ncols + NC - 1) / NC;
+    const int grid = ((w.nrb + 7) / 8) * ncg * 8;
+    const size_t lds = NC == 1 ? (size_t) w.nchunks * 288 : 0;       // the single-column variant keeps its operand in LDS
+    if (epi == EPI_RESID)
+        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_RESID, DB, WPE>), dim3(grid), dim3(64), lds, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+    else
+        hipLaunchKernelGGL((k_gemm_rows<NC, EPI_STORE, DB, WPE>), dim3(grid), dim3(64), lds, st, w.rows, w.nrb, w.nchunks, w.M, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_tiles_to_mtiles(const QMat &w, hipStream_t st) {
+    const long total = (long) w.nrb32 * w.nchunks * 2 * 4 * 64;
+    hipLaunchKernelGGL(k_tiles_to_mtiles, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_qa_to_qb(const uint32_t *qa_A, uint8_t *qb, int nchunks, int N, hipStream_t st) {
+    const long total = (long) N * nchunks * 8 * 2;
+    hipLaunchKernelGGL(k_qa_to_qb, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, qa_A, qb, nchunks, N);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+static hipError_t launch_gemm_mfma(const QMat &w, int epi, const uint8_t *qb, const float *qa_d, int ncols,
+                                   float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, bool fast) {
+    const int nct = (ncols + 63) / 64, nq = w.nchunks * 2;
+    const int nrp = (w.nrb32 + 1) / 2;
+    const int grid = ((nrp + 7) / 8) * nct * 8;
+#define LH_MF(E, F) hipLaunchKernelGGL((k_gemm_mfma<E, F>), dim3(grid), dim3(256), 0, st, w.mt, w.nrb32, nq, w.M, qb, qa_d, ncols, nct, y, y_stride, resid, resid_stride)
+    if (epi == EPI_RESID) { if (fast) LH_MF(EPI_RESID, true); else LH_MF(EPI_RESID, false); }
+    else                  { if (fast) LH_MF(EPI_STORE, true); else LH_MF(EPI_STORE, false); }
+#undef LH_MF
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_tiles_to_mt16(const QMat &w, hipStream_t st) {
+    const long total = (long) w.nrb32 * w.nchunks * 2 * 4 * 64;
+    hipLaunchKernelGGL(k_tiles_to_mt16, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt16, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+static hipError_t launch_gemm_mfma16(const QMat &w, int epi, const uint32_t *qa_A, uint8_t *qb16, const float *qa_d, int ncols,
+                                     float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+    const long tot = (long) ncols * w.nchunks * 8 * 8;
+    hipLaunchKernelGGL(k_qa_to_qb16, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, qa_A, qb16, w.nchunks, ncols);
+    LH_LAUNCH_CHECK();
+    const int nct = (ncols + 63) / 64, nq = w.nchunks * 2;
+    const int nrp = (w.nrb32 + 1) / 2;
+    const int grid = ((nrp + 7) / 8) * nct * 8;
+    if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_mfma16<EPI_RESID>), dim3(grid), dim3(256), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+    else                  hipLaunchKernelGGL((k_gemm_mfma16<EPI_STORE>), dim3(grid), dim3(256), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
+    const long total = (long) w.nrb * (w.nchunks + 1) * 10 * 64;
+    hipLaunchKernelGGL(k_tiles_to_rows, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, w.tiles, w.rows, w.ngroups, w.nchunks, w.nrb, w.gmapF8);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// N activation rows (QA precomputed, row stride = Kp bytes / Kp/32 floats).
+//   matrix has a row-lane copy: one k_gemm_rows launch (column-group width: see below)
+//   else: LDS-staged column tiles of 16 (the last one clamped), small remainders as 8 / 4 columns
+//   a single row always goes through the decode GEMV
+// which kernel family served a mat-mul (tests assert that the full-size shapes take the path they are meant to)
+long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0 };
+
+hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
+                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws, bool fast) {
+    // Matrix-core path when its 64 x 64-output workgroups fill the chip twice over (measured crossover
+    // against the row-per-lane kernel on MI355X: N ~ 256 for the 7B matrices; 1.25x faster at N = 1024).
+    static const int mfma_min = getenv("LLAMAHIP_MFMA_MIN") ? atoi(getenv("LLAMAHIP_MFMA_MIN")) : 0;     // measurement override
+    const long mfma_wgs = (long) ((w.nrb32 + 1) / 2) * ((N + 63) / 64);
+    if (w.mt16 && !fast && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
+        // matrix-core path, exact: fp16 operands (QB16: 2 bytes per element of these N activation rows), two chains per MFMA
+        g_gemm_path_counts[GEMM_PATH_MFMA]++;
+        return launch_gemm_mfma16(w, epi, qa_A, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
+    }
+    if (w.mt && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
+        // matrix-core path on the int8 tiles (the opt-in fast path; LLAMAHIP_MFMA_I8: the round-1 exact kernel): needs the int8 operand (QB)
+        g_gemm_path_counts[GEMM_PATH_MFMA]++;
+        hipError_t e = launch_qa_to_qb(qa_A, qb_ws, w.nchunks, N, st);
+        if (e != hipSuccess) return e;
+        return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st, fast);
+    }
+    const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
+    // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put
+    // ~1500 waves on the chip (LLAMAHIP_SKINNY_MAX = 0 switches it off, LLAMAHIP_SKINNY_NC forces the width)
+    if (N >= 2 && N <= skinny_max_rows()) {
+        // two row-groups per wave (halves the LDS operand reads per row) measured 3-7 % slower at 9 columns
+        static const int skinny_rg = getenv("LLAMAHIP_SKINNY_RG") ? atoi(getenv("LLAMAHIP_SKINNY_RG")) : 0;
+        const int nc = skinny_pick_nc(w, N), ncg = (N + nc - 1) / nc;
+        const int rg = skinny_rg == 2 ? 2 : 1;
+        g_gemm_path_counts[GEMM_PATH_SKINNY]++;
+#define LH_SK_ARGS w, epi, qa_A, qa_d, N, ncg, y, y_stride, resid, resid_stride, st
+#define LH_SK_CASE(NCV) case NCV: return rg == 2 ? launch_gemm_skinny_t<NCV, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
+        switch (nc) {
+        LH_SK_CASE(5);
+        LH_SK_CASE(4);
+        LH_SK_CASE(3);
+        LH_SK_CASE(2);
+        default: return rg == 2 ? launch_gemm_skinny_t<1, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<1, 1>(LH_SK_ARGS);
+        }
+#undef LH_SK_CASE
+#undef LH_SK_ARGS
+    }
+    static const bool no_rows = getenv("LLAMAHIP_GEMM_LDS") != nullptr;     // measurement: skip the row-lane kernel
+    static const int force_nc = getenv("LLAMAHIP_GEMM_ROWS_NC") ? atoi(getenv("LLAMAHIP_GEMM_ROWS_NC")) : 0;
+    if (w.rows && N >= 2 && !no_rows) {
+        // widest column group that still gives the chip >= 2 waves per SIMD.  Wider groups (8, 16
+        // columns: 191 / 249 VGPRs, 2 waves per SIMD) measured 10-16 % slower than 4 columns at 3 waves
+        // per SIMD on a 512-token prompt: the kernel runs at ~85 % of its VALU issue limit and the third
+        // wave is what hides the scalar-load latency of the operand.
+        int nc = 1;
+        for (int cand : { 4, 2 })
+            if ((long) w.nrb * ((N + cand - 1) / cand) >= 2048) { nc = cand; break; }
+        if (force_nc) nc = force_nc;
+        g_gemm_path_counts[GEMM_PATH_ROWS]++;
+#define LH_ROWS_ARGS w, epi, qa_A, qa_d, N, y, y_stride, resid, resid_stride, st
+        switch (nc) {
+        case 16: return launch_gemm_rows_t<16, true, 2>(LH_ROWS_ARGS);
+        case 8:  return launch_gemm_rows_t<8, true, 2>(LH_ROWS_ARGS);
+        case 4:  return launch_gemm_rows_t<4, true, 3>(LH_ROWS_ARGS);
+        case 2:  return launch_gemm_rows_t<2, true, 3>(LH_ROWS_ARGS);
+        default: return launch_gemm_rows_t<1, true, 2>(LH_ROWS_ARGS);
+        }
+#undef LH_ROWS_ARGS
+    }
+    g_gemm_path_counts[N == 1 ? GEMM_PATH_GEMV : GEMM_PATH_LDS]++;
+    int n0 = 0;
+    while (n0 < N) {
+        const int rem = N - n0;
+        const uint32_t *A = qa_A + n0 * strideA;
+        const float *D = qa_d + n0 * strideD;
+        float *yy = y + (size_t) n0 * y_stride;
+        const float *rr = resid ? resid + (size_t) n0 * resid_stride : nullptr;
+        hipError_t e;
+        int step;
+        if (rem == 1)   { step = 1;  e = launch_gemv(w, PRE_QA, epi, A, D, nullptr, nullptr, yy, rr, nullptr, nullptr, nullptr, st); }
+        else if (rem > 8)      { step = rem < 16 ? rem : 16; e = launch_gemm_lds_t<16>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
+        else if (rem > 4)      { step = rem;                 e = launch_gemm_lds_t<8>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
+        else                   { step = rem;                 e = launch_gemm_lds_t<4>(w, epi, A, D, step, yy, y_stride, rr, resid_stride, st); }
+        if (e != hipSuccess) return e;
+        n0 += step;
+    }
+    return hipSuccess;
+}
+
+
+hipError_t init_attrs_prompt_gemm() {
+    const int cap = 160 * 1024;          // fused prologues / wide rows need more than the default 64 KB of dynamic LDS
+#define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
+#define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
+    LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>));
+    LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
+    LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
+#undef LH_ATTR
+    return hipSuccess;
+}
+
+}  // namespace lh
