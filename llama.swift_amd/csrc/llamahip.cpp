@@ -313,39 +313,44 @@ int alloc_qmat(QMat &q, int M, int K, llamahip_model *m, char *err, size_t err_c
 // instead of 13 GB).  LLAMAHIP_FLAG_NO_PREFILL_COPY never builds them (the LDS-staged GEMM then serves long
 // prompts); LLAMAHIP_EAGER_PREFILL_COPY=1 builds them at load time (measurement: keeps the first long eval's
 // time free of the 10-20 ms build).
-int make_rows(QMat &q, llamahip_model *m, char *err, size_t err_cap) {
+// The extra weight layouts of the prompt path, built lazily.  Returns 0 when the copies of `q` exist afterwards, 1 when device memory
+// ran out or a conversion launch failed: whatever was allocated for `q` is released again and its pointers stay null (launch_gemm
+// then takes the bit-identical LDS-staged kernel for this matrix) -- a pointer is only published after its conversion launch succeeded.
+int make_rows(QMat &q, llamahip_model *m) {
     if (m->flags & LLAMAHIP_FLAG_NO_PREFILL_COPY) return 0;
-    if (!q.rows) {
-        q.nrb = (q.M + 63) / 64;
-        HIP_TRY(hipMalloc((void **) &q.rows, q.rows_bytes()), LLAMAHIP_ERR_PREDICT);
-        m->weight_bytes += (int64_t) q.rows_bytes();
-        HIP_TRY(launch_tiles_to_rows(q, m->stream), LLAMAHIP_ERR_PREDICT);
-    }
+    auto build = [&](uint8_t **slot, size_t bytes, auto convert) -> bool {
+        if (*slot) return true;
+        uint8_t *p = nullptr;
+        if (hipMalloc((void **) &p, bytes) != hipSuccess) { (void) hipGetLastError(); return false; }
+        *slot = p;                                   // (the conversion launchers read the destination from the QMat)
+        if (convert() != hipSuccess) { (void) hipGetLastError(); (void) hipFree(p); *slot = nullptr; return false; }
+        m->weight_bytes += (int64_t) bytes;
+        return true;
+    };
+    q.nrb = (q.M + 63) / 64;
+    if (!build(&q.rows, q.rows_bytes(), [&]() { return launch_tiles_to_rows(q, m->stream); })) return 1;
     // matrix-core tiles: fp16 two-chain order for the exact path; the int8 order only for a handle opened with
     // LLAMAHIP_FLAG_FAST_PREFILL (or LLAMAHIP_MFMA_I8=1: the round-1 exact kernel, for A/B) -- one of the two, same size
     static const bool want_i8 = getenv("LLAMAHIP_MFMA_I8") != nullptr;
     q.nrb32 = (q.M + 31) / 32;
     if ((m->flags & LLAMAHIP_FLAG_FAST_PREFILL) || want_i8) {
-        if (!q.mt) {
-            HIP_TRY(hipMalloc((void **) &q.mt, q.mt_bytes()), LLAMAHIP_ERR_PREDICT);
-            m->weight_bytes += (int64_t) q.mt_bytes();
-            HIP_TRY(launch_tiles_to_mtiles(q, m->stream), LLAMAHIP_ERR_PREDICT);
-        }
-    } else if (!q.mt16) {
-        HIP_TRY(hipMalloc((void **) &q.mt16, q.mt_bytes()), LLAMAHIP_ERR_PREDICT);
-        m->weight_bytes += (int64_t) q.mt_bytes();
-        HIP_TRY(launch_tiles_to_mt16(q, m->stream), LLAMAHIP_ERR_PREDICT);
-    }
+        if (!build(&q.mt, q.mt_bytes(), [&]() { return launch_tiles_to_mtiles(q, m->stream); })) return 1;
+    } else if (!build(&q.mt16, q.mt_bytes(), [&]() { return launch_tiles_to_mt16(q, m->stream); })) return 1;
     return 0;
 }
 constexpr int PROMPT_COPY_MIN_ROWS = 61;       // evals up to 60 rows take k_gemm_skinny on the decode tiles
 int ensure_prompt_copies(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N < PROMPT_COPY_MIN_ROWS || m->dense || m->prompt_copies || (m->flags & LLAMAHIP_FLAG_NO_PREFILL_COPY)) return 0;
+    (void) err; (void) err_cap;
     for (Layer &L : m->layers)
-        for (QMat *q : { &L.qkv, &L.wo, &L.w13, &L.w2 }) {
-            const int rc = make_rows(*q, m, err, err_cap);
-            if (rc) return rc;
-        }
+        for (QMat *q : { &L.qkv, &L.wo, &L.w13, &L.w2 })
+            if (make_rows(*q, m)) {
+                // out of device memory (the copies triple the resident weights): remember it as if the handle had been opened with
+                // LLAMAHIP_FLAG_NO_PREFILL_COPY -- matrices that already have their copies keep using them, the rest run the
+                // LDS-staged kernel on the decode tiles, every later long eval goes straight there instead of failing again
+                m->flags |= LLAMAHIP_FLAG_NO_PREFILL_COPY;
+                return 0;
+            }
     m->prompt_copies = true;
     return 0;
 }
@@ -1460,7 +1465,7 @@ int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t 
 int32_t llamahip_debug_lut_math(void) { return g_lut_math; }
 
 int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap) {
-    for (int i = 0; i < cap && i < GEMM_PATH_COUNT; i++) out[i] = g_gemm_path_counts[i];
+    for (int i = 0; out && i < cap && i < GEMM_PATH_COUNT; i++) out[i] = g_gemm_path_counts[i];
     return GEMM_PATH_COUNT;
 }
 

@@ -180,6 +180,7 @@ int32_t llamahip_sample_from_candidates(llamahip_sampler *s, const double *score
 
 int32_t llamahip_sampler_window(const llamahip_sampler *s, int32_t *out, int32_t cap) {
     if (!s) return 0;
+    if (!out) cap = 0;
     const int32_t n = (int32_t) s->last_n_tokens.size();
     for (int32_t i = 0; i < n && i < cap; i++) out[i] = s->last_n_tokens[i];
     return n;
@@ -290,9 +291,13 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
             // libstdc++'s partial_sort can order -- the full row came back and the host path below decides)
             const bool samples_next = embd_inp.size() <= consumed && !cfg.greedy && !host_sampler;
             if (samples_next) {
-                int32_t win[64], exact = 0;
-                const int32_t nw = llamahip_sampler_window(sampler, win, 64);
-                if (llamahip_eval_topk(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), win, std::min(nw, 64), repeat_penalty, top_k, temp,
+                // (the whole repetition window goes along, whatever repeat_last_n is: the device path takes up to 1024 ids and
+                //  llamahip_eval_topk falls back to the host sampler beyond that)
+                int32_t exact = 0;
+                std::vector<int32_t> winv((size_t) std::max(repeat_last_n, 1));
+                int32_t *win = winv.data();
+                const int32_t nw = std::min(llamahip_sampler_window(sampler, win, (int32_t) winv.size()), (int32_t) winv.size());
+                if (llamahip_eval_topk(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), win, nw, repeat_penalty, top_k, temp,
                                        cand_scores, cand_ids, &exact, logits.data(), err, sizeof(err)) != 0) return fail();
                 have_cand = exact == 1;
             } else if (llamahip_eval(model, n_threads, n_past, embd.data(), (int32_t) embd.size(), logits.data(), err, sizeof(err)) != 0) return fail();
