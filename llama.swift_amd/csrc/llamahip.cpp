@@ -1324,11 +1324,13 @@ int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, size_t e
     io.token = sl.token_in; io.state = state;
     io.x_first = m->first_stage ? nullptr : sl.hidden_in;
     io.x_last = m->last_stage ? nullptr : sl.hidden_out;
-    io.mb_in = m->first_stage ? nullptr : sl.inbox_hidden;
-    io.mb_out = m->last_stage ? nullptr : sl.peer_hidden;
-    io.mb_token = m->first_stage ? sl.inbox_token : nullptr;
-    if (io.mb_in) io.x_first = nullptr;
-    if (io.mb_out) io.x_last = nullptr;
+    // a slot bound WITHOUT hidden buffers runs on its mailboxes; one bound with them keeps the caller-ordered buffers (RCCL schedule)
+    // even if mailboxes exist -- the way back when the mailbox handshake of a multi-GPU run fails
+    const bool mb_mode = (m->first_stage || !sl.hidden_in) && (m->last_stage || !sl.hidden_out) && !(m->first_stage && m->last_stage);
+    io.mb_in = (mb_mode && !m->first_stage) ? sl.inbox_hidden : nullptr;
+    io.mb_out = (mb_mode && !m->last_stage) ? sl.peer_hidden : nullptr;
+    io.mb_token = (mb_mode && m->first_stage) ? sl.inbox_token : nullptr;
+    uint64_t *mb_token_out = (mb_mode && m->last_stage) ? sl.peer_token : nullptr;
     const int save_seq = m->cur_seq;
     m->cur_seq = seq;
     int rc = forward(m, nth, 0, 1, sl.hidden_in, true, false, -1, nullptr, err, err_cap, &io);
@@ -1339,7 +1341,7 @@ int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, size_t e
         HIP_TRY(hipMemcpyAsync(sl.hidden_out, m->x, d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     if (m->last_stage) {
         // greedy pick on the device: trace[step] = token; token_out (if any) = token; position advances
-        HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_slot_trace + (size_t) seq * m->hp.n_ctx, 0, sl.token_out, state, m->stream, sl.peer_token), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(launch_argmax(m->logits, m->hp.n_vocab, m->d_slot_trace + (size_t) seq * m->hp.n_ctx, 0, sl.token_out, state, m->stream, mb_token_out), LLAMAHIP_ERR_PREDICT);
     } else {
         HIP_TRY(launch_advance(state, m->stream), LLAMAHIP_ERR_PREDICT);
     }

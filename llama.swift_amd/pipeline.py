@@ -378,8 +378,16 @@ def bench_main(args, cfg, model_path_fn, log, models=None):
     watchdog.daemon = True
     watchdog.start()
     guard = lambda fn, what: run_guarded(fn, rank, world, limit, what, on_timeout=(lambda msg: _emit_and_exit(0)) if headline else None)
+    # (smoke test of the multi-rank path on ONE GPU: LLAMAHIP_PIPE_ONE_GPU=1 puts every rank on cuda:0 and LLAMAHIP_PIPE_BACKEND=gloo
+    #  replaces RCCL, which refuses two ranks on one device; the mailboxes then run over HIP IPC between the processes)
+    if os.environ.get("LLAMAHIP_PIPE_ONE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("LLAMAHIP_PIPE_BACKEND", "nccl")
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        dist.init_process_group(backend)
     token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
     fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]   # forward edges by sender parity
     sync_schedule = os.environ.get("LLAMAHIP_PIPELINE_SYNC", "0") == "1"
@@ -428,11 +436,35 @@ def bench_main(args, cfg, model_path_fn, log, models=None):
                 mailbox = int(flag.item()) == 1
                 if not mailbox:
                     stage.mailboxes = False
-            if mailbox:
-                hand_off = "device-side mailboxes: position-tagged granules stored into the next stage's memory (HIP IPC / xGMI) by the last kernel of a stage step, polled by the first kernel of the next; no collective and no host call per token"
             for s in range(S):
                 stage.bind(s, n_past[s], firsts[s])
             lane = torch.cuda.Stream()               # the decode loop's own stream
+            if mailbox:
+                # handshake: ONE token of sequence 0 through every stage on the mailboxes, then every rank reads its fault word.  A
+                # row that does not arrive (peer mapping that does not carry stores, ...) costs one poll bound here, not one per step
+                # of the timed loop; all ranks agree on the outcome and fall back to the RCCL hand-off together.
+                ok = 1
+                try:
+                    with torch.cuda.stream(lane):
+                        stage.step(0)
+                    torch.cuda.synchronize()
+                    n_done, pos0, _ = stage.trace(0, 1)
+                    ok = int(n_done == 1 and pos0 == n_past[0] + 1)
+                except Exception as e:
+                    log(f"[bench] rank {rank}: mailbox handshake failed ({type(e).__name__}: {str(e)[:200]}); RCCL hand-off")
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local}")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) != 1:
+                    mailbox = False
+                    stage.mailboxes = False
+                    toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt, again)")
+                    firsts = [int(toks[s, -1]) for s in range(S)]
+                    for s in range(S):
+                        stage.bind(s, n_past[s], firsts[s])
+            handshake_tokens = 1 if mailbox else 0
+            if mailbox:
+                hand_off = "device-side mailboxes: position-tagged granules stored into the next stage's memory (HIP IPC / xGMI) by the last kernel of a stage step, polled by the first kernel of the next; no collective and no host call per token"
 
             def decode(n, seqs=None):
                 with torch.cuda.stream(lane):
@@ -458,7 +490,7 @@ def bench_main(args, cfg, model_path_fn, log, models=None):
                 dist.all_reduce(ds, op=dist.ReduceOp.MAX)
                 single = {"tokens": n_single, "ms_per_token": float(ds.item()) * 1e3 / n_single, "tokens_per_s": n_single / float(ds.item()),
                           "note": "sequence 0 alone: one token at a time through every stage (the latency a single user sees)"}
-            traces, _pos = guard(lambda: gather_traces(stage, rank, world, dist, torch, S, warmup + steps + (n_single if world > 1 else 0)), "gather_traces")
+            traces, _pos = guard(lambda: gather_traces(stage, rank, world, dist, torch, S, handshake_tokens + warmup + steps + (n_single if world > 1 else 0)), "gather_traces")
         dt = torch.tensor([dt_loc], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         dt = float(dt.item())
