@@ -358,6 +358,44 @@ def run_single(args, cfg, path):
     return res
 
 
+def concurrent_sequences(args, cfg, path, n_seq):
+    """NOT the headline workload: `n_seq` independent greedy sequences decoded at the same time on ONE GPU -- one handle (its own weight
+    copy, KV cache, stream and captured graph) and one host thread per sequence, no batching across sequences.  Every sequence is the
+    headline's single-token decode; what changes is that one sequence's latency-bound phases (attention chain, norm prologues, launch
+    ramps) are filled by the other sequences' weight streams.  Reports the aggregate rate and checks that every sequence produced the
+    single-stream tokens."""
+    import threading
+    import llama_swift_amd as L
+    prompt = PROMPT % cfg["n_vocab"]
+    prompt[0] = 1
+    steps = args.n_ctx - len(prompt) - 8
+    ms = [L.Model(path, n_ctx=args.n_ctx) for _ in range(n_seq)]
+    firsts, outs = [], [None] * n_seq
+    for m in ms:
+        firsts.append(int(np.argmax(m.eval(prompt, 0, args.threads))))
+        m.decode_greedy(firsts[-1], len(prompt), 8, args.threads)            # captures the graph
+    ref = ms[0].decode_greedy(firsts[0], len(prompt), steps, args.threads)   # single stream, same handle: the tokens to reproduce
+    go = threading.Barrier(n_seq + 1)
+
+    def work(i):
+        go.wait()
+        outs[i] = ms[i].decode_greedy(firsts[i], len(prompt), steps, args.threads)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_seq)]
+    for t in th:
+        t.start()
+    go.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    same = all(o is not None and [int(x) for x in o] == [int(x) for x in ref] for o in outs)
+    for m in ms:
+        m.close()
+    return {"sequences": n_seq, "tokens": n_seq * steps, "seconds": dt, "aggregate_tokens_per_s": n_seq * steps / dt,
+            "per_sequence_tokens_per_s": steps / dt, "tokens_equal_single_stream": same,
+            "note": "independent sequences, one handle + host thread each, no cross-sequence batching; not the headline metric (one sequence)"}
+
+
 def prefill_2048(args, cfg, path):
     """configs[2]: one 2048-token eval at n_ctx 2560 (second handle), with the rates the north star asks for."""
     import llama_swift_amd as L
@@ -401,6 +439,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-insitu", action="store_true", help="skip the rocprofv3 child that times the launches of the decode step")
     ap.add_argument("--no-prefill-2048", action="store_true")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-sequences leg (2 and 4 independent sequences on the one GPU)")
     ap.add_argument("--save-profile", default="", help="write the in-situ kernel table (rocprofv3 summary) to this file")
     ap.add_argument("--insitu-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -576,6 +615,11 @@ def main():
             result["prefill"]["configs2_2048_tokens_one_eval"] = prefill_2048(args, cfg, path)
         except Exception as e:
             result["prefill"]["configs2_2048_tokens_one_eval"] = {"error": repr(e)}
+    if args.model == "7B" and not args.no_concurrent:
+        try:
+            result["concurrent_sequences"] = [concurrent_sequences(args, cfg, path, n) for n in (2, 4)]
+        except Exception as e:
+            result["concurrent_sequences"] = {"error": repr(e)}
     # the reference's user-facing flow (LlamaRunner.run: load once, 8-token prompt batches, one llama_eval and one
     # host-side top-k / top-p sample per token, token text through the event callback) -- not the headline metric
     try:
