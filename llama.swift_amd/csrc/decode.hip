@@ -615,6 +615,10 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
     float *qs = (float *) smem_d;          // roped q of this head
     float *kn = qs + dh;                   // roped new k of this head
     const int h = blockIdx.x;
+#if LH_PHASE_PROBE == 3        /* timeline probe (tools/pv_stream_timeline.py): kind 0xB2 */
+    const unsigned long long probe_wall = wall_clock64(), probe_t0 = __builtin_readcyclecounter();
+    unsigned long long probe_t1 = 0, probe_t2 = 0;
+#endif
     const int n_past = st[0];
     const int t0 = blockIdx.y * DEC_TS;
     if (t0 > n_past) return;
@@ -622,23 +626,14 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
     const bool owns_new = n_past < t0 + DEC_TS;          // this slice contains key n_past
     const double *tab = sincos_tab + (size_t) n_past * dh;
     const float *q = qkv + h * dh, *kk = qkv + d + h * dh, *vv = qkv + 2 * d + h * dh;
-    if (tid < dh / 2) {
-        const int e = 2 * tid;
-        const double cs = tab[e], sn = tab[e + 1];
-        const double x0 = (double) q[e], x1 = (double) q[e + 1];
-        qs[e] = (float) (x0 * cs - x1 * sn);
-        qs[e + 1] = (float) (x0 * sn + x1 * cs);
-        if (owns_new) {
-            const double k0 = (double) kk[e], k1 = (double) kk[e + 1];
-            const float r0 = (float) (k0 * cs - k1 * sn), r1 = (float) (k0 * sn + k1 * cs);
-            kn[e] = r0; kn[e + 1] = r1;
-            Kc[(size_t) n_past * d + h * dh + e] = r0;
-            Kc[(size_t) n_past * d + h * dh + e + 1] = r1;
-            Vc[(size_t) n_past * d + h * dh + e] = vv[e];
-            Vc[(size_t) n_past * d + h * dh + e + 1] = vv[e + 1];
-        }
-    }
-    __syncthreads();
+    // the rotation's operands first, then the K rows, then the rotation: loads return in order, so the rotation waits for its few
+    // operands only while the K rows -- at long contexts this launch is one round trip of K -- are already on their way (the rows
+    // used to be requested behind the rotation and its barrier)
+    const bool rot = tid < dh / 2;
+    const int e = rot ? 2 * tid : 0;
+    const double cs = tab[e], sn = tab[e + 1];
+    const float q0 = q[e], q1 = q[e + 1];
+    const float kr0 = kk[e], kr1 = kk[e + 1], vr0 = vv[e], vr1 = vv[e + 1];
     // each half-wave owns DEC_TS/8 consecutive keys and keeps all their loads in flight at once
     const int hw = tid >> 5, l = tid & 31;
     constexpr int KPH = DEC_TS / 8;
@@ -651,6 +646,24 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
 #pragma unroll
         for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
     }
+    if (rot) {
+        const double x0 = (double) q0, x1 = (double) q1;
+        qs[e] = (float) (x0 * cs - x1 * sn);
+        qs[e + 1] = (float) (x0 * sn + x1 * cs);
+        if (owns_new) {
+            const double k0 = (double) kr0, k1 = (double) kr1;
+            const float r0 = (float) (k0 * cs - k1 * sn), r1 = (float) (k0 * sn + k1 * cs);
+            kn[e] = r0; kn[e + 1] = r1;
+            Kc[(size_t) n_past * d + h * dh + e] = r0;
+            Kc[(size_t) n_past * d + h * dh + e + 1] = r1;
+            Vc[(size_t) n_past * d + h * dh + e] = vr0;
+            Vc[(size_t) n_past * d + h * dh + e + 1] = vr1;
+        }
+    }
+    __syncthreads();
+#if LH_PHASE_PROBE == 3
+    probe_t1 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int u = 0; u < KPH; u++) {
         const int t = tb + u;
@@ -665,6 +678,14 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
         s = tree32_to_lane0(s);
         if (l == 0 && t <= n_past) sc[(size_t) h * n_ctx + t] = s * kq_scale;
     }
+#if LH_PHASE_PROBE == 3
+    probe_t2 = __builtin_readcyclecounter();
+    if (g_phase_probe && tid == 0) {
+        unsigned long long *pb = g_phase_probe; const unsigned long long slot = atomicAdd(pb, 1ull);
+        if (slot < pb[1]) { unsigned long long *e = pb + 8 * (1 + slot); e[0] = probe_t0; e[1] = probe_t1; e[2] = probe_t2; e[3] = e[4] = probe_t2;
+            e[5] = (0xB2ull << 48) | ((unsigned long long) blockIdx.y << 32) | (unsigned) h; e[6] = wall_clock64(); e[7] = probe_wall; }
+    }
+#endif
 }
 
 // Short prompt chunks (2 <= N <= 16 rows, the reference's n_batch = 8 flow): the decode work distribution with
@@ -712,6 +733,47 @@ k_decn_scores(const float *__restrict__ qr, int d, int dh, const float *__restri
 //   MULTI (short prompt chunks): blockIdx.z = row n of the chunk, position n_past0 + n (host value, `st` unused);
 //         sc is [row][head][n_ctx], merged / QA are per row (strides d, qa_strideA dwords, qa_strideD floats) and
 //         the last workgroup of a row zeroes the QA blocks that pad K up to a multiple of 256.
+// soft_max of one head's score row into LDS (p[0..T)): max, fp16-table exp, double sum, scale (ggml.c:5619-5665); every thread
+// of the workgroup calls it, the caller synchronizes before reading p
+static __device__ __forceinline__ void pv_soft_max(const float *__restrict__ row, float *p, int T, int tid, int nt, double *red,
+                                                   const uint16_t *__restrict__ T_exp, int lut_math) {
+    float mx = -INFINITY;
+    for (int t = tid; t < T; t += nt) { const float v = row[t]; p[t] = v; mx = fmaxf(mx, v); }
+    mx = block_max_f(mx, red, 0);
+    double sum = 0.0;
+    for (int t = tid; t < T; t += nt) {
+        const uint16_t xh = f2h_bits(p[t] - mx);
+        const float e = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
+        p[t] = e;
+        sum += (double) e;
+    }
+    sum = block_sum_d(sum, red, 1);
+    const float inv = (float) (1.0 / sum);
+    for (int t = tid; t < T; t += nt) p[t] *= inv;
+}
+// the nth partial sums of 32 columns added in thread order, stored (fp32 row, if asked) and quantized to one Q4_0 activation
+// block of the QA layout; lanes 0..31 of the workgroup's first wave work
+static __device__ __forceinline__ void pv_store_block(const float *part, int nth, int tid, int col, int h, int dh, int cb,
+                                                      float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d) {
+    if (tid < 32) {
+        float s = part[tid];
+        for (int th = 1; th < nth; th++) s += part[th * 32 + tid];          // thread order (ggml.c:5553-5577)
+        if (merged) merged[col] = s;
+        // quantize this 32-element block (ggml.c:456-523), one element per lane
+        float amax = fabsf(s);
+        amax = max_lanes_0_31(amax);
+        const float dd = amax / 7.0f;
+        const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+        const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
+        const int kk = tid & 7;
+        const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+        const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+        const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
+        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+        if (tid == 0) qa_d[b] = dd;
+    }
+}
+
 template <bool MULTI>
 __global__ void __launch_bounds__(1024)
 k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth,
@@ -740,19 +802,7 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
                 qa_d[pb] = 0.0f;
             }
     }
-    float mx = -INFINITY;
-    for (int t = tid; t < T; t += nt) { const float v = row[t]; p[t] = v; mx = fmaxf(mx, v); }
-    mx = block_max_f(mx, red, 0);
-    double sum = 0.0;
-    for (int t = tid; t < T; t += nt) {
-        const uint16_t xh = f2h_bits(p[t] - mx);
-        const float e = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
-        p[t] = e;
-        sum += (double) e;
-    }
-    sum = block_sum_d(sum, red, 1);
-    const float inv = (float) (1.0 / sum);
-    for (int t = tid; t < T; t += nt) p[t] *= inv;
+    pv_soft_max(row, p, T, tid, nt, red, T_exp, lut_math);
     // a chunk row is as long as the whole chunk's context (ggml.c:5459-5480 splits n_past + N keys over the
     // threads for every row); the masked tail has weight exp(-inf) = 0 and is walked like the reference does
     const int Tpv = MULTI ? n_past0 + (int) gridDim.z : T;
@@ -793,24 +843,162 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
         part[th * 32 + c] = acc;
     }
     __syncthreads();
-    if (tid < 32) {
-        float s = part[tid];
-        for (int th = 1; th < nth; th++) s += part[th * 32 + tid];          // thread order (ggml.c:5553-5577)
-        if (merged) merged[col] = s;
-        // quantize this 32-element block (ggml.c:456-523), one element per lane
-        float amax = fabsf(s);
-        amax = max_lanes_0_31(amax);
-        const float dd = amax / 7.0f;
-        const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
-        const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s * id)) & 0xF;
-        const int kk = tid & 7;
-        const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
-        const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
-        const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
-        if (tid < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
-        if (tid == 0) qa_d[b] = dd;
-    }
+    pv_store_block(part, nth, tid, col, h, dh, cb, merged, qa_A, qa_d);
 }
+
+// k_dec_pv_stream: k_dec_pv_blk<false> for long contexts (decode after a long prompt).  A chain walks T / nth rows of V that lie
+// 4 d bytes apart, and the register batches of k_dec_pv_blk keep 32 of them in flight per chain: at 2 048 keys that is 8 dependent
+// memory round trips with 4 MB in flight chip-wide (H dh/32 workgroups x nth 32 chains x 32 rows x 4 B).  Here ALL 1 024 threads of the
+// workgroup fetch (16 B each, 8 lanes per 128-byte row segment) and only the chain owners do arithmetic: a stage is SR consecutive
+// rows of every chain of the workgroup ([chain][SR][32] floats in LDS), two stages are in flight in registers (NL 16-byte loads per
+// thread each) while the owners consume the one before from the LDS double buffer -- one barrier per stage.  The chains themselves
+// are the reference's: rows dc th .. dc th + dc - 1 in order, one fp32 FMA each (ggml.c:5459-5480), so the sums are bit-identical
+// to k_dec_pv_blk's.
+// What a CU can pull from memory is bounded (about 20 GB/s each when all 256 stream; 17.6 us per launch at 2 048 keys with the 7B's
+// H dh/32 = 128 workgroups on 128 CUs), so the chains of a (head, column block) are SPLIT over `split` workgroups where that fills
+// the chip: workgroup z owns chains [z cpw, z cpw + cpw), the ones with z < split - 1 leave their sums as tagged granules
+// {sum, make_tag(epoch, layer + 1)} in xpart, the last one (dispatched last: the others are resident or done when it looks) takes
+// them with bounded polls and adds all nth in thread order.  Workgroups of a (head, column block) are 8 apart in the 1-D grid:
+// one XCD, one L2 (the placement xcd_selftest checked at load) -- workgroup-scope stores, L1-bypassing loads, no fences.
+// grid H dh/32 x split (1-D), 1 024 threads, LDS = red + p[n_ctx] + part + 2 stages.
+template <int NL>
+__global__ void __launch_bounds__(1024)
+k_dec_pv_stream(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth, int SR,
+                float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
+                const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st, int lut_math,
+                int H, int split, uint64_t *__restrict__ xpart, const uint32_t *__restrict__ epoch, int layer, uint32_t *__restrict__ fault) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ double smem_d[];
+    double *red = smem_d;
+    float *p = (float *) (smem_d + 32);
+    float *part = p + ((n_ctx + 3) & ~3);
+    f32x4 *stage = (f32x4 *) (part + nth * 32);                          // 2 x [cpw][SR][8] quads
+    const int tid = threadIdx.x;
+#if LH_PHASE_PROBE == 3        /* timeline probe (tools/pv_stream_timeline.py): kinds 0xB0 / 0xB1 = first / second half of a workgroup's stamps */
+    unsigned long long probe_t[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const unsigned long long probe_wall = wall_clock64();
+#define LH_PSTAMP(IDX) do { probe_t[IDX] = __builtin_readcyclecounter(); } while (0)
+#define LH_PFLUSH() do { if (g_phase_probe && tid == 0) { unsigned long long *pb = g_phase_probe; const unsigned long long wall_ = wall_clock64(); \
+        for (int half_ = 0; half_ < 2; half_++) { const unsigned long long slot = atomicAdd(pb, 1ull); \
+        if (slot < pb[1]) { unsigned long long *e = pb + 8 * (1 + slot); for (int i = 0; i < 5; i++) e[i] = probe_t[5 * half_ + i]; \
+            e[5] = ((unsigned long long) (0xB0 + half_) << 48) | ((unsigned long long) z << 32) | (unsigned) base; e[6] = wall_; e[7] = probe_wall; } } } } while (0)
+#else
+#define LH_PSTAMP(IDX) do { } while (0)
+#define LH_PFLUSH() do { } while (0)
+#endif
+    const int bid = blockIdx.x, z = (bid >> 3) % split, base = (bid / (8 * split)) * 8 + (bid & 7);
+    const int h = base % H, cb = base / H;
+    const int cpw = (nth + split - 1) / split, th_lo = z * cpw, nloc = min(nth, th_lo + cpw) - th_lo;      // this workgroup's chains
+    LH_PSTAMP(0);
+    const int T = st[0] + 1;
+    const int dc = (T + nth - 1) / nth;
+    const int nstage = (dc + SR - 1) / SR;
+    const int col0 = h * dh + cb * 32;
+    const int stage_quads = nloc * SR * 8;                              // <= NL * 1024
+    // the head's score row first (registers; PV_ROW values per thread cover n_ctx <= 4 096): loads complete in order, so the
+    // soft_max below waits for these and not for the V stages issued right after them
+    constexpr int PV_ROW = 4;
+    const float *row = sc + (size_t) h * n_ctx;
+    float rv[PV_ROW];
+#pragma unroll
+    for (int i = 0; i < PV_ROW; i++) rv[i] = row[min(i * 1024 + tid, T - 1)];
+    // quad e of a stage: row r = e / 8 of the stage (local chain r / SR, its u-th row), columns 4 (e % 8) ..; rows past the chain's
+    // end are clamped re-reads nobody consumes
+    auto fetch = [&](int sidx, f32x4 (&v)[NL]) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = min(i * 1024 + tid, stage_quads - 1);
+            const int r = e >> 3, q = e & 7;
+            const int lc = r / SR, u = r - lc * SR, th = th_lo + lc;
+            const int t = min(min(dc * th + sidx * SR + u, dc * th + dc - 1), T - 1);
+            v[i] = __builtin_nontemporal_load((const f32x4 *) (Vc + (size_t) t * d + col0 + q * 4));
+        }
+    };
+    auto put = [&](int buf, const f32x4 (&v)[NL]) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = i * 1024 + tid;
+            if (e < stage_quads) stage[(size_t) buf * stage_quads + e] = v[i];
+        }
+    };
+    f32x4 va[NL], vb[NL];
+    {   // soft_max (pv_soft_max's arithmetic on the register copy: max, fp16-table exp, double sum, scale -- ggml.c:5619-5665)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) if (i * 1024 + tid < T) mx = fmaxf(mx, rv[i]);
+        mx = block_max_f(mx, red, 0);
+        LH_PSTAMP(1);
+        // The V stages are requested only now, with the score row in hand: every workgroup of the launch asks for its whole share of
+        // V within the first microsecond, and a row requested alongside arrives behind all of it (7.3 us after entry at 2 048 keys,
+        // in-kernel timeline) with the soft_max still to do; asked for alone it is back in ~2 us and the soft_max runs under the V stream.
+        fetch(0, va);
+        if (nstage > 1) fetch(1, vb);
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) {
+            if (i * 1024 + tid < T) {
+                const uint16_t xh = f2h_bits(rv[i] - mx);
+                rv[i] = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
+                sum += (double) rv[i];
+            }
+        }
+        sum = block_sum_d(sum, red, 1);
+        const float inv = (float) (1.0 / sum);
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) if (i * 1024 + tid < T) p[i * 1024 + tid] = rv[i] * inv;
+    }
+    LH_PSTAMP(2);
+    const int lc = tid >> 5, c = tid & 31, th = th_lo + lc;
+    const bool owner = lc < nloc;
+    const int t0 = dc * th, t1 = min(t0 + dc, T);
+    float acc = 0.0f;
+    auto consume = [&](int sidx, int buf) {
+        if (!owner) return;
+        const float *vs = (const float *) (stage + (size_t) buf * stage_quads) + (size_t) lc * SR * 32 + c;
+        const int tb = t0 + sidx * SR, n = min(SR, t1 - tb);
+        int u = 0;
+        for (; u + 16 <= n; u += 16) {                                   // LDS reads batched, the FMA chain in key order
+            float v[16], w[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { v[k] = vs[(u + k) * 32]; w[k] = p[tb + u + k]; }
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc = fmaf(v[k], w[k], acc);
+        }
+        for (; u < n; u++) acc = fmaf(vs[u * 32], p[tb + u], acc);
+    };
+    for (int sidx = 0; sidx < nstage; sidx += 2) {
+        put(0, va);
+        __syncthreads();                                                // (the first one also orders p before the owners' reads)
+        if (sidx == 0) LH_PSTAMP(3); else if (sidx == 2) LH_PSTAMP(7);
+        if (sidx + 2 < nstage) fetch(sidx + 2, va);
+        consume(sidx, 0);
+        if (sidx == 0) LH_PSTAMP(4);
+        if (sidx + 1 < nstage) {
+            put(1, vb);
+            __syncthreads();
+            if (sidx == 0) LH_PSTAMP(5);
+            if (sidx + 3 < nstage) fetch(sidx + 3, vb);
+            consume(sidx + 1, 1);
+            if (sidx == 0) LH_PSTAMP(6);
+        }
+    }
+    LH_PSTAMP(8);
+    if (z + 1 < split) {                                                // not the last workgroup of this column block: publish and leave
+        if (owner) store_tagged(xpart + ((size_t) base * nth + th) * 32 + c, acc, make_tag(epoch[0], layer + 1) ^ ((lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test)
+        LH_PSTAMP(9);
+        LH_PFLUSH();
+        return;
+    }
+    if (owner) part[th * 32 + c] = acc;
+    if (split > 1 && tid < th_lo * 32)                                  // the chains before this workgroup's, from their owners
+        part[tid] = poll_tagged(xpart + (size_t) base * nth * 32 + tid, make_tag(epoch[0], layer + 1), fault, (lut_math & 0x1000) ? 4 : 0);
+    __syncthreads();
+    pv_store_block(part, nth, tid, col0 + tid, h, dh, cb, merged, qa_A, qa_d);
+    LH_PSTAMP(9);
+    LH_PFLUSH();
+}
+#undef LH_PSTAMP
+#undef LH_PFLUSH
 
 // ------------------------------------------------------------------------------------------------
 // k_dec_attn_x: k_dec_scores + k_dec_pv_blk<false> in ONE launch with a hand-off that stays inside one XCD.
@@ -1529,12 +1717,44 @@ bool xcd_selftest(int H, int Y, hipStream_t st) {
     return ok;
 }
 
+// the streaming soft_max . V (k_dec_pv_stream): one chain owner per (thread of the split, column) in a 1 024-thread workgroup,
+// the score row in 4 registers per thread, 16-byte column quads
+// (LLAMAHIP_HANDOFF_FAULT_TEST=4: the polls of k_dec_pv_stream give up after 256 looks and its publishers use a tag nobody waits for)
+static const int g_pv_fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) == 4) ? 0x1000 : 0;
+bool pv_stream_applies(int dh, int n_ctx, int nth) { return nth >= 1 && nth <= 32 && n_ctx <= 4096 && dh % 32 == 0; }
+
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
-                           const uint16_t *T_exp, const int32_t *state, hipStream_t st, uint32_t *xsync, uint32_t *fault) {
+                           const uint16_t *T_exp, const int32_t *state, hipStream_t st, uint32_t *xsync, uint32_t *fault, bool long_ctx,
+                           uint64_t *xpart, const uint32_t *epoch, int layer) {
     const int dh = d / H;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     (void) part;
+    // long contexts (the caller knows the position): scores, then the streaming soft_max . V
+    if (long_ctx && pv_stream_applies(dh, n_ctx, nth)) {
+        const int nsl = (n_ctx + DEC_TS - 1) / DEC_TS;
+        hipLaunchKernelGGL(k_dec_scores, dim3(H, nsl), dim3(256), 2 * dh * sizeof(float), st, qkv, d, dh, tab, Kc, Vc, sc, n_ctx, kq_scale, state);
+        LH_LAUNCH_CHECK();
+        // chains of a (head, column block) over `split` workgroups until the chip is full (needs the XCD placement: xpart is only
+        // passed when the load-time self-test confirmed it); every workgroup must own at least one chain
+        static const int split_env = getenv("LLAMAHIP_PV_SPLIT") ? atoi(getenv("LLAMAHIP_PV_SPLIT")) : 0;
+        const int W = H * (dh / 32);
+        auto valid = [&](int s) { const int cpw = (nth + s - 1) / s; return s >= 1 && s <= nth && (s - 1) * cpw < nth; };
+        int split = 1;
+        if (xpart && epoch && fault && W % 8 == 0) {
+            if (split_env > 0) { if (valid(split_env)) split = split_env; }
+            else while (W * split * 2 <= 256 && valid(split * 2)) split *= 2;       // (13B: 160 workgroups stay unsplit -- 320 would need two rounds: 322 against 298 tokens/s at 2 048 keys)
+        }
+        const int cpw = (nth + split - 1) / split;
+        constexpr int nl = 4;                   // 16-byte loads per thread and stage: 64 KB stages, 128 KB of LDS, one workgroup per CU
+        // (LLAMAHIP_PV_STAGE_ROWS shortens the stages so that small test contexts run many of them; tests only)
+        static const int sr_cap = getenv("LLAMAHIP_PV_STAGE_ROWS") ? std::max(1, atoi(getenv("LLAMAHIP_PV_STAGE_ROWS"))) : 1 << 20;
+        const int SR = std::min(nl * 128 / cpw, sr_cap);
+        const size_t lds = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 32) * sizeof(float) + (size_t) 2 * cpw * SR * 128;
+        hipLaunchKernelGGL(k_dec_pv_stream<4>, dim3(W * split), dim3(1024), lds, st, sc, Vc, d, dh, n_ctx, nth, SR, merged, qa_A, qa_d, T_exp, state, g_lut_math | g_pv_fault_test, H, split, xpart, epoch, layer, fault);
+        LH_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     // scores and soft_max . V in one launch with an XCD-local hand-off (k_dec_attn_x); the caller passes xsync only
     // after xcd_selftest() confirmed the placement it relies on
     // (contexts beyond 1 024: the score slices no longer fit the chip next to the waiting workgroups at this kernel's 4 waves per
@@ -1807,7 +2027,7 @@ hipError_t init_attrs_decode() {
     LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
     LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 1); LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 2); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 4); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 12);
 #undef LH_ATTR_G1
-    LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));
+    LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_pv_stream<4>); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));
     LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 4, 2>));
 #undef LH_ATTR
     return hipSuccess;

@@ -173,13 +173,15 @@ struct llamahip_model {
     uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
+    uint64_t *d_pvx = nullptr;           // tagged partial sums of k_dec_pv_stream's split workgroups: [H dh/32][32 threads of the split][32]
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
                                                      // a: of the row in x (attention / final norm), b: of the row in x1 (ffn norm)
     int n_seq = 1, cur_seq = 0;          // KV caches: [seq][layer][n_ctx][d]
     AttnWs attn_ws;                      // many-row prompt attention workspace (allocated with the first eval of >= 32 tokens)
-    std::map<int, hipGraphExec_t> decode_graphs;   // keyed by nth * 4096 + seq
+    std::map<int, hipGraphExec_t> decode_graphs;   // keyed by nth * 4096 + seq + (attention schedule << 24)
+    int attn_sched = 0;                            // decode attention schedule of the single-row pass being launched / captured (attn_sched_at): 0 fused, 1 two launches, 2 long-context
     // asynchronous pipeline-stage steps (llamahip_stage_bind / llamahip_stage_step)
     struct StageSlot {
         int32_t *token_in = nullptr, *token_out = nullptr;     // caller-owned device buffers
@@ -190,7 +192,7 @@ struct llamahip_model {
         bool peer_hidden_ipc = false, peer_token_ipc = false;         // opened with hipIpcOpenMemHandle (closed with the handle)
         bool bound = false;
         int next_pos = 0;                                       // host mirror of the device position (bounds check)
-        std::map<int, hipGraphExec_t> graphs;                   // keyed by nth
+        std::map<int, hipGraphExec_t> graphs;                   // keyed by nth + (attention schedule << 16)
     };
     std::vector<StageSlot> slots;        // one per sequence slot
     int32_t *d_slot_state = nullptr;     // [n_seq][2]: {position, step index}, advanced on the device
@@ -204,6 +206,20 @@ struct llamahip_model {
 };
 
 static void free_dev(void *p) { if (p) (void) hipFree(p); }
+// A pipeline mailbox is polled by this GPU's kernels while ANOTHER GPU's kernel stores into it over xGMI.  Ordinary hipMalloc
+// memory is coarse-grained: the local L2 may keep serving a line it cached on an earlier look, and coherence with other agents is
+// only promised at kernel boundaries.  Uncached (else fine-grained) device memory is what in-kernel flags between GPUs need;
+// both can be exported with hipIpcGetMemHandle like any device allocation.  LLAMAHIP_MAILBOX_COARSE=1: plain hipMalloc (measurement).
+static hipError_t malloc_mailbox(void **p, size_t bytes) {
+    static const bool coarse = getenv("LLAMAHIP_MAILBOX_COARSE") != nullptr;
+    if (!coarse) {
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) == hipSuccess) return hipSuccess;
+        (void) hipGetLastError();
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
+        (void) hipGetLastError();
+    }
+    return hipMalloc(p, bytes);
+}
 
 llamahip_model::~llamahip_model() {
     if (host_only) return;
@@ -223,7 +239,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch);
+    free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_pvx);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
     free_dev(d_state); free_dev(sc); free_dev(part); free_dev(qa1_A); free_dev(qa2_A); free_dev(qa1_d); free_dev(qa2_d);
@@ -521,6 +537,23 @@ struct StepIO {
     uint64_t *mb_out = nullptr;
     const uint64_t *mb_token = nullptr;
 };
+// The decode attention schedule by position (a host-side fact at every entry point: n_past, or the slot's next position; graphs are
+// captured per schedule):
+//   0  wq|wk|wv + attention in one launch (k_qkv_attn)                                        short contexts
+//   1  mat-vec, k_dec_scores, k_dec_pv_blk (three launches)                                   from LLAMAHIP_ATTN_TWO_FROM
+//   2  mat-vec, k_dec_scores, k_dec_pv_stream (V through LDS, every thread of the chip loading) from LLAMAHIP_ATTN_LONG_FROM
+// Defaults are the measured crossovers (profiles/r03_attn_by_context.txt): the fused launch's attention workgroups wait inside the
+// launch, which costs more the longer the context; how soon depends on how many of them there are (H dh/32).  -1 = never.
+static int attn_sched_at(const llamahip_model *m, int pos) {
+    static const int env_two = getenv("LLAMAHIP_ATTN_TWO_FROM") ? atoi(getenv("LLAMAHIP_ATTN_TWO_FROM")) : -2;
+    static const int env_long = getenv("LLAMAHIP_ATTN_LONG_FROM") ? atoi(getenv("LLAMAHIP_ATTN_LONG_FROM")) : -2;
+    const int W = m->hp.n_embd / 32;                        // soft_max . V workgroups per launch: 128 (7B), 160 (13B), 256 (65B)
+    const int two_from = env_two != -2 ? env_two : (W <= 128 ? -1 : W < 256 ? 544 : 448);
+    const int long_from = env_long != -2 ? env_long : (W <= 128 ? 1280 : W < 256 ? 1600 : 2048);
+    if (long_from >= 0 && pos >= long_from) return 2;
+    if (two_from >= 0 && pos >= two_from) return 1;
+    return 0;
+}
 int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool state_on_device,
             bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap, const StepIO *io = nullptr) {
     const HParams &hp = m->hp;
@@ -554,12 +587,17 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     const bool use_part = fused && m->w13_interleaved && !no_norm_part;
     int n_part_x = 0;                                       // pairs in npart_a valid for the row currently in x (0: none)
     // decode: wq|wk|wv + attention as one launch with tagged hand-offs (k_qkv_attn); one forward pass = one epoch
-    const bool use_qkvx = fused && m->d_attn_sync && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
-    if (use_qkvx && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
+    // (long contexts: soft_max . V is a bandwidth problem of its own there -- separate mat-vec, k_dec_scores, k_dec_pv_stream)
+    const bool long_attn = fused && m->attn_sched == 2 && pv_stream_applies((int) (d / H), (int) C, nth);
+    const bool two_attn = fused && (m->attn_sched == 1 || (m->attn_sched == 2 && !long_attn));
+    const bool use_qkvx = !long_attn && !two_attn && fused && m->d_attn_sync && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
+    const bool pv_split = long_attn && m->d_pvx && m->l1 - m->l0 <= TAG_MAX_LAYERS;          // (its tags are (epoch, layer) too)
+    const bool use_epoch = use_qkvx || pv_split;
+    if (use_epoch && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (io && fused && io->mb_token && m->first_stage && !use_part) { set_err(err, err_cap, "pipeline mailboxes need the default norm-statistics mode (LLAMAHIP_NORM_MODE unset)"); return LLAMAHIP_ERR_PREDICT; }
     if (m->first_stage) {
         if (use_part) {
-            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_qkvx ? m->d_epoch : nullptr, nullptr,
+            HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_epoch ? m->d_epoch : nullptr, nullptr,
                                       (io && fused) ? io->mb_token : nullptr, state, m->d_fault, hp.n_vocab), LLAMAHIP_ERR_PREDICT);
             n_part_x = 1;
         } else
@@ -601,7 +639,8 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
                                         m->qa1_A, m->qa1_d, m->T_silu, m->T_exp, state, m->d_fault, st, mbi), LLAMAHIP_ERR_PREDICT);
             } else {
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv, mbi), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, m->d_attn_sync, m->d_fault), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, two_attn ? nullptr : m->d_attn_sync, m->d_fault, long_attn,
+                                    pv_split ? m->d_pvx : nullptr, m->d_epoch, il - m->l0), LLAMAHIP_ERR_PREDICT);
             }
             HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo, mbi), LLAMAHIP_ERR_PREDICT);
             if (m->w13_interleaved) {
@@ -936,6 +975,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
             HIP_TRY(hipMemset(m->d_qkv2, 0, (size_t) 3 * d * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMalloc((void **) &m->d_sc2, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
             HIP_TRY(hipMemset(m->d_sc2, 0, (size_t) H * n_ctx * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMalloc((void **) &m->d_pvx, (size_t) d * 32 * 8), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_pvx, 0, (size_t) d * 32 * 8), LLAMAHIP_ERR_LOAD);
         }
         HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
@@ -1020,6 +1061,7 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
     }
     const bool want_all = logits_all != nullptr;
     m->tok_src = tok_mapped ? m->d_io->tok : nullptr;
+    m->attn_sched = N == 1 ? attn_sched_at(m, n_past) : 0;
     rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap);
     m->tok_src = nullptr;
     if (rc) return rc;
@@ -1105,6 +1147,7 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
     rc = ensure_prompt_copies(m, N, err, err_cap);
     if (rc) return rc;
     if (m->first_stage) HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
+    m->attn_sched = N == 1 ? attn_sched_at(m, n_past) : 0;
     rc = forward(m, n_threads, n_past, N, (const float *) hidden_in, false, false, -1, nullptr, err, err_cap);
     if (rc) return rc;
     const size_t d = m->hp.n_embd, V = m->hp.n_vocab;
@@ -1146,26 +1189,30 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         // One decode step (embed -> layers -> lm head -> argmax) captured once per n_threads value.
         // Nothing in it depends on the step: position and token slots live in device memory and
         // k_argmax advances them, so the same executable graph is replayed n_steps times.
-        const int gkey = nth * 4096 + m->cur_seq;
-        auto it = m->decode_graphs.find(gkey);
-        if (it == m->decode_graphs.end()) {
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal), LLAMAHIP_ERR_PREDICT);
-            rc = forward(m, nth, 0, 1, nullptr, true, false, -1, nullptr, err, err_cap);
-            hipError_t e1 = rc ? hipErrorUnknown : launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, 0, m->d_tokens, m->d_state, m->stream);
-            hipError_t e2 = hipStreamEndCapture(m->stream, &graph);
-            if (rc) return rc;
-            HIP_TRY(e1, LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(e2, LLAMAHIP_ERR_PREDICT);
-            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), LLAMAHIP_ERR_PREDICT);
-            (void) hipGraphDestroy(graph);
-            it = m->decode_graphs.emplace(gkey, exec).first;
+        for (int i = 0; i < n_steps; i++) {
+            m->attn_sched = attn_sched_at(m, n_past + i);
+            const int gkey = nth * 4096 + m->cur_seq + (m->attn_sched << 24);
+            auto it = m->decode_graphs.find(gkey);
+            if (it == m->decode_graphs.end()) {
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal), LLAMAHIP_ERR_PREDICT);
+                rc = forward(m, nth, 0, 1, nullptr, true, false, -1, nullptr, err, err_cap);
+                hipError_t e1 = rc ? hipErrorUnknown : launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, 0, m->d_tokens, m->d_state, m->stream);
+                hipError_t e2 = hipStreamEndCapture(m->stream, &graph);
+                if (rc) return rc;
+                HIP_TRY(e1, LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(e2, LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), LLAMAHIP_ERR_PREDICT);
+                (void) hipGraphDestroy(graph);
+                it = m->decode_graphs.emplace(gkey, exec).first;
+            }
+            HIP_TRY(hipGraphLaunch(it->second, m->stream), LLAMAHIP_ERR_PREDICT);
         }
-        for (int i = 0; i < n_steps; i++) HIP_TRY(hipGraphLaunch(it->second, m->stream), LLAMAHIP_ERR_PREDICT);
     } else {
         for (int i = 0; i < n_steps; i++) {
+            m->attn_sched = attn_sched_at(m, n_past + i);
             rc = forward(m, n_threads, n_past + i, 1, nullptr, fusable, false, -1, nullptr, err, err_cap);
             if (rc) return rc;
             // argmax feeds the next step's token slot (and advances the position) on the device
@@ -1261,12 +1308,12 @@ int llamahip_stage_mailbox(llamahip_model *m, int32_t seq, void **hidden_inbox, 
     auto &sl = m->slots[seq];
     if (!m->first_stage && !sl.inbox_hidden) {
         if ((rc = drop_slot_graphs(m, seq, err, err_cap)) != 0) return rc;
-        HIP_TRY(hipMalloc((void **) &sl.inbox_hidden, (size_t) m->hp.n_embd * 8), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(malloc_mailbox((void **) &sl.inbox_hidden, (size_t) m->hp.n_embd * 8), LLAMAHIP_ERR_PREDICT);
         HIP_TRY(hipMemset(sl.inbox_hidden, 0, (size_t) m->hp.n_embd * 8), LLAMAHIP_ERR_PREDICT);
     }
     if (m->first_stage && !m->last_stage && !sl.inbox_token) {
         if ((rc = drop_slot_graphs(m, seq, err, err_cap)) != 0) return rc;
-        HIP_TRY(hipMalloc((void **) &sl.inbox_token, 64), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(malloc_mailbox((void **) &sl.inbox_token, 64), LLAMAHIP_ERR_PREDICT);
         HIP_TRY(hipMemset(sl.inbox_token, 0, 64), LLAMAHIP_ERR_PREDICT);
     }
     if (hidden_inbox) *hidden_inbox = sl.inbox_hidden;
@@ -1358,13 +1405,16 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
     auto &sl = m->slots[seq];
     if (sl.next_pos >= m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (1) > n_ctx (%d)", sl.next_pos, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
     if (m->flags & LLAMAHIP_FLAG_NO_GRAPH) {
+        m->attn_sched = attn_sched_at(m, sl.next_pos);
         hipStream_t own = m->stream;
         m->stream = run_on;
         int rc = stage_step_launches(m, seq, nth, err, err_cap);
         m->stream = own;
         if (rc) return rc;
     } else {
-        auto it = sl.graphs.find(nth);
+        m->attn_sched = attn_sched_at(m, sl.next_pos);
+        const int gkey = nth + (m->attn_sched << 16);
+        auto it = sl.graphs.find(gkey);
         if (it == sl.graphs.end()) {
             // One step of this stage (embed | stream in -> layers -> stream out | lm head + argmax)
             // captured once per (slot, n_threads); the position lives in device memory and the last
@@ -1379,7 +1429,7 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
             HIP_TRY(e2, LLAMAHIP_ERR_PREDICT);
             HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), LLAMAHIP_ERR_PREDICT);
             (void) hipGraphDestroy(graph);
-            it = sl.graphs.emplace(nth, exec).first;
+            it = sl.graphs.emplace(gkey, exec).first;
         }
         HIP_TRY(hipGraphLaunch(it->second, run_on), LLAMAHIP_ERR_PREDICT);
     }

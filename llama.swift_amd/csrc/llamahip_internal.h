@@ -128,7 +128,10 @@ hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, 
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st,
-                           uint32_t *xsync = nullptr, uint32_t *fault = nullptr);     // xsync: H * 32 zeroed dwords -> single-launch k_dec_attn_x
+                           uint32_t *xsync = nullptr, uint32_t *fault = nullptr,      // xsync: H * 32 zeroed dwords -> single-launch k_dec_attn_x
+                           bool long_ctx = false,                                     // long_ctx: k_dec_scores + k_dec_pv_stream (pv_stream_applies) ...
+                           uint64_t *xpart = nullptr, const uint32_t *epoch = nullptr, int layer = 0);      // ... its chains split over workgroups: [H dh/32][nth][32] granules, tag = (epoch, layer + 1)
+bool pv_stream_applies(int dh, int n_ctx, int nth);
 bool xcd_selftest(int H, int Y, hipStream_t st);
 // wq|wk|wv mat-vec + decode attention as one launch (k_qkv_attn); xsync / fault as launch_dec_attn
 constexpr int TAG_MAX_LAYERS = 250;                                 // hand-off tags carry the layer index in 8 bits (kernels.hip make_tag)

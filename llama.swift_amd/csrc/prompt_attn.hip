@@ -120,91 +120,29 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 }
 
 // ------------------------------------------------------------------------------------------------
-// Prompt attention for many query rows (N >= 32, head size 128): lane = QUERY ROW.
-// k_attn above gives every (head, query) its own workgroup and re-reads the head's whole K and V for
-// each query: 2048 rows stream 69 GB per layer through L2.  Here a wave owns 64 consecutive queries
-// of one head and walks the keys; the key row (scores) / value row (V*P) is the same for all 64 lanes,
-// so it is fetched with SCALAR loads and used as an SGPR operand of v_fma_f32 -- no LDS, no
-// cross-lane reduction (each lane runs the reference's 32 FMA chains and its reduction tree itself),
-// and K / V are read once per 64 queries.  Scores are materialised like the reference's KQ tensor
-// (.mm:614), in a [head][key][query] workspace so that lanes read and write it coalesced; queries
-// are processed in batches of NB rows to bound it.
-//   k_attnq_scores   grid (NB/64, H, KS): KQ * scale for its key slice, running max      -> S, pmax
-//   k_attnq_softmax  grid (NB/64, H) x (64 queries x 16 key phases): exp LUT, double sum  -> S = e, inv
-//   k_attnq_pv       grid (NB/64, H, 4 column groups x nth): p = e * inv; one FMA chain per chunk of the
-//                    reference's nth-way key split                                       -> part
-//   k_attnq_merge    the ordered add of the nth partials                                 -> merged
-// Arithmetic is identical to k_attn.
+// Prompt attention for many query rows (head size 128) on the fp32 matrix cores.
+// k_attn above gives every (head, query) its own workgroup and re-reads the head's whole K and V for each query: 2 048 rows stream
+// 69 GB per layer through L2.  Here scores are materialised like the reference's KQ tensor (.mm:614), in a [head][key][query]
+// workspace so that lanes read and write it coalesced; queries are processed in batches of NB rows to bound it.
+//   k_attnq_scores_mfma  grid (NB/16, H, KS): KQ * scale for its key slice, running max   -> S, pmax
+//   k_attnq_softmax      grid (NB/64, H) x (64 queries x 16 key phases): exp LUT, double sum -> S = e, inv
+//   k_attnq_pv_mfma      grid (NB/64, H, nth): p = e * inv; the FMA chains of ONE chunk of the reference's nth-way key split -> part
+//   k_attnq_merge        the ordered add of the nth partials                              -> merged
+// Arithmetic is identical to k_attn.  (Rounds 1-2 had three more score kernels / one more V*P kernel with lane = query row and the key /
+// value row as SGPR operands, through LDS broadcasts, or on the VALU: 201 / 152 us per score launch at 2 048 tokens against 100 here;
+// removed in round 3, DESIGN_HISTORY.md.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
-k_attnq_scores(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
-               int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
-    // (one wave per workgroup: grouping four query blocks of a head into a workgroup so that they share
-    // the K rows in the scalar cache measured 7x SLOWER)
-    const int lane = threadIdx.x, h = blockIdx.y, ks = blockIdx.z;
-    const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
-    const bool valid = n < N;
-    const int nq = valid ? n : N - 1;
-    const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
-    const int Tb = n_past + nb_end;                       // keys any query of this block can see
-    const int per = (Tb + KS - 1) / KS, t0 = ks * per, t1 = min(Tb, t0 + per);
-    const int tq = n_past + nq;                           // last key this lane's query sees
-    float q[128];
-    {
-        const f32x4 *qp = (const f32x4 *) (qr + (size_t) nq * d + h * 128);
-#pragma unroll
-        for (int i = 0; i < 32; i++) { const f32x4 v = qp[i]; q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w; }
-    }
-    float mx = -INFINITY;
-    // ggml_vec_dot_f32 (ggml.c:1223-1258): chain l (0..31) = elements l, l+32, l+64, l+96 by FMA from 0;
-    // reduction tree (ggml.c:872-887) = lanes xor 8, 16, 4, 1, 2.  Chains 0..15 first, then 16..31.
-    // The key row reaches the FMAs as SGPR operands, 16 floats (one s_load_dwordx16) per PIECE; a key is
-    // 8 pieces, consumed in the order (half, j): piece pi covers elements 32 * (pi & 3) + 16 * (pi >> 2) + e.
-    // A whole row (128 SGPRs) cannot be resident, so the pieces of consecutive keys form one stream that is
-    // software-pipelined three pieces ahead through four 16-SGPR buffers (the scalar-cache round trip
-    // per piece was this kernel's critical path).
-    float kb[4][16];
-#define LH_LOADP(BUF, TT, PI)                                                                      \
-    {                                                                                              \
-        const float *p_ = Kc + (size_t) min((TT), t1 - 1) * d + h * 128 + 32 * ((PI) & 3) + 16 * ((PI) >> 2);   /* wave-uniform */ \
-        _Pragma("unroll") for (int e = 0; e < 16; e++) kb[BUF][e] = p_[e];                         \
-    }
-    if (t0 < t1) { LH_LOADP(0, t0, 0) LH_LOADP(1, t0, 1) LH_LOADP(2, t0, 2) }
-    for (int t = t0; t < t1; t++) {
-        float r1[2][8];
-        float c[16];
-#pragma unroll
-        for (int pi = 0; pi < 8; pi++) {
-            LH_LOADP((pi + 3) & 3, t + ((pi + 3) >> 3), (pi + 3) & 7)
-            const int base = 32 * (pi & 3) + 16 * (pi >> 2);
-#pragma unroll
-            for (int e = 0; e < 16; e++) c[e] = fmaf(kb[pi & 3][e], q[base + e], (pi & 3) == 0 ? 0.0f : c[e]);
-            if ((pi & 3) == 3) {
-#pragma unroll
-                for (int l = 0; l < 8; l++) r1[pi >> 2][l] = c[l] + c[l + 8];
-            }
-        }
-        float u[8];
-#pragma unroll
-        for (int l = 0; l < 8; l++) u[l] = r1[0][l] + r1[1][l];
-        const float v0 = u[0] + u[4], v1 = u[1] + u[5], v2 = u[2] + u[6], v3 = u[3] + u[7];
-        const float sc = ((v0 + v1) + (v2 + v3)) * kq_scale;
-        if (t <= tq) mx = fmaxf(mx, sc);
-        S[((size_t) h * T + t) * NB + nl] = sc;
-    }
-#undef LH_LOADP
-    pmax[((size_t) h * KS + ks) * NB + nl] = mx;
-}
-
-// The same scores on the fp32 matrix cores (round 2, after k_attnq_scores_lds).  v_mfma_f32_16x16x4_f32 is bit-for-bit the k-ordered
+// Scores.  ggml_vec_dot_f32 (ggml.c:1223-1258): chain l (0..31) = elements l, l + 32, l + 64, l + 96 of the two rows by FMA from 0; reduction tree
+// (ggml.c:872-887) = lanes xor 8, 16, 4, 1, 2 of the AVX accumulators, i.e. ((c_l + c_{l+8}) halves added, then u0+u4 .. as written below.
+// v_mfma_f32_16x16x4_f32 is bit-for-bit the k-ordered
 // fmaf chain fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C)))) per output: with A = query elements {l, l + 32, l + 64, l + 96} and
 // B = the same elements of a key it IS chain l of ggml_vec_dot_f32 (ggml.c:1223-1258) for a 16 x 16 tile of (query, key) pairs.  Lane
 // (m = lane % 16, kk = lane / 16) supplies element l + 32 kk of row m: the 32 operands a lane needs for the 32 chains are the 32
 // CONSECUTIVE floats [32 kk, 32 kk + 32) of its query / key row -- loaded straight into registers, no LDS, no scalar loads.  One wave =
 // 16 queries (registers, loaded once) against its key slice, 16 keys per step = 32 independent MFMAs (C = 0) + the reduction tree
 // (ggml.c:872-887) on the VALU, 31 additions per pair.  Result registers: lane holds key n = lane % 16, queries 4 kk + r.
-// 153 (LDS variant) -> 100 us per launch at 2 048 tokens, logits bit-identical; requesting the next step's key rows a step ahead
-// (+32 registers) measured 109 us: two waves per SIMD already cover the load.
+// 100 us per launch at 2 048 tokens, logits bit-identical; requesting the next step's key rows a step ahead (+32 registers) measured 109 us:
+// two waves per SIMD already cover the load.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
@@ -275,93 +213,6 @@ k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, 
     }
 }
 
-// The same scores with the K rows staged in LDS (round 2): a workgroup = 4 waves = 256 consecutive queries of one head; a
-// tile of 32 keys (16 KB) is fetched with coalesced vector loads (next tile in registers while this one is consumed,
-// two LDS buffers, one barrier per tile) and every lane reads the key's elements as LDS BROADCASTS (wave-uniform
-// address, ds_read_b128).  k_attnq_scores above brings the key row in through the scalar cache instead: its loop carries
-// 134 s_mov + 170 v_mov per key for the SGPR buffer rotation, spills, and every piece waits on lgkmcnt(0) because
-// scalar loads return out of order -- 201 us per launch at 2 048 tokens where the FMAs need ~60.  Measured here: 152 us
-// (2 048-token eval 212.5 -> 202.7 ms): now LDS-bound -- a broadcast ds_read_b128 costs the LDS pipe as much as a spread one
-// (8 clocks per wave), i.e. 2 clocks per key element and wave, the price of the FMA it feeds, and the LDS is shared by the
-// CU's four SIMDs.  Arithmetic identical (same chains, same tree); a wave skips the tiles none of its 64 queries can see
-// (k_attnq_softmax never reads them).
-constexpr int AQ_TK = 32;
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_attnq_scores_lds(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
-                   int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
-    __shared__ f32x4 sK[2][AQ_TK * 32];
-    const int tid = threadIdx.x, wave = tid >> 6, h = blockIdx.y, ks = blockIdx.z;
-    const int q0 = nb0 + (int) blockIdx.x * 256;
-    const int nl = blockIdx.x * 256 + tid, n = nb0 + nl;
-    const int nq = n < N ? n : N - 1;
-    const int Tb = n_past + min(q0 + 256, N);                          // keys any query of this workgroup can see
-    const int Tw = n_past + min(q0 + (wave + 1) * 64, N);               // ... of this wave (its 64-query block, as k_attnq_softmax counts)
-    const int per = (Tb + KS - 1) / KS, t0 = ks * per, t1 = min(Tb, t0 + per);
-    const int tq = n_past + nq;
-    float mx = -INFINITY;
-    if (t0 < t1) {
-        float q[128];
-        {
-            const f32x4 *qp = (const f32x4 *) (qr + (size_t) nq * d + h * 128);
-#pragma unroll
-            for (int i = 0; i < 32; i++) { const f32x4 v = qp[i]; q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w; }
-        }
-        f32x4 g[4];
-#define LH_GLOAD(TBASE)                                                                                     \
-        _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                     \
-            const int idx_ = tid + u * 256;                                                                 \
-            g[u] = ((const f32x4 *) (Kc + (size_t) min((TBASE) + (idx_ >> 5), t1 - 1) * d + h * 128))[idx_ & 31]; \
-        }
-        LH_GLOAD(t0)
-#pragma unroll
-        for (int u = 0; u < 4; u++) sK[0][tid + u * 256] = g[u];
-        __syncthreads();
-        int buf = 0;
-        for (int tbase = t0; tbase < t1; tbase += AQ_TK, buf ^= 1) {
-            const bool more = tbase + AQ_TK < t1;
-            if (more) LH_GLOAD(tbase + AQ_TK)
-            const int kend = min(AQ_TK, min(t1, Tw) - tbase);              // (<= 0: nothing of this tile is visible to this wave)
-            for (int kk = 0; kk < kend; kk++) {
-                const int t = tbase + kk;
-                const f32x4 *kr = &sK[buf][kk * 32];
-                float r1[2][8];
-                float c[16];
-#pragma unroll
-                for (int pi = 0; pi < 8; pi++) {
-                    const int base = 32 * (pi & 3) + 16 * (pi >> 2);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const f32x4 kv = kr[base / 4 + j];                  // wave-uniform address: LDS broadcast
-                        c[4 * j + 0] = fmaf(kv.x, q[base + 4 * j + 0], (pi & 3) == 0 ? 0.0f : c[4 * j + 0]);
-                        c[4 * j + 1] = fmaf(kv.y, q[base + 4 * j + 1], (pi & 3) == 0 ? 0.0f : c[4 * j + 1]);
-                        c[4 * j + 2] = fmaf(kv.z, q[base + 4 * j + 2], (pi & 3) == 0 ? 0.0f : c[4 * j + 2]);
-                        c[4 * j + 3] = fmaf(kv.w, q[base + 4 * j + 3], (pi & 3) == 0 ? 0.0f : c[4 * j + 3]);
-                    }
-                    if ((pi & 3) == 3) {
-#pragma unroll
-                        for (int l = 0; l < 8; l++) r1[pi >> 2][l] = c[l] + c[l + 8];
-                    }
-                    asm volatile("" ::: "memory");                          // one or two pieces (16 key elements each) live at a time: left alone the scheduler
-                }                                                           // hoists a whole key's 32 LDS reads and spills the query row
-                float u[8];
-#pragma unroll
-                for (int l = 0; l < 8; l++) u[l] = r1[0][l] + r1[1][l];
-                const float v0 = u[0] + u[4], v1 = u[1] + u[5], v2 = u[2] + u[6], v3 = u[3] + u[7];
-                const float sc = ((v0 + v1) + (v2 + v3)) * kq_scale;
-                if (t <= tq) mx = fmaxf(mx, sc);
-                S[((size_t) h * T + t) * NB + nl] = sc;
-            }
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) sK[buf ^ 1][tid + u * 256] = g[u];
-            }
-            __syncthreads();
-        }
-#undef LH_GLOAD
-    }
-    pmax[((size_t) h * KS + ks) * NB + nl] = mx;
-}
-
 __global__ void __launch_bounds__(1024)
 k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__restrict__ inv,
                 int n_past, int N, int nb0, int NB, int T, int KS, const uint16_t *__restrict__ T_exp) {
@@ -392,61 +243,7 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
     }
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
-k_attnq_pv(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ part,
-           int n_past, int N, int nb0, int NB, int d, int T, int nth) {
-    // one wave = 64 queries x 32 columns x ONE chunk of the reference's nth-way key split; the chunks'
-    // partial sums are added in thread order by k_attnq_merge (ggml.c:5553-5577)
-    const int lane = threadIdx.x, h = blockIdx.y, cg = blockIdx.z & 3, th = blockIdx.z >> 2, c0 = cg * 32;
-    const int nl = blockIdx.x * 64 + lane;
-    const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
-    const int Tb = n_past + nb_end;
-    const float iv = inv[(size_t) h * NB + nl];
-    const int dc = (T + nth - 1) / nth;
-    const int t0 = dc * th;
-    const int t1 = min(min(t0 + dc, T), Tb);              // beyond Tb every P of this block is 0: fma(v, 0, acc) == acc
-    float acc[32];
-#pragma unroll
-    for (int c = 0; c < 32; c++) acc[c] = 0.0f;
-    const float *sp = S + ((size_t) h * T + t0) * NB + nl;
-    // Two keys per trip, the next trip's operands requested before this trip's FMAs (round 2): the loop used to be one
-    // dependent round trip per key -- the lane's probability (vector load) and the value row (two s_load_dwordx16, which only
-    // lgkmcnt(0) can wait for) were requested and awaited inside the same iteration.  The FMA order per column is unchanged.
-    if (t0 < t1) {
-        float pa = sp[0], pb = sp[(size_t) min(1, t1 - 1 - t0) * NB];
-        float va[32], vb[32];
-        {
-            const float *r0 = Vc + (size_t) t0 * d + h * 128 + c0, *r1 = Vc + (size_t) min(t0 + 1, t1 - 1) * d + h * 128 + c0;      // wave-uniform: scalar loads
-#pragma unroll
-            for (int c = 0; c < 32; c++) { va[c] = r0[c]; vb[c] = r1[c]; }
-        }
-        for (int t = t0; t < t1; t += 2) {
-            const float p0 = pa * iv, p1 = (t + 1 < t1) ? pb * iv : 0.0f;        // soft_max's final scale (ggml.c:7036-7041); a clamped re-read is weighted 0: fma(v, 0, acc) == acc
-            float na[32], nb[32];
-            const int ta = min(t + 2, t1 - 1), tb = min(t + 3, t1 - 1);
-            const float npa = sp[(size_t) (ta - t0) * NB], npb = sp[(size_t) (tb - t0) * NB];
-            {
-                const float *r0 = Vc + (size_t) ta * d + h * 128 + c0, *r1 = Vc + (size_t) tb * d + h * 128 + c0;
-#pragma unroll
-                for (int c = 0; c < 32; c++) { na[c] = r0[c]; nb[c] = r1[c]; }
-            }
-#pragma unroll
-            for (int c = 0; c < 32; c++) acc[c] = fmaf(va[c], p0, acc[c]);
-#pragma unroll
-            for (int c = 0; c < 32; c++) acc[c] = fmaf(vb[c], p1, acc[c]);
-#pragma unroll
-            for (int c = 0; c < 32; c++) { va[c] = na[c]; vb[c] = nb[c]; }
-            pa = npa; pb = npb;
-        }
-    }
-    // part[th][h][nl][128]
-    f32x4 *o = (f32x4 *) (part + (((size_t) th * gridDim.y + h) * NB + nl) * 128 + c0);
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = f32x4{ acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3] };
-}
-
-// merged[n][h*128 + c] = part[0] + part[1] + ... in thread order.  grid (NB/2, H), 256 threads = 2 queries x 128 columns
-// The same V*P partial sums on the matrix cores (round 2).  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fmaf chain per
+// V*P partial sums on the matrix cores.  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fmaf chain per
 // output -- D = fma(a1, b1, fma(a0, b0, C)), one rounding per product, subnormals kept (cdna_hip_programming.md, "Numerics" of the
 // f32 MFMAs) -- i.e. exactly acc = fma(v, p, acc) over two consecutive keys, which is what the chain of a (chunk, query, column)
 // is.  One wave = 64 queries x the head's 128 columns x ONE chunk of the nth-way key split: 8 accumulator tiles (128 registers),
@@ -473,7 +270,8 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
             for (int r = 0; r < 16; r++) D[a][b][r] = 0.0f;
     const float iv0 = inv[(size_t) h * NB + q0 + i], iv1 = inv[(size_t) h * NB + q0 + 32 + i];
     const int nk = t1 - t0;
-    // operands of PF pair-steps in flight: a step is 512 matrix-pipe cycles, a load round trip several times that
+    // operands of PF pair-steps in flight: a step is 512 matrix-pipe cycles, a load round trip several times that (8 and 12 steps at two
+    // waves per SIMD measured the same 2 048-token eval: 191.9 / 191.0 / 190.8 ms)
     constexpr int PF = 4;
     float pa0[PF], pa1[PF], pb0[PF], pb1[PF], pb2[PF], pb3[PF];
     const int tstart = t0 - (nk > 0 ? (nk & 1) : 0);
@@ -522,6 +320,7 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
         }
 }
 
+// merged[n][h*128 + c] = part[0] + part[1] + ... in thread order (ggml.c:5553-5577).  grid (NB/2, H), 256 threads = 2 queries x 128 columns
 __global__ void __launch_bounds__(256)
 k_attnq_merge(const float *__restrict__ part, float *__restrict__ merged, int N, int nb0, int NB, int d, int nth) {
     const int c = threadIdx.x & 127, nl = blockIdx.x * 2 + (threadIdx.x >> 7), h = blockIdx.y, H = gridDim.y;
@@ -549,33 +348,15 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
     if (ws && ws->S && dh == 128 && N >= attnq_min && !dbg_p && !dbg_kqv && T <= ws->T_cap && nth <= ws->nth_cap && !old_only) {
         for (int nb0 = 0; nb0 < N; nb0 += ws->NB) {
             const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
-            int KS = (6144 + qb * H - 1) / (qb * H);      // ~2 rounds of 3 waves per SIMD: the waves are latency-bound
+            // scores: 16 queries per wave, ~4 waves per SIMD over key slices
+            const int qt = (nb + 15) / 16;
+            int KS = (4096 + qt * H - 1) / (qt * H);
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
-            // scores: K rows through LDS broadcasts (k_attnq_scores_lds, 256 queries per workgroup) unless LLAMAHIP_ATTNQ_SCALAR
-            // asks for round 1's scalar-cache variant; ~3 workgroups per CU: KS key slices
-            static const bool scalar_k = getenv("LLAMAHIP_ATTNQ_SCALAR") != nullptr;
-            static const bool lds_k = getenv("LLAMAHIP_ATTNQ_LDS") != nullptr;
-            if (!scalar_k && !lds_k) {
-                // scores on the fp32 matrix cores (k_attnq_scores_mfma): 16 queries per wave, ~4 waves per SIMD over key slices
-                const int qt = (nb + 15) / 16;
-                KS = (4096 + qt * H - 1) / (qt * H);
-                KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
-                hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
-            } else if (!scalar_k) {
-                const int qb4 = (nb + 255) / 256;
-                KS = (768 + qb4 * H - 1) / (qb4 * H);
-                KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
-                hipLaunchKernelGGL(k_attnq_scores_lds, dim3(qb4, H, KS), dim3(256), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
-            } else
-            hipLaunchKernelGGL(k_attnq_scores, dim3(qb, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
+            hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
-            // V*P on the fp32 matrix cores (k_attnq_pv_mfma: bit-identical fmaf chains) unless LLAMAHIP_ATTNQ_PV_VALU asks for round 1's kernel
-            static const bool pv_valu = getenv("LLAMAHIP_ATTNQ_PV_VALU") != nullptr;
-            if (!pv_valu) hipLaunchKernelGGL(k_attnq_pv_mfma, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
-            else
-            hipLaunchKernelGGL(k_attnq_pv, dim3(qb, H, 4 * nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
+            hipLaunchKernelGGL(k_attnq_pv_mfma, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_merge, dim3((nb + 1) / 2, H), dim3(256), 0, st, ws->part, merged, N, nb0, ws->NB, d, nth);
             LH_LAUNCH_CHECK();

@@ -234,17 +234,31 @@ def test_matrix_core_prompt_gemm_forced_on_small_models():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("switch", ["LLAMAHIP_NO_QKV_ATTN", "LLAMAHIP_NO_ATTN_X"])
-def test_decode_attention_fallback_paths(switch):
+_FULL = "wider_models or greedy_trace_128 or tiny_model_golden or prompt_continuation or thread_splits"
+_SMALL = "wider_models or tiny_model_golden or prompt_continuation or thread_splits"
+
+
+@pytest.mark.parametrize("switch,select", [
+    ({"LLAMAHIP_NO_QKV_ATTN": "1"}, _FULL), ({"LLAMAHIP_NO_ATTN_X": "1"}, _FULL),
+    ({"LLAMAHIP_ATTN_TWO_FROM": "0", "LLAMAHIP_ATTN_LONG_FROM": "-1"}, _SMALL),
+    ({"LLAMAHIP_ATTN_LONG_FROM": "0"}, _FULL),
+    ({"LLAMAHIP_ATTN_TWO_FROM": "33", "LLAMAHIP_ATTN_LONG_FROM": "50", "LLAMAHIP_PV_STAGE_ROWS": "3"}, _SMALL),
+    ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_STAGE_ROWS": "2", "LLAMAHIP_PV_SPLIT": "1"}, _SMALL)],
+    ids=["no_qkv_attn", "no_attn_x", "two_launch_everywhere", "stream_everywhere", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
+def test_decode_attention_fallback_paths(switch, select):
     """The decode step runs wq|wk|wv + attention as one launch with in-launch hand-offs (k_qkv_attn) where the shapes allow;
     the paths it replaces stay in the library for every other shape: the single-launch attention with per-head counters
-    (k_dec_attn_x: LLAMAHIP_NO_QKV_ATTN=1) and the two-launch attention (LLAMAHIP_NO_ATTN_X=1).  The switches are read once
-    per process, hence the subprocess; same parity tests, same oracle."""
+    (k_dec_attn_x: LLAMAHIP_NO_QKV_ATTN=1) and the two-launch attention (LLAMAHIP_NO_ATTN_X=1).  The schedule also changes with
+    the POSITION (llamahip.cpp attn_sched_at; defaults = measured crossovers, far beyond these tests' contexts): separate mat-vec +
+    k_dec_scores + k_dec_pv_blk from LLAMAHIP_ATTN_TWO_FROM, + the streaming soft_max . V (k_dec_pv_stream, its chains split over
+    workgroups with tagged partial sums) from LLAMAHIP_ATTN_LONG_FROM -- run here from position 0, and with both switch points
+    inside the thread-split test's one decode call (27 -> 71: three captured graphs replayed in turn), with stages of 3 / 2 rows per
+    chain so that these small contexts walk the whole load / LDS pipeline (many stages, both buffers, ragged last stage).
+    The switches are read once per process, hence the subprocess; same parity tests, same oracle."""
     import subprocess
     import sys
-    env = dict(os.environ, **{switch: "1"})
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "wider_models or greedy_trace_128 or tiny_model_golden or prompt_continuation or thread_splits"],
+    env = dict(os.environ, **switch)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", select],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -297,10 +311,12 @@ def test_production_fallbacks_and_selectable_variants(env):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b):
+@pytest.mark.parametrize("which", [{"LLAMAHIP_HANDOFF_FAULT_TEST": "1"}, {"LLAMAHIP_HANDOFF_FAULT_TEST": "4", "LLAMAHIP_ATTN_LONG_FROM": "0"}])
+def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b, which):
     """The tagged hand-offs of the decode step are bounded polls; one that runs out raises a sticky fault word in
     pinned host memory and the next synchronisation returns PredictionFailed.  LLAMAHIP_HANDOFF_FAULT_TEST=1 makes the
-    mat-vec role of k_qkv_attn publish a tag nobody waits for and shortens the polls (read once per process: subprocess)."""
+    mat-vec role of k_qkv_attn publish a tag nobody waits for and shortens the polls (read once per process: subprocess);
+    =4 does the same to the split workgroups of the long-context soft_max . V (k_dec_pv_stream), run here from position 0."""
     import subprocess
     import sys
     code = (
@@ -316,7 +332,7 @@ def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b):
         "    print('ERR', e.code, str(e)); print('SECONDS', time.time() - t0)\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LLAMAHIP_HANDOFF_FAULT_TEST="1", PYTHONPATH=root)
+    env = dict(os.environ, PYTHONPATH=root, **which)
     r = subprocess.run([sys.executable, "-c", code, model7b], env=env, capture_output=True, text=True, cwd=root, timeout=300)
     assert "ERR -1001" in r.stdout and "hand-off" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert float(r.stdout.split("SECONDS")[1].split()[0]) < 30.0, r.stdout

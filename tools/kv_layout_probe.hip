@@ -61,13 +61,13 @@ __global__ void __launch_bounds__(256) k_stream(const float4 *__restrict__ p, si
     if (acc == 123.456f) out[0] = acc;
 }
 
-int main() {
-    const int H = 32, dh = 128, n_ctx = 512, NB = 40;
+int main(int argc, char **argv) {
+    const int H = 32, dh = 128, n_ctx = argc > 1 ? atoi(argv[1]) : 512, NB = 40;          // usage: kv_layout_probe [n_ctx = 512]
     const size_t layer = (size_t) n_ctx * H * dh;
     float *buf, *d_out;
     CHECK(hipMalloc((void **) &buf, layer * 4 * NB)); CHECK(hipMemset(buf, 0, layer * 4 * NB)); CHECK(hipMalloc((void **) &d_out, 4096));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int T : { 64, 128, 256, 512 }) {
+    for (int T : { n_ctx / 8, n_ctx / 4, n_ctx / 2, n_ctx == 512 ? 512 : n_ctx * 4 / 5 }) {
         for (int var = 0; var < 4; var++) {
             auto launch = [&](int i) {
                 const float *p = buf + (size_t) (i % NB) * layer;
@@ -84,7 +84,7 @@ int main() {
             CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             const char *names[] = { "K rows (scores pattern), pos-major ", "K rows (scores pattern), head-major", "V columns (V.P pattern), pos-major ", "V columns (V.P pattern), head-major" };
-            printf("T = %3d   %s  %6.2f us per launch   (%5.2f MB -> %5.2f TB/s)\n", T, names[var], ms * 1e3 / iters, T * H * dh * 4 / 1e6, T * H * dh * 4.0 / (ms * 1e3 / iters) * 1e-6);
+            printf("T = %4d   %s  %6.2f us per launch   (%5.2f MB -> %5.2f TB/s)\n", T, names[var], ms * 1e3 / iters, T * H * dh * 4 / 1e6, T * H * dh * 4.0 / (ms * 1e3 / iters) * 1e-6);
         }
     }
     // the same launches with 140 MB of OTHER memory streamed in between (a layer's weights), out of a 4.4 GB buffer: does the

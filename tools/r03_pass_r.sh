@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-3 GPU pass r: k_dec_pv_stream with its chains split over workgroups (all 256 CUs streaming)
+O=gpurun_out; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "(fallback_paths and (switch2 or switch3 or switch4)) or width_2048 or handoff_timeout" > $O/r03r_quick.txt 2>&1; tail -3 $O/r03r_quick.txt
+cat > /tmp/v7.txt <<EOV
+fused|LLAMAHIP_ATTN_LONG_FROM=-1
+split1|LLAMAHIP_ATTN_LONG_FROM=0 LLAMAHIP_PV_SPLIT=1
+split2|LLAMAHIP_ATTN_LONG_FROM=0
+split4_nl2|LLAMAHIP_ATTN_LONG_FROM=0 LLAMAHIP_PV_SPLIT=4
+split4_nl4|LLAMAHIP_ATTN_LONG_FROM=0 LLAMAHIP_PV_SPLIT=4 LLAMAHIP_PV_STAGE=4
+split8|LLAMAHIP_ATTN_LONG_FROM=0 LLAMAHIP_PV_SPLIT=8
+EOV
+N_CTX=2560 STEPS=64 AT=128,520,800,1024,1536,2048 timeout 1500 bash tools/decode_ab.sh /tmp/v7.txt > $O/r03r_7b.txt 2>&1
+cat $O/r03r_7b.txt
+cat > /tmp/v13.txt <<EOV
+fused|LLAMAHIP_ATTN_LONG_FROM=-1
+split1|LLAMAHIP_ATTN_LONG_FROM=0 LLAMAHIP_PV_SPLIT=1
+split2_nl2|LLAMAHIP_ATTN_LONG_FROM=0
+split2_nl4|LLAMAHIP_ATTN_LONG_FROM=0 LLAMAHIP_PV_STAGE=4
+split4|LLAMAHIP_ATTN_LONG_FROM=0 LLAMAHIP_PV_SPLIT=4
+EOV
+MODEL=13B N_CTX=2560 STEPS=64 AT=128,400,800,2048 timeout 1200 bash tools/decode_ab.sh /tmp/v13.txt > $O/r03r_13b.txt 2>&1
+cat $O/r03r_13b.txt
+cat > /tmp/v1.txt <<EOV
+split2_at_2048|LLAMAHIP_ATTN_LONG_FROM=0
+EOV
+PROF=1 KEEP=1 N_CTX=2560 STEPS=64 AT=8 PROF_AT=2048 FILTER='k_gemv\|k_qkv\|k_dec\|k_embed\|k_argmax' timeout 900 bash tools/decode_ab.sh /tmp/v1.txt > $O/r03r_prof.txt 2>&1
+cat $O/r03r_prof.txt
