@@ -29,7 +29,7 @@
 //                               epilogues (store | +residual | SiLU*up -> Q4_0 | tagged rows), register ring of weight chunks
 //   k_dec_scores, k_decn_scores, k_dec_pv_blk   attention of one row (decode fallback) / of a short eval (2..60 rows)
 //   attn_x_body, k_dec_attn_x, k_qkv_attn       attention in one launch; wq|wk|wv mat-vec + attention in one launch (XCD-local tagged hand-offs)
-//   k_xcd_selftest, k_argmax, k_topk_candidates, k_advance, k_bump_epoch, k_topk_keys, k_topk_select
+//   k_xcd_selftest, k_argmax, k_advance, k_bump_epoch, k_topk_keys, k_topk_select
 //   launchers: set_phase_probe, launch_gemv (+ kernel selection rules), launch_attn_short, xcd_selftest, launch_dec_attn,
 //              launch_qkv_attn, launch_bump_epoch, launch_topk_candidates, launch_argmax, launch_advance, init_kernel_attrs
 #define LH_DEFINE_PHASE_PROBE 1
@@ -68,14 +68,14 @@ namespace lh {
 
 // 8-byte granule {value, tag}: written with one 8-byte store, read with one 8-byte load that bypasses the L1 (sc1), so a
 // reader sees the value together with its tag or not at all.  The spin is bounded; running out raises the fault word.
-__device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, int nowait /* bit 0: pass at once (measurement), bit 1: no sleep between polls, bit 2: give up after 256 polls (fault-injection test) */) {
+__device__ __forceinline__ float poll_tagged(const uint64_t *p, uint32_t tag, uint32_t *fault, bool short_fuse /* give up after 256 polls: fault-injection test */) {
     uint64_t v;
     int spins = 0;
     for (;;) {
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t) (v >> 32) == tag || (nowait & 1)) break;
-        if (!(nowait & 2)) __builtin_amdgcn_s_sleep(1);
-        if (poll_give_up(spins, (nowait & 4) ? (1 << 8) : (1 << 20), fault)) break;
+        if ((uint32_t) (v >> 32) == tag) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (poll_give_up(spins, short_fuse ? (1 << 8) : (1 << 20), fault)) break;
     }
     return __builtin_bit_cast(float, (uint32_t) v);
 }
@@ -496,10 +496,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     if (EPI == EPI_SILU_QA) {
         // 8 waves: waves 0-3 hold gate rows b*32 .. b*32+31, waves 4-7 the matching up rows (b = blockIdx.x)
         float *gu = (float *) red;                      // prologue scratch is free again
-        if (!(ga.lut_math & 8)) __syncthreads();
+        __syncthreads();
         if (k == 0) gu[wave * 8 + (lane >> 3)] = acc;
         __syncthreads();
-        if (wave == 0 && !(ga.lut_math & 4)) {
+        if (wave == 0) {
             const int i = lane & 31;
             const uint16_t gh = f2h_bits(gu[i]);
             const float act = h2f_bits((ga.lut_math & 1) ? silu_math_bits(gh) : T_silu[gh]) * gu[32 + i];
@@ -991,7 +991,7 @@ k_dec_pv_stream(const float *__restrict__ sc, const float *__restrict__ Vc, int 
     }
     if (owner) part[th * 32 + c] = acc;
     if (split > 1 && tid < th_lo * 32)                                  // the chains before this workgroup's, from their owners
-        part[tid] = poll_tagged(xpart + (size_t) base * nth * 32 + tid, make_tag(epoch[0], layer + 1), fault, (lut_math & 0x1000) ? 4 : 0);
+        part[tid] = poll_tagged(xpart + (size_t) base * nth * 32 + tid, make_tag(epoch[0], layer + 1), fault, (lut_math & 0x1000) != 0);
     __syncthreads();
     pv_store_block(part, nth, tid, col0 + tid, h, dh, cb, merged, qa_A, qa_d);
     LH_PSTAMP(9);
@@ -1079,7 +1079,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
                 for (int i = 0; i < 8; i++) kv[u][i] = (i * 32 < dh) ? kr[min(i * 32, dh - 32) + l] : 0.0f;
             }
         };
-        const int nowait = ((lut_math & 0x400) ? 1 : 0) | ((lut_math >> 8) & 2) | ((lut_math & 0x1000) ? 4 : 0);     // (measurement-only switches: 0x400 this hop does not wait, results invalid; 0x200 polls without sleep; 0x1000 fault-injection test)
+        const bool nowait = (lut_math & 0x1000) != 0;     // (fault-injection test: short poll bound)
         const uint32_t tag = QKV_WAIT ? (make_tag(aa.epoch[0], aa.layer + 1)) : 0u;
         if (QKV_WAIT) load_keys();                              // in flight while the mat-vec workgroups finish
         if (tid < dh / 2) {
@@ -1178,7 +1178,7 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
     float mx = -INFINITY;
     if (QKV_WAIT) {
         const uint32_t tag = make_tag(aa.epoch[0], aa.layer + 1);
-        const int nowait = ((lut_math & 0x800) ? 1 : 0) | ((lut_math >> 8) & 2) | ((lut_math & 0x1000) ? 4 : 0);
+        const bool nowait = (lut_math & 0x1000) != 0;
         for (int t = tid; t < T; t += nt) { const float v = poll_tagged(aa.sc2 + (size_t) h * n_ctx + t, tag, fault, nowait); p[t] = v; mx = fmaxf(mx, v); }
     } else
     for (int t = tid; t < T; t += nt) { const float v = load_f32_sc1(row + t); p[t] = v; mx = fmaxf(mx, v); }
@@ -1366,7 +1366,8 @@ k_argmax(const float *__restrict__ logits, int V, int32_t *__restrict__ out, int
 // That cannot be reproduced from a candidate set, so the kernel reports `exact` = 0 whenever an equality could
 // matter (a tie among the k + at the boundary, or a NaN) and the caller falls back to the host path on the full
 // logits; with exact = 1 the k pairs are unambiguous and identical to the reference's cand[0..k).
-// One workgroup of 1024 threads, <= 32 values per thread (n_vocab <= 32768), order-preserving 64-bit keys:
+// (Round 2a's first version was ONE workgroup of 1024 threads doing all of the below, 39 us; the two launches further down replaced it
+//  -- 17.6 us -- and it was removed in round 3.)  <= 32 values per thread (n_vocab <= 32768), order-preserving 64-bit keys:
 //   1. the maximum of every group of 16 threads (512 values, DPP row reduction): 64 group maxima.  Their minimum T is a
 //      LOWER bound of the k-th largest value overall for any k <= 64 (64 values >= T exist), so each of the k best is
 //      >= T -- and only a few hundred other values are;
@@ -1383,100 +1384,6 @@ __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
     const int hi = __builtin_amdgcn_mov_dpp((int) (uint32_t) (v >> 32), CTRL, 0xF, 0xF, true);
     return ((unsigned long long) (uint32_t) hi << 32) | (uint32_t) lo;
 }
-__global__ void __launch_bounds__(1024)
-k_topk_candidates(const float *__restrict__ logits, int V, const int32_t *__restrict__ window, int n_window,
-                  double scale, double repeat_penalty, int k,
-                  double *__restrict__ out_score, int32_t *__restrict__ out_id, int32_t *__restrict__ flags) {
-    constexpr int NPT = 32, LCAP = 768;
-    __shared__ uint32_t seen[1024];                    // bitmap of the last-n window (n_vocab <= 32768)
-    __shared__ unsigned long long gmax[64];
-    __shared__ unsigned long long list_key[LCAP];
-    __shared__ int32_t list_id[LCAP];
-    __shared__ uint32_t n_list, bad;
-    const int tid = threadIdx.x;
-    seen[tid] = 0u;
-    if (tid == 0) { n_list = 0u; bad = 0u; }
-    __syncthreads();
-    if (tid < n_window) { const int id = window[tid]; if (id >= 0 && id < V) atomicOr(&seen[id >> 5], 1u << (id & 31)); }
-    __syncthreads();
-    unsigned long long key[NPT], best = 0ull;
-    float lv[NPT];
-#pragma unroll
-    for (int u = 0; u < NPT; u++) lv[u] = logits[min(tid + u * 1024, V - 1)];
-#pragma unroll
-    for (int u = 0; u < NPT; u++) {
-        const int i = tid + u * 1024;
-        unsigned long long kk = 0ull;                  // below every real key
-        if (i < V) {
-            const float lf = lv[u];
-            double sc;
-            if ((seen[i >> 5] >> (i & 31)) & 1u) sc = lf < 0.0f ? (double) lf * scale * repeat_penalty : (double) lf * scale / repeat_penalty;   // utils.cpp:363-368
-            else sc = (double) lf * scale;
-            if (sc != sc) bad = 1u;
-            const unsigned long long b = (unsigned long long) __double_as_longlong(sc);
-            kk = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-            if (kk == 0ull) kk = 1ull;
-        }
-        key[u] = kk;
-        best = kk > best ? kk : best;
-    }
-    // maximum over each 16-lane DPP row, then the minimum of the 64 row maxima
-    best = dpp_max_u64(best, dpp_u64<DPP_QUAD_XOR1>(best));
-    best = dpp_max_u64(best, dpp_u64<DPP_QUAD_XOR2>(best));
-    best = dpp_max_u64(best, dpp_u64<DPP_ROW_HALF_MIRROR>(best));
-    best = dpp_max_u64(best, dpp_u64<DPP_ROW_MIRROR>(best));
-    if ((tid & 15) == 0) gmax[tid >> 4] = best;
-    __syncthreads();
-    unsigned long long T = gmax[0];
-#pragma unroll
-    for (int j = 1; j < 64; j++) { const unsigned long long o = gmax[j]; T = o < T ? o : T; }      // (unrolled: the 63 LDS reads go out together)
-    if (T == 0ull) {                                   // a group without a real value: V < 1024 * ... (tiny vocabularies) -- host path
-        if (tid == 0) { flags[0] = 0; flags[1] = 0; }
-        return;
-    }
-#pragma unroll
-    for (int u = 0; u < NPT; u++) {
-        if (key[u] >= T) {
-            const uint32_t at = atomicAdd(&n_list, 1u);
-            if (at < (uint32_t) LCAP) { list_key[at] = key[u]; list_id[at] = tid + u * 1024; }
-        }
-    }
-    __syncthreads();
-    const int n = (int) (n_list < (uint32_t) LCAP ? n_list : (uint32_t) LCAP);
-    if (n_list > (uint32_t) LCAP) bad = 1u;            // (a flood of equal values at T)
-    if (tid < n) {
-        const unsigned long long mine = list_key[tid];
-        const int my_id = list_id[tid];
-        int rank = 0;
-        bool dup = false;
-        // (eight entries per trip so that their LDS reads are in flight together: rolled, every entry was a dependent LDS round
-        //  trip -- ~300 of them, the largest part of this kernel's 39 us)
-        int j = 0;
-        for (; j + 8 <= n; j += 8) {
-            unsigned long long o[8]; int oid[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { o[u] = list_key[j + u]; oid[u] = list_id[j + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                dup = dup || (j + u != tid && o[u] == mine);
-                rank += (o[u] > mine || (o[u] == mine && oid[u] < my_id)) ? 1 : 0;
-            }
-        }
-        for (; j < n; j++) {
-            const unsigned long long o = list_key[j];
-            dup = dup || (j != tid && o == mine);
-            rank += (o > mine || (o == mine && list_id[j] < my_id)) ? 1 : 0;
-        }
-        if (rank <= k && dup) bad = 1u;                // an equality among the k best or between the k-th and its runner-up
-        if (rank < k) {
-            const unsigned long long b = (mine >> 63) ? (mine & 0x7fffffffffffffffull) : ~mine;
-            out_score[rank] = __longlong_as_double((long long) b);
-            out_id[rank] = my_id;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) { flags[0] = (bad == 0u && n >= k) ? 1 : 0; flags[1] = n; }
-}
 
 // a pipeline stage that does not pick the token still has to advance its device-resident position
 __global__ void k_advance(int32_t *__restrict__ st) {
@@ -1489,8 +1396,6 @@ hipError_t set_phase_probe(unsigned long long *dev_buf) {
 
 
 static int pick_waves(int ngroups) {
-    static const int ovr = getenv("LLAMAHIP_WAVES") ? atoi(getenv("LLAMAHIP_WAVES")) : 0;      // tuning override (measurement only)
-    if (ovr == 1 || ovr == 2 || ovr == 4) return ovr;
     // aim for >= 2 workgroups per CU (256 CUs) before growing the workgroup
     if (ngroups >= 4 * 512) return 4;
     if (ngroups >= 2 * 512) return 2;
@@ -1502,14 +1407,6 @@ static int pick_waves(int ngroups) {
 // CU) need the depth for bytes in flight.  Among the candidates the one padding the fewest zero-tile
 // chunks wins, ties go to the deeper ring.
 static int pick_depth(int nchunks, int ngroups) {
-    // tuning override (measurement only): LLAMAHIP_DEPTH="small,mid,big" ring depths by launch size
-    static int ovr[3] = { -1, -1, -1 };
-    if (ovr[0] == -1) {
-        ovr[0] = ovr[1] = ovr[2] = 0;
-        if (const char *e = getenv("LLAMAHIP_DEPTH")) sscanf(e, "%d,%d,%d", &ovr[0], &ovr[1], &ovr[2]);
-    }
-    const int o = ovr[ngroups >= 2048 ? 2 : ngroups >= 1024 ? 1 : 0];
-    if (o == 4 || o == 8 || o == 10 || o == 14 || o == 16 || o == 18 || o == 22) return o;
     static const int very_shallow[] = { 4 }, shallow[] = { 10, 8 }, deep[] = { 10, 14, 16, 18, 22, 8 };
     // >= 8 waves per CU: a 4-deep ring (24 VGPRs) still keeps > 40 KB per CU in flight.
     // Small launches: measured on MI355X (w2, 43 chunks) the 10-deep ring beats 14..22 although it
@@ -1546,8 +1443,7 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
     if (np.out && grid > NORM_PART_MAX) return hipErrorInvalidValue;
     // rows that fit 16 slots: whole row in flight (latency-bound small matrices) unless the launch
     // already has >= 4 waves per CU, where an 8-deep ring saves 48 VGPRs and keeps 4 waves/SIMD resident
-    static const bool no_full = getenv("LLAMAHIP_NO_FULL") != nullptr;      // tuning override (measurement only)
-    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024) && !(no_full && w.nchunks == 16)) {
+    if (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024)) {
         LH_GO(16, false);
     } else {
         switch (pick_depth(w.nchunks, w.ngroups)) {
@@ -1571,14 +1467,12 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
 // workgroup size of the decode mat-vec for a (prologue, matrix) pair -- also what sizes the partial-sum
 // array an EPI_RESID launch writes (gemv_resid_parts)
 static int gemv_pick_nw_qa(const QMat &w, int *pg) {
-    static const int resid_waves = getenv("LLAMAHIP_QA_WAVES") ? atoi(getenv("LLAMAHIP_QA_WAVES")) : 0;      // tuning override (measurement only)
     // Workgroups of ngroups / 256 waves (1, 2 or 4): ONE workgroup per CU where the matrix has fewer than 1024
     // row-groups.  Measured on the 7B decode step: w2 (512 row-groups) as 256 x 2 waves with the 12-granule operand
     // budget 7.60 us, as 128 x 4 waves with the 4-granule budget 8.52 us, as 512 x 1 wave 7.99 us; wo as 256 x 2 waves
     // 5.15 us against 5.41 us as 512 x 1 (profiles/r02_d_small_matvec_ab.txt).  The operand budget (4 or 12 granules
     // of 16 B per thread) follows from the workgroup size, not the other way round.
     int nw = w.ngroups >= 1024 ? 4 : w.ngroups >= 512 ? 2 : 1;
-    if (resid_waves == 1 || resid_waves == 2 || resid_waves == 4) nw = resid_waves;
     const int need = w.nchunks * 16;
     for (; nw <= 4; nw *= 2) {
         if (need <= 4 * nw * 64) { *pg = 4; return nw; }
@@ -1819,17 +1713,13 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     const size_t lds_pv = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
     const size_t lds = std::max(std::max(lds_mv, lds_pv), (size_t) 2 * dh * sizeof(float));
     // the mat-vec role writes tagged granules: y -> qkv2, sync -> the epoch word, sync_epoch = layer
-    // measurement only, RESULTS ARE INVALID: LLAMAHIP_ATTN_NOWAIT=1 no poll waits, =2 only the soft_max . V role does not wait, =3 only the score role
-    static const int nw_mode = getenv("LLAMAHIP_ATTN_NOWAIT") ? atoi(getenv("LLAMAHIP_ATTN_NOWAIT")) : 0;
-    static const int nowait = nw_mode == 1 ? (0x100 | 0x400 | 0x800) : nw_mode == 2 ? 0x800 : nw_mode == 3 ? 0x400 : 0;
-    static const int nosleep = (getenv("LLAMAHIP_POLL_SLEEP") && atoi(getenv("LLAMAHIP_POLL_SLEEP")) == 0) ? 0x200 : 0;     // measurement only
     // test only (tests/test_gpu_parity.py): the mat-vec role publishes a wrong tag and every poll gives up after 256 looks -> the
     // sticky fault word must come back as an error
     static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) < 2) ? 0x1000 : 0;     // (2: the wo launch of the overlapped schedule misbehaves instead)
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
                     (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
     if (x_t) { ga.in_t = x_t; ga.slot_in = 0; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; ga.pos_w = mb->pos_w; ga.patience = 7; ga.lut_math |= mb->test_bits; }
-    const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | nowait | nosleep | fault_test,
+    const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | fault_test,
                            qkv2, sc2, epoch, layer };
     const int grid = gridA + H * (nsl + dh / 32);
 #define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
@@ -1974,17 +1864,12 @@ k_topk_select(int V, int k, unsigned long long *__restrict__ keys, unsigned long
 hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *window, int n_window, double scale, double repeat_penalty, int k,
                                   double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st, void *ws) {
     if (V > 32768 || k < 1 || k > 64 || n_window > 1024) return hipErrorInvalidValue;
-    static const bool one_launch = getenv("LLAMAHIP_TOPK_ONE") != nullptr;          // measurement: round-2a single-workgroup kernel
-    if (ws && !one_launch) {
-        unsigned long long *keys = (unsigned long long *) ws, *gmax = keys + 32768;
-        uint32_t *badw = (uint32_t *) (gmax + 64);
-        hipLaunchKernelGGL(k_topk_keys, dim3((V + 1023) / 1024), dim3(1024), 0, st, logits, V, window, n_window, scale, repeat_penalty, keys, gmax, badw);
-        LH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_topk_select, dim3(1), dim3(1024), 0, st, V, k, keys, gmax, badw, out_score, out_id, flags);
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
-    hipLaunchKernelGGL(k_topk_candidates, dim3(1), dim3(1024), 0, st, logits, V, window, n_window, scale, repeat_penalty, k, out_score, out_id, flags);
+    if (!ws) return hipErrorInvalidValue;
+    unsigned long long *keys = (unsigned long long *) ws, *gmax = keys + 32768;
+    uint32_t *badw = (uint32_t *) (gmax + 64);
+    hipLaunchKernelGGL(k_topk_keys, dim3((V + 1023) / 1024), dim3(1024), 0, st, logits, V, window, n_window, scale, repeat_penalty, keys, gmax, badw);
+    LH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_topk_select, dim3(1), dim3(1024), 0, st, V, k, keys, gmax, badw, out_score, out_id, flags);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -365,8 +365,7 @@ template <int WT, int NC>
 hipError_t go(const DMat &w, int epi, const float *x, long x_stride, int N, float *y, long y_stride,
               const float *resid, long resid_stride, hipStream_t st, float *scratch) {
     if (x) hipLaunchKernelGGL(k_dense_perm_act<WT>, dim3(N), dim3(256), 0, st, x, x_stride, w.K, scratch);     // x == nullptr: scratch already holds the prepared rows
-    static const bool old_mv = getenv("LLAMAHIP_DENSE_MM1") != nullptr;      // measurement: the un-pipelined kernel for one row too
-    if (N == 1 && !old_mv) {
+    if (N == 1) {
         // small matrices: 4 half-waves per workgroup so that every CU gets one (a 4096-row matrix is 256 workgroups)
         const int nhw = (w.M + 8 * RG - 1) / (8 * RG) >= 512 ? 8 : 4;
         const dim3 g1((w.M + nhw * RG - 1) / (nhw * RG));
@@ -559,9 +558,7 @@ hipError_t launch_dense_mm(const DMat &w, int epi, const float *x, long x_stride
 // norm / plain / SiLU*up -> rounded, permuted activation rows in `scratch` (then launch_dense_mm with x = nullptr).
 // false = not available for this weight type / row width: use launch_prep + launch_dense_mm.
 bool dense_prep_applies(int wtype, int mode, int K) {
-    static const bool off = getenv("LLAMAHIP_DENSE_NO_FUSED_PREP") != nullptr;     // measurement
-    static const int mask = getenv("LLAMAHIP_DENSE_FUSED_MODES") ? atoi(getenv("LLAMAHIP_DENSE_FUSED_MODES")) : 14;   // bit per PREP_* mode
-    return !off && ((mask >> mode) & 1) && (wtype == 0 || wtype == 1) && K % 32 == 0 && (mode != PREP_NORM || K / 16 <= 1024);
+    return mode >= 1 && mode <= 3 && (wtype == 0 || wtype == 1) && K % 32 == 0 && (mode != PREP_NORM || K / 16 <= 1024);
 }
 hipError_t launch_dense_prep(int mode, int wtype, const float *in0, const float *in1, long in_stride, long in1_stride,
                              int K, int N, float *scratch, const uint16_t *T_silu, hipStream_t st) {

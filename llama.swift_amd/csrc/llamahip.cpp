@@ -209,15 +209,12 @@ static void free_dev(void *p) { if (p) (void) hipFree(p); }
 // A pipeline mailbox is polled by this GPU's kernels while ANOTHER GPU's kernel stores into it over xGMI.  Ordinary hipMalloc
 // memory is coarse-grained: the local L2 may keep serving a line it cached on an earlier look, and coherence with other agents is
 // only promised at kernel boundaries.  Uncached (else fine-grained) device memory is what in-kernel flags between GPUs need;
-// both can be exported with hipIpcGetMemHandle like any device allocation.  LLAMAHIP_MAILBOX_COARSE=1: plain hipMalloc (measurement).
+// both can be exported with hipIpcGetMemHandle like any device allocation.
 static hipError_t malloc_mailbox(void **p, size_t bytes) {
-    static const bool coarse = getenv("LLAMAHIP_MAILBOX_COARSE") != nullptr;
-    if (!coarse) {
-        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) == hipSuccess) return hipSuccess;
-        (void) hipGetLastError();
-        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
-        (void) hipGetLastError();
-    }
+    if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) == hipSuccess) return hipSuccess;
+    (void) hipGetLastError();
+    if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
+    (void) hipGetLastError();
     return hipMalloc(p, bytes);
 }
 
@@ -575,7 +572,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
 
     // short prompt chunks (the reference evaluates prompts 8 tokens at a time, .mm / LlamaRunner n_batch) take
     // the decode-shaped attention; LLAMAHIP_SHORT_MAX = 0 switches it off (measurement)
-    static const int short_max = getenv("LLAMAHIP_SHORT_MAX") ? atoi(getenv("LLAMAHIP_SHORT_MAX")) : 60;
+    constexpr int short_max = 60;
     const bool short_chunk = N >= 2 && N <= short_max && m->attn_ws.S && N <= m->attn_ws.NB && dh % 32 == 0 && dh <= 256;
     int32_t *state = (io && io->state) ? io->state : m->d_state;
     const float *x_first = (io && fused && m->l1 > m->l0) ? io->x_first : nullptr;
@@ -1566,7 +1563,7 @@ int llamahip_op_mul_mat_q4_0(const void *w_q4_0, int32_t M, int32_t K, const flo
         if (hipMemcpyAsync(d_w, w_q4_0, wbytes, hipMemcpyHostToDevice, st) != hipSuccess) break;
         if (hipMemcpyAsync(d_x, x, (size_t) N * K * 4, hipMemcpyHostToDevice, st) != hipSuccess) break;
         if (launch_repack(d_w, q.tiles, M, K, 0, 0, st) != hipSuccess) break;
-        if (N >= 2 && !getenv("LLAMAHIP_GEMM_LDS")) {          // the model path's prompt GEMM: row-lane copy
+        if (N >= 2) {          // the model path's prompt GEMM: row-lane copy
             q.nrb = (M + 63) / 64;
             if (hipMalloc((void **) &q.rows, q.rows_bytes()) != hipSuccess) break;
             if (launch_tiles_to_rows(q, st) != hipSuccess) break;

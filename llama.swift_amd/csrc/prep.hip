@@ -333,7 +333,6 @@ hipError_t launch_check_lut_math(const uint16_t *T_silu, const uint16_t *T_exp, 
     (void) hipFree(d_counts);
     if (e != hipSuccess) return e;
     g_lut_math = off ? 0 : ((h[0] == 0 ? 1 : 0) | (h[1] == 0 ? 2 : 0));
-    if (const char *ab = getenv("LLAMAHIP_EPI_ABLATE")) g_lut_math |= (atoi(ab) & 3) << 2;
     return hipSuccess;
 }
 
@@ -377,9 +376,8 @@ hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_str
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
                        hipStream_t st) {
     const int Kp = (K + 255) / 256 * 256;
-    static const bool slow_only = getenv("LLAMAHIP_PREP_LDS") != nullptr;      // measurement: the LDS-staged kernel for everything
     const int nh = K / 16;
-    if (!y_out && !raw_out && !slow_only && (mode != PREP_NORM || nh <= 1024)) {
+    if (!y_out && !raw_out && (mode != PREP_NORM || nh <= 1024)) {
         // register-resident kernel: NORM = one workgroup per row, the others sliced 256 half-blocks per workgroup
         const int nt = mode == PREP_NORM ? (nh + 63) / 64 * 64 : 256;
         const dim3 grid(N, mode == PREP_NORM ? 1 : (nh + nt - 1) / nt);

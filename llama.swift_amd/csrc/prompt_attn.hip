@@ -343,9 +343,7 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st) {
     const int dh = d / H, T = n_past + N;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
-    static const bool old_only = getenv("LLAMAHIP_ATTN_ROWWISE") != nullptr;     // measurement: per-row kernel for every N
-    static const int attnq_min = getenv("LLAMAHIP_ATTNQ_MIN") ? atoi(getenv("LLAMAHIP_ATTNQ_MIN")) : 2;
-    if (ws && ws->S && dh == 128 && N >= attnq_min && !dbg_p && !dbg_kqv && T <= ws->T_cap && nth <= ws->nth_cap && !old_only) {
+    if (ws && ws->S && dh == 128 && N >= 2 && !dbg_p && !dbg_kqv && T <= ws->T_cap && nth <= ws->nth_cap) {
         for (int nb0 = 0; nb0 < N; nb0 += ws->NB) {
             const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
             // scores: 16 queries per wave, ~4 waves per SIMD over key slices

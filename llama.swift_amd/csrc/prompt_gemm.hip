@@ -1082,16 +1082,13 @@ static hipError_t launch_gemm_skinny_rope_t(const QMat &w, const uint32_t *qa_A,
 
 static int skinny_max_rows() {
     // measured crossover against the row-per-lane kernel at 7B shapes: +25 % at 33 rows, +7 % at 56, -1 % at 63
-    static const int v = getenv("LLAMAHIP_SKINNY_MAX") ? atoi(getenv("LLAMAHIP_SKINNY_MAX")) : 60;
-    return v;
+    return 60;
 }
 // column-group width of k_gemm_skinny for N rows: the widest (<= 4) that still leaves ~1500 waves, balanced
 static int skinny_pick_nc(const QMat &w, int N) {
-    static const int skinny_nc = getenv("LLAMAHIP_SKINNY_NC") ? atoi(getenv("LLAMAHIP_SKINNY_NC")) : 0;
     int nc = 4;
     while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
     if (nc > N) nc = N;
-    if (skinny_nc >= 1 && skinny_nc <= 5) nc = skinny_nc;
     while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
     const int ncg = (N + nc - 1) / nc;
     return (N + ncg - 1) / ncg;                            // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
@@ -1099,13 +1096,11 @@ static int skinny_pick_nc(const QMat &w, int N) {
 
 // Short evals, wq|wk|wv: mat-mul + RoPE + KV append in one launch (k_gemm_skinny<EPI_ROPE_KV>)
 bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
-    static const bool off = getenv("LLAMAHIP_NO_SKINNY_ROPE") != nullptr;      // measurement
-    return !off && N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
+    return N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
 }
 hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
     const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
-    case 5:  return launch_gemm_skinny_rope_t<5>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 4:  return launch_gemm_skinny_rope_t<4>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 3:  return launch_gemm_skinny_rope_t<3>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 2:  return launch_gemm_skinny_rope_t<2>(wqkv, qa_A, qa_d, N, ncg, ra, st);
@@ -1116,14 +1111,12 @@ hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const flo
 // Short evals on the interleaved w1|w3 matrix: mat-mul + SiLU * up + Q4_0 quantization of the result in one
 // launch (k_gemm_skinny<EPI_SILU_QA>).  false = not applicable (row count, layout): use the separate steps.
 bool gemm_silu_qa_applies(const QMat &w13, int N) {
-    static const bool off = getenv("LLAMAHIP_NO_SKINNY_SILU") != nullptr;      // measurement
-    return !off && N >= 2 && N <= skinny_max_rows() && w13.gmapF8 != 0 && w13.ngroups % 8 == 0;
+    return N >= 2 && N <= skinny_max_rows() && w13.gmapF8 != 0 && w13.ngroups % 8 == 0;
 }
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
     const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
-    case 5:  return launch_gemm_skinny_silu_t<5>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 3:  return launch_gemm_skinny_silu_t<3>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 2:  return launch_gemm_skinny_silu_t<2>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
@@ -1228,26 +1221,21 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
     // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put
     // ~1500 waves on the chip (LLAMAHIP_SKINNY_MAX = 0 switches it off, LLAMAHIP_SKINNY_NC forces the width)
     if (N >= 2 && N <= skinny_max_rows()) {
-        // two row-groups per wave (halves the LDS operand reads per row) measured 3-7 % slower at 9 columns
-        static const int skinny_rg = getenv("LLAMAHIP_SKINNY_RG") ? atoi(getenv("LLAMAHIP_SKINNY_RG")) : 0;
+        // (two row-groups per wave -- half the LDS operand reads per row -- measured 3-7 % slower at 9 columns; removed in round 3)
         const int nc = skinny_pick_nc(w, N), ncg = (N + nc - 1) / nc;
-        const int rg = skinny_rg == 2 ? 2 : 1;
         g_gemm_path_counts[GEMM_PATH_SKINNY]++;
 #define LH_SK_ARGS w, epi, qa_A, qa_d, N, ncg, y, y_stride, resid, resid_stride, st
-#define LH_SK_CASE(NCV) case NCV: return rg == 2 ? launch_gemm_skinny_t<NCV, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
+#define LH_SK_CASE(NCV) case NCV: return launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
         switch (nc) {
-        LH_SK_CASE(5);
         LH_SK_CASE(4);
         LH_SK_CASE(3);
         LH_SK_CASE(2);
-        default: return rg == 2 ? launch_gemm_skinny_t<1, 2>(LH_SK_ARGS) : launch_gemm_skinny_t<1, 1>(LH_SK_ARGS);
+        default: return launch_gemm_skinny_t<1, 1>(LH_SK_ARGS);
         }
 #undef LH_SK_CASE
 #undef LH_SK_ARGS
     }
-    static const bool no_rows = getenv("LLAMAHIP_GEMM_LDS") != nullptr;     // measurement: skip the row-lane kernel
-    static const int force_nc = getenv("LLAMAHIP_GEMM_ROWS_NC") ? atoi(getenv("LLAMAHIP_GEMM_ROWS_NC")) : 0;
-    if (w.rows && N >= 2 && !no_rows) {
+    if (w.rows && N >= 2) {
         // widest column group that still gives the chip >= 2 waves per SIMD.  Wider groups (8, 16
         // columns: 191 / 249 VGPRs, 2 waves per SIMD) measured 10-16 % slower than 4 columns at 3 waves
         // per SIMD on a 512-token prompt: the kernel runs at ~85 % of its VALU issue limit and the third
@@ -1255,12 +1243,9 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         int nc = 1;
         for (int cand : { 4, 2 })
             if ((long) w.nrb * ((N + cand - 1) / cand) >= 2048) { nc = cand; break; }
-        if (force_nc) nc = force_nc;
         g_gemm_path_counts[GEMM_PATH_ROWS]++;
 #define LH_ROWS_ARGS w, epi, qa_A, qa_d, N, y, y_stride, resid, resid_stride, st
         switch (nc) {
-        case 16: return launch_gemm_rows_t<16, true, 2>(LH_ROWS_ARGS);
-        case 8:  return launch_gemm_rows_t<8, true, 2>(LH_ROWS_ARGS);
         case 4:  return launch_gemm_rows_t<4, true, 3>(LH_ROWS_ARGS);
         case 2:  return launch_gemm_rows_t<2, true, 3>(LH_ROWS_ARGS);
         default: return launch_gemm_rows_t<1, true, 2>(LH_ROWS_ARGS);
@@ -1291,8 +1276,6 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
 hipError_t init_attrs_prompt_gemm() {
     const int cap = 160 * 1024;          // fused prologues / wide rows need more than the default 64 KB of dynamic LDS
 #define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
-#define LH_ATTR_SK(NC) LH_ATTR((k_gemm_skinny<NC, 1, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 1, EPI_RESID>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_STORE>)); LH_ATTR((k_gemm_skinny<NC, 2, EPI_RESID>))
-    LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
 #undef LH_ATTR

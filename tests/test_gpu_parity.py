@@ -295,13 +295,14 @@ def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape
 
 @pytest.mark.parametrize("env", [{"LLAMAHIP_NO_LUT_MATH": "1"}, {"LLAMAHIP_NORM_MODE": "0"}, {"LLAMAHIP_NORM_MODE": "1"},
                                  {"LLAMAHIP_NO_HOST_IO": "1", "LLAMAHIP_HOST_SAMPLER": "1"},
-                                 {"LLAMAHIP_MFMA_I8": "1", "LLAMAHIP_MFMA_MIN": "32"}])
+                                 {"LLAMAHIP_MFMA_I8": "1", "LLAMAHIP_MFMA_MIN": "32"}, {"LLAMAHIP_EAGER_PREFILL_COPY": "1"}])
 def test_production_fallbacks_and_selectable_variants(env):
     """Arithmetic that ships in libllamahip.so but that the default configuration of this box never selects:
     NO_LUT_MATH -- the SiLU / exp fp16 tables GATHERED (ggml.c:1956-1963, 7024-7036) instead of evaluated, what a device whose
     double-precision exp failed the exhaustive load-time check would run; NORM_MODE 0 / 1 -- the reference's two-pass statistics /
     the one-pass statistics reduced inside every prologue instead of handed over by the producer; NO_HOST_IO + HOST_SAMPLER -- blit
-    copies and the host-side candidate selection; MFMA_I8 -- the int8 matrix-core prompt GEMM of round 1.  Switches are read once
+    copies and the host-side candidate selection; MFMA_I8 -- the int8 matrix-core prompt GEMM of round 1; EAGER_PREFILL_COPY -- the
+    prompt-only weight copies built at load.  Switches are read once
     per process, hence the subprocess; same parity tests, same oracle."""
     import subprocess
     import sys

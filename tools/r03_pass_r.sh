@@ -1,4 +1,5 @@
 #!/bin/bash
+# (as run at the time: LLAMAHIP_PV_STAGE / LLAMAHIP_ATTNQ_PF were tuning switches of that build; removed with the variants that lost)
 # Round-3 GPU pass r: k_dec_pv_stream with its chains split over workgroups (all 256 CUs streaming)
 O=gpurun_out; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "(fallback_paths and (switch2 or switch3 or switch4)) or width_2048 or handoff_timeout" > $O/r03r_quick.txt 2>&1; tail -3 $O/r03r_quick.txt

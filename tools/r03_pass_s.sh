@@ -1,4 +1,5 @@
 #!/bin/bash
+# (as run at the time: LLAMAHIP_PV_STAGE / LLAMAHIP_ATTNQ_PF were tuning switches of that build; removed with the variants that lost)
 # Round-3 GPU pass s: where k_dec_pv_stream's 16 us go (in-kernel timeline), prompt V*P prefetch depth
 O=gpurun_out; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fallback_paths and (switch1 or switch3)" > $O/r03s_quick.txt 2>&1; tail -3 $O/r03s_quick.txt
