@@ -407,12 +407,25 @@ def prefill_2048(args, cfg, path):
     m.eval(ptoks, 0, args.threads)
     best = 1e9
     for _ in range(2):
-        t0 = time.perf_counter(); m.eval(ptoks, 0, args.threads); best = min(best, time.perf_counter() - t0)
+        t0 = time.perf_counter(); lg = m.eval(ptoks, 0, args.threads); best = min(best, time.perf_counter() - t0)
+    # ... and the decode that follows such a prompt: 64 greedy tokens from position 2048 (the long-context attention schedule,
+    # DESIGN.md section 9.5; round 2: 480 tokens/s on the 7B)
+    after = None
+    try:
+        tok, nd = int(np.argmax(lg)), 64
+        m.decode_greedy(tok, N, 4, args.threads)
+        bd = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter(); m.decode_greedy(tok, N, nd, args.threads); bd = min(bd, time.perf_counter() - t0)
+        after = {"context": [N, N + nd], "tokens_per_s": nd / bd, "ms_per_token": bd / nd * 1e3,
+                 "e2e_frac_of_hbm_peak": sum(token_bytes(cfg, N + i) for i in range(nd)) / bd / 1e9 / HBM_PEAK_GBPS}
+    except Exception as e:                                  # never at the cost of the prefill numbers
+        after = {"error": repr(e)}
     m.close()
     d, F, V, Lr = cfg["n_embd"], n_ff(cfg), cfg["n_vocab"], cfg["n_layer"]
     useful = 2.0 * N * Lr * (4 * d * d + 3 * d * F) + 2.0 * V * d            # mat-mul ops, last row of the lm head only
     fma_flops = useful / 4.0                                                  # the exact path: 8 fp32 FMAs per 32-element block and output
-    return {"tokens": N, "n_ctx": n_ctx, "seconds": best, "tokens_per_s": N / best,
+    return {"tokens": N, "n_ctx": n_ctx, "seconds": best, "tokens_per_s": N / best, "decode_after_prompt": after,
             "roofline": {"useful_ops": useful, "useful_TOPs": useful / best / 1e12,
                          "f16_mfma_peak_TFLOPs": F16_MFMA_PEAK_TFLOPS, "frac_of_f16_mfma_peak": useful / best / 1e12 / F16_MFMA_PEAK_TFLOPS,
                          "int8_mfma_peak_TOPs": INT8_MFMA_PEAK_TOPS, "frac_of_int8_mfma_peak": useful / best / 1e12 / INT8_MFMA_PEAK_TOPS,
