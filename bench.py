@@ -25,7 +25,8 @@ Objects next to the contract's fields (N = 1):
                 to every performance number.
   cpu_baseline  the reference's own ggml.c (oracle/_ref; the standalone restatement if that did not travel) on the
                 host: 8 threads (the reference default) and, as `all_cores`, min(nproc, 64) threads.
-  prefill       exact-path prompt evaluation: one 504-token eval, the reference's 9-token chunks, and
+  prefill       exact-path prompt evaluation: one 504-token eval, the reference's 9-token chunks (eval by eval, and
+                in one chunk-exact pass: llamahip_eval_chunks), and
                 configs[2] (2048 tokens in one eval at n_ctx 2560) with its useful-op rate against the int8
                 matrix-core peak and its fp32 FMA rate against the vector peak.
 
@@ -342,8 +343,15 @@ def run_single(args, cfg, path):
         m.eval(ptoks[c0:c0 + 9], c0, args.threads)
         n9 += len(ptoks[c0:c0 + 9])
     dt_9 = time.perf_counter() - t2
+    # ... and the same chunks in ONE pass that leaves the KV cache / logits of the chunk-by-chunk loop bit for bit (llamahip_eval_chunks:
+    # what LlamaRunner.run does with a prompt)
+    lg_loop = m.eval(ptoks[n9 - 9:n9], n9 - 9, args.threads) if n9 >= 9 else None
+    lg_pass = m.eval_chunks(ptoks[:n9], 0, 9, args.threads)
+    t2 = time.perf_counter(); m.eval_chunks(ptoks[:n9], 0, 9, args.threads); dt_9p = time.perf_counter() - t2
     prefill = {"one_eval": {"tokens": int(len(ptoks)), "tokens_per_s": len(ptoks) / dt_pre},
                "reference_9_token_chunks": {"tokens": int(n9), "tokens_per_s": n9 / dt_9},
+               "reference_9_token_chunks_in_one_pass": {"tokens": int(n9), "tokens_per_s": n9 / dt_9p,
+                                                        "logits_equal_chunk_by_chunk": bool(lg_loop is not None and np.array_equal(lg_loop, lg_pass))},
                "note": "exact path (bit-identical to the reference); host logits copy included"}
 
     def gpu_logits_at(n_tokens):

@@ -90,6 +90,16 @@ int llamahip_eval(llamahip_model *m, int32_t n_threads, int32_t n_past,
                   const int32_t *tokens, int32_t n_tokens, float *logits_out,
                   char *err, size_t err_cap);
 
+/* The caller's prompt loop in one call: the reference feeds a prompt to llama_eval n_batch + 1 = 9 tokens at a time
+ * (-[LlamaPredictOperation main], .mm:840-848 + 880-888).  Afterwards the KV cache and `logits_out` (may be NULL) are bit for bit
+ * what ceil(n_tokens / chunk_tokens) successive llamahip_eval calls of chunk_tokens tokens (the last one shorter) leave behind:
+ * every operator of llama_eval's graph works row by row except the V*P key split, which depends on the eval a row belongs to
+ * (ggml.c:5459-5480) and is applied per row.  One pass over all rows runs the matrix-core GEMMs instead of 9-row ones
+ * (about 4x the tokens/s of the chunk-by-chunk loop on a 500-token prompt).  n_tokens <= chunk_tokens: llamahip_eval. */
+int llamahip_eval_chunks(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                         const int32_t *tokens, int32_t n_tokens, int32_t chunk_tokens, float *logits_out,
+                         char *err, size_t err_cap);
+
 /* Replaces ggml_free(model.ctx)  (.mm:900). */
 void llamahip_model_free(llamahip_model *m);
 

@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
     L.llamahip_version.restype = cp
     L.llamahip_model_load.argtypes = [cp, i32, C.POINTER(_Opts), C.POINTER(vp), cp, sz]
     L.llamahip_eval.argtypes = [vp, i32, i32, vp, i32, vp, cp, sz]
+    L.llamahip_eval_chunks.argtypes = [vp, i32, i32, vp, i32, i32, vp, cp, sz]
     L.llamahip_model_free.argtypes = [vp]
     for fn in ("n_vocab", "n_ctx", "n_embd", "n_head", "n_layer", "n_ff", "n_parts"):
         getattr(L, "llamahip_" + fn).argtypes = [vp]
@@ -217,6 +218,15 @@ class Model:
         logits = np.empty(self.n_vocab, np.float32)
         err = C.create_string_buffer(1024)
         rc = lib().llamahip_eval(self._h, n_threads, n_past, _ptr(tokens), tokens.size, _ptr(logits), err, len(err))
+        _check(rc, err)
+        return logits
+
+    def eval_chunks(self, tokens, n_past: int, chunk_tokens: int = 9, n_threads: int = 8) -> np.ndarray:
+        """The reference's prompt loop (successive llama_eval calls of `chunk_tokens` tokens, .mm:880-888) in one pass, bit for bit."""
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        logits = np.empty(self.n_vocab, np.float32)
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_eval_chunks(self._h, n_threads, n_past, _ptr(tokens), tokens.size, chunk_tokens, _ptr(logits), err, len(err))
         _check(rc, err)
         return logits
 

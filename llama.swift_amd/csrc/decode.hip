@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(1024)
 k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth,
              float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
              const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st,
-             int n_past0, long qa_strideA, long qa_strideD, int lut_math) {
+             int n_past0, long qa_strideA, long qa_strideD, int lut_math, int chunk) {
     extern __shared__ double smem_d[];
     double *red = smem_d;
     float *p = (float *) (smem_d + 32);
@@ -805,7 +805,8 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     pv_soft_max(row, p, T, tid, nt, red, T_exp, lut_math);
     // a chunk row is as long as the whole chunk's context (ggml.c:5459-5480 splits n_past + N keys over the
     // threads for every row); the masked tail has weight exp(-inf) = 0 and is walked like the reference does
-    const int Tpv = MULTI ? n_past0 + (int) gridDim.z : T;
+    // (a chunked pass -- prompt_attn.hip split_keys -- stands for successive evals of `chunk` rows: the row's own eval ends with its chunk)
+    const int Tpv = MULTI ? (chunk > 0 ? n_past0 + min((int) gridDim.z, ((int) blockIdx.z / chunk + 1) * chunk) : n_past0 + (int) gridDim.z) : T;
     if (MULTI)
         for (int t = T + tid; t < Tpv; t += nt) p[t] = 0.0f;
     __syncthreads();
@@ -1563,7 +1564,7 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
 //   sc : scratch of N * H * n_ctx floats
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
-                             const uint16_t *T_exp, hipStream_t st) {
+                             const uint16_t *T_exp, hipStream_t st, int chunk) {
     const int dh = d / H, T = n_past + N;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     const int Kp = (d + 255) / 256 * 256;
@@ -1572,7 +1573,7 @@ hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, 
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
     hipLaunchKernelGGL(k_dec_pv_blk<true>, dim3(H, dh / 32, N), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp,
-                       (const int32_t *) nullptr, n_past, (long) Kp / 4, (long) Kp / 32, g_lut_math);
+                       (const int32_t *) nullptr, n_past, (long) Kp / 4, (long) Kp / 32, g_lut_math, chunk);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1669,7 +1670,7 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
     LH_LAUNCH_CHECK();
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;      // whole waves: the DPP reductions need every lane live
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L, g_lut_math);
+    hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L, g_lut_math, 0);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

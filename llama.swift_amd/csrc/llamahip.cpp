@@ -552,7 +552,7 @@ static int attn_sched_at(const llamahip_model *m, int pos) {
     return 0;
 }
 int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool state_on_device,
-            bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap, const StepIO *io = nullptr) {
+            bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap, const StepIO *io = nullptr, int chunk = 0) {
     const HParams &hp = m->hp;
     const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx;
     const int nth = std::max(1, std::min(n_threads, 64));
@@ -673,9 +673,9 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         if (short_chunk && !dmp) {
             // the reference's n_batch = 8 prompt flow: per-row decode-style attention that also quantizes
             // the merged rows for wo (scores scratch: the many-row path's score matrix)
-            HIP_TRY(launch_attn_short(m->qr, Kl, Vl, m->attn_ws.S, nullptr, m->qa_A, m->qa_d, n_past, N, d, H, C, nth, m->T_exp, st), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
+            HIP_TRY(launch_attn_short(m->qr, Kl, Vl, m->attn_ws.S, nullptr, m->qa_A, m->qa_d, n_past, N, d, H, C, nth, m->T_exp, st, chunk), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
         } else {
-        HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, dmp ? m->dbg_p : nullptr, dmp ? m->dbg_kqv : nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
+        HIP_TRY(launch_attn(m->qr, Kl, Vl, m->merged, dmp ? m->dbg_p : nullptr, dmp ? m->dbg_kqv : nullptr, n_past, N, d, H, nth, m->T_exp, &m->attn_ws, st, chunk), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
         if (dmp) {
             if (!sink->put(6, m->dbg_p, (int64_t) H * N * (n_past + N))) goto dump_fail;
             if (!sink->put(7, m->dbg_kqv, (int64_t) N * d)) goto dump_fail;
@@ -1036,7 +1036,7 @@ const char *llamahip_token_text(const llamahip_model *m, int32_t id, uint32_t *l
 static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
                      const int32_t *tokens, int32_t N, float *logits_last, float *logits_all,
                      int32_t dump_layer, float *dump, int64_t dump_cap, int64_t *dump_sizes,
-                     bool sync, char *err, size_t err_cap) {
+                     bool sync, char *err, size_t err_cap, int chunk = 0) {
     int rc = check_eval_args(m, n_past, tokens, N, true, err, err_cap);
     if (rc) return rc;
     if (!m->first_stage || !m->last_stage) { set_err(err, err_cap, "llamahip_eval on a pipeline-stage handle: use llamahip_eval_stage"); return LLAMAHIP_ERR_PREDICT; }
@@ -1059,7 +1059,7 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
     const bool want_all = logits_all != nullptr;
     m->tok_src = tok_mapped ? m->d_io->tok : nullptr;
     m->attn_sched = N == 1 ? attn_sched_at(m, n_past) : 0;
-    rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap);
+    rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap, nullptr, chunk);
     m->tok_src = nullptr;
     if (rc) return rc;
     const size_t V = m->hp.n_vocab;
@@ -1083,6 +1083,24 @@ int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,
 int llamahip_eval(llamahip_model *m, int32_t n_threads, int32_t n_past,
                   const int32_t *tokens, int32_t n_tokens, float *logits_out, char *err, size_t err_cap) {
     return llamahip_eval_debug(m, n_threads, n_past, tokens, n_tokens, logits_out, nullptr, -1, nullptr, 0, nullptr, err, err_cap);
+}
+
+// The reference feeds a prompt to llama_eval n_batch + 1 = 9 tokens at a time (.mm:880-888).  One pass over all the rows gives the
+// same bits -- every operator of the graph works row by row except the V*P key split, which depends on the eval a row belongs to
+// (prompt_attn.hip split_keys) and is applied per row here -- at the speed of a long eval (matrix-core GEMMs) instead of 9-row ones.
+int llamahip_eval_chunks(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t n_tokens,
+                         int32_t chunk_tokens, float *logits_out, char *err, size_t err_cap) {
+    if (chunk_tokens < 1) { set_err(err, err_cap, "llamahip_eval_chunks: chunk_tokens must be >= 1"); return LLAMAHIP_ERR_PREDICT; }
+    if (!m || n_tokens <= chunk_tokens) return llamahip_eval(m, n_threads, n_past, tokens, n_tokens, logits_out, err, err_cap);
+    if (m->host_only || m->dense) {          // f16 / f32 model files: the evals themselves, one after the other
+        for (int32_t c0 = 0; c0 < n_tokens; c0 += chunk_tokens) {
+            const int32_t n = std::min(chunk_tokens, n_tokens - c0);
+            const int rc = llamahip_eval(m, n_threads, n_past + c0, tokens + c0, n, c0 + n == n_tokens ? logits_out : nullptr, err, err_cap);
+            if (rc) return rc;
+        }
+        return LLAMAHIP_OK;
+    }
+    return eval_impl(m, n_threads, n_past, tokens, n_tokens, logits_out, nullptr, -1, nullptr, 0, nullptr, true, err, err_cap, chunk_tokens);
 }
 
 // llamahip_eval + the candidate selection of llama_sample_top_p_top_k on the device (utils.cpp:345-395): 816 bytes come

@@ -116,7 +116,8 @@ struct AttnWs {
     int nth_cap = 8;   // chunks of the V*P key split the workspace can hold (larger n_threads: per-row kernel)
 };
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
-                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st);
+                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st,
+                       int chunk = 0);       // chunk > 0: the pass stands for successive evals of `chunk` rows (prompt_attn.hip split_keys)
 bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d);
 hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st);
 bool gemm_silu_qa_applies(const QMat &w13, int N);
@@ -124,7 +125,7 @@ hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const floa
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st);
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
-                             const uint16_t *T_exp, hipStream_t st);
+                             const uint16_t *T_exp, hipStream_t st, int chunk = 0);
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st,

@@ -37,6 +37,14 @@ __global__ void k_rope_kv(const float *__restrict__ qkv, long qkv_stride, int d,
     }
 }
 
+// An eval of N rows can stand for the reference's SEQUENCE of evals of `chunk` rows each (its prompt flow, .mm:880-888: n_batch + 1 = 9
+// tokens per llama_eval): every row-wise operator gives the same bits either way, and the one place where the reference's arithmetic
+// depends on the eval a row belongs to is the V*P key split -- dc = ceil(keys / n_threads) with keys = n_past + N OF THAT EVAL
+// (ggml.c:5459-5480).  Row n of a chunked pass therefore splits n_past + (its chunk's last row + 1) keys; chunk = 0: one eval.
+__device__ __host__ __forceinline__ int split_keys(int n_past, int N, int n, int chunk) {
+    return chunk > 0 ? n_past + min(N, (n / chunk + 1) * chunk) : n_past + N;
+}
+
 // ------------------------------------------------------------------------------------------------
 // attention for one (head, query row): KQ -> scale -> mask -> soft_max -> V*P
 //   KQ      ggml_vec_dot_f32, AVX macro layer (ggml.c:1223-1258, reduce :872-887): 4 vectors x 8 lanes
@@ -51,7 +59,7 @@ __global__ void k_rope_kv(const float *__restrict__ qkv, long qkv_stride, int d,
 __global__ void __launch_bounds__(256)
 k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *__restrict__ Vc,
        float *__restrict__ merged, float *__restrict__ dbg_p, float *__restrict__ dbg_kqv,
-       int n_past, int N, int d, int dh, int nth, float kq_scale, const uint16_t *__restrict__ T_exp) {
+       int n_past, int N, int d, int dh, int nth, float kq_scale, const uint16_t *__restrict__ T_exp, int chunk) {
     extern __shared__ double smem_d[];
     const int h = blockIdx.x, n = blockIdx.y;
     const int T = n_past + N;
@@ -100,10 +108,11 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
     // ---- V*P with the reference's per-thread split of the key range
     {
         const int c = tid % dh, sub = tid / dh, nsub = blockDim.x / dh;
-        const int dc = (T + nth - 1) / nth;
+        const int Ts = split_keys(n_past, N, n, chunk);      // the key count the reference splits for this row (chunk_keys.h rule below)
+        const int dc = (Ts + nth - 1) / nth;
         for (int th = sub; th < nth; th += nsub) {
             const int t0 = dc * th;
-            int t1 = t0 + dc < T ? t0 + dc : T;
+            int t1 = t0 + dc < Ts ? t0 + dc : Ts;
             if (t1 > tmax + 1) t1 = tmax + 1;         // P = 0 beyond tmax: fma(v, 0, acc) == acc
             float acc = 0.0f;
             for (int t = t0; t < t1; t++) acc = fmaf(Vc[(size_t) t * d + h * dh + c], sc[t], acc);
@@ -253,14 +262,21 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ part,
-                int n_past, int N, int nb0, int NB, int d, int T, int nth) {
+                int n_past, int N, int nb0, int NB, int d, int T, int nth, int chunk) {
     const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5, h = blockIdx.y, th = blockIdx.z;
     const int q0 = blockIdx.x * 64;
     const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
     const int Tb = n_past + nb_end;
-    const int dc = (T + nth - 1) / nth;
-    const int t0 = dc * th;
-    const int t1 = min(min(t0 + dc, T), Tb);              // beyond Tb every P of this block is 0: fma(v, 0, acc) == acc
+    // key range of chunk th of the split, per QUERY: a chunked pass (split_keys) gives the queries of a block different ranges.  The
+    // ranges are monotone in the query index, so the wave walks [lo of its first query, hi of its last) and a lane's probability is
+    // zeroed outside its own query's range: fma(v, 0, acc) == acc wherever the zero falls (before the range acc is still +0).
+    const int qlast = min(nb0 + q0 + 63, N - 1);
+    auto lo_of = [&](int n) { const int Ts = split_keys(n_past, N, n, chunk); return ((Ts + nth - 1) / nth) * th; };
+    auto hi_of = [&](int n) { const int Ts = split_keys(n_past, N, n, chunk); const int dcq = (Ts + nth - 1) / nth; return min(min(dcq * th + dcq, Ts), Tb); };   // beyond Tb every P of this block is 0
+    const int t0 = lo_of(min(nb0 + q0, N - 1));
+    const int t1 = hi_of(qlast);
+    const int nA = min(nb0 + q0 + i, N - 1), nB = min(nb0 + q0 + 32 + i, N - 1);
+    const int loA = lo_of(nA), hiA = hi_of(nA), loB = lo_of(nB), hiB = hi_of(nB);
     f32x16v D[2][4];
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -274,7 +290,7 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
     // waves per SIMD measured the same 2 048-token eval: 191.9 / 191.0 / 190.8 ms)
     constexpr int PF = 4;
     float pa0[PF], pa1[PF], pb0[PF], pb1[PF], pb2[PF], pb3[PF];
-    const int tstart = t0 - (nk > 0 ? (nk & 1) : 0);
+    const int tstart = t0 - (nk > 0 ? (nk & 1) : 0);          // (an even number of steps; the extra front key is outside every range)
 #define LH_PVLOAD(ST, TP)                                                                           \
     {                                                                                               \
         const int key_ = (TP) + kk;                                                                 \
@@ -283,7 +299,8 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
         const float *sp_ = S + ((size_t) h * T + kc_) * NB + q0 + i;                                \
         const float *vp_ = Vc + (size_t) kc_ * d + h * 128 + i;                                     \
         const float s0_ = sp_[0], s1_ = sp_[32], v0_ = vp_[0], v1_ = vp_[32], v2_ = vp_[64], v3_ = vp_[96]; \
-        pa0[ST] = real_ ? s0_ * iv0 : 0.0f; pa1[ST] = real_ ? s1_ * iv1 : 0.0f;     /* soft_max's final scale (ggml.c:7036-7041) */ \
+        pa0[ST] = (real_ && key_ >= loA && key_ < hiA) ? s0_ * iv0 : 0.0f;          /* soft_max's final scale (ggml.c:7036-7041) */ \
+        pa1[ST] = (real_ && key_ >= loB && key_ < hiB) ? s1_ * iv1 : 0.0f;          \
         pb0[ST] = real_ ? v0_ : 0.0f; pb1[ST] = real_ ? v1_ : 0.0f; pb2[ST] = real_ ? v2_ : 0.0f; pb3[ST] = real_ ? v3_ : 0.0f; \
     }
     if (nk > 0) {
@@ -340,7 +357,7 @@ hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, cons
 }
 
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
-                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st) {
+                       int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st, int chunk) {
     const int dh = d / H, T = n_past + N;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     if (ws && ws->S && dh == 128 && N >= 2 && !dbg_p && !dbg_kqv && T <= ws->T_cap && nth <= ws->nth_cap) {
@@ -354,7 +371,7 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_attnq_pv_mfma, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth);
+            hipLaunchKernelGGL(k_attnq_pv_mfma, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_merge, dim3((nb + 1) / 2, H), dim3(256), 0, st, ws->part, merged, N, nb0, ws->NB, d, nth);
             LH_LAUNCH_CHECK();
@@ -362,7 +379,7 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
         return hipSuccess;
     }
     const size_t lds = 32 * sizeof(double) + ((size_t) T + (size_t) nth * dh + dh + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_attn, dim3(H, N), dim3(256), lds, st, qr, Kc, Vc, merged, dbg_p, dbg_kqv, n_past, N, d, dh, nth, kq_scale, T_exp);
+    hipLaunchKernelGGL(k_attn, dim3(H, N), dim3(256), lds, st, qr, Kc, Vc, merged, dbg_p, dbg_kqv, n_past, N, d, dh, nth, kq_scale, T_exp, chunk);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -285,6 +285,14 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
     size_t consumed = 0;
     while (remaining > 0) {                                                         // .mm:834
         bool have_cand = false;
+        if ((int32_t) embd.size() > n_batch + 1) {
+            // a run of prompt chunks (gathered below): everything but the last chunk in ONE pass that leaves the KV cache exactly as the
+            // reference's chunk-by-chunk evals do (llamahip_eval_chunks); the last chunk takes the usual route, its logits may be sampled
+            const int32_t chunk = n_batch + 1, n_full = (((int32_t) embd.size() - 1) / chunk) * chunk;
+            if (llamahip_eval_chunks(model, n_threads, n_past, embd.data(), n_full, chunk, nullptr, err, sizeof(err)) != 0) return fail();
+            n_past += n_full;
+            embd.erase(embd.begin(), embd.begin() + n_full);
+        }
         if (!embd.empty()) {
             // the logits of this eval are sampled next iff the prompt is used up (.mm:851): then the candidate scores and
             // the top-k selection run on the device and 816 bytes come back instead of 128 KB (exact = 0: a tie only
@@ -317,11 +325,12 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt_c, co
             embd.push_back(id);
             --remaining;
         } else {
-            while (embd_inp.size() > consumed) {                                    // .mm:880-888 (chunks of n_batch + 1)
+            // .mm:880-888 hands the prompt over in chunks of n_batch + 1 tokens, one llama_eval each; here the whole rest of the prompt is
+            // taken at once (same tokens, same order, same sampler window) and evaluated chunk-exactly above
+            while (embd_inp.size() > consumed) {
                 embd.push_back(embd_inp[consumed]);
                 llamahip_sampler_accept(sampler, embd_inp[consumed]);
                 ++consumed;
-                if ((int32_t) embd.size() > n_batch) break;
             }
         }
         for (int32_t id : embd) {                                                   // .mm:892-895

@@ -38,6 +38,7 @@ int llamahip_eval(llamahip_model *, int32_t, int32_t, const int32_t *, int32_t, 
     snprintf(err, err_cap, "no HIP device available: libllamahip has no CPU fallback");
     return LLAMAHIP_ERR_PREDICT;
 }
+int llamahip_eval_chunks(llamahip_model *m, int32_t nt, int32_t np, const int32_t *t, int32_t n, int32_t, float *lg, char *err, size_t err_cap) { return llamahip_eval(m, nt, np, t, n, lg, err, err_cap); }
 int llamahip_eval_topk(llamahip_model *m, int32_t nt, int32_t np, const int32_t *t, int32_t n, const int32_t *, int32_t, double, int32_t, double,
                        double *, int32_t *, int32_t *exact, float *lg, char *err, size_t err_cap) { *exact = 0; return llamahip_eval(m, nt, np, t, n, lg, err, err_cap); }
 }

@@ -168,6 +168,54 @@ def test_prompt_continuation_and_ragged_batches(L, oracle, tmp_path, nth):
         assert gm.decode_greedy(tok, n_past, 12, nth).tolist() == want
 
 
+@pytest.mark.parametrize("shape,nth,chunk,n_prompt", [("small", 8, 9, 23), ("small", 3, 9, 200), ("small_dh64", 5, 4, 77), ("small_dh64", 8, 9, 30),
+                                                     ("7b_width", 8, 9, 23), ("7b_width", 8, 9, 150), ("7b_width", 3, 9, 197), ("7b_width", 8, 5, 131)])
+def test_prompt_chunks_in_one_pass_vs_chunk_by_chunk_oracle(L, oracle, tmp_path, shape, nth, chunk, n_prompt):
+    """llamahip_eval_chunks: the reference's prompt loop -- successive llama_eval calls of n_batch + 1 = 9 tokens (.mm:880-888) -- as ONE
+    pass over all rows.  The KV cache of every layer and the logits after the last token must be bit for bit what the chunk-by-chunk
+    evals of the oracle leave behind: the one eval-dependent piece of arithmetic, the V*P key split over n_threads (ggml.c:5459-5480),
+    is applied per row.  Starts at n_past = 4 behind a 4-token eval (the warm-up of the reference's driver), row counts on both sides of
+    the per-row / lane-per-query attention threshold (60) and of the 64-query blocks, ragged last chunk, uneven thread counts, another
+    chunk size; head size 128 (matrix-core attention kernels) and 64 (per-row kernels); decode on top of the cache."""
+    if shape != "7b_width":
+        hp = synth.HParams(n_vocab=128, n_embd=256, n_mult=64, n_head=2 if shape == "small" else 4, n_layer=2)
+        path = str(tmp_path / "m.bin")
+        synth.write_model(path, hp, synth.random_tensors(hp, seed=77))
+        n_vocab, n_layer = hp.n_vocab, hp.n_layer
+    else:
+        path = synth_tool(tmp_path / "m.bin", seed=13, n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2)
+        n_vocab, n_layer = 512, 2
+    n_ctx = n_prompt + 24
+    om = oracle.load(path, n_ctx)
+    prompt = synth.synth_prompt(n_prompt, n_vocab, seed=5)
+    warm = np.array([0, 1, 2, 3], np.int32)
+    om.eval(warm, 0, nth)
+    n_past = 4
+    for c0 in range(0, n_prompt, chunk):
+        want = om.eval(prompt[c0:c0 + chunk], n_past + c0, nth)["logits"]
+    with L.Model(path, n_ctx=n_ctx) as gm:
+        gm.eval(warm, 0, nth)
+        got = gm.eval_chunks(prompt, n_past, chunk, nth)
+        assert same(got, want), describe(got, want)
+        T = n_past + n_prompt
+        for il in range(n_layer):
+            gk, gv = gm.kv(il, T)
+            ok, ov = om.kv(il, T)
+            assert same(gk, ok) and same(gv, ov), f"kv cache layer {il}"
+        tok, seq = int(np.argmax(want)), []
+        t = tok
+        for i in range(6):
+            lo = om.eval(np.array([t], np.int32), T + i, nth)["logits"]
+            t = int(np.argmax(lo)); seq.append(t)
+        assert gm.decode_greedy(tok, T, 6, nth).tolist() == seq
+        # and the one-pass eval of the same rows as ONE eval differs from it where the split differs (the test would be vacuous otherwise)
+        if n_prompt > 60 and nth > 1:
+            with L.Model(path, n_ctx=n_ctx) as g1:
+                g1.eval(warm, 0, nth)
+                one = g1.eval(prompt, n_past, nth)
+                assert not same(one, want)
+
+
 @pytest.mark.parametrize("nth", [1, 4, 8])
 def test_short_chunks_vs_oracle(L, oracle, tmp_path, nth):
     """The reference feeds a prompt n_batch = 8 tokens at a time, so short evals are THE prompt path of the

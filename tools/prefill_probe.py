@@ -22,6 +22,10 @@ for c0 in range(0, 504, 9):
     m.eval(toks[c0:c0 + 9], n_past); n_past += len(toks[c0:c0 + 9])
 dt = time.perf_counter() - t0
 print(f"prompt in 9-token chunks (reference behaviour): {n_past} tokens in {dt * 1e3:.1f} ms = {n_past / dt:.0f} tok/s")
+m.eval(np.array([0, 1, 2, 3], np.int32), 0)
+m.eval_chunks(toks[:504], 0, 9)
+t0 = time.perf_counter(); m.eval_chunks(toks[:504], 0, 9); dt = time.perf_counter() - t0
+print(f"the same 9-token chunks in one chunk-exact pass (llamahip_eval_chunks): 504 tokens in {dt * 1e3:.1f} ms = {504 / dt:.0f} tok/s")
 for N in (64, 512, 2048):
     m.eval(toks[:N], 0)                               # (the first eval of a size allocates its attention workspace)
     t0 = time.perf_counter(); m.eval(toks[:N], 0); dt = time.perf_counter() - t0
