@@ -117,3 +117,27 @@ def test_7b_full_depth_2048_token_prefill_vs_cpu_path(L):
         assert same(a, lg), "last-row logits of the 2048-token eval: " + describe(a, lg)
         got, last = gm.decode_greedy(first, 2048, 3, 8, want_logits=True)
         assert got.tolist() == want and same(last, lo), (got.tolist(), want, describe(last, lo))
+
+
+def test_7b_full_depth_2048_token_prompt_in_the_reference_flow_vs_reference(L):
+    """configs[2] the way the REFERENCE evaluates a 2048-token prompt -- the bridge's loop of nine-token llama_eval calls behind its
+    4-token warm-up (.mm:820-822, 840-848, 880-888), 228 evals of the reference's own ggml.c on the host -- against ONE
+    llamahip_eval_chunks pass over the 2048 rows on the device: final logits bit for bit, then 3 greedy tokens (the long-context
+    decode schedule) against one reference eval each, final logits bit for bit."""
+    path = _model("7B")
+    prompt = synth.synth_prompt(2048, 32000, seed=6)
+    cpu = _cpu_load(path, 2560, 8)
+    for c0 in range(0, 2048, 9):
+        lg = cpu.eval(prompt[c0:c0 + 9], c0, 8)["logits"]
+    t, want = int(np.argmax(lg)), []
+    first = t
+    for i in range(3):
+        lo = cpu.eval(np.array([t], np.int32), 2048 + i, 8)["logits"]
+        t = int(np.argmax(lo)); want.append(t)
+    cpu.close()
+    with L.Model(path, n_ctx=2560) as gm:
+        gm.eval(np.array([0, 1, 2, 3], np.int32), 0, 8)
+        a = gm.eval_chunks(prompt, 0, 9, 8)
+        assert same(a, lg), "logits after the 2048-token prompt: " + describe(a, lg)
+        got, last = gm.decode_greedy(first, 2048, 3, 8, want_logits=True)
+        assert got.tolist() == want and same(last, lo), (got.tolist(), want, describe(last, lo))
