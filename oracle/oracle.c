@@ -509,6 +509,9 @@ static void norm_mul(const float *x, const float *w, float *y, int d, int N) {
 #define DUMP(idx, ptr, count) do { if (dmp && dump && dump_sizes) { const long c_ = (long) (count); \
     if (dump_used + c_ <= dump_cap) { memcpy(dump + dump_used, (ptr), sizeof(float) * c_); dump_sizes[idx] = c_; dump_used += c_; } } } while (0)
 
+static int g_split_chunk = 0;
+void orc_set_split_chunk(int chunk) { g_split_chunk = chunk > 0 ? chunk : 0; }
+
 /* layers [l0, l1): a pipeline stage.  The first stage embeds `tokens`, later stages start from
  * hidden_in (the fp32 residual stream, .mm:563-564, 687-690); the last stage applies the final norm
  * and lm head, earlier stages return the residual stream in hidden_out. */
@@ -578,7 +581,6 @@ static int eval_range(orc_model *m, int n_threads, int n_past, const int32_t *to
          * private zeroed buffer (ggml.c:5619-5665), then adds the buffers in thread order
          * (ggml.c:5553-5577).  The split therefore is part of the numerics.                     */
         {
-            const int dc = (T + nth - 1) / nth;
             const int nwk = omp_workers(nth);
             float *part_all = (float *) malloc((size_t) nwk * nth * dh * 4);      /* one set of n_threads buffers per OpenMP worker */
 #pragma omp parallel for num_threads(nwk) collapse(2) schedule(static)
@@ -587,8 +589,13 @@ static int eval_range(orc_model *m, int n_threads, int n_past, const int32_t *to
                     const float *P = kq + ((size_t) h * N + n) * T;
                     float *part = part_all + (size_t) omp_get_thread_num() * nth * dh;
                     memset(part, 0, (size_t) nth * dh * 4);
+                    /* keys the reference splits for this row: n_past + N of the llama_eval call the row belongs to.  g_split_chunk > 0
+                     * (orc_set_split_chunk, tests only) evaluates the rows as if they had arrived in successive calls of that many
+                     * rows -- the claim behind llamahip_eval_chunks, checked against real successive calls by tests/test_oracle_chunks.py */
+                    const int Ts = g_split_chunk > 0 ? n_past + ((n / g_split_chunk + 1) * g_split_chunk < N ? (n / g_split_chunk + 1) * g_split_chunk : N) : T;
+                    const int dc = (Ts + nth - 1) / nth;
                     for (int th = 0; th < nth; th++) {
-                        const int t0 = dc * th, t1 = (t0 + dc < T) ? t0 + dc : T;
+                        const int t0 = dc * th, t1 = (t0 + dc < Ts) ? t0 + dc : Ts;
                         float *acc = part + (size_t) th * dh;
                         for (int t = t0; t < t1; t++) {
                             const float *vr = Vc + (size_t) t * d + h * dh;

@@ -43,6 +43,8 @@ void       orc_kv(const orc_model *m, int il, int n_pos, float *out_k, float *ou
 /* forward pass (.mm:510-735); n_threads reproduces the reference's thread-count-dependent
  * summation split in the V*P product (ggml.c:5619-5665, 5553-5577) and sets the OpenMP team size.
  * dump_layer >= 0 copies that layer's intermediates (17 tensors, same order as oracle/ref_driver.cpp). */
+/* tests only: rows of one orc_eval call split their V*P keys as if they had arrived in successive calls of `chunk` rows (0: off) */
+void       orc_set_split_chunk(int chunk);
 int        orc_eval(orc_model *m, int n_threads, int n_past, const int32_t *tokens, int N,
                     float *logits_last, float *logits_all,
                     int dump_layer, float *dump, long dump_cap, long *dump_sizes);
