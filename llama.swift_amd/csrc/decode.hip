@@ -1740,7 +1740,7 @@ hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st) {
 }
 
 
-// The same selection in two launches (round 2): k_topk_candidates is ONE workgroup, i.e. 16 waves x ~5 000 instructions of
+// The selection in two launches (round 2; the single-workgroup first version, k_topk_candidates, was removed in round 3): that was ONE workgroup, i.e. 16 waves x ~5 000 instructions of
 // fp64 key arithmetic on a single CU -- 34-39 us.  k_topk_keys spreads the per-logit work (penalty, score, order-preserving
 // key, the 64 group maxima) over V / 1024 workgroups; k_topk_select (one workgroup) only compares the finished keys with the
 // threshold and ranks the survivors.  Same groups (element i belongs to group (i % 1024) / 16), same threshold, same flags.
@@ -1787,7 +1787,7 @@ k_topk_select(int V, int k, unsigned long long *__restrict__ keys, unsigned long
 #pragma unroll
     for (int u = 0; u < NPT; u++) key[u] = keys[tid + u * 1024];              // (entries past V are 0: below every threshold)
     // threshold = the k-th LARGEST of the 64 group maxima (k <= 64): at least k logits are >= it, so the k best and anything tied
-    // with the k-th are among the survivors -- and only a few more (the minimum of the maxima, as k_topk_candidates uses, lets
+    // with the k-th are among the survivors -- and only a few more (the minimum of the maxima, as the single-workgroup version used, lets
     // 300-700 through, and the rank pass below is quadratic in that)
     __shared__ unsigned long long s_T;
     if (tid == 0) s_T = 0ull;

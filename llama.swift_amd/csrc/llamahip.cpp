@@ -572,7 +572,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     }
 
     // short prompt chunks (the reference evaluates prompts 8 tokens at a time, .mm / LlamaRunner n_batch) take
-    // the decode-shaped attention; LLAMAHIP_SHORT_MAX = 0 switches it off (measurement)
+    // the decode-shaped attention
     constexpr int short_max = 60;
     const bool short_chunk = N >= 2 && N <= short_max && m->attn_ws.S && N <= m->attn_ws.NB && dh % 32 == 0 && dh <= 256;
     int32_t *state = (io && io->state) ? io->state : m->d_state;

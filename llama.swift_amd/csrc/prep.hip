@@ -317,7 +317,7 @@ __global__ void k_check_lut_math(const uint16_t *__restrict__ T_silu, const uint
     if (silu_math_bits(h) != T_silu[i]) atomicAdd(counts, 1u);
     if (exp_math_bits(h) != T_exp[i]) atomicAdd(counts + 1, 1u);
 }
-int g_lut_math = 0;          // bit 0: SiLU, bit 1: exp (bits 2, 3: epilogue ablation switches of LLAMAHIP_EPI_ABLATE, measurement only) -- set by launch_check_lut_math (process-wide: the tables are the same for every model)
+int g_lut_math = 0;          // bit 0: SiLU, bit 1: exp (0x1000 / 0x2000 are OR-ed in per launch by the fault-injection tests) -- set by launch_check_lut_math (process-wide: the tables are the same for every model)
 hipError_t launch_check_lut_math(const uint16_t *T_silu, const uint16_t *T_exp, hipStream_t st) {
     static const bool off = getenv("LLAMAHIP_NO_LUT_MATH") != nullptr;       // measurement only
     uint32_t *d_counts = nullptr, h[2] = { 1, 1 };

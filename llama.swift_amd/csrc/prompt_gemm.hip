@@ -1219,7 +1219,7 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
     }
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
     // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put
-    // ~1500 waves on the chip (LLAMAHIP_SKINNY_MAX = 0 switches it off, LLAMAHIP_SKINNY_NC forces the width)
+    // ~1500 waves on the chip
     if (N >= 2 && N <= skinny_max_rows()) {
         // (two row-groups per wave -- half the LDS operand reads per row -- measured 3-7 % slower at 9 columns; removed in round 3)
         const int nc = skinny_pick_nc(w, N), ncg = (N + nc - 1) / nc;
