@@ -100,7 +100,9 @@ struct GemvArgs {
     const uint64_t *resid_t; int slot_resid;          // EPI_RESID_TAG: the residual row [M] arrives tagged (null: plain `resid`)
     uint64_t *out_t;        int slot_out;             // EPI_RESID_TAG: y [M] also leaves tagged (null: plain `y` only)
     const int32_t *pos_w;                             // mailbox tags are made from the sequence position, *pos_w + 1, not from the epoch (null: epoch)
-    int patience;                                     // mailbox polls wait for ANOTHER process / device: their bounds are shifted left by this
+    int patience;                                     // mailbox polls wait for ANOTHER process / device: their bounds are shifted left by this (3: ~20 s of
+                                                      // looks at an uncached / remote granule -- legitimate waits are milliseconds, and a mapping that does not carry
+                                                      // the stores must cost the bench's one-token handshake seconds, not minutes, before it falls back to RCCL)
 };
 template <int PRE, int EPI, int D, bool RING, int PG>
 __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, const int nw, double *smem_d) {
@@ -1438,7 +1440,7 @@ static hipError_t launch_gemv_pg(const QMat &w, int nw, const uint32_t *qa_A, co
                     (const f64x2 *) np.in, np.n_in, (f64x2 *) np.out, nullptr, 0, 0, g_lut_math };
     if (mb) {       // a row of a pipeline mailbox on one side of this launch
         ga.in_t = mb->in_t; ga.resid_t = mb->resid_t; ga.out_t = mb->out_t; ga.slot_in = ga.slot_resid = ga.slot_out = 0;
-        ga.pos_w = mb->pos_w; ga.patience = 7; ga.fault = mb->fault; ga.sync = mb->epoch; ga.lut_math |= mb->test_bits;
+        ga.pos_w = mb->pos_w; ga.patience = 3; ga.fault = mb->fault; ga.sync = mb->epoch; ga.lut_math |= mb->test_bits;
     }
 #define LH_GO(D, RING) hipLaunchKernelGGL((k_gemv<PRE, EPI, D, RING, PG>), dim3(grid), dim3(nw * 64), lds + ((LH_GEMV_PAD && (RING)) ? (D) * 288 : 0), st, ga)
     if (np.out && grid > NORM_PART_MAX) return hipErrorInvalidValue;
@@ -1719,7 +1721,7 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) < 2) ? 0x1000 : 0;     // (2: the wo launch of the overlapped schedule misbehaves instead)
     GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, x, norm_w, w.K, (float *) qkv2, nullptr, T_silu, nullptr, nullptr,
                     (const f64x2 *) (normp ? np.in : nullptr), normp ? np.n_in : (norm_mode == 0 ? -1 : 0), nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
-    if (x_t) { ga.in_t = x_t; ga.slot_in = 0; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; ga.pos_w = mb->pos_w; ga.patience = 7; ga.lut_math |= mb->test_bits; }
+    if (x_t) { ga.in_t = x_t; ga.slot_in = 0; ga.part_in = nullptr; ga.npart = norm_mode == 0 ? -1 : 0; ga.pos_w = mb->pos_w; ga.patience = 3; ga.lut_math |= mb->test_bits; }
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | fault_test,
                            qkv2, sc2, epoch, layer };
     const int grid = gridA + H * (nsl + dh / 32);

@@ -139,7 +139,7 @@ k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb
                 g = load_granule_sys(token_mb);
                 if ((uint32_t) (g >> 32) == want) break;
                 __builtin_amdgcn_s_sleep(16);
-                if (poll_give_up(spins, 1 << 27, fault)) break;
+                if (poll_give_up(spins, 1 << 23, fault)) break;
             }
             const uint32_t t = (uint32_t) g;
             tok_s = t < (uint32_t) n_vocab ? (int) t : 0;        // (a poll that ran out: the fault word is up, keep the gather in bounds)

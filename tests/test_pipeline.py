@@ -556,3 +556,19 @@ def test_device_side_mailbox_lost_row_is_an_error_not_a_hang(tmp_path):
                        capture_output=True, text=True, cwd=root, timeout=300)
     assert "ERR -1001" in r.stdout and "hand-off" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert float(r.stdout.split("SECONDS")[1].split()[0]) < 30.0, r.stdout
+
+
+@pytest.mark.gpu
+def test_device_side_mailbox_silent_peer_costs_seconds_with_the_production_poll_bounds(tmp_path):
+    """No fault injection, no shortened polls: a consumer stage whose producer never steps, and a first stage whose token never comes
+    back, raise the fault word and return PredictionFailed after seconds (measured 5.1 / 4.7 s on one GPU) -- the price the N > 1
+    bench's one-token handshake pays once before all ranks fall back to the RCCL hand-off (tools/mailbox_silence_probe.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mailbox_silence_probe.py"), str(tmp_path / "m.bin")],
+                       env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, cwd=root, timeout=400)
+    out = r.stdout
+    assert out.count("ERR -1001") == 2 and "NO ERROR" not in out, out[-2000:] + r.stderr[-2000:]
+    secs = [float(l.split()[-1]) for l in out.splitlines() if l.startswith("SECONDS")]
+    assert len(secs) == 2 and max(secs) < 90.0, out
