@@ -313,6 +313,20 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(L):
     assert "no CPU fallback" in e.value.message
 
 
+def test_eval_entry_points_refuse_a_host_only_handle(L, tmp_path):
+    """llamahip_eval / llamahip_eval_chunks / greedy decode on a handle that has no device state (LLAMAHIP_FLAG_HOST_ONLY: the file
+    reader alone) are PredictionFailed, never a silent CPU path."""
+    hp = synth.HParams(n_vocab=64, n_embd=64, n_mult=32, n_head=2, n_layer=1)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=3))
+    with L.Model(path, n_ctx=32, flags=4) as m:          # 4 = LLAMAHIP_FLAG_HOST_ONLY
+        for call in (lambda: m.eval(np.arange(3, 8, dtype=np.int32), 0), lambda: m.eval_chunks(np.arange(3, 23, dtype=np.int32), 0, 9),
+                     lambda: m.decode_greedy(5, 0, 2)):
+            with pytest.raises(L.LlamaHipError) as e:
+                call()
+            assert e.value.code == -1001
+
+
 def test_dense_model_files_parse_on_the_host(L, tmp_path):
     """f16 / f32 model files (f16 = 1 / 0) are accepted by the reader; a HOST_ONLY handle serves their
     merged tensors byte for byte (two part files: column and row shards); a header / tensor type mismatch is an error."""
