@@ -4,7 +4,8 @@
 // entry points the driver calls are replaced by stubs that parse the file and then fail like a box without a GPU, so
 // the run exercises: header / vocabulary / tensor-directory parsing (valid, truncated and corrupted files), multi-part
 // shard merging through read_tensor, llamahip_tokenize, llamahip_sample_top_p_top_k / _from_candidates, and the
-// bridge's failure path.  usage: host_sanitize <model file> [n_parts]   (exit code 0 = clean)
+// bridge's failure path, and -- with evals that succeed on made-up logits -- the driver's whole control flow (prompt taken at once,
+// chunk-exact pass + last chunk, one eval per generated token, event counts).  usage: host_sanitize <model file> [n_parts]   (exit code 0 = clean)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -34,13 +35,24 @@ const char *llamahip_token_text(const llamahip_model *m, int32_t id, uint32_t *l
     if (len) *len = (uint32_t) m->file.id_to_token[id].size();
     return m->file.id_to_token[id].data();
 }
-int llamahip_eval(llamahip_model *, int32_t, int32_t, const int32_t *, int32_t, float *, char *err, size_t err_cap) {
-    snprintf(err, err_cap, "no HIP device available: libllamahip has no CPU fallback");
-    return LLAMAHIP_ERR_PREDICT;
+// Two modes.  Default: every eval fails like a box without a GPU.  g_drive: evals SUCCEED with deterministic made-up logits and are
+// logged, so that the generation driver's control flow (warm-up, the prompt taken at once and evaluated chunk-exactly, the last
+// chunk's sampled logits, one eval per generated token, the event sequence) runs end to end on the host, under the sanitizers.
+struct EvalCall { int kind /* 0 eval, 1 eval_chunks, 2 eval_topk */, n_past, n, chunk; };
+static bool g_drive = false;
+static std::vector<EvalCall> g_calls;
+static int fake_eval(llamahip_model *m, int kind, int32_t np, const int32_t *t, int32_t n, int32_t chunk, float *lg, char *err, size_t err_cap) {
+    if (!g_drive) { snprintf(err, err_cap, "no HIP device available: libllamahip has no CPU fallback"); return LLAMAHIP_ERR_PREDICT; }
+    if (!m || !t || n < 1 || np < 0 || np + n > m->file.hp.n_ctx) { snprintf(err, err_cap, "context overflow: n_past (%d) + n_tokens (%d) > n_ctx (%d)", np, n, m ? m->file.hp.n_ctx : 0); return LLAMAHIP_ERR_PREDICT; }
+    g_calls.push_back({ kind, np, n, chunk });
+    const int V = m->file.hp.n_vocab;
+    for (int i = 0; lg && i < V; i++) lg[i] = (float) (((uint32_t) i * 2654435761u + (uint32_t) (np + n) * 97u + (uint32_t) t[n - 1] * 13u) >> 20 & 0xffu) * 0.03125f;
+    return 0;
 }
-int llamahip_eval_chunks(llamahip_model *m, int32_t nt, int32_t np, const int32_t *t, int32_t n, int32_t, float *lg, char *err, size_t err_cap) { return llamahip_eval(m, nt, np, t, n, lg, err, err_cap); }
-int llamahip_eval_topk(llamahip_model *m, int32_t nt, int32_t np, const int32_t *t, int32_t n, const int32_t *, int32_t, double, int32_t, double,
-                       double *, int32_t *, int32_t *exact, float *lg, char *err, size_t err_cap) { *exact = 0; return llamahip_eval(m, nt, np, t, n, lg, err, err_cap); }
+int llamahip_eval(llamahip_model *m, int32_t, int32_t np, const int32_t *t, int32_t n, float *lg, char *err, size_t err_cap) { return fake_eval(m, 0, np, t, n, 0, lg, err, err_cap); }
+int llamahip_eval_chunks(llamahip_model *m, int32_t, int32_t np, const int32_t *t, int32_t n, int32_t chunk, float *lg, char *err, size_t err_cap) { return fake_eval(m, 1, np, t, n, chunk, lg, err, err_cap); }
+int llamahip_eval_topk(llamahip_model *m, int32_t, int32_t np, const int32_t *t, int32_t n, const int32_t *, int32_t, double, int32_t, double,
+                       double *, int32_t *, int32_t *exact, float *lg, char *err, size_t err_cap) { *exact = 0; return fake_eval(m, 2, np, t, n, 0, lg, err, err_cap); }
 }
 
 static int failures = 0;
@@ -128,6 +140,51 @@ int main(int argc, char **argv) {
         Ev *e = (Ev *) u; if (t == LLAMA_EVENT_FAILED) e->failed++; if (t == LLAMA_EVENT_COMPLETED) e->completed++; }, &ev);
     EXPECT((rc == LLAMAHIP_ERR_PREDICT || rc == LLAMAHIP_ERR_LOAD) && ev.failed == 1 && ev.completed == 0);   // (a multi-part file of a non-LLaMA width fails in the loader: the bridge cannot force the part count)
     llama_runner_bridge_free(b);
+    // the bridge's control flow with evals that succeed (made-up logits): prompts of 1 ... 40 tokens (one-part files: the bridge derives the
+    // part count from n_embd, .mm:33-38, and cannot be told that a test file of another width has two)
+    if (parts <= 1) {
+        g_drive = true;
+        llamahip_model *mv = nullptr;
+        EXPECT(llamahip_model_load(path.c_str(), 64, &o, &mv, err, sizeof(err)) == 0);
+        for (int want_tokens : { 1, 5, 9, 10, 18, 19, 27, 40 }) {
+            if (!mv) break;
+            // a prompt text made of vocabulary pieces; P = what the tokenizer (with BOS) makes of it
+            std::string text;
+            std::vector<int32_t> toks(512);
+            int32_t P = 1;
+            for (int tries = 0; tries < 400 && P < want_tokens; tries++) {
+                uint32_t len = 0;
+                const char *t = llamahip_token_text(mv, (int32_t) (3 + rng() % (uint32_t) (V - 3)), &len);
+                if (!t || !len || memchr(t, 0, len)) continue;
+                const std::string cand = text + std::string(t, len);
+                const int32_t n = llamahip_tokenize(mv, cand.c_str(), 1, toks.data(), (int32_t) toks.size());
+                if (n <= want_tokens) { text = cand; P = n; }
+            }
+            g_calls.clear();
+            struct Ev2 { int tokens = 0, failed = 0, completed = 0; } e2;
+            llama_runner_bridge *b2 = llama_runner_bridge_new(path.c_str());
+            llama_runner_config c2; llama_runner_config_default(&c2); c2.numberOfTokens = 6; c2.n_ctx = 64;
+            const int32_t rc2 = llama_runner_bridge_run(b2, text.c_str(), &c2, [](void *u, llama_event_type t, const char *, uint32_t, int32_t) {
+                Ev2 *e = (Ev2 *) u; if (t == LLAMA_EVENT_OUTPUT_TOKEN) e->tokens++; if (t == LLAMA_EVENT_FAILED) e->failed++; if (t == LLAMA_EVENT_COMPLETED) e->completed++; }, &e2);
+            llama_runner_bridge_free(b2);
+            const int n_predict = std::min(6, 64 - P), chunk = 9;
+            const int n_full = P > chunk ? ((P - 1) / chunk) * chunk : 0;
+            EXPECT(rc2 == 0 && e2.failed == 0 && e2.completed == 1);
+            EXPECT(e2.tokens == P + n_predict);                                        // the prompt echoed, then the generated tokens (.mm:892-895)
+            size_t k = 0;
+            EXPECT(g_calls.size() == (size_t) (1 + (n_full ? 1 : 0) + 1 + (n_predict - 1)));
+            if (g_calls.size() == (size_t) (1 + (n_full ? 1 : 0) + 1 + (n_predict - 1))) {
+                EXPECT(g_calls[k].kind == 0 && g_calls[k].n_past == 0 && g_calls[k].n == 4); k++;                      // warm-up (.mm:820-822)
+                if (n_full) { EXPECT(g_calls[k].kind == 1 && g_calls[k].n_past == 0 && g_calls[k].n == n_full && g_calls[k].chunk == chunk); k++; }
+                EXPECT(g_calls[k].kind == 2 && g_calls[k].n_past == n_full && g_calls[k].n == P - n_full); k++;          // the last chunk: its logits are sampled
+                for (int g = 0; g + 1 < n_predict; g++, k++) EXPECT(g_calls[k].n_past == P + g && g_calls[k].n == 1);
+            }
+            printf("host_sanitize: driver with a %d-token prompt: %zu evals (%d tokens in one chunk-exact pass, %d in the last chunk), %d token events\n",
+                   P, g_calls.size(), n_full, P - n_full, e2.tokens);
+        }
+        if (mv) llamahip_model_free(mv);
+        g_drive = false;
+    }
     printf("host_sanitize: %zu tensor bytes merged, tokenizer + sampler + bridge failure path exercised: %s\n", total, failures ? "FAILED" : "clean");
     return failures ? 1 : 0;
 }

@@ -279,7 +279,7 @@ def test_corrupt_headers_are_load_errors_not_aborts(L, tmp_path):
 
 
 def test_host_half_is_clean_under_asan_and_ubsan(built, tmp_path):
-    """`make asan`: model-file reader, shard merge, tokenizer, sampler and the bridge's failure path compiled with
+    """`make asan`: model-file reader, shard merge, tokenizer, sampler, the bridge's failure path and its whole control flow compiled with
     -fsanitize=address,undefined (device entry points stubbed) and run on a one-part and a two-part file, on corrupted
     headers and on truncated files (memory-error detection for the host shim)."""
     import subprocess
@@ -292,6 +292,12 @@ def test_host_half_is_clean_under_asan_and_ubsan(built, tmp_path):
         synth.write_model(path, hp, t, n_parts=parts)
         r = subprocess.run([os.path.join(csrc, "tools", "host_sanitize"), path, str(parts)], capture_output=True, text=True)
         assert r.returncode == 0 and "clean" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stdout + r.stderr
+        if parts == 1:
+            # ... and the generation driver end to end with evals that succeed on made-up logits: the prompt is taken at once, everything but
+            # its last nine-token chunk goes through ONE llamahip_eval_chunks call, the last chunk's logits are sampled, one eval per
+            # generated token, prompt + generated tokens echoed (the harness checks the call sequence itself; here: that it ran)
+            assert "driver with a 40-token prompt: 8 evals (36 tokens in one chunk-exact pass, 4 in the last chunk), 46 token events" in r.stdout, r.stdout
+            assert "driver with a 9-token prompt: 7 evals (0 tokens in one chunk-exact pass, 9 in the last chunk)" in r.stdout, r.stdout
 
 
 def test_runner_reports_load_failure_like_the_bridge(L, tmp_path):
