@@ -103,6 +103,8 @@ def decode_roles(cfg):
         [("wq|wk|wv+attention", gemv_bytes(3 * d, d), "k_qkv_attn")] + tail,
         [("wq|wk|wv", gemv_bytes(3 * d, d), "k_gemv"), ("attention", None, "k_dec_attn_x")] + tail,
         [("wq|wk|wv", gemv_bytes(3 * d, d), "k_gemv"), ("attn_scores", None, "k_dec_scores"), ("attn_softmax_pv", None, "k_dec_pv_blk")] + tail,
+        # long contexts (llamahip.cpp attn_sched_at): the streaming soft_max . V
+        [("wq|wk|wv", gemv_bytes(3 * d, d), "k_gemv"), ("attn_scores", None, "k_dec_scores"), ("attn_softmax_pv", None, "k_dec_pv_stream")] + tail,
     ]
     return layouts, ("output", gemv_bytes(V, d)), L
 

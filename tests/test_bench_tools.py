@@ -18,6 +18,8 @@ LAYOUTS = {
                "void lh::k_gemv<0, 1, 10, true, 12>(a)"],
     "two": ["void lh::k_gemv<4, 0, 8, true, 1>(a)", "lh::k_dec_scores(a)", "void lh::k_dec_pv_blk<false>(a)", "void lh::k_gemv<0, 1, 16, false, 4>(a)",
             "void lh::k_gemv<4, 2, 4, true, 1>(a)", "void lh::k_gemv<0, 1, 10, true, 12>(a)"],
+    "stream": ["void lh::k_gemv<4, 0, 8, true, 1>(a)", "lh::k_dec_scores(a)", "void lh::k_dec_pv_stream<4>(a)", "void lh::k_gemv<0, 1, 16, false, 4>(a)",
+               "void lh::k_gemv<4, 2, 4, true, 1>(a)", "void lh::k_gemv<0, 1, 10, true, 12>(a)"],
 }
 
 
@@ -49,6 +51,7 @@ def test_insitu_trace_parser_knows_every_decode_layout(tmp_path, kind):
         assert {"wq|wk|wv", "attention"} <= roles
     else:
         assert {"wq|wk|wv", "attn_scores", "attn_softmax_pv"} <= roles
+        assert ("k_dec_pv_stream" if kind == "stream" else "k_dec_pv_blk") in prof["kernel"]["attn_softmax_pv"]
     assert "k_gemv<4, 2, 4" in prof["kernel"]["w1|w3"]
 
 
