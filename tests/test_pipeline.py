@@ -158,6 +158,54 @@ def test_pipeline_peer_failure_is_reported_not_hung(built, tmp_path, mode):
     assert took < 80
 
 
+def _mailbox_wiring_worker(rank, world, init_file, n_seq, out_dir):
+    """HipStage.setup_mailboxes with a recording stand-in for the model handle: which inbox handle does each rank open?"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    import json
+
+    import torch.distributed as dist
+    from llama_swift_amd.pipeline import HipStage
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+
+    class FakeModel:
+        def __init__(self):
+            self.connected = {}
+
+        def stage_mailbox(self, s):          # (hidden inbox ptr, token inbox ptr, hidden handle, token handle): 64-byte handles naming (rank, slot, kind)
+            tag = lambda kind: (b"%c%03d%03d" % (kind, rank, s)).ljust(64, b".")
+            return 0, 0, (tag(ord("H")) if rank > 0 else None), (tag(ord("T")) if rank == 0 and world > 1 else None)
+
+        def stage_mailbox_connect(self, s, next_hidden_handle=None, next_hidden_ptr=0, token_handle=None, token_ptr=0):
+            self.connected[s] = (None if next_hidden_handle is None else bytes(next_hidden_handle)[:7].decode(), None if token_handle is None else bytes(token_handle)[:7].decode())
+
+    class Stub:
+        model = FakeModel()
+    st = Stub()
+    HipStage.setup_mailboxes(st, dist, rank, world, n_seq)
+    assert st.mailboxes is True
+    json.dump({str(k): v for k, v in st.model.connected.items()}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_mailbox_handle_exchange_wires_every_stage_to_its_successor_gloo(tmp_path, world):
+    """The one collective of the device-side hand-off (HipStage.setup_mailboxes: an object all-gather of the 64-byte IPC handles): for
+    every sequence slot, stage r opens the hidden inbox of stage r + 1 and nothing else, the last stage also the first stage's token
+    inbox -- for worlds larger than the two ranks the one-GPU tests can run."""
+    import json
+
+    import torch.multiprocessing as mp
+    n_seq = 3
+    mp.spawn(_mailbox_wiring_worker, args=(world, str(tmp_path / "rdv"), n_seq, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = json.load(open(tmp_path / f"rank{r}.json"))
+        for s in range(n_seq):
+            hid, tok = got[str(s)]
+            assert hid == (f"H{r + 1:03d}{s:03d}" if r + 1 < world else None), (world, r, s, hid)
+            assert tok == (f"T000{s:03d}" if r == world - 1 else None), (world, r, s, tok)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_pipeline_schedule_gloo(built, tmp_path, world):
     import torch.multiprocessing as mp
@@ -440,6 +488,69 @@ def test_device_side_mailboxes_two_stages_two_streams(L, tmp_path, shape):
         whole.eval(prompts[s], 0, 8)
         assert got.tolist() == whole.decode_greedy(firsts[s], len(prompts[s]), 3, 8).tolist()
     for m in (whole, a, b):
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["small", "7b_width"])
+def test_device_side_mailboxes_three_stages_with_a_one_layer_middle_stage(L, tmp_path, shape):
+    """What a pipeline of more than two GPUs adds: a MIDDLE stage, whose step takes its row from one mailbox and leaves it in another --
+    here with a single layer, so the mailbox prologue (first layer) and the mailbox epilogue (last layer's w2) belong to the same
+    layer.  Three stage handles, three streams, the consumers' steps enqueued before their producers'; tokens = the whole model's."""
+    import torch
+    path, n_vocab, n_embd, n_layer = _mailbox_model(tmp_path, shape)
+    a = L.Model(path, n_ctx=64, layer_begin=0, layer_end=1, n_seq=2)
+    mid = L.Model(path, n_ctx=64, layer_begin=1, layer_end=2, n_seq=2)
+    c = L.Model(path, n_ctx=64, layer_begin=2, layer_end=n_layer, n_seq=2)
+    whole = L.Model(path, n_ctx=64)
+    prompts = [synth.synth_prompt(9, n_vocab, seed=1), synth.synth_prompt(6, n_vocab, seed=2)]
+    firsts = []
+    for s, p in enumerate(prompts):
+        h1 = torch.empty(len(p) * n_embd, dtype=torch.float32, device="cuda")
+        h2 = torch.empty(len(p) * n_embd, dtype=torch.float32, device="cuda")
+        for m in (a, mid, c):
+            m.set_seq(s)
+        a.eval_stage(0, tokens=p, hidden_out=h1.data_ptr())
+        mid.eval_stage(0, n_tokens=len(p), hidden_in=h1.data_ptr(), hidden_out=h2.data_ptr())
+        firsts.append(int(np.argmax(c.eval_stage(0, n_tokens=len(p), hidden_in=h2.data_ptr(), want_logits=True))))
+    torch.cuda.synchronize()
+    tok = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(2)]
+    for s in range(2):
+        _, a_tok, _, _ = a.stage_mailbox(s)
+        m_hid, _, _, _ = mid.stage_mailbox(s)
+        c_hid, _, _, _ = c.stage_mailbox(s)
+        assert a_tok and m_hid and c_hid
+        a.stage_mailbox_connect(s, next_hidden_ptr=m_hid)
+        mid.stage_mailbox_connect(s, next_hidden_ptr=c_hid)
+        c.stage_mailbox_connect(s, token_ptr=a_tok)
+        tok[s].fill_(firsts[s])
+        torch.cuda.synchronize()
+        a.stage_bind(s, len(prompts[s]), token_in=tok[s].data_ptr())
+        mid.stage_bind(s, len(prompts[s]))                                        # neither hidden_in nor hidden_out: two mailboxes
+        c.stage_bind(s, len(prompts[s]))
+    sa, sm, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    n_steps = 6
+    for _ in range(n_steps):
+        for s in (1, 0):
+            if shape == "small":
+                c.stage_step(s, 8, sc.cuda_stream)               # consumers first: their kernels really wait
+                mid.stage_step(s, 8, sm.cuda_stream)
+                a.stage_step(s, 8, sa.cuda_stream)
+            else:
+                # 7B-wide stages: the waiting first launches of TWO stages (576 polling workgroups each) fill the ONE GPU of this test and the
+                # producer's launch would never become resident -- a co-location artefact, every stage has its own GPU in the pipeline.
+                # Producer first, one stage at a time: the rows still travel through the mailboxes.
+                for m, st in ((a, sa), (mid, sm), (c, sc)):
+                    m.stage_step(s, 8, st.cuda_stream)
+                    torch.cuda.synchronize()
+    for s in range(2):
+        n, pos, got = c.stage_trace(s, n_steps)
+        assert (n, pos) == (n_steps, len(prompts[s]) + n_steps)
+        assert mid.stage_trace(s, 0)[:2] == (n_steps, len(prompts[s]) + n_steps)
+        assert int(np.argmax(whole.eval(prompts[s], 0, 8))) == firsts[s]
+        want = whole.decode_greedy(firsts[s], len(prompts[s]), n_steps, 8)
+        assert got.tolist() == want.tolist(), f"{shape}: sequence {s}: {got.tolist()} vs {want.tolist()}"
+    for m in (whole, a, mid, c):
         m.close()
 
 
