@@ -34,7 +34,7 @@
 namespace lh {
 
 constexpr int QUAD_BYTES = 5120;      // 4 tiles: [4][1024 B nibbles][4][256 B scales]
-constexpr int ENG_F = 8;              // quads that may be in flight behind the one whose landing is awaited (5 DMA instructions each; vmcnt holds 63)
+constexpr int ENG_F = 11;             // quads that may be in flight behind the one whose landing is awaited (5 DMA instructions each; vmcnt holds 63)
 constexpr int ENG_CW = 4;             // consumer waves
 constexpr int ENG_NT = 64 * (1 + ENG_CW);
 
@@ -53,6 +53,7 @@ struct FfnEngArgs {
     int R, U;                           // row-groups of wo / w2 (d / 8), units of w1|w3 (F / 8)
     int S;                              // ring slots (quads)
     int maxrg, maxu;                    // bounds of row-groups / units per workgroup (LDS carve)
+    const int32_t *utab;                // [G][maxu + 1]: {n, unit ids in processing order} of each workgroup (ffn_engine_geometry)
     const uint32_t *qa_A; const float *qa_d;    // QA operand of wo (the attention output, K = d)
     const float *x_in; float *x_out;    // residual stream into / out of the layer (may be the same buffer: a workgroup reads and writes its own rows only)
     const float *norm_w;                // ffn_norm
@@ -92,6 +93,8 @@ struct EngLds {
     uint8_t *un;                        // union: fp32 row h [d]  |  QA operand of w2 {A [nqF * 4 * 64 dwords], d [nqF * 32]}
     float *hown;                        // [maxrg][8] this workgroup's rows of h (w2's residual operand)
     float *actb; float *amaxb;          // [maxu][8] SiLU(gate) * up of this workgroup's units, [maxu] their partial amax
+    float *gub;                         // [maxu][2][8] gate / up results of a unit (its two row-groups run on different waves)
+    uint32_t *ucnt;                     // [maxu] row-groups of the unit finished (the second finisher completes the unit)
     double *red;                        // [2][ENG_CW] reduction scratch
     uint32_t *landed, *cbar, *done;     // flags: quads landed | consumer barrier counter | [S] release words
 };
@@ -149,29 +152,47 @@ struct EngCtx {
     }
 };
 
+// Two chunks ahead: operand set t belongs to chunk t of the current quad; while chunk t is computed the loads of chunk t + 2 are in
+// flight (the next quad's chunks 0 / 1 once it has landed).  The release of a slot is a plain LDS store: a wave's LDS operations
+// are performed in order, so the store follows the reads of the quad it frees.
+__device__ __forceinline__ void release_slot(uint32_t *done, uint32_t v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(done, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ float run_rowgroup(EngCtx &cx, int qb, int nq, const uint32_t *A, const float *D, int lane) {
     float acc = 0.0f;
-    ChunkOps o0, o1;
+    ChunkOps o0, o1, o2, o3;
     int slot = qb % cx.S;
     cx.wait_landed(qb);
-    load_chunk(o0, cx.L.ring + slot * QUAD_BYTES, 0, A, D, 0, lane);
+    const uint8_t *quad = cx.L.ring + slot * QUAD_BYTES;
+    load_chunk(o0, quad, 0, A, D, 0, lane);
+    load_chunk(o1, quad, 1, A, D, 1, lane);
     for (int qq = 0; qq < nq; qq++) {
-        const uint8_t *quad = cx.L.ring + slot * QUAD_BYTES;
         const int ch = qq * 4;
-        load_chunk(o1, quad, 1, A, D, ch + 1, lane);
+        load_chunk(o2, quad, 2, A, D, ch + 2, lane);
         compute_chunk(acc, o0);
-        load_chunk(o0, quad, 2, A, D, ch + 2, lane);
+        load_chunk(o3, quad, 3, A, D, ch + 3, lane);
         compute_chunk(acc, o1);
-        load_chunk(o1, quad, 3, A, D, ch + 3, lane);
-        compute_chunk(acc, o0);
         const int nslot = slot + 1 == cx.S ? 0 : slot + 1;
+        const uint8_t *nquad = cx.L.ring + nslot * QUAD_BYTES;
         const bool more = qq + 1 < nq;
-        const bool pre = more && cx.is_landed(qb + qq + 1);
-        if (pre) load_chunk(o0, cx.L.ring + nslot * QUAD_BYTES, 0, A, D, ch + 4, lane);
-        compute_chunk(acc, o1);
-        st_rel(cx.L.done + slot, (uint32_t) (qb + qq + 1));            // every read of this quad has been consumed: the slot is free
-        if (more && !pre) { cx.wait_landed(qb + qq + 1); load_chunk(o0, cx.L.ring + nslot * QUAD_BYTES, 0, A, D, ch + 4, lane); }
-        slot = nslot;
+        if (more && cx.is_landed(qb + qq + 1)) {
+            load_chunk(o0, nquad, 0, A, D, ch + 4, lane);
+            compute_chunk(acc, o2);
+            load_chunk(o1, nquad, 1, A, D, ch + 5, lane);
+            compute_chunk(acc, o3);
+            release_slot(cx.L.done + slot, (uint32_t) (qb + qq + 1));
+        } else {
+            compute_chunk(acc, o2);
+            compute_chunk(acc, o3);
+            release_slot(cx.L.done + slot, (uint32_t) (qb + qq + 1));
+            if (more) {
+                cx.wait_landed(qb + qq + 1);
+                load_chunk(o0, nquad, 0, A, D, ch + 4, lane);
+                load_chunk(o1, nquad, 1, A, D, ch + 5, lane);
+            }
+        }
+        slot = nslot; quad = nquad;
     }
     return acc;
 }
@@ -219,15 +240,19 @@ k_ffn_engine(const FfnEngArgs a) {
         L.hown = (float *) p; p += (size_t) a.maxrg * 32;
         L.actb = (float *) p; p += (size_t) a.maxu * 32;
         L.amaxb = (float *) p; p += (size_t) ((a.maxu * 4 + 15) & ~15);
+        L.gub = (float *) p; p += (size_t) a.maxu * 64;
+        L.ucnt = (uint32_t *) p; p += (size_t) ((a.maxu * 4 + 15) & ~15);
         L.red = (double *) p; p += 2 * ENG_CW * 8;
         L.landed = (uint32_t *) p; L.cbar = L.landed + 1; L.done = L.landed + 4;
     }
     // ---- this workgroup's work
     const int nrg = c < a.R ? (a.R - c + G - 1) / G : 0;                   // wo / w2 row-groups c, c + G, ...
-    const int u0 = (int) ((long) c * a.U / G), u1 = (int) ((long) (c + 1) * a.U / G), nu = u1 - u0;   // w1|w3 units [u0, u1)
+    const int32_t *ut = a.utab + (size_t) c * (a.maxu + 1);
+    const int nu = ut[0];                                                  // w1|w3 units ut[1 .. nu], in processing order
     const int Q0 = nrg * a.nqd, Q1 = Q0 + nu * 2 * a.nqd, Q2 = Q1 + nrg * a.nqF;      // quad ranges: wo | w1|w3 | w2
     const int limit = (a.lut_math & 0x1000) ? (1 << 8) : (1 << 20);
     if (tid < 4 + S) L.landed[tid] = 0u;
+    if (tid < a.maxu) L.ucnt[tid] = 0u;
     __syncthreads();                        // the only workgroup barrier: from here on the loader and the consumers run apart
 #if LH_PHASE_PROBE == 3
     unsigned long long pt[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -414,43 +439,61 @@ k_ffn_engine(const FfnEngArgs a) {
         }
         cons_barrier(L.cbar, round, lane, a.fault);
         ENG_STAMP(pt, 3);
-        // ---- phase C: w1 | w3, one unit (gate row-group + up row-group) per consumer wave at a time
-        for (int ul = cw; ul < nu; ul += ENG_CW) {
-            const int qb = Q0 + ul * 2 * a.nqd;
-            float ag = run_rowgroup(cx, qb, a.nqd, L.qa1A, L.qa1D, lane);
-            ag = fold8(ag);
-            float au = run_rowgroup(cx, qb + a.nqd, a.nqd, L.qa1A, L.qa1D, lane);
-            au = fold8(au);
-            const uint16_t gh = f2h_bits(ag);
-            const float act = h2f_bits((a.lut_math & 1) ? silu_math_bits(gh) : a.T_silu[gh]) * au;     // ggml.c:1956-1963, .mm:678-680
-            const float am = wave_max_f(k == 0 ? fabsf(act) : 0.0f);
-            if (k == 0) L.actb[ul * 8 + r] = act;
-            if (lane == 0) { L.amaxb[ul] = am; store_tagged_agent(a.amax_t + (u0 + ul), __builtin_bit_cast(uint32_t, am), tag); }
+        // ---- phase C: w1 | w3.  Task i = row-group i of this workgroup's stream (gate, up of its units in turn), one per consumer wave
+        // at a time; the wave that finishes a unit's second row-group completes the unit: SiLU(gate) * up (ggml.c:1956-1963,
+        // .mm:678-680) and the unit's partial amax, published at once (units of a Q4_0 block shared with another workgroup come first
+        // in the stream, so the partner has the partial amax long before it quantizes)
+        for (int i = cw; i < 2 * nu; i += ENG_CW) {
+            const int ul = i >> 1, part = i & 1;
+            float av = run_rowgroup(cx, Q0 + i * a.nqd, a.nqd, L.qa1A, L.qa1D, lane);
+            av = fold8(av);
+            if (k == 0) L.gub[(ul * 2 + part) * 8 + r] = av;
+            uint32_t prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(L.ucnt + ul, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = (uint32_t) __builtin_amdgcn_readfirstlane((int) prev);
+            if (prev == 1u) {
+                float act = 0.0f;
+                if (lane < 8) {
+                    const float gv = L.gub[(ul * 2) * 8 + lane], uv = L.gub[(ul * 2 + 1) * 8 + lane];
+                    const uint16_t gh = f2h_bits(gv);
+                    act = h2f_bits((a.lut_math & 1) ? silu_math_bits(gh) : a.T_silu[gh]) * uv;
+                    L.actb[ul * 8 + lane] = act;
+                }
+                const float am = wave_max_f(lane < 8 ? fabsf(act) : 0.0f);
+                if (lane == 0) { L.amaxb[ul] = am; store_tagged_agent(a.amax_t + ut[1 + ul], __builtin_bit_cast(uint32_t, am), tag); }
+            }
         }
         cons_barrier(L.cbar, round, lane, a.fault);
         ENG_STAMP(pt, 4);
-        // ---- quantize this workgroup's FFN activations (ggml.c:456-523) with the amax of their whole Q4_0 block: lane = (unit, row)
+        // ---- quantize this workgroup's FFN activations (ggml.c:456-523) with the amax of their whole Q4_0 block: lane = (unit, row).
+        // Partial amaxes of the block's other units: this workgroup's from LDS, the others' granules polled together.
         for (int base = 0; base < nu * 8; base += 64 * ENG_CW) {
             const int i = base + ctid;
             const bool live = i < nu * 8;
-            const int ul = live ? i >> 3 : 0, rr = i & 7, u = u0 + ul, b = u >> 2;
+            const int ul = live ? i >> 3 : 0, rr = i & 7, u = ut[1 + ul], b = u >> 2;
             float amax = 0.0f;
+            bool need[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int uu = b * 4 + t;
-                float av;
-                if (uu >= u0 && uu < u1) av = L.amaxb[uu - u0];
-                else {
-                    uint64_t gv; int spins = 0;
-                    for (;;) {
-                        gv = ld_granule(a.amax_t + uu);
-                        if ((uint32_t) (gv >> 32) == tag) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        if (poll_give_up(spins, limit, a.fault)) break;
-                    }
-                    av = __builtin_bit_cast(float, (uint32_t) gv);
-                }
-                amax = fmaxf(amax, av);
+                int li = -1;
+                for (int j = 0; j < nu; j++) if (ut[1 + j] == uu) li = j;
+                need[t] = li < 0;
+                if (li >= 0) amax = fmaxf(amax, L.amaxb[li]);
+            }
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+                uint64_t gv[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) gv[t] = need[t] ? ld_granule(a.amax_t + b * 4 + t) : 0ull;
+                float am2 = amax;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (need[t]) { ok = ok && (uint32_t) (gv[t] >> 32) == tag; am2 = fmaxf(am2, __builtin_bit_cast(float, (uint32_t) gv[t])); }
+                if (ok) { amax = am2; break; }
+                __builtin_amdgcn_s_sleep(1);
+                if (poll_give_up(spins, limit, a.fault)) break;
             }
             const float act = L.actb[ul * 8 + rr];
             const float dd = amax / 7.0f;
@@ -533,16 +576,17 @@ k_ffn_engine(const FfnEngArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_tiles_to_engine(const uint8_t *__restrict__ wo, const uint8_t *__restrict__ w13, const uint8_t *__restrict__ w2, uint8_t *__restrict__ eng,
-                  int G, int R, int U, int ncd, int nqd, int ncF, int nqF) {
+                  int G, int R, const int32_t *__restrict__ utab, int maxu, int ncd, int nqd, int ncF, int nqF) {
     const int c = blockIdx.x, q = blockIdx.y, t = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nrg = c < R ? (R - c + G - 1) / G : 0;
-    const int u0 = (int) ((long) c * U / G), u1 = (int) ((long) (c + 1) * U / G), nu = u1 - u0;
+    const int32_t *ut = utab + (size_t) c * (maxu + 1);
+    const int nu = ut[0];
     const int Q0 = nrg * nqd, Q1 = Q0 + nu * 2 * nqd, Q2 = Q1 + nrg * nqF;
     if (q >= Q2) return;
     const uint8_t *tiles; int tg, nch, ch;                // source matrix, tile group (row-group in tile order), its chunk count, first chunk
     if (q < Q0) { tiles = wo; tg = c + G * (q / nqd); nch = ncd; ch = (q % nqd) * 4; }
     else if (q < Q1) {
-        const int qq = q - Q0, ul = qq / (2 * nqd), part = (qq / nqd) & 1, u = u0 + ul;     // part 0: gate row-group u, 1: up row-group u
+        const int qq = q - Q0, ul = qq / (2 * nqd), part = (qq / nqd) & 1, u = ut[1 + ul];     // part 0: gate row-group u, 1: up row-group u
         tiles = w13; tg = (u >> 2) * 8 + part * 4 + (u & 3); nch = ncd; ch = (qq % nqd) * 4;      // (interleaved w1|w3 tile order, k_repack_q4)
     } else { const int qq = q - Q1; tiles = w2; tg = c + G * (qq / nqF); nch = ncF; ch = (qq % nqF) * 4; }
     uint8_t *dst = eng + ((size_t) q * G + c) * QUAD_BYTES;
@@ -566,10 +610,56 @@ static int eng_ncu() {
     return n;
 }
 
-// geometry of the engine for a layer shape; G = 0: the engine does not apply
-FfnEngGeom ffn_engine_geometry(int d, int F) {
+// ---- the split of w1|w3 over the workgroups: UNITS (gate row-group u + up row-group u) in the order each workgroup processes them.
+// A Q4_0 block of the FFN activation is 4 consecutive units; a workgroup that holds only part of a block exchanges partial amaxes
+// with the holders of the rest, so (i) as few blocks as possible should be shared and (ii) shared units come FIRST in a workgroup's
+// order: the exchange then hides behind the rest of its units.
+//   scheme 1 (half blocks): workgroups get whole HALF blocks (2 units); those with an odd number of halves sit in adjacent pairs
+//            that share exactly one block -- at most one shared block per workgroup, its 2 units first.  7B: 88 pairs x 3 halves
+//            + 80 x 2 halves.
+//   scheme 0 (units): contiguous, balanced to +-1 unit; up to two shared blocks per workgroup (head and tail), both first.
+// The scheme with the smaller maximum load wins (ties: 1); LLAMAHIP_ENGINE_SPLIT forces one (tests).
+static int build_units(int U, int G, int scheme, std::vector<std::vector<int>> &out) {
+    out.assign(G, {});
+    int maxu = 0;
+    if (scheme == 1) {
+        const int H2 = U / 2, base = H2 / G, extra = H2 % G;        // halves per workgroup: base or base + 1
+        std::vector<int> cnt(G);
+        // workgroups with an ODD number of halves first (there is an even number of them), so that every pair starts block-aligned
+        const int n_hi = extra, n_lo = G - extra;
+        const bool hi_odd = ((base + 1) & 1) != 0;
+        for (int c = 0; c < G; c++) cnt[c] = hi_odd ? (c < n_hi ? base + 1 : base) : (c < n_lo ? base : base + 1);
+        int h = 0;
+        for (int c = 0; c < G; c++) {
+            const int h0 = h, h1 = h + cnt[c];
+            h = h1;
+            std::vector<int> halves;
+            // the shared half first: the LAST half when this workgroup's range ends inside a block, the FIRST when it starts inside one
+            if (cnt[c] > 0 && (h1 & 1)) halves.push_back(h1 - 1);
+            if (cnt[c] > 0 && (h0 & 1)) halves.push_back(h0);
+            for (int x = h0; x < h1; x++) if (std::find(halves.begin(), halves.end(), x) == halves.end()) halves.push_back(x);
+            for (int x : halves) { out[c].push_back(2 * x); out[c].push_back(2 * x + 1); }
+            maxu = std::max(maxu, (int) out[c].size());
+        }
+    } else {
+        for (int c = 0; c < G; c++) {
+            const int u0 = (int) ((long) c * U / G), u1 = (int) ((long) (c + 1) * U / G);
+            std::vector<int> &o = out[c];
+            // units of the partial block at the tail, then at the head, then the whole blocks
+            for (int u = u0; u < u1; u++) if ((u >> 2) == ((u1 - 1) >> 2) && (u1 & 3) != 0) o.push_back(u);
+            for (int u = u0; u < u1; u++) if ((u >> 2) == (u0 >> 2) && (u0 & 3) != 0 && std::find(o.begin(), o.end(), u) == o.end()) o.push_back(u);
+            for (int u = u0; u < u1; u++) if (std::find(o.begin(), o.end(), u) == o.end()) o.push_back(u);
+            maxu = std::max(maxu, (int) o.size());
+        }
+    }
+    return maxu;
+}
+
+// geometry of the engine for a layer shape; G = 0: the engine does not apply.  utab: [G][maxu + 1] {n, units...} for the device
+FfnEngGeom ffn_engine_geometry(int d, int F, std::vector<int32_t> *utab) {
     FfnEngGeom g = {};
     static const int grid_env = getenv("LLAMAHIP_ENGINE_GRID") ? atoi(getenv("LLAMAHIP_ENGINE_GRID")) : 0;      // tests: other work splits
+    static const int split_env = getenv("LLAMAHIP_ENGINE_SPLIT") ? atoi(getenv("LLAMAHIP_ENGINE_SPLIT")) : -1;
     const int ncu = eng_ncu();
     if (d % 32 != 0 || F % 32 != 0 || d < 32 || F < 32 || d > 8192 || ncu < 1) return g;
     g.d = d; g.F = F;
@@ -578,36 +668,47 @@ FfnEngGeom ffn_engine_geometry(int d, int F) {
     int G = std::min(ncu, std::max(g.R, g.U));
     if (grid_env > 0) G = std::min(ncu, grid_env);
     g.G = G;
-    g.maxrg = (g.R + G - 1) / G; g.maxu = (g.U + G - 1) / G + 1;
+    std::vector<std::vector<int>> u0s, u1s;
+    const int m0 = build_units(g.U, G, 0, u0s), m1 = build_units(g.U, G, 1, u1s);
+    const int scheme = split_env >= 0 ? (split_env ? 1 : 0) : (m1 <= m0 ? 1 : 0);
+    const std::vector<std::vector<int>> &us = scheme ? u1s : u0s;
+    g.scheme = scheme;
+    g.maxrg = (g.R + G - 1) / G; g.maxu = std::max(1, scheme ? m1 : m0);
+    if (utab) {
+        utab->assign((size_t) G * (g.maxu + 1), -1);
+        for (int c = 0; c < G; c++) {
+            (*utab)[(size_t) c * (g.maxu + 1)] = (int32_t) us[c].size();
+            for (size_t j = 0; j < us[c].size(); j++) (*utab)[(size_t) c * (g.maxu + 1) + 1 + j] = us[c][j];
+        }
+    }
     g.Qmax = 0;
     for (int c = 0; c < G; c++) {
         const int nrg = c < g.R ? (g.R - c + G - 1) / G : 0;
-        const int nu = (int) ((long) (c + 1) * g.U / G) - (int) ((long) c * g.U / G);
-        g.Qmax = std::max(g.Qmax, nrg * g.nqd + nu * 2 * g.nqd + nrg * g.nqF);
+        g.Qmax = std::max(g.Qmax, nrg * g.nqd + (int) us[c].size() * 2 * g.nqd + nrg * g.nqF);
     }
     const size_t fixed = (size_t) g.nqd * 4 * 288 + (size_t) std::max(d * 4, g.nqF * 4 * 288) + (size_t) g.maxrg * 32 + (size_t) g.maxu * 32 +
-                         (size_t) ((g.maxu * 4 + 15) & ~15) + 2 * ENG_CW * 8 + 16;
+                         (size_t) ((g.maxu * 4 + 15) & ~15) + (size_t) g.maxu * 64 + (size_t) ((g.maxu * 4 + 15) & ~15) + 2 * ENG_CW * 8 + 16;
     const size_t cap = 160 * 1024;
-    // ring: what is left, at most 64 slots (the release words), never more than the longest stream
+    // ring: what is left, at most 60 slots (the release words), never more than the longest stream
     long S = ((long) cap - (long) fixed - 64 * 4) / QUAD_BYTES;
     S = std::min<long>(S, 60);
-    if (S < 2 * ENG_F) { g.G = 0; return g; }
-    g.S = (int) std::min<long>(S, std::max(g.Qmax, 2 * ENG_F));
+    if (S < ENG_F + 4) { g.G = 0; return g; }
+    g.S = (int) std::min<long>(S, std::max(g.Qmax, ENG_F + 4));
     g.lds = (size_t) g.S * QUAD_BYTES + fixed + (size_t) g.S * 4;
     g.lds = (g.lds + 15) & ~(size_t) 15;
     return g;
 }
 
-hipError_t launch_tiles_to_engine(const FfnEngGeom &g, const QMat &wo, const QMat &w13, const QMat &w2, uint8_t *eng, hipStream_t st) {
-    if (g.G < 1 || wo.nchunks != g.ncd || w13.nchunks != g.ncd || w2.nchunks != g.ncF || !w13.gmapF8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tiles_to_engine, dim3(g.G, g.Qmax), dim3(256), 0, st, wo.tiles, w13.tiles, w2.tiles, eng, g.G, g.R, g.U, g.ncd, g.nqd, g.ncF, g.nqF);
+hipError_t launch_tiles_to_engine(const FfnEngGeom &g, const int32_t *d_utab, const QMat &wo, const QMat &w13, const QMat &w2, uint8_t *eng, hipStream_t st) {
+    if (g.G < 1 || !d_utab || wo.nchunks != g.ncd || w13.nchunks != g.ncd || w2.nchunks != g.ncF || !w13.gmapF8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tiles_to_engine, dim3(g.G, g.Qmax), dim3(256), 0, st, wo.tiles, w13.tiles, w2.tiles, eng, g.G, g.R, d_utab, g.maxu, g.ncd, g.nqd, g.ncF, g.nqF);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_ffn_engine(const FfnEngGeom &g, const FfnEngIO &io, hipStream_t st) {
     static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) == 5) ? 0x1000 : 0;
-    const FfnEngArgs a = { io.eng, g.G, g.d, g.F, g.ncd, g.nqd, g.ncF, g.nqF, g.R, g.U, g.S, g.maxrg, g.maxu, io.qa_A, io.qa_d, io.x_in, io.x_out, io.norm_w,
+    const FfnEngArgs a = { io.eng, g.G, g.d, g.F, g.ncd, g.nqd, g.ncF, g.nqF, g.R, g.U, g.S, g.maxrg, g.maxu, io.utab, io.qa_A, io.qa_d, io.x_in, io.x_out, io.norm_w,
                            io.T_silu, g_lut_math | fault_test, io.h_t, io.amax_t, io.act_t, io.d2_t, io.epoch, io.layer, (f64x2 *) io.part_out, io.fault };
     if (g.d <= 4096) hipLaunchKernelGGL(k_ffn_engine<1>, dim3(g.G), dim3(ENG_NT), g.lds, st, a);
     else hipLaunchKernelGGL(k_ffn_engine<2>, dim3(g.G), dim3(ENG_NT), g.lds, st, a);

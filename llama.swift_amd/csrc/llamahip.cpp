@@ -179,6 +179,7 @@ struct llamahip_model {
     FfnEngGeom eng_geom;
     std::vector<uint8_t *> eng_w;        // [layer - l0], null where the copy could not be built
     uint64_t *d_eng_t = nullptr;         // tagged hand-off buffers: h [d] | amax [F/8] | act [F/8] | d2 [F/32]
+    int32_t *d_eng_utab = nullptr;       // the w1|w3 work split (ffn_engine_geometry)
     bool counted_live = false;           // this handle is counted in g_live_handles (engine launches need the GPU's CUs to themselves)
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
@@ -247,7 +248,7 @@ llamahip_model::~llamahip_model() {
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
     for (uint8_t *e : eng_w) free_dev(e);
-    free_dev(d_eng_t);
+    free_dev(d_eng_t); free_dev(d_eng_utab);
     if (counted_live) g_live_handles[device & 63].fetch_sub(1);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_pvx);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
@@ -660,7 +661,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             if (use_eng && !mbi && !mbo && m->eng_w[il - m->l0]) {
                 const FfnEngGeom &eg = m->eng_geom;
                 uint64_t *t = m->d_eng_t;
-                const FfnEngIO eio = { m->eng_w[il - m->l0], m->qa1_A, m->qa1_d, xa, xo, L.ffn_norm, m->T_silu, t, t + d, t + d + eg.U, t + d + 2 * (size_t) eg.U,
+                const FfnEngIO eio = { m->eng_w[il - m->l0], m->d_eng_utab, m->qa1_A, m->qa1_d, xa, xo, L.ffn_norm, m->T_silu, t, t + d, t + d + eg.U, t + d + 2 * (size_t) eg.U,
                                        m->d_epoch, il - m->l0, m->npart_a, m->d_fault };
                 HIP_TRY(launch_ffn_engine(eg, eio, st), LLAMAHIP_ERR_PREDICT);
                 n_part_x = use_part ? eg.G : 0;
@@ -1024,17 +1025,19 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
     m->counted_live = true;
     g_live_handles[m->device & 63].fetch_add(1);
     if (!m->dense && m->w13_interleaved && !getenv("LLAMAHIP_NO_ENGINE") && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS) {
-        const FfnEngGeom g = ffn_engine_geometry(d, F);
+        std::vector<int32_t> utab;
+        const FfnEngGeom g = ffn_engine_geometry(d, F, &utab);
         if (g.G > 0) {
             const size_t nt = (size_t) d + 2 * (size_t) g.U + (size_t) F / 32;
-            bool ok = hipMalloc((void **) &m->d_eng_t, nt * 8) == hipSuccess && hipMemset(m->d_eng_t, 0, nt * 8) == hipSuccess;
+            bool ok = hipMalloc((void **) &m->d_eng_t, nt * 8) == hipSuccess && hipMemset(m->d_eng_t, 0, nt * 8) == hipSuccess &&
+                      hipMalloc((void **) &m->d_eng_utab, utab.size() * 4) == hipSuccess && hipMemcpy(m->d_eng_utab, utab.data(), utab.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
             m->eng_w.assign(m->l1 - m->l0, nullptr);
             for (int il = m->l0; ok && il < m->l1; il++) {
                 const Layer &L = m->layers[il - m->l0];
                 uint8_t *e = nullptr;
                 if (hipMalloc((void **) &e, g.bytes()) != hipSuccess) { ok = false; break; }
                 m->eng_w[il - m->l0] = e;
-                if (hipMemsetAsync(e, 0, g.bytes(), m->stream) != hipSuccess || launch_tiles_to_engine(g, L.wo, L.w13, L.w2, e, m->stream) != hipSuccess) { ok = false; break; }
+                if (hipMemsetAsync(e, 0, g.bytes(), m->stream) != hipSuccess || launch_tiles_to_engine(g, m->d_eng_utab, L.wo, L.w13, L.w2, e, m->stream) != hipSuccess) { ok = false; break; }
                 m->weight_bytes += (int64_t) g.bytes();
             }
             if (ok) m->eng_geom = g;

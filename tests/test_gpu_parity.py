@@ -313,16 +313,19 @@ def test_decode_attention_fallback_paths(switch, select):
 
 
 @pytest.mark.parametrize("switch,select", [
-    ({"LLAMAHIP_ENGINE_GRID": "7"}, _SMALL + " or dc_offset"), ({"LLAMAHIP_ENGINE_GRID": "33"}, _SMALL + " or dc_offset"),
-    ({"LLAMAHIP_ENGINE_GRID": "200"}, "greedy_trace_128 or dc_offset or 7b_logits"), ({"LLAMAHIP_NO_ENGINE": "1"}, _FULL + " or dc_offset")],
-    ids=["grid7", "grid33", "grid200_7b", "three_launches"])
+    ({"LLAMAHIP_ENGINE_GRID": "7", "LLAMAHIP_ENGINE_SPLIT": "1"}, _SMALL + " or dc_offset"), ({"LLAMAHIP_ENGINE_GRID": "33"}, _SMALL + " or dc_offset"),
+    ({"LLAMAHIP_ENGINE_SPLIT": "1"}, _SMALL + " or dc_offset"),
+    ({"LLAMAHIP_ENGINE_GRID": "200", "LLAMAHIP_ENGINE_SPLIT": "0"}, "greedy_trace_128 or dc_offset or 7b_logits"), ({"LLAMAHIP_NO_ENGINE": "1"}, _FULL + " or dc_offset")],
+    ids=["grid7_halves", "grid33_units", "default_grid_halves", "grid200_units_7b", "three_launches"])
 def test_ffn_engine_work_splits_and_the_three_launch_fallback(switch, select):
     """The feed-forward half of a decode layer runs as ONE persistent launch (k_ffn_engine, ffn_engine.hip: loader wave + consumer
     waves per CU, the row h and the FFN activation's Q4_0 operand handed between workgroups as tagged granules).  Its work split
     follows the grid: wo / w2 row-group g on workgroup g % G, w1|w3 units contiguous -- so a Q4_0 block of the FFN activation may
     straddle 2-4 workgroups (partial amax exchange).  The default grid of the small models is one unit per workgroup (every block
     straddles four); LLAMAHIP_ENGINE_GRID re-runs the parity tests with 7 / 33 workgroups (several row-groups and units per
-    workgroup, ring wrap-around, ragged splits) and the 7B tests with 200 (uneven 2 / 3 row-groups, 6 / 7 units).  LLAMAHIP_NO_ENGINE
+    workgroup, ring wrap-around, ragged splits) and the 7B tests with 200 (uneven 2 / 3 row-groups, 6 / 7 units).  The split of
+    w1|w3 comes in two schemes (ffn_engine.hip build_units: half blocks -- pairs of workgroups share one block -- or balanced
+    units); LLAMAHIP_ENGINE_SPLIT forces the one the shape would not pick (the 7B default is half blocks).  LLAMAHIP_NO_ENGINE
     keeps the three launches the engine replaces (what mailbox-fed pipeline layers and co-resident handles run).
     Switches are read once per process, hence the subprocess; same parity tests, same oracle."""
     import subprocess
