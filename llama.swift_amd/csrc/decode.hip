@@ -1394,8 +1394,6 @@ __global__ void k_advance(int32_t *__restrict__ st) {
 }
 
 hipError_t set_phase_probe(unsigned long long *dev_buf) {
-    hipError_t e = set_phase_probe_engine(dev_buf);
-    if (e != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_probe), &dev_buf, sizeof(dev_buf));
 }
 
@@ -1901,7 +1899,6 @@ hipError_t init_kernel_attrs() {
     hipError_t e;
     if ((e = init_attrs_prep()) != hipSuccess) return e;
     if ((e = init_attrs_decode()) != hipSuccess) return e;
-    if ((e = init_attrs_engine()) != hipSuccess) return e;
     if ((e = init_attrs_prompt_gemm()) != hipSuccess) return e;
     return init_attrs_prompt_attn();
 }

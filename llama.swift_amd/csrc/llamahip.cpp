@@ -7,7 +7,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -175,12 +174,6 @@ struct llamahip_model {
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
     uint64_t *d_pvx = nullptr;           // tagged partial sums of k_dec_pv_stream's split workgroups: [H dh/32][32 threads of the split][32]
-    // the feed-forward half of a decode layer as one persistent launch (ffn_engine.hip): per-layer weights in engine order + hand-off granules
-    FfnEngGeom eng_geom;
-    std::vector<uint8_t *> eng_w;        // [layer - l0], null where the copy could not be built
-    uint64_t *d_eng_t = nullptr;         // tagged hand-off buffers: h [d] | amax [F/8] | act [F/8] | d2 [F/32]
-    int32_t *d_eng_utab = nullptr;       // the w1|w3 work split (ffn_engine_geometry)
-    bool counted_live = false;           // this handle is counted in g_live_handles (engine launches need the GPU's CUs to themselves)
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
     double *npart_a = nullptr, *npart_b = nullptr;   // norm statistics handed between decode launches: [NORM_PART_MAX]{sum, sum2}
@@ -213,10 +206,6 @@ struct llamahip_model {
 };
 
 static void free_dev(void *p) { if (p) (void) hipFree(p); }
-// Handles with device state alive in this process, per device.  The persistent feed-forward launch (ffn_engine.hip) needs every one of
-// its workgroups resident at once; two such launches from two handles' streams could each hold half of the CUs and wait for the other
-// half until their bounded polls give up.  So the engine runs only while its handle is the only one on the device (forward()).
-static std::atomic<int> g_live_handles[64];
 // A pipeline mailbox is polled by this GPU's kernels while ANOTHER GPU's kernel stores into it over xGMI.  Ordinary hipMalloc
 // memory is coarse-grained: the local L2 may keep serving a line it cached on an earlier look, and coherence with other agents is
 // only promised at kernel boundaries.  Uncached (else fine-grained) device memory is what in-kernel flags between GPUs need;
@@ -247,9 +236,6 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    for (uint8_t *e : eng_w) free_dev(e);
-    free_dev(d_eng_t); free_dev(d_eng_utab);
-    if (counted_live) g_live_handles[device & 63].fetch_sub(1);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_pvx);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
@@ -566,7 +552,6 @@ static int attn_sched_at(const llamahip_model *m, int pos) {
     if (two_from >= 0 && pos >= two_from) return 1;
     return 0;
 }
-static bool engine_live(const llamahip_model *m) { return m->eng_geom.G > 0 && !m->eng_w.empty() && g_live_handles[m->device & 63].load() <= 1; }
 int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hidden_in, bool state_on_device,
             bool want_all, int dump_layer, DumpSink *sink, char *err, size_t err_cap, const StepIO *io = nullptr, int chunk = 0) {
     const HParams &hp = m->hp;
@@ -605,10 +590,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     const bool two_attn = fused && (m->attn_sched == 1 || (m->attn_sched == 2 && !long_attn));
     const bool use_qkvx = !long_attn && !two_attn && fused && m->d_attn_sync && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
     const bool pv_split = long_attn && m->d_pvx && m->l1 - m->l0 <= TAG_MAX_LAYERS;          // (its tags are (epoch, layer) too)
-    // the feed-forward half as one persistent launch (ffn_engine.hip): needs the GPU's CUs to itself -> only while this is the only
-    // handle with device state on the device (see g_live_handles)
-    const bool use_eng = fused && engine_live(m);
-    const bool use_epoch = use_qkvx || pv_split || use_eng;
+    const bool use_epoch = use_qkvx || pv_split;
     if (use_epoch && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (io && fused && io->mb_token && m->first_stage && !use_part) { set_err(err, err_cap, "pipeline mailboxes need the default norm-statistics mode (LLAMAHIP_NORM_MODE unset)"); return LLAMAHIP_ERR_PREDICT; }
     if (m->first_stage) {
@@ -657,15 +639,6 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             HIP_TRY(launch_gemv(L.qkv, PREP_NORM, EPI_STORE, nullptr, nullptr, xa, L.attention_norm, m->qkv, nullptr, m->T_silu, nullptr, nullptr, st, &np_qkv, mbi), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_dec_attn(m->qkv, d, H, C, nth, m->sincos, Kl, Vl, m->sc, m->part, nullptr, m->qa1_A, m->qa1_d, m->T_exp, state, st, two_attn ? nullptr : m->d_attn_sync, m->d_fault, long_attn,
                                     pv_split ? m->d_pvx : nullptr, m->d_epoch, il - m->l0), LLAMAHIP_ERR_PREDICT);
-            }
-            if (use_eng && !mbi && !mbo && m->eng_w[il - m->l0]) {
-                const FfnEngGeom &eg = m->eng_geom;
-                uint64_t *t = m->d_eng_t;
-                const FfnEngIO eio = { m->eng_w[il - m->l0], m->d_eng_utab, m->qa1_A, m->qa1_d, xa, xo, L.ffn_norm, m->T_silu, t, t + d, t + d + eg.U, t + d + 2 * (size_t) eg.U,
-                                       m->d_epoch, il - m->l0, m->npart_a, m->d_fault };
-                HIP_TRY(launch_ffn_engine(eg, eio, st), LLAMAHIP_ERR_PREDICT);
-                n_part_x = use_part ? eg.G : 0;
-                continue;
             }
             HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo, mbi), LLAMAHIP_ERR_PREDICT);
             if (m->w13_interleaved) {
@@ -775,7 +748,7 @@ dump_fail:
 int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
     if (m->h_fault && *(volatile uint32_t *) m->h_fault) {
         *(volatile uint32_t *) m->h_fault = 0;
-        set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch or the persistent feed-forward launch) timed out; LLAMAHIP_NO_ATTN_X=1 / LLAMAHIP_NO_ENGINE=1 select the launches without them");
+        set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch, or between the overlapped decode launches) timed out; LLAMAHIP_NO_ATTN_X=1 selects the attention launches without them (the overlapped schedule is opt-in: LLAMAHIP_OVERLAP)");
         return LLAMAHIP_ERR_PREDICT;
     }
     return 0;
@@ -1020,35 +993,6 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipMemset(m->qa2_d, 0, Kp_F / 32 * 4), LLAMAHIP_ERR_LOAD);
     }
 
-    // ---- the persistent feed-forward launch of the decode step: a second copy of wo / w1|w3 / w2 per layer in the order its loader
-    // streams them (ffn_engine.hip).  Skipped silently when device memory does not allow it (the three launches remain).
-    m->counted_live = true;
-    g_live_handles[m->device & 63].fetch_add(1);
-    if (!m->dense && m->w13_interleaved && !getenv("LLAMAHIP_NO_ENGINE") && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS) {
-        std::vector<int32_t> utab;
-        const FfnEngGeom g = ffn_engine_geometry(d, F, &utab);
-        if (g.G > 0) {
-            const size_t nt = (size_t) d + 2 * (size_t) g.U + (size_t) F / 32;
-            bool ok = hipMalloc((void **) &m->d_eng_t, nt * 8) == hipSuccess && hipMemset(m->d_eng_t, 0, nt * 8) == hipSuccess &&
-                      hipMalloc((void **) &m->d_eng_utab, utab.size() * 4) == hipSuccess && hipMemcpy(m->d_eng_utab, utab.data(), utab.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-            m->eng_w.assign(m->l1 - m->l0, nullptr);
-            for (int il = m->l0; ok && il < m->l1; il++) {
-                const Layer &L = m->layers[il - m->l0];
-                uint8_t *e = nullptr;
-                if (hipMalloc((void **) &e, g.bytes()) != hipSuccess) { ok = false; break; }
-                m->eng_w[il - m->l0] = e;
-                if (hipMemsetAsync(e, 0, g.bytes(), m->stream) != hipSuccess || launch_tiles_to_engine(g, m->d_eng_utab, L.wo, L.w13, L.w2, e, m->stream) != hipSuccess) { ok = false; break; }
-                m->weight_bytes += (int64_t) g.bytes();
-            }
-            if (ok) m->eng_geom = g;
-            else {
-                (void) hipGetLastError();
-                for (uint8_t *&e : m->eng_w) { free_dev(e); e = nullptr; }
-                m->eng_w.clear();
-            }
-        }
-    }
-
     rc = ensure_workspace(m.get(), 16, err, err_cap);
     if (rc != 0) return LLAMAHIP_ERR_LOAD;
     if (getenv("LLAMAHIP_EAGER_PREFILL_COPY") && ensure_prompt_copies(m.get(), PROMPT_COPY_MIN_ROWS, err, err_cap) != 0) return LLAMAHIP_ERR_LOAD;
@@ -1263,7 +1207,7 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         // k_argmax advances them, so the same executable graph is replayed n_steps times.
         for (int i = 0; i < n_steps; i++) {
             m->attn_sched = attn_sched_at(m, n_past + i);
-            const int gkey = nth * 4096 + m->cur_seq + (m->attn_sched << 24) + (engine_live(m) ? 1 << 27 : 0);      // (graphs are captured per launch schedule)
+            const int gkey = nth * 4096 + m->cur_seq + (m->attn_sched << 24);
             auto it = m->decode_graphs.find(gkey);
             if (it == m->decode_graphs.end()) {
                 hipGraph_t graph = nullptr;
@@ -1485,7 +1429,7 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
         if (rc) return rc;
     } else {
         m->attn_sched = attn_sched_at(m, sl.next_pos);
-        const int gkey = nth + (m->attn_sched << 16) + (engine_live(m) ? 1 << 20 : 0);
+        const int gkey = nth + (m->attn_sched << 16);
         auto it = sl.graphs.find(gkey);
         if (it == sl.graphs.end()) {
             // One step of this stage (embed | stream in -> layers -> stream out | lm head + argmax)

@@ -4,8 +4,6 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include <vector>
-
 namespace lh {
 
 constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 64 fp32 scales
@@ -153,23 +151,5 @@ hipError_t launch_topk_candidates(const float *logits, int V, const int32_t *win
                                   double *out_score, int32_t *out_id, int32_t *flags, hipStream_t st, void *ws = nullptr);      // ws: TOPK_WS_BYTES zeroed once -> the two-launch variant
 constexpr size_t TOPK_WS_BYTES = 32768 * 8 + 64 * 8 + 64;
 hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, int32_t *next_token, int32_t *state, hipStream_t st, uint64_t *token_mb = nullptr);
-
-// ---- the feed-forward half of a decode layer as one persistent launch (ffn_engine.hip) ----
-struct FfnEngGeom {
-    int G = 0;                          // workgroups (0: the engine does not apply to this shape / device)
-    int d = 0, F = 0, ncd = 0, nqd = 0, ncF = 0, nqF = 0, R = 0, U = 0, S = 0, maxrg = 0, maxu = 0, Qmax = 0, scheme = 0;
-    size_t lds = 0;
-    size_t bytes() const { return (size_t) Qmax * G * 5120; }       // one layer's weights in engine order
-};
-struct FfnEngIO {
-    const uint8_t *eng; const int32_t *utab; const uint32_t *qa_A; const float *qa_d;
-    const float *x_in; float *x_out; const float *norm_w; const uint16_t *T_silu;
-    uint64_t *h_t, *amax_t, *act_t, *d2_t; const uint32_t *epoch; int layer; double *part_out; uint32_t *fault;
-};
-FfnEngGeom ffn_engine_geometry(int d, int F, std::vector<int32_t> *utab);      // utab: the work split for the device, [G][maxu + 1]
-hipError_t launch_tiles_to_engine(const FfnEngGeom &g, const int32_t *d_utab, const QMat &wo, const QMat &w13, const QMat &w2, uint8_t *eng, hipStream_t st);
-hipError_t launch_ffn_engine(const FfnEngGeom &g, const FfnEngIO &io, hipStream_t st);
-hipError_t init_attrs_engine();
-hipError_t set_phase_probe_engine(unsigned long long *dev_buf);
 
 }  // namespace lh

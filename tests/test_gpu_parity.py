@@ -311,31 +311,6 @@ def test_decode_attention_fallback_paths(switch, select):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-
-@pytest.mark.parametrize("switch,select", [
-    ({"LLAMAHIP_ENGINE_GRID": "7", "LLAMAHIP_ENGINE_SPLIT": "1"}, _SMALL + " or dc_offset"), ({"LLAMAHIP_ENGINE_GRID": "33"}, _SMALL + " or dc_offset"),
-    ({"LLAMAHIP_ENGINE_SPLIT": "1"}, _SMALL + " or dc_offset"),
-    ({"LLAMAHIP_ENGINE_GRID": "200", "LLAMAHIP_ENGINE_SPLIT": "0"}, "greedy_trace_128 or dc_offset or 7b_logits"), ({"LLAMAHIP_NO_ENGINE": "1"}, _FULL + " or dc_offset")],
-    ids=["grid7_halves", "grid33_units", "default_grid_halves", "grid200_units_7b", "three_launches"])
-def test_ffn_engine_work_splits_and_the_three_launch_fallback(switch, select):
-    """The feed-forward half of a decode layer runs as ONE persistent launch (k_ffn_engine, ffn_engine.hip: loader wave + consumer
-    waves per CU, the row h and the FFN activation's Q4_0 operand handed between workgroups as tagged granules).  Its work split
-    follows the grid: wo / w2 row-group g on workgroup g % G, w1|w3 units contiguous -- so a Q4_0 block of the FFN activation may
-    straddle 2-4 workgroups (partial amax exchange).  The default grid of the small models is one unit per workgroup (every block
-    straddles four); LLAMAHIP_ENGINE_GRID re-runs the parity tests with 7 / 33 workgroups (several row-groups and units per
-    workgroup, ring wrap-around, ragged splits) and the 7B tests with 200 (uneven 2 / 3 row-groups, 6 / 7 units).  The split of
-    w1|w3 comes in two schemes (ffn_engine.hip build_units: half blocks -- pairs of workgroups share one block -- or balanced
-    units); LLAMAHIP_ENGINE_SPLIT forces the one the shape would not pick (the 7B default is half blocks).  LLAMAHIP_NO_ENGINE
-    keeps the three launches the engine replaces (what mailbox-fed pipeline layers and co-resident handles run).
-    Switches are read once per process, hence the subprocess; same parity tests, same oracle."""
-    import subprocess
-    import sys
-    env = dict(os.environ, **switch)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", select],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("shape", ["small", "7b_width"])
 def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape):
     """The decode kernels' norm prologue computes the second moment in one pass (S2 - mean * S1, from the producer's partial sums)
@@ -385,14 +360,12 @@ def test_production_fallbacks_and_selectable_variants(env):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("which", [{"LLAMAHIP_HANDOFF_FAULT_TEST": "1"}, {"LLAMAHIP_HANDOFF_FAULT_TEST": "4", "LLAMAHIP_ATTN_LONG_FROM": "0"},
-                                   {"LLAMAHIP_HANDOFF_FAULT_TEST": "5"}])
+@pytest.mark.parametrize("which", [{"LLAMAHIP_HANDOFF_FAULT_TEST": "1"}, {"LLAMAHIP_HANDOFF_FAULT_TEST": "4", "LLAMAHIP_ATTN_LONG_FROM": "0"}])
 def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b, which):
     """The tagged hand-offs of the decode step are bounded polls; one that runs out raises a sticky fault word in
     pinned host memory and the next synchronisation returns PredictionFailed.  LLAMAHIP_HANDOFF_FAULT_TEST=1 makes the
     mat-vec role of k_qkv_attn publish a tag nobody waits for and shortens the polls (read once per process: subprocess);
-    =4 does the same to the split workgroups of the long-context soft_max . V (k_dec_pv_stream), run here from position 0;
-    =5 to the persistent feed-forward launch (k_ffn_engine: the row h is published under a wrong tag, every edge's polls are short)."""
+    =4 does the same to the split workgroups of the long-context soft_max . V (k_dec_pv_stream), run here from position 0."""
     import subprocess
     import sys
     code = (
