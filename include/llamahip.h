@@ -197,6 +197,14 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
 int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_t *tokens, int32_t cap,
                          char *err, size_t err_cap);
 
+/* One decode step for a SET of bound slots at once: the result is bit for bit that of n_seqs llamahip_stage_step calls, one per slot
+ * (every operator of llama_eval's graph works row by row, .mm:563-705; each row keeps its own position, KV cache and V*P key split of
+ * its own single-token eval, ggml.c:5459-5480) -- but every weight matrix is streamed ONCE per step for all the sequences, which is
+ * what a decode step costs ("throughput scales only with independent sequences in flight").  2 .. 16 distinct
+ * slots, each bound with plain buffers (no mailbox); one graph is captured per (set, n_threads).  n_seqs = 1 is llamahip_stage_step. */
+int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_seqs, int32_t n_threads, void *stream,
+                            char *err, size_t err_cap);
+
 /* Device-side mailboxes between pipeline stages: instead of the caller moving hidden_out -> hidden_in (and token_out -> token_in)
  * between stages with a collective per token, the LAST kernel of a stage step stores the residual-stream row (.mm:563-564, 687-690)
  * straight into the NEXT stage's inbox -- memory of the next stage's process / GPU, peer-mapped through HIP IPC (xGMI stores between
@@ -215,6 +223,10 @@ int llamahip_stage_mailbox(llamahip_model *m, int32_t seq, void **hidden_inbox, 
                            void *hidden_handle64, void *token_handle64, char *err, size_t err_cap);
 int llamahip_stage_mailbox_connect(llamahip_model *m, int32_t seq, const void *next_hidden_handle64, void *next_hidden_ptr,
                                    const void *token_handle64, void *token_ptr, char *err, size_t err_cap);
+
+/* Row `row` of the logits the most recent step / eval left on the device (last stage; waits for the device): row 0 after
+ * llamahip_stage_step, row i = the i-th slot of the set after llamahip_stage_step_set.  Parity tooling. */
+int llamahip_stage_logits(llamahip_model *m, int32_t row, float *logits_out, char *err, size_t err_cap);
 
 /* Select which of the handle's n_seq KV caches subsequent evals read and write (default 0). */
 int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap);

@@ -111,6 +111,8 @@ def lib() -> C.CDLL:
     L.llamahip_stage_bind.argtypes = [vp, i32, i32, vp, vp, vp, vp, cp, sz]
     L.llamahip_stage_step.argtypes = [vp, i32, i32, vp, cp, sz]
     L.llamahip_stage_trace.argtypes = [vp, i32, vp, vp, i32, cp, sz]
+    L.llamahip_stage_step_set.argtypes = [vp, vp, i32, i32, vp, cp, sz]
+    L.llamahip_stage_logits.argtypes = [vp, i32, vp, cp, sz]
     L.llamahip_stage_mailbox.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vp, vp, cp, sz]
     L.llamahip_stage_mailbox_connect.argtypes = [vp, i32, vp, vp, vp, vp, cp, sz]
     L.llamahip_quantize_file.argtypes = [cp, cp, i32, cp, sz]
@@ -316,6 +318,20 @@ class Model:
         """Enqueue one token step of this stage on `stream` (hipStream_t address, 0 = the null stream); asynchronous."""
         err = C.create_string_buffer(256)
         _check(lib().llamahip_stage_step(self._h, seq, n_threads, C.c_void_p(stream), err, len(err)), err)
+
+    def stage_step_set(self, seqs, n_threads: int = 8, stream: int = 0):
+        """One decode step for all the slots in `seqs` at once (bit-identical to stepping them one by one; the weights are
+        streamed once for the whole set); asynchronous like stage_step."""
+        err = C.create_string_buffer(1024)
+        sq = np.ascontiguousarray(seqs, dtype=np.int32)
+        _check(lib().llamahip_stage_step_set(self._h, _ptr(sq), len(sq), n_threads, C.c_void_p(stream), err, len(err)), err)
+
+    def stage_logits(self, row: int = 0) -> np.ndarray:
+        """Row `row` of the logits of the most recent step (waits for the device)."""
+        err = C.create_string_buffer(1024)
+        out = np.empty(self.n_vocab, np.float32)
+        _check(lib().llamahip_stage_logits(self._h, row, _ptr(out), err, len(err)), err)
+        return out
 
     def stage_trace(self, seq: int, cap: int = 0):
         """Waits for the device.  Returns (steps taken since bind, current position, tokens picked [last stage])."""

@@ -696,9 +696,10 @@ k_dec_scores(const float *__restrict__ qkv, int d, int dh, const double *__restr
 // and reduction tree as k_dec_scores / k_attn.   sc: [row][head][n_ctx]
 __global__ void __launch_bounds__(256)
 k_decn_scores(const float *__restrict__ qr, int d, int dh, const float *__restrict__ Kc, float *__restrict__ sc,
-              int n_ctx, float kq_scale, int n_past) {
+              int n_ctx, float kq_scale, int n_past, const SeqSet *__restrict__ set) {
     const int h = blockIdx.x, n = blockIdx.z, H = gridDim.x;
-    const int np = n_past + n;
+    const int np = set ? set->state[n][0] : n_past + n;         // (set: row n is the next token of its own sequence)
+    if (set) Kc += set->kv_off[n];
     const int t0 = blockIdx.y * DEC_TS;
     if (t0 > np) return;
     const int tid = threadIdx.x, hw = tid >> 5, l = tid & 31;
@@ -781,13 +782,15 @@ __global__ void __launch_bounds__(1024)
 k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth,
              float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
              const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st,
-             int n_past0, long qa_strideA, long qa_strideD, int lut_math, int chunk) {
+             int n_past0, long qa_strideA, long qa_strideD, int lut_math, int chunk, const SeqSet *__restrict__ set) {
     extern __shared__ double smem_d[];
     double *red = smem_d;
     float *p = (float *) (smem_d + 32);
     float *part = p + n_ctx;
     const int h = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const int n_past = MULTI ? n_past0 + (int) blockIdx.z : st[0];
+    // (MULTI with a set: row blockIdx.z is a single-row eval of its own sequence -- own position, own cache, own key split)
+    const int n_past = MULTI ? (set ? set->state[blockIdx.z][0] : n_past0 + (int) blockIdx.z) : st[0];
+    if (MULTI && set) Vc += set->kv_off[blockIdx.z];
     const int T = n_past + 1;
     const float *row = sc + (size_t) h * n_ctx;
     if (MULTI) {
@@ -808,8 +811,8 @@ k_dec_pv_blk(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     // a chunk row is as long as the whole chunk's context (ggml.c:5459-5480 splits n_past + N keys over the
     // threads for every row); the masked tail has weight exp(-inf) = 0 and is walked like the reference does
     // (a chunked pass -- prompt_attn.hip split_keys -- stands for successive evals of `chunk` rows: the row's own eval ends with its chunk)
-    const int Tpv = MULTI ? (chunk > 0 ? n_past0 + min((int) gridDim.z, ((int) blockIdx.z / chunk + 1) * chunk) : n_past0 + (int) gridDim.z) : T;
-    if (MULTI)
+    const int Tpv = (MULTI && !set) ? (chunk > 0 ? n_past0 + min((int) gridDim.z, ((int) blockIdx.z / chunk + 1) * chunk) : n_past0 + (int) gridDim.z) : T;
+    if (MULTI && !set)
         for (int t = T + tid; t < Tpv; t += nt) p[t] = 0.0f;
     __syncthreads();
 
@@ -1393,6 +1396,55 @@ __global__ void k_advance(int32_t *__restrict__ st) {
     if (threadIdx.x == 0) { st[0] += 1; st[1] += 1; }
 }
 
+// batched decode step (SeqSet): one workgroup per row -- k_argmax on the row's logits with the row's slot state, trace and pick buffer
+__global__ void __launch_bounds__(1024)
+k_argmax_set(const float *__restrict__ logits, int V, const SeqSet *__restrict__ set) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    logits += (size_t) b * V;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i0 = tid; i0 < V; i0 += 32 * nt) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) v[u] = logits[min(i0 + u * nt, V - 1)];
+#pragma unroll
+        for (int u = 0; u < 32; u++) {
+            const int i = i0 + u * nt;
+            if (i < V) argmax_take(best, idx, v[u], i);       // ascending i: a tie keeps the lower index
+        }
+    }
+    argmax_dpp<DPP_QUAD_XOR1>(best, idx);
+    argmax_dpp<DPP_QUAD_XOR2>(best, idx);
+    argmax_dpp<DPP_ROW_HALF_MIRROR>(best, idx);
+    argmax_dpp<DPP_ROW_MIRROR>(best, idx);
+    {
+        const int vb = __builtin_bit_cast(int, best);
+        float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 0));
+        int wi = __builtin_amdgcn_readlane(idx, 0);
+        argmax_take(wv, wi, __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 16)), __builtin_amdgcn_readlane(idx, 16));
+        argmax_take(wv, wi, __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 32)), __builtin_amdgcn_readlane(idx, 32));
+        argmax_take(wv, wi, __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 48)), __builtin_amdgcn_readlane(idx, 48));
+        if ((tid & 63) == 0) { bv[tid >> 6] = wv; bi[tid >> 6] = wi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float v = bv[0];
+        int i = bi[0];
+        for (int w = 1; w < (nt >> 6); w++) argmax_take(v, i, bv[w], bi[w]);
+        const int r = i == 0x7fffffff ? 0 : i;
+        int32_t *st = set->state[b];
+        set->trace[b][st[1]] = r;
+        if (set->tok_out[b]) *set->tok_out[b] = r;
+        st[0] += 1; st[1] += 1;
+    }
+}
+__global__ void k_advance_set(const SeqSet *__restrict__ set, int n) {
+    const int b = threadIdx.x;
+    if (b < n) { int32_t *st = set->state[b]; st[0] += 1; st[1] += 1; }
+}
+
 hipError_t set_phase_probe(unsigned long long *dev_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_probe), &dev_buf, sizeof(dev_buf));
 }
@@ -1566,16 +1618,16 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
 //   sc : scratch of N * H * n_ctx floats
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
-                             const uint16_t *T_exp, hipStream_t st, int chunk) {
-    const int dh = d / H, T = n_past + N;
+                             const uint16_t *T_exp, hipStream_t st, int chunk, const SeqSet *set) {
+    const int dh = d / H, T = set ? n_ctx : n_past + N;      // (set: positions live on the device -- every key slice is launched, those beyond a row's position return at once)
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     const int Kp = (d + 255) / 256 * 256;
-    hipLaunchKernelGGL(k_decn_scores, dim3(H, (T + DEC_TS - 1) / DEC_TS, N), dim3(256), 0, st, qr, d, dh, Kc, sc, n_ctx, kq_scale, n_past);
+    hipLaunchKernelGGL(k_decn_scores, dim3(H, (T + DEC_TS - 1) / DEC_TS, N), dim3(256), 0, st, qr, d, dh, Kc, sc, n_ctx, kq_scale, n_past, set);
     LH_LAUNCH_CHECK();
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
     hipLaunchKernelGGL(k_dec_pv_blk<true>, dim3(H, dh / 32, N), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp,
-                       (const int32_t *) nullptr, n_past, (long) Kp / 4, (long) Kp / 32, g_lut_math, chunk);
+                       (const int32_t *) nullptr, n_past, (long) Kp / 4, (long) Kp / 32, g_lut_math, chunk, set);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1672,7 +1724,7 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
     LH_LAUNCH_CHECK();
     const int nt = (32 * (nth < 32 ? nth : 32) + 63) / 64 * 64;      // whole waves: the DPP reductions need every lane live
     const size_t lds = 32 * sizeof(double) + ((size_t) n_ctx + (size_t) nth * 32 + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L, g_lut_math, 0);
+    hipLaunchKernelGGL(k_dec_pv_blk<false>, dim3(H, dh / 32), dim3(nt), lds, st, sc, Vc, d, dh, n_ctx, nth, merged, qa_A, qa_d, T_exp, state, 0, 0L, 0L, g_lut_math, 0, (const SeqSet *) nullptr);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1884,6 +1936,16 @@ hipError_t launch_argmax(const float *logits, int V, int32_t *out, int out_idx, 
 }
 
 
+hipError_t launch_argmax_set(const float *logits, int V, const SeqSet *set, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_argmax_set, dim3(n), dim3(1024), 0, st, logits, V, set);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_advance_set(const SeqSet *set, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_advance_set, dim3(1), dim3(64), 0, st, set, n);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
 hipError_t launch_advance(int32_t *state, hipStream_t st) {
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, state);
     LH_LAUNCH_CHECK();

@@ -195,6 +195,10 @@ struct llamahip_model {
         std::map<int, hipGraphExec_t> graphs;                   // keyed by nth + (attention schedule << 16)
     };
     std::vector<StageSlot> slots;        // one per sequence slot
+    // batched decode steps over a SET of slots (llamahip_stage_step_set): one captured graph + device-resident row descriptor per set
+    struct SetGraph { SeqSet *d_set = nullptr; hipGraphExec_t exec = nullptr; };
+    std::map<std::vector<int>, SetGraph> set_graphs;      // key: {n_threads, slot ids...}
+    float *set_sc = nullptr;             // attention scores of a set step: [SET_MAX][H][n_ctx]
     int32_t *d_slot_state = nullptr;     // [n_seq][2]: {position, step index}, advanced on the device
     int32_t *d_slot_trace = nullptr;     // [n_seq][n_ctx]: tokens picked by the last stage
 
@@ -247,6 +251,8 @@ llamahip_model::~llamahip_model() {
         if (sl.peer_token && sl.peer_token_ipc) (void) hipIpcCloseMemHandle(sl.peer_token);
         free_dev(sl.inbox_hidden); free_dev(sl.inbox_token);
     }
+    for (auto &kv : set_graphs) { if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec); free_dev(kv.second.d_set); }
+    free_dev(set_sc);
     free_dev(d_slot_state); free_dev(d_slot_trace);
     free_dev(attn_ws.S); free_dev(attn_ws.pmax); free_dev(attn_ws.inv); free_dev(attn_ws.part);
     if (stream) (void) hipStreamDestroy(stream);
@@ -378,10 +384,15 @@ int upload_f32(llamahip_model *m, const std::string &name, float **dst, char *er
     return 0;
 }
 
+void drop_set_graphs(llamahip_model *m) {
+    for (auto &kv : m->set_graphs) { if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec); free_dev(kv.second.d_set); }
+    m->set_graphs.clear();
+}
 int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N <= m->ws_cap) return 0;
     // captured graphs hold the old workspace pointers
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    drop_set_graphs(m);
     for (auto &kv : m->decode_graphs) (void) hipGraphExecDestroy(kv.second);
     m->decode_graphs.clear();
     for (auto &sl : m->slots) {
@@ -1274,6 +1285,7 @@ int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
         HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
         for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
         sl.graphs.clear();
+        drop_set_graphs(m);
     }
     sl.token_in = (int32_t *) token_in; sl.token_out = (int32_t *) token_out;
     sl.hidden_in = (const float *) hidden_in; sl.hidden_out = (float *) hidden_out;
@@ -1454,6 +1466,121 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
     return LLAMAHIP_OK;
 }
 
+namespace {
+// One decode step for B rows = B sequences (device-resident descriptor `d_set`): the 2..60-row schedule of forward() -- every operator of
+// llama_eval's graph works row by row (.mm:563-705), so row b is bit for bit a single-token llama_eval of its sequence: its own
+// position in RoPE / the KV append / the causal range, its own cache, and the V*P key split of ITS eval, n_past_b + 1 keys over
+// n_threads (ggml.c:5459-5480).  The weights are streamed once per step for all rows.
+int forward_set(llamahip_model *m, int nth, const SeqSet *d_set, int B, char *err, size_t err_cap) {
+    const HParams &hp = m->hp;
+    const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx, V = hp.n_vocab;
+    hipStream_t st = m->stream;
+    if (m->first_stage) HIP_TRY(launch_embed_set(d_set, B, m->tok_emb, m->x, d, st), LLAMAHIP_ERR_PREDICT);                // .mm:558-561
+    else HIP_TRY(launch_rows_set(d_set, B, m->x, d, true, st), LLAMAHIP_ERR_PREDICT);
+    const long KpF = ((long) F + 255) / 256 * 256;
+    for (int il = m->l0; il < m->l1; il++) {
+        const Layer &L = m->layers[il - m->l0];
+        float *Kl = m->Kc + (size_t) (il - m->l0) * C * d, *Vl = m->Vc + (size_t) (il - m->l0) * C * d;      // slot 0's cache of this layer; rows add their slot's offset
+        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
+        RopeKvArgs ra = { m->sincos, m->qr, Kl, Vl, 0, d, dh };
+        ra.set = d_set;
+        HIP_TRY(launch_gemm_rope_kv(L.qkv, m->qa_A, m->qa_d, B, ra, st), LLAMAHIP_ERR_PREDICT);                                // .mm:580-611
+        HIP_TRY(launch_attn_short(m->qr, Kl, Vl, m->set_sc, nullptr, m->qa_A, m->qa_d, 0, B, d, H, C, nth, m->T_exp, st, 0, d_set), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
+        HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, B, m->x1, d, m->x, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);  // .mm:649-654
+        HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
+        if (m->w13_interleaved && gemm_silu_qa_applies(L.w13, B)) {
+            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, B, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st), LLAMAHIP_ERR_PREDICT);       // .mm:668-680
+            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, B, m->x, d, m->x1, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);                 // .mm:682-687
+        } else {
+            HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, B, m->gu, 2L * F, nullptr, 0, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_prep(PREP_SILU_MUL, m->gu, m->gu + F, 2L * F, 2L * F, F, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qa_A, m->qa_d, B, m->x, d, m->x1, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);
+        }
+    }
+    if (m->last_stage) {
+        HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);          // .mm:695-705
+        HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, B, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(launch_argmax_set(m->logits, V, d_set, B, st), LLAMAHIP_ERR_PREDICT);
+    } else {
+        HIP_TRY(launch_rows_set(d_set, B, m->x, d, false, st), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(launch_advance_set(d_set, B, st), LLAMAHIP_ERR_PREDICT);
+    }
+    return 0;
+}
+}  // namespace
+
+int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_seqs, int32_t n_threads, void *stream, char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    if (!seqs || n_seqs < 1 || n_seqs > SET_MAX) { set_err(err, err_cap, "llamahip_stage_step_set: 1 .. %d slots per step (got %d)", SET_MAX, n_seqs); return LLAMAHIP_ERR_PREDICT; }
+    if (n_seqs == 1) return llamahip_stage_step(m, seqs[0], n_threads, stream, err, err_cap);
+    const HParams &hp = m->hp;
+    const int d = hp.n_embd, H = hp.n_head, dh = d / H, C = hp.n_ctx;
+    const int nth = std::max(1, std::min(n_threads, 64));
+    for (int i = 0; i < n_seqs; i++) {
+        const int sq = seqs[i];
+        if (sq < 0 || sq >= (int32_t) m->slots.size() || !m->slots[sq].bound) { set_err(err, err_cap, "sequence slot %d is not bound (llamahip_stage_bind)", sq); return LLAMAHIP_ERR_PREDICT; }
+        for (int j = 0; j < i; j++) if (seqs[j] == sq) { set_err(err, err_cap, "sequence slot %d appears twice in the set", sq); return LLAMAHIP_ERR_PREDICT; }
+        const auto &sl = m->slots[sq];
+        if (sl.next_pos >= C) { set_err(err, err_cap, "context overflow: n_past (%d) + n_tokens (1) > n_ctx (%d)", sl.next_pos, C); return LLAMAHIP_ERR_PREDICT; }
+        if ((!m->first_stage && !sl.hidden_in) || (!m->last_stage && !sl.hidden_out)) { set_err(err, err_cap, "slot %d runs on its mailboxes: set steps need slots bound with hidden_in / hidden_out buffers", sq); return LLAMAHIP_ERR_PREDICT; }
+    }
+    if (m->dense || (m->flags & LLAMAHIP_FLAG_UNFUSED) || m->l1 <= m->l0 || dh % 32 != 0 || dh > 256 || nth > 32 || !gemm_rope_kv_applies(m->layers[0].qkv, n_seqs, d)) {
+        set_err(err, err_cap, "llamahip_stage_step_set needs a Q4_0 handle with layers, a head size that is a multiple of 32 (<= 256) and n_threads <= 32: step the slots one by one");
+        return LLAMAHIP_ERR_PREDICT;
+    }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    int rc = ensure_workspace(m, SET_MAX, err, err_cap);
+    if (rc) return rc;
+    if (!m->set_sc) HIP_TRY(hipMalloc((void **) &m->set_sc, (size_t) SET_MAX * H * C * 4), LLAMAHIP_ERR_PREDICT);
+    hipStream_t run_on = (hipStream_t) stream;
+    std::vector<int> key;
+    key.push_back(nth);
+    for (int i = 0; i < n_seqs; i++) key.push_back(seqs[i]);
+    auto it = m->set_graphs.find(key);
+    if (it == m->set_graphs.end()) {
+        SeqSet hs;
+        memset(&hs, 0, sizeof(hs));
+        hs.n = n_seqs;
+        for (int i = 0; i < n_seqs; i++) {
+            const auto &sl = m->slots[seqs[i]];
+            hs.state[i] = m->d_slot_state + 2 * seqs[i];
+            hs.tok_in[i] = sl.token_in; hs.tok_out[i] = sl.token_out;
+            hs.trace[i] = m->d_slot_trace + (size_t) seqs[i] * C;
+            hs.hid_in[i] = sl.hidden_in; hs.hid_out[i] = sl.hidden_out;
+            hs.kv_off[i] = (long) ((size_t) seqs[i] * (m->l1 - m->l0) * C * d);
+        }
+        llamahip_model::SetGraph sg;
+        HIP_TRY(hipMalloc((void **) &sg.d_set, sizeof(SeqSet)), LLAMAHIP_ERR_PREDICT);
+        if (hipMemcpy(sg.d_set, &hs, sizeof(SeqSet), hipMemcpyHostToDevice) != hipSuccess) { free_dev(sg.d_set); set_err(err, err_cap, "HIP error copying the set descriptor"); return LLAMAHIP_ERR_PREDICT; }
+        if (!(m->flags & LLAMAHIP_FLAG_NO_GRAPH)) {
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+            if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { free_dev(sg.d_set); set_err(err, err_cap, "HIP error: stream capture"); return LLAMAHIP_ERR_PREDICT; }
+            rc = forward_set(m, nth, sg.d_set, n_seqs, err, err_cap);
+            hipError_t e2 = hipStreamEndCapture(m->stream, &graph);
+            if (rc || e2 != hipSuccess || hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                if (graph) (void) hipGraphDestroy(graph);
+                free_dev(sg.d_set);
+                if (!rc) set_err(err, err_cap, "HIP error capturing the set step");
+                return rc ? rc : LLAMAHIP_ERR_PREDICT;
+            }
+            (void) hipGraphDestroy(graph);
+        }
+        it = m->set_graphs.emplace(key, sg).first;
+    }
+    if (it->second.exec) HIP_TRY(hipGraphLaunch(it->second.exec, run_on), LLAMAHIP_ERR_PREDICT);
+    else {
+        hipStream_t own = m->stream;
+        m->stream = run_on;
+        rc = forward_set(m, nth, it->second.d_set, n_seqs, err, err_cap);
+        m->stream = own;
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n_seqs; i++) m->slots[seqs[i]].next_pos++;
+    m->n_evals += n_seqs;
+    return LLAMAHIP_OK;
+}
+
 int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_t *tokens, int32_t cap, char *err, size_t err_cap) {
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (seq < 0 || seq >= (int32_t) m->slots.size() || !m->slots[seq].bound) { set_err(err, err_cap, "sequence slot %d is not bound (llamahip_stage_bind)", seq); return LLAMAHIP_ERR_PREDICT; }
@@ -1467,6 +1594,15 @@ int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_
     if (tokens && m->last_stage && n > 0)
         HIP_TRY(hipMemcpy(tokens, m->d_slot_trace + (size_t) seq * m->hp.n_ctx, (size_t) n * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
     return hs[1];
+}
+
+int llamahip_stage_logits(llamahip_model *m, int32_t row, float *logits_out, char *err, size_t err_cap) {
+    if (!m || m->host_only || !logits_out) { set_err(err, err_cap, "bad arguments"); return LLAMAHIP_ERR_PREDICT; }
+    if (!m->last_stage || !m->logits || row < 0 || row >= m->ws_cap) { set_err(err, err_cap, "no logits row %d on this handle", row); return LLAMAHIP_ERR_PREDICT; }
+    HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMemcpy(logits_out, m->logits + (size_t) row * m->hp.n_vocab, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    return check_sync_timeout(m, err, err_cap);
 }
 
 int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap) {

@@ -14,8 +14,23 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 //  hand-offs inside k_qkv_attn, and the residual-stream row between pipeline stages through a device-side mailbox)
 enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PREP_NORM_TAG = 6 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5 };
+// The rows of a BATCHED decode step (llamahip_stage_step_set): row b is the next token of sequence slot b' -- its own position (device
+// resident, so a captured step replays unchanged), its own KV cache, its own token / pick / residual-stream buffers.  Lives in device
+// memory; kernels that take a `const SeqSet *` treat null as "one sequence, consecutive positions" (the prompt-chunk meaning).
+constexpr int SET_MAX = 16;
+struct SeqSet {
+    int32_t *state[SET_MAX];            // {position, step} of the row's slot
+    const int32_t *tok_in[SET_MAX];     // first stage: where the row's token is read
+    int32_t *tok_out[SET_MAX];          // last stage: where the greedy pick goes (may be null)
+    int32_t *trace[SET_MAX];            // last stage: the slot's list of picks
+    const float *hid_in[SET_MAX];       // stages after the first: the row of the residual stream coming in
+    float *hid_out[SET_MAX];            // stages before the last: ... going out
+    long kv_off[SET_MAX];               // elements from slot 0's KV cache to the row's slot's
+    int n;
+};
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
-struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; };
+// (set: row n is at position set->state[n][0] of the cache at Kc / Vc + set->kv_off[n] instead of n_past + n)
+struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; const SeqSet *set = nullptr; };
 
 // a Q4_0 weight matrix resident in HBM in chain-major tile layout
 struct QMat {
@@ -125,7 +140,12 @@ hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const floa
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st);
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
-                             const uint16_t *T_exp, hipStream_t st, int chunk = 0);
+                             const uint16_t *T_exp, hipStream_t st, int chunk = 0, const SeqSet *set = nullptr);      // set: N independent single-row evals (batched decode step)
+// batched decode step: embedding rows / residual rows in and out / greedy picks of the set's rows
+hipError_t launch_embed_set(const SeqSet *set, int n, const uint8_t *emb, float *x, int d, hipStream_t st);
+hipError_t launch_rows_set(const SeqSet *set, int n, float *x, int d, bool gather, hipStream_t st);      // gather: hid_in -> x rows; else x rows -> hid_out
+hipError_t launch_argmax_set(const float *logits, int V, const SeqSet *set, int n, hipStream_t st);   // + trace, tok_out, position advance
+hipError_t launch_advance_set(const SeqSet *set, int n, hipStream_t st);
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
                            float *sc, float *part, float *merged, uint32_t *qa_A, float *qa_d,
                            const uint16_t *T_exp, const int32_t *state, hipStream_t st,

@@ -120,6 +120,30 @@ __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__res
     }
 }
 
+// batched decode step: row n = the token at *set->tok_in[n] (same dequantization as k_embed)
+__global__ void k_embed_set(const SeqSet *__restrict__ set, const uint8_t *__restrict__ emb, float *__restrict__ x, int d) {
+    const int n = blockIdx.x;
+    const int tok = *set->tok_in[n];
+    const uint8_t *row = emb + (size_t) tok * (d / 32) * 20;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < d / 2; i += gridDim.y * blockDim.x) {
+        const int b = i >> 4, j = i & 15;
+        const uint8_t *blk = row + b * 20;
+        const uint32_t bits = blk[0] | (blk[1] << 8) | (blk[2] << 16) | ((uint32_t) blk[3] << 24);
+        const float dd = __builtin_bit_cast(float, bits);
+        const uint32_t q = blk[4 + j];
+        x[(size_t) n * d + 2 * i + 0] = (float) ((int) (q & 0xF) - 8) * dd;
+        x[(size_t) n * d + 2 * i + 1] = (float) ((int) (q >> 4) - 8) * dd;
+    }
+}
+// ... and the residual-stream rows of a pipeline stage's set: hid_in[n] -> x row n (gather) or x row n -> hid_out[n]
+__global__ void k_rows_set(const SeqSet *__restrict__ set, float *__restrict__ x, int d, int gather) {
+    const int n = blockIdx.x;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < d; i += gridDim.y * blockDim.x) {
+        if (gather) x[(size_t) n * d + i] = set->hid_in[n][i];
+        else set->hid_out[n][i] = x[(size_t) n * d + i];
+    }
+}
+
 // decode: the embedding row of one token, plus the {sum x, sum x^2} pair (double) the first layer's norm-fused
 // mat-vec folds instead of reducing the row itself (PREP_NORMP).  One workgroup; same dequantization.
 __global__ void __launch_bounds__(256)
@@ -354,6 +378,17 @@ hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int
 
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st) {
     hipLaunchKernelGGL(k_embed, dim3(N, N <= 64 ? (d / 2 + 255) / 256 : 1), dim3(256), 0, st, tokens, emb, x, d);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_embed_set(const SeqSet *set, int n, const uint8_t *emb, float *x, int d, hipStream_t st) {
+    hipLaunchKernelGGL(k_embed_set, dim3(n, (d / 2 + 255) / 256), dim3(256), 0, st, set, emb, x, d);
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_rows_set(const SeqSet *set, int n, float *x, int d, bool gather, hipStream_t st) {
+    hipLaunchKernelGGL(k_rows_set, dim3(n, (d + 1023) / 1024), dim3(256), 0, st, set, x, d, gather ? 1 : 0);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

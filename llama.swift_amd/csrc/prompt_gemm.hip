@@ -356,16 +356,19 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
                 // (ggml.c:7076-7131, .mm:586-611; see k_rope_kv) rows m, m^1 = lanes 8 apart; m is even iff the lane's row is
                 const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
                 if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
-                    const int which = m / ra.d, c = m - which * ra.d, pos = ra.n_past + n0 + n;
+                    const int which = m / ra.d, c = m - which * ra.d;
+                    // (batched decode step: the row's own position and cache)
+                    const int pos = ra.set ? ra.set->state[n0 + n][0] : ra.n_past + n0 + n;
+                    const long kvo = ra.set ? ra.set->kv_off[n0 + n] : 0L;
                     if (which == 2) {
-                        ra.Vc[(size_t) pos * ra.d + c] = acc;
+                        ra.Vc[kvo + (size_t) pos * ra.d + c] = acc;
                     } else {
                         const int pe = (c % ra.dh) & ~1;
                         const double cs = ra.tab[(size_t) pos * ra.dh + pe], sn = ra.tab[(size_t) pos * ra.dh + pe + 1];
                         const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
                         const float val = (c & 1) ? (float) (x0 * sn + x1 * cs) : (float) (x0 * cs - x1 * sn);
                         if (which == 0) ra.qr[(size_t) (n0 + n) * ra.d + c] = val;
-                        else ra.Kc[(size_t) pos * ra.d + c] = val;
+                        else ra.Kc[kvo + (size_t) pos * ra.d + c] = val;
                     }
                 }
                 continue;

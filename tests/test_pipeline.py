@@ -13,6 +13,11 @@ import pytest
 
 import synth
 
+
+def same(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
@@ -683,3 +688,108 @@ def test_device_side_mailbox_silent_peer_costs_seconds_with_the_production_poll_
     assert out.count("ERR -1001") == 2 and "NO ERROR" not in out, out[-2000:] + r.stderr[-2000:]
     secs = [float(l.split()[-1]) for l in out.splitlines() if l.startswith("SECONDS")]
     assert len(secs) == 2 and max(secs) < 90.0, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,shape,nth", [(2, "d512", 8), (4, "d256", 3), (8, "d512", 5), (16, "d256", 8), (5, "7b_width", 8)])
+def test_batched_set_steps_equal_one_eval_per_sequence_on_the_oracle(L, oracle, tmp_path, S, shape, nth):
+    """llamahip_stage_step_set: ONE decode step for S sequences at DIFFERENT positions (the weights are streamed once per step for
+    all of them).  Every sequence's picked tokens, the logits of its last step and the KV rows of every layer must be bit for bit
+    what one llama_eval per token and sequence gives on the oracle (.mm:510-735 row by row; the V*P key split of each row's own
+    eval, ggml.c:5459-5480, n_threads 8 / 3 / 5).  Sets and single steps are interchangeable on the same slots (a few single
+    steps in between, then a smaller set), captured graphs replay as the positions grow."""
+    import torch
+    kw = {"d512": dict(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=3), "d256": dict(n_vocab=96, n_embd=256, n_mult=64, n_head=2, n_layer=2),
+          "7b_width": dict(n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2)}[shape]
+    hp = synth.HParams(**kw)
+    path = str(tmp_path / "m.bin")
+    if shape == "7b_width":
+        from conftest import synth_tool
+        path = synth_tool(tmp_path / "m.bin", seed=23, **kw)
+    else:
+        synth.write_model(path, hp, synth.random_tensors(hp, seed=23 + S))
+    n_ctx = 96
+    prompts = [synth.synth_prompt(3 + (5 * s) % 23, hp.n_vocab, seed=60 + s) for s in range(S)]      # positions 3 .. 25, all different mod 23
+    K1, K2, K3 = 5, 2, 4                                       # set steps | single steps of every slot | steps of a smaller set
+    with L.Model(path, n_ctx=n_ctx, n_seq=S) as gm:
+        toks = []
+        for s in range(S):
+            gm.set_seq(s)
+            toks.append(int(np.argmax(gm.eval(prompts[s], 0, nth))))
+        gm.set_seq(0)
+        bufs = [torch.tensor([toks[s]], dtype=torch.int32, device="cuda") for s in range(S)]
+        for s in range(S):
+            gm.stage_bind(s, len(prompts[s]), token_in=bufs[s].data_ptr(), token_out=bufs[s].data_ptr())
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(K1):
+            gm.stage_step_set(list(range(S)), nth, st)
+        last_full = [gm.stage_logits(s) for s in range(S)]
+        for _ in range(K2):
+            for s in range(S):
+                gm.stage_step(s, nth, st)
+        sub = list(range(S - 1, 0, -2))                        # a smaller set in another order (its own graph and descriptor)
+        if len(sub) >= 2:
+            for _ in range(K3):
+                gm.stage_step_set(sub, nth, st)
+        last_sub = [gm.stage_logits(i) for i in range(len(sub))] if len(sub) >= 2 else []
+        for s in range(S):
+            n_steps = K1 + K2 + (K3 if (s in sub and len(sub) >= 2) else 0)
+            n, pos, got = gm.stage_trace(s, n_steps)
+            assert n == n_steps and pos == len(prompts[s]) + n_steps
+            om = oracle.load(path, n_ctx)
+            lo = om.eval(prompts[s], 0, nth)["logits"]
+            t = int(np.argmax(lo))
+            assert t == toks[s]
+            want = []
+            for i in range(n_steps):
+                lo = om.eval(np.array([t], np.int32), len(prompts[s]) + i, nth)["logits"]
+                if i == K1 - 1:
+                    assert same(last_full[s], lo), f"sequence {s}: logits of the last full-set step"
+                t = int(np.argmax(lo)); want.append(t)
+            assert got.tolist() == want, f"sequence {s}: {got.tolist()} vs {want}"
+            if s in sub and len(sub) >= 2:
+                assert same(last_sub[sub.index(s)], lo), f"sequence {s}: logits of the last sub-set step"
+            gm.set_seq(s)
+            for il in range(hp.n_layer):
+                gk, gv = gm.kv(il, len(prompts[s]) + n_steps)
+                ok, ov = om.kv(il, len(prompts[s]) + n_steps)
+                assert same(gk, ok) and same(gv, ov), f"sequence {s}: KV cache layer {il}"
+            om.close()
+        with pytest.raises(L.LlamaHipError, match="twice"):
+            gm.stage_step_set([0, 1, 0], nth, st)
+
+
+@pytest.mark.gpu
+def test_batched_set_steps_through_two_stage_handles(L, tmp_path):
+    """Set steps on layer-range handles: the set's residual rows are gathered from / scattered to the slots' hidden buffers; two
+    stages on one GPU chained on one stream equal the whole-model greedy loop for every sequence."""
+    import torch
+    hp = synth.HParams(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=4)
+    path = str(tmp_path / "m.bin")
+    synth.write_model(path, hp, synth.random_tensors(hp, seed=31))
+    S, K = 4, 6
+    prompts = [synth.synth_prompt(4 + 3 * s, hp.n_vocab, seed=80 + s) for s in range(S)]
+    with L.Model(path, n_ctx=64) as whole:
+        firsts, wants = [], []
+        for s in range(S):
+            f = int(np.argmax(whole.eval(prompts[s], 0, 8)))
+            firsts.append(f); wants.append(whole.decode_greedy(f, len(prompts[s]), K, 8).tolist())
+    a = L.Model(path, n_ctx=64, layer_begin=0, layer_end=2, n_seq=S)
+    b = L.Model(path, n_ctx=64, layer_begin=2, layer_end=4, n_seq=S)
+    hid = [torch.zeros(hp.n_embd, dtype=torch.float32, device="cuda") for _ in range(S)]
+    tok = [torch.tensor([firsts[s]], dtype=torch.int32, device="cuda") for s in range(S)]
+    for s in range(S):
+        a.set_seq(s); b.set_seq(s)
+        h = torch.zeros(len(prompts[s]) * hp.n_embd, dtype=torch.float32, device="cuda")
+        a.eval_stage(0, tokens=prompts[s], hidden_out=h.data_ptr())
+        b.eval_stage(0, n_tokens=len(prompts[s]), hidden_in=h.data_ptr())
+        a.stage_bind(s, len(prompts[s]), token_in=tok[s].data_ptr(), hidden_out=hid[s].data_ptr())
+        b.stage_bind(s, len(prompts[s]), hidden_in=hid[s].data_ptr(), token_out=tok[s].data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(K):
+        a.stage_step_set(list(range(S)), 8, st)
+        b.stage_step_set(list(range(S)), 8, st)
+    for s in range(S):
+        n, pos, got = b.stage_trace(s, K)
+        assert n == K and got.tolist() == wants[s], f"sequence {s}"
+    a.close(); b.close()
