@@ -151,6 +151,69 @@ def insitu_child(args, cfg, path):
     m.close()
 
 
+def insitu_stage_child(args, cfg, path):
+    """(child of rocprofv3) the decode loop of ONE pipeline stage as the N > 1 bench runs it: a first-stage handle holding
+    `--stage-layers` layers, `--stage-set` sequences stepped as one set (1: one sequence per step)."""
+    import torch
+    import llama_swift_amd as L
+    B, nl = max(1, args.stage_set), args.stage_layers
+    m = L.Model(path, n_ctx=args.n_ctx, layer_begin=0, layer_end=nl, n_seq=B)
+    last = nl >= cfg["n_layer"]
+    tok = torch.tensor([5 + 3 * s for s in range(B)], dtype=torch.int32, device="cuda")
+    hid = None if last else torch.zeros(B, cfg["n_embd"], dtype=torch.float32, device="cuda")
+    for s in range(B):
+        m.stage_bind(s, 8 + s % 3, token_in=tok[s:s + 1].data_ptr(), hidden_out=0 if last else hid[s].data_ptr(), token_out=tok[s:s + 1].data_ptr() if last else 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(max(args.warmup, 1) + args.steps):
+        if B > 1:
+            m.stage_step_set(list(range(B)), args.threads, st)
+        else:
+            m.stage_step(0, args.threads, st)
+    torch.cuda.synchronize()
+    m.close()
+
+
+def insitu_stage_profile(args, model_name, cfg, stage_layers, stage_set):
+    """The dominant mat-vec / mat-mul of a pipeline stage's decode step (w1|w3) IN SITU: rocprofv3 --kernel-trace --stats over a child
+    that runs the stage's own step loop (insitu_stage_child); returns the roofline object of the N > 1 line, or (None, reason)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    outdir = tempfile.mkdtemp(prefix="llamahip_stage_", dir="/tmp")
+    steps = 48
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", outdir, "-o", "stage", "--",
+           sys.executable, os.path.abspath(__file__), "--insitu-stage-child", "--model", model_name, "--n_ctx", str(args.n_ctx), "--stage-layers", str(stage_layers),
+           "--stage-set", str(stage_set), "--steps", str(steps), "--warmup", "4", "--threads", str(args.threads), "--seed", str(args.seed)]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", LLAMAHIP_WITH_TORCH="1"), capture_output=True, text=True, timeout=300)
+    except Exception as e:
+        shutil.rmtree(outdir, ignore_errors=True)
+        return None, repr(e)
+    stats = glob.glob(os.path.join(outdir, "**", "*kernel_stats.csv"), recursive=True)
+    if r.returncode != 0 or not stats:
+        shutil.rmtree(outdir, ignore_errors=True)
+        return None, f"rocprofv3 rc={r.returncode}: {r.stderr[-300:]}"
+    rows = list(csv.DictReader(open(stats[0])))
+    shutil.rmtree(outdir, ignore_errors=True)
+    # w1|w3: the launch with the SiLU * up -> Q4_0 epilogue (EPI_SILU_QA = 2): k_gemm_skinny<NC, 1, 2> for a set, k_gemv<.., 2, ..> for single steps
+    pick = None
+    for row in rows:
+        n = row["Name"]
+        n = (n[:n.index("(")] if "(" in n else n).replace("void ", "")
+        hit = ("k_gemm_skinny<" in n and n.rstrip(">").split(",")[-1].strip() == "2") if stage_set > 1 else ("k_gemv<" in n and n.split("<")[1].split(",")[1].strip() == "2")
+        if hit and int(row["Calls"]) >= steps * stage_layers // 2:
+            pick = (n, float(row["AverageNs"]) / 1e3, int(row["Calls"]))
+    if not pick:
+        return None, "no w1|w3 launch found in the stage's kernel statistics"
+    d, F = cfg["n_embd"], n_ff(cfg)
+    algo = 2 * F * (d // 32) * 20 + stage_set * (d // 32) * 20 + 4 * 2 * F * stage_set       # SURVEY.md 8d with N = stage_set activation rows
+    gbps = algo / pick[1] / 1e3
+    return {"bound": "hbm", "kernel": f"{pick[0]} -- the w1|w3 launch of a stage step as it runs in the stage's captured step ({stage_layers} layers, {stage_set} sequence(s) per step)",
+            "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": algo,
+            "us_per_launch": pick[1], "launches": pick[2],
+            "method": "rocprofv3 --kernel-trace --stats of a child process running rank 0's stage loop (first-stage handle, same layer count and set size)"}, None
+
+
 def parse_kernel_trace(outdir, cfg):
     """Label every dispatch of the decode loop by its position in the token's launch sequence (embedding -> per
     layer {wq|wk|wv, scores, soft_max * V, wo, w1|w3, w2} -> output -> argmax) and average the durations."""
@@ -456,6 +519,349 @@ def batched_sequences(args, cfg, path, n_seq):
                     "not the headline metric (one sequence)"}
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# N > 1: the layer pipeline (llama_swift_amd/pipeline.py holds the schedules; the bench leg and its CPU parity checker live here)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _cpu_trace(path: str, prompt: np.ndarray, n_tokens: int, n_ctx: int, budget_s: float):
+    """Greedy tokens of the CPU path (the reference's ggml.c build when it travelled with the snapshot, else the restatement) for one
+    prompt: the parity gate of the multi-GPU line.  Bounded by `budget_s` seconds of decoding.  Checker only, after the timed loops."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import reflib
+    kind = "reference" if reflib.have_ref() else "port"
+    lib = reflib.RefLib() if kind == "reference" else reflib.OracleLib()
+    m = lib.load(path, n_ctx, 0)
+    m.eval(np.array([0, 1, 2, 3], np.int32), 0, 8)            # the bridge's scratch-sizing eval (.mm:820-822)
+    lg = m.eval(prompt, 0, 8)["logits"]
+    t, toks, n_past = int(np.argmax(lg)), [], len(prompt)
+    first = t
+    t0 = time.time()
+    while len(toks) < n_tokens and time.time() - t0 < budget_s:
+        lg = m.eval(np.array([t], np.int32), n_past, 8)["logits"]
+        t = int(np.argmax(lg)); toks.append(t); n_past += 1
+    m.close()
+    return kind, first, toks
+
+
+class CudaEnv:
+    """Where the pipeline bench runs: one MI355X per rank, RCCL.  (tests/test_pipeline.py drives the same control flow on the CPU with
+    gloo and oracle stages through an environment of the same shape.)"""
+    backend_default = "nccl"
+
+    def __init__(self, local):
+        import torch
+        self.torch, self.local, self.device = torch, local, f"cuda:{local}"
+        torch.cuda.set_device(local)
+
+    def init_process_group(self, dist, backend):
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=self.torch.device(self.device))
+        else:
+            dist.init_process_group(backend)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def lane(self):
+        return self.torch.cuda.Stream()
+
+    def on(self, lane):
+        return self.torch.cuda.stream(lane)
+
+    def make_stage(self, path, n_ctx, rank, world, n_seq, n_layer, n_threads):
+        from llama_swift_amd.pipeline import HipStage
+        return HipStage(path, n_ctx, rank, world, n_seq, n_layer, self.local, n_threads)
+
+    def stage_roofline(self, stage, args, cfg, model_name=None, stage_layers=0, stage_set=1, rank=0):
+        """The dominant launch of rank 0's stage IN SITU: a rocprofv3 child runs the stage's own step loop (same layer count, same set
+        size: the stage's launches, kernels and shapes); falls back to the stand-alone probe and says so."""
+        if rank != 0:
+            return None
+        if model_name and stage_layers > 0 and os.environ.get("LLAMAHIP_PIPE_NO_INSITU") != "1":
+            roof, why = insitu_stage_profile(args, model_name, cfg, stage_layers, stage_set)
+            if roof:
+                roof["per_stage_weight_bytes"] = stage.model.stats()["weight_bytes_device"]
+                return roof
+            log(f"[bench] in-situ stage profile unavailable ({why}); stand-alone probe")
+        try:
+            r = stage.model.bench_gemv(2, -1, 1, 10)
+            return {"bound": "hbm", "kernel": "lh::k_gemv PRE_QA / STORE probe variant on w1|w3 of rank 0's layers (stand-alone, not in situ)", "achieved": r["GBps"], "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": r["GBps"] / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": r["algo_bytes"], "us_per_launch": r["us_per_launch"],
+                    "per_stage_weight_bytes": stage.model.stats()["weight_bytes_device"]}
+        except Exception as e:                       # measurement extras never cost the headline line
+            return {"error": repr(e)}
+
+    def close_stage(self, stage):
+        stage.model.close()
+
+
+def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, emit=None):
+    """`bench.py --gpus N` for N > 1 (launched by torch.distributed.run, one rank per GPU).  `env` / `emit`: the CPU control-flow test
+    substitutes gloo + oracle stages and collects the line instead of printing it."""
+    import threading
+
+    import torch
+    import torch.distributed as dist
+
+    from llama_swift_amd.pipeline import ERR_PREDICT, gather_traces, layer_range, mailbox_decode, pipeline_decode, pipeline_decode_sets, pipeline_rounds, run_guarded
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with {args.gpus} ranks (WORLD_SIZE={world}); "
+                         f"use: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    in_test = env is not None
+    # RCCL prints a version banner on STDOUT when it creates a communicator; the bench contract is ONE
+    # JSON line on stdout, so everything before that line goes to stderr at the file-descriptor level
+    saved_stdout = None
+    if not in_test:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+
+    # a multi-rank run that stops making progress (a peer died, a hand-off never matched) must not hang the
+    # caller forever: every schedule call below runs under run_guarded (transport error -> PipelineError, silence ->
+    # exit code 3 after `limit` seconds), and the whole bench under one more timer of the same length
+    limit = float(os.environ.get("LLAMAHIP_PIPE_WATCHDOG_S", "900"))
+    headline = {}                                # rank 0: the finished JSON line of the headline model (printed by whoever ends the run)
+    headline_done = [False]                      # EVERY rank: the headline leg is over (what follows is the optional 65B leg)
+
+    def _emit_and_exit(code):
+        if rank == 0 and headline and saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+            os.write(1, (json.dumps(headline) + "\n").encode())
+        # a stuck EXTRA leg must not cost the headline that is already measured -- on ANY rank: a non-zero exit of rank r > 0 makes the
+        # launcher kill rank 0, possibly before it has printed
+        os._exit(0 if headline_done[0] else code)
+
+    def _abort():
+        os.write(2, f"[bench] rank {rank}/{world}: no result after {limit:.0f} s -- PredictionFailed ({ERR_PREDICT}), aborting\n".encode())
+        _emit_and_exit(3)
+
+    watchdog = threading.Timer(limit, _abort)
+    watchdog.daemon = True
+    watchdog.start()
+    guard = lambda fn, what: run_guarded(fn, rank, world, limit, what, on_timeout=(lambda msg: _emit_and_exit(3)) if headline_done[0] else None)
+    # (smoke test of the multi-rank path on ONE GPU: LLAMAHIP_PIPE_ONE_GPU=1 puts every rank on cuda:0 and LLAMAHIP_PIPE_BACKEND=gloo
+    #  replaces RCCL, which refuses two ranks on one device; the mailboxes then run over HIP IPC between the processes)
+    if os.environ.get("LLAMAHIP_PIPE_ONE_GPU") == "1":
+        local = 0
+    if env is None:
+        env = CudaEnv(local)
+        env.init_process_group(dist, os.environ.get("LLAMAHIP_PIPE_BACKEND", env.backend_default))
+    dev = env.device
+    token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
+    fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]   # forward edges by sender parity
+    sync_schedule = os.environ.get("LLAMAHIP_PIPELINE_SYNC", "0") == "1"
+    # sequences per stage: a stage steps them as ONE set (llamahip_stage_step_set: its weights are streamed once per step for all of
+    # them) and the set's rows cross to the next stage in one message.  LLAMAHIP_PIPE_SET=0: one sequence per step, device-side
+    # mailboxes between the stages (round 3's schedule; the single-stream latency leg always runs one sequence per step).
+    per_stage = max(1, int(os.environ.get("LLAMAHIP_PIPE_SEQS_PER_STAGE", "4")))
+    set_mode = os.environ.get("LLAMAHIP_PIPE_SET", "1") != "0" and per_stage >= 2 and not sync_schedule
+    want_mailbox = os.environ.get("LLAMAHIP_PIPE_MAILBOX", "1") != "0" and not sync_schedule and world > 1 and not set_mode
+
+    def run_model(model_name, mcfg, steps_req, warmup, parity_tokens):
+        if rank == 0:
+            model_path_fn(model_name, mcfg, args.seed)
+        dist.barrier()
+        path = model_path_fn(model_name, mcfg, args.seed)
+        # sequences in flight (weak scaling): `per_stage` per stage.  One group of `per_stage` consecutive slots per stage in set mode;
+        # with one sequence per step a second one per stage keeps a ready item queued behind the hand-off latency.
+        S = world * per_stage if (world > 1 or set_mode) else 1
+        if not set_mode and world > 1:
+            S = world * min(per_stage, 2) if "LLAMAHIP_PIPE_SEQS_PER_STAGE" not in os.environ else world * per_stage
+        groups = [list(range(g * per_stage, (g + 1) * per_stage)) for g in range(S // per_stage)] if set_mode else None
+        stage = env.make_stage(path, args.n_ctx, rank, world, S, mcfg["n_layer"], args.threads)
+        rng = np.random.default_rng(1234)
+        prompts = [np.concatenate([[1], rng.integers(3, mcfg["n_vocab"], 7 + (s % 3 if set_mode else 0))]).astype(np.int32) for s in range(S)]   # (set mode: rows of a set at different positions)
+        n_single = 16                                          # single-stream latency leg: tokens of sequence 0 alone
+        steps = max(1, min(steps_req, args.n_ctx - 11 - warmup - 1 - n_single))
+        hand_off = "RCCL point-to-point per token (torch.distributed isend / recv, stream-ordered)"
+        if set_mode:
+            hand_off = f"RCCL point-to-point, one message per set of {per_stage} sequences and step (torch.distributed isend / recv, stream-ordered)"
+        if sync_schedule:
+            toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + warmup, token_group), "pipeline_rounds (prompt + warm-up)")
+            last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
+            dist.barrier(); env.sync()
+            t0 = time.perf_counter()
+            toks2, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group), "pipeline_rounds (timed decode)")
+            dist.barrier(); env.sync()
+            dt_loc = time.perf_counter() - t0
+            firsts = [int(toks[s, 0]) for s in range(S)]
+            traces = np.concatenate([toks[:, 1:], toks2], axis=1)
+            single = None
+        else:
+            toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt)")
+            firsts = [int(toks[s, -1]) for s in range(S)]
+            mailbox = False
+            if want_mailbox:
+                # device-side mailboxes: one object all-gather of IPC handles now, no collective per token afterwards.  Every rank
+                # must take the same branch: agree on the outcome.
+                ok = 1
+                try:
+                    stage.setup_mailboxes(dist, rank, world, S)
+                except Exception as e:                          # e.g. IPC not permitted on this box
+                    log(f"[bench] rank {rank}: mailboxes unavailable ({type(e).__name__}: {e}); RCCL hand-off")
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                mailbox = int(flag.item()) == 1
+                if not mailbox:
+                    stage.mailboxes = False
+            for s in range(S):
+                stage.bind(s, n_past[s], firsts[s])
+            # binding clears a slot's inbox: no stage may store into its neighbour's before every stage has bound
+            env.sync(); dist.barrier()
+            lane = env.lane()                        # the decode loop's own stream
+            if mailbox:
+                # handshake: ONE token of sequence 0 through every stage on the mailboxes, then every rank reads its fault word.  A
+                # row that does not arrive (peer mapping that does not carry stores, ...) costs one poll bound here, not one per step
+                # of the timed loop; all ranks agree on the outcome and fall back to the RCCL hand-off together.
+                ok = 1
+                try:
+                    with env.on(lane):
+                        stage.step(0)
+                    env.sync()
+                    n_done, pos0, _ = stage.trace(0, 1)
+                    ok = int(n_done == 1 and pos0 == n_past[0] + 1)
+                except Exception as e:
+                    log(f"[bench] rank {rank}: mailbox handshake failed ({type(e).__name__}: {str(e)[:200]}); RCCL hand-off")
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) != 1:
+                    mailbox = False
+                    stage.mailboxes = False
+                    toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt, again)")
+                    firsts = [int(toks[s, -1]) for s in range(S)]
+                    for s in range(S):
+                        stage.bind(s, n_past[s], firsts[s])
+                    env.sync(); dist.barrier()
+            handshake_tokens = 1 if mailbox else 0
+            if mailbox:
+                hand_off = "device-side mailboxes: position-tagged granules stored into the next stage's memory (HIP IPC / xGMI) by the last kernel of a stage step, polled by the first kernel of the next; no collective and no host call per token"
+
+            def decode(n, seqs=None):
+                with env.on(lane):
+                    if mailbox:
+                        mailbox_decode(stage, S, n, seqs)
+                    elif set_mode and seqs is None:
+                        pipeline_decode_sets(stage, rank, world, dist, groups, n, fwd_groups, token_group)
+                    else:
+                        pipeline_decode(stage, rank, world, dist, S if seqs is None else len(seqs), n, fwd_groups, token_group)
+                env.sync()
+            guard(lambda: decode(warmup), "decode (warm-up)")                                # untimed; captures the graphs
+            dist.barrier(); env.sync()
+            t0 = time.perf_counter()
+            guard(lambda: decode(steps), "decode (timed)")
+            dist.barrier(); env.sync()
+            dt_loc = time.perf_counter() - t0
+            # single-stream latency, measured: sequence 0 alone through all stages
+            single = None
+            if world > 1:
+                dist.barrier(); env.sync()
+                t1 = time.perf_counter()
+                guard(lambda: decode(n_single, [0]), "decode (single stream)")
+                dist.barrier(); env.sync()
+                ds = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                dist.all_reduce(ds, op=dist.ReduceOp.MAX)
+                single = {"tokens": n_single, "ms_per_token": float(ds.item()) * 1e3 / n_single, "tokens_per_s": n_single / float(ds.item()),
+                          "note": "sequence 0 alone: one token at a time through every stage (the latency a single user sees)"}
+            traces, _pos = guard(lambda: gather_traces(stage, rank, world, dist, torch, S, handshake_tokens + warmup + steps + (n_single if world > 1 else 0)), "gather_traces")
+        dt = torch.tensor([dt_loc], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        # parity gate: sequence 0's prompt pick and first generated tokens against the CPU path (rank 0 computes it, bounded);
+        # in set mode also the last sequence of the last set (another row of a batched step, another position)
+        parity = {"checked": False}
+        if rank == 0 and parity_tokens > 0:
+            try:
+                budget = float(os.environ.get("LLAMAHIP_PIPE_PARITY_S", "30"))
+                checked = []
+                for sq in ([0, S - 1] if (set_mode and S > 1) else [0]):
+                    kind, cfirst, ctoks = _cpu_trace(path, prompts[sq], parity_tokens, args.n_ctx, budget / (2 if set_mode and S > 1 else 1))
+                    have = (0 if sync_schedule else handshake_tokens) + warmup + steps + (n_single if (world > 1 and sq == 0 and not sync_schedule) else 0)      # tokens this sequence generated
+                    ctoks = ctoks[:have]
+                    got = [int(t) for t in traces[sq][:len(ctoks)]]
+                    checked.append({"sequence": sq, "prompt_pick_identical": cfirst == firsts[sq], "tokens_compared": len(ctoks), "identical": cfirst == firsts[sq] and got == ctoks,
+                                    "first_divergence": next((i for i, (x, y) in enumerate(zip(got, ctoks)) if x != y), None)})
+                parity = {"checked": True, "against": f"{kind} CPU path, 8 threads, sequence(s) {[c['sequence'] for c in checked]}",
+                          "prompt_pick_identical": all(c["prompt_pick_identical"] for c in checked), "tokens_compared": sum(c["tokens_compared"] for c in checked),
+                          "identical": all(c["identical"] for c in checked), "first_divergence": next((c["first_divergence"] for c in checked if c["first_divergence"] is not None), None),
+                          "per_sequence": checked}
+            except Exception as e:                              # the checker must never take the measurement down
+                parity = {"checked": False, "error": repr(e)}
+        lo_, hi_ = layer_range(mcfg["n_layer"], 0, world)
+        roof = env.stage_roofline(stage, args, mcfg, model_name, hi_ - lo_, per_stage if set_mode else 1, rank)
+        env.close_stage(stage)
+        return dict(S=S, steps=steps, dt=dt, parity=parity, roof=roof, single=single, hand_off=hand_off, n_layer=mcfg["n_layer"], set_mode=set_mode)
+
+    r = run_model(args.model, cfg, args.steps, args.warmup, 8)
+    headline_done[0] = True
+    if rank == 0:
+        total = r["S"] * r["steps"]
+        headline.update({
+            "metric": f"decode tokens/sec LLaMA-{args.model} Q4_0 @{world} GPUs (layer pipeline, {r['S']} sequences in flight); % HBM-roofline on Q4_0 GEMV",
+            "value": total / r["dt"], "unit": "tokens/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
+            "ms_per_step": r["dt"] * 1e3 / r["steps"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "q4_0 x q4_0 -> int32 block sums, fp32 scales/accumulate",
+            "data": "synthetic (random-init weights in the reference file format, synthetic token ids)",
+            "config": {"workload": f"LLaMA-{args.model} Q4_0 greedy decode, {world}-stage layer pipeline "
+                                   f"({r['n_layer']} layers / {world}), {r['S']} independent sequences in flight"
+                                   + (f" ({per_stage} per stage, stepped as one set: llamahip_stage_step_set)" if r["set_mode"] else "") + f", n_ctx {args.n_ctx}; "
+                                   f"a step = one token for every sequence",
+                       "parallelism": f"pp{world}", "hand_off": r["hand_off"],
+                       "sequences": r["S"], "tokens_timed": total},
+            "roofline": r["roof"],
+            "parity": r["parity"],
+            "cpu_baseline": None,
+            "cpu_baseline_note": "timed at N = 1 only (bench.py --gpus 1)",
+            "single_stream": r["single"],
+            "schedule": "host-synchronous" if sync_schedule else "stream-ordered (hipGraph stage steps, device-side greedy pick)",
+        })
+    # BASELINE.json configs[4]: the 65B model is what the 8-GPU pipeline is for.  A bounded extra leg (32 timed steps) with its OWN
+    # timer, reported next to the headline; whatever happens to it -- on any rank -- the headline above is printed and every rank exits 0.
+    if models and args.model != "65B" and os.environ.get("LLAMAHIP_BENCH_65B", "1") != "0" and "65B" in models:
+        leg_limit = float(os.environ.get("LLAMAHIP_PIPE_65B_S", "420"))
+        leg_timer = threading.Timer(leg_limit, lambda: (os.write(2, f"[bench] rank {rank}: the 65B leg did not finish in {leg_limit:.0f} s; the headline stands\n".encode()), _emit_and_exit(0)))
+        leg_timer.daemon = True
+        leg_timer.start()
+        ok65, r65, e65 = 1, None, None
+        try:
+            r65 = run_model("65B", models["65B"], int(os.environ.get("LLAMAHIP_PIPE_65B_STEPS", "32")), 4, 4)
+        except BaseException as e:                   # (SystemExit from a guard included: the headline survives)
+            ok65, e65 = 0, e
+            import traceback
+            os.write(2, f"[bench] rank {rank}: the 65B leg failed: {e!r}\n{traceback.format_exc()[-1500:]}\n".encode())
+        leg_timer.cancel()
+        if rank == 0:
+            if ok65:
+                t65 = r65["S"] * r65["steps"]
+                headline["config4_65B"] = {"workload": f"LLaMA-65B Q4_0, {r65['n_layer']} layers over {world} stages, {r65['S']} sequences in flight",
+                                           "tokens_per_s": t65 / r65["dt"], "ms_per_step": r65["dt"] * 1e3 / r65["steps"], "steps": r65["steps"],
+                                           "parity": r65["parity"], "single_stream": r65["single"], "hand_off": r65["hand_off"], "roofline": r65["roof"]}
+            else:
+                headline["config4_65B"] = {"error": repr(e65)}
+        if not ok65:
+            # this rank left the leg early: its peers may sit in a collective of it until their guards fire.  Do not enter another
+            # collective (destroy_process_group) with them: print and leave.
+            watchdog.cancel()
+            if emit is not None and rank == 0:
+                emit(headline)
+            _emit_and_exit(0)
+    watchdog.cancel()
+    if emit is not None:
+        if rank == 0:
+            emit(headline)
+        return
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(headline), flush=True)
+    os.dup2(2, 1)                                # communicator teardown may print as well
+    dist.destroy_process_group()
+
+
 def prefill_2048(args, cfg, path):
     """configs[2]: one 2048-token eval at n_ctx 2560 (second handle), with the rates the north star asks for."""
     import llama_swift_amd as L
@@ -523,6 +929,9 @@ def main():
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-sequences leg (2 and 4 independent sequences on the one GPU)")
     ap.add_argument("--save-profile", default="", help="write the in-situ kernel table (rocprofv3 summary) to this file")
     ap.add_argument("--insitu-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--insitu-stage-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--stage-layers", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--stage-set", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -531,13 +940,14 @@ def main():
 
     if args.insitu_child:
         return insitu_child(args, cfg, model_path(args.model, cfg, args.seed))
+    if args.insitu_stage_child:
+        return insitu_stage_child(args, cfg, model_path(args.model, cfg, args.seed))
 
     if world > 1 or args.gpus > 1 or os.environ.get("LLAMAHIP_FORCE_PIPELINE"):      # FORCE: exercise the N > 1 code path on one GPU
         # every stream of a rank (compute, one per RCCL communicator) gets its own hardware queue, so
         # a point-to-point kernel waiting for its peer can never sit in front of unrelated work
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-        from llama_swift_amd import pipeline
-        return pipeline.bench_main(args, cfg, model_path, log, MODELS)
+        return pipeline_bench_main(args, cfg, model_path, log, MODELS)
 
     import torch
     if not torch.cuda.is_available():

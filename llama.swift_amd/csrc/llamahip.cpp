@@ -219,7 +219,9 @@ static hipError_t malloc_mailbox(void **p, size_t bytes) {
     (void) hipGetLastError();
     if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
     (void) hipGetLastError();
-    return hipMalloc(p, bytes);
+    // no coarse-grained fall-back: such an inbox could pass a one-token handshake and serve a stale line later in the run -- the caller
+    // gets an error, reports "mailboxes unavailable" and the pipeline keeps its RCCL hand-off
+    return hipErrorNotSupported;
 }
 
 llamahip_model::~llamahip_model() {

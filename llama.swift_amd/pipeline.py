@@ -155,11 +155,18 @@ class HipStage:
         all-gather), every stage opens its successor's hidden inbox and the last stage the first stage's token inbox.  From then on
         a token step is `step(seq)` alone: the row and the token move between the GPUs inside the kernels (include/llamahip.h)."""
         mine = []
-        for s in range(n_seq):
-            _, _, hh, th = self.model.stage_mailbox(s)
-            mine.append((hh, th))
+        try:
+            for s in range(n_seq):
+                _, _, hh, th = self.model.stage_mailbox(s)
+                mine.append((hh, th))
+        except Exception as e:                  # (allocation / IPC export refused on this rank only: still take part in the collective)
+            mine = None
+            local_err = e
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
+        if any(x is None for x in everyone):    # ... and every rank draws the same conclusion
+            raise RuntimeError("mailboxes unavailable on rank(s) " + ", ".join(str(r) for r, x in enumerate(everyone) if x is None) +
+                               (f" ({type(local_err).__name__}: {local_err})" if mine is None else ""))
         for s in range(n_seq):
             nxt_h = everyone[rank + 1][s][0] if rank + 1 < world else None
             tok_h = everyone[0][s][1] if (rank == world - 1 and world > 1) else None
@@ -176,13 +183,18 @@ class HipStage:
             torch.cuda.current_stream().synchronize()
             self.model.stage_bind(seq, n_past, token_in=self.tok_in[seq].data_ptr() if self.is_first else 0)
             return
-        if not hasattr(self, "tok_in"):
+        if not hasattr(self, "tok_all"):
+            # one tensor per kind, row s = slot s: consecutive slots form a contiguous block, so a set of sequences is ONE send / receive
             S, dev = self.model.n_seq, self.device
-            self.tok_in = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(S)]
+            self.tok_all = torch.zeros(S, dtype=torch.int32, device=dev)
             # a whole-model stage feeds its own pick back: same buffer
-            self.tok_out = self.tok_in if (self.is_first and self.is_last) else [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(S)]
-            self.hid_in = [None if self.is_first else torch.zeros(self.n_embd, dtype=torch.float32, device=dev) for _ in range(S)]
-            self.hid_out = [None if self.is_last else torch.zeros(self.n_embd, dtype=torch.float32, device=dev) for _ in range(S)]
+            self.tok_out_all = self.tok_all if (self.is_first and self.is_last) else torch.zeros(S, dtype=torch.int32, device=dev)
+            self.hid_in_all = None if self.is_first else torch.zeros(S, self.n_embd, dtype=torch.float32, device=dev)
+            self.hid_out_all = None if self.is_last else torch.zeros(S, self.n_embd, dtype=torch.float32, device=dev)
+            self.tok_in = [self.tok_all[s:s + 1] for s in range(S)]
+            self.tok_out = [self.tok_out_all[s:s + 1] for s in range(S)]
+            self.hid_in = [None if self.is_first else self.hid_in_all[s] for s in range(S)]
+            self.hid_out = [None if self.is_last else self.hid_out_all[s] for s in range(S)]
         self.tok_in[seq].fill_(int(first_token))
         torch.cuda.current_stream().synchronize()
         ptr = lambda t: 0 if t is None else t.data_ptr()
@@ -193,6 +205,10 @@ class HipStage:
 
     def step(self, seq):
         self.model.stage_step(seq, self.n_threads, self._torch.cuda.current_stream().cuda_stream)
+
+    def step_set(self, seqs):
+        """One decode step for all of `seqs` at once (llamahip_stage_step_set: weights streamed once for the set)."""
+        self.model.stage_step_set(list(seqs), self.n_threads, self._torch.cuda.current_stream().cuda_stream)
 
     def trace(self, seq, cap):
         return self.model.stage_trace(seq, cap)
@@ -293,6 +309,44 @@ def pipeline_decode(stage: Stage, rank: int, world: int, dist, n_seq: int, round
     reap(0)
 
 
+def pipeline_decode_sets(stage: Stage, rank: int, world: int, dist, groups: Sequence[Sequence[int]], rounds: int,
+                         fwd_groups=None, token_group=None):
+    """The micro-batched schedule: the bound sequences are split into `groups` (consecutive slots each); a stage takes
+    a whole group per step -- ONE receive of the group's rows, ONE llamahip_stage_step_set (the stage's weights are streamed once for
+    all of its sequences), ONE send -- so with as many groups as stages every stage is busy and every weight byte serves a group's
+    worth of tokens.  Same contract as pipeline_decode: round 0 evaluates the tokens bound into ``stage.tok_in``, the call ends with
+    stage 0 having received the last round's picks; results through ``stage.trace``."""
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    grp = (lambda sender: fwd_groups[sender % 2]) if fwd_groups else (lambda sender: None)
+    pending = []
+
+    def reap(limit):
+        while len(pending) > limit:
+            pending.pop(0).wait()
+
+    for k in range(rounds):
+        for seqs in groups:
+            lo, hi = seqs[0], seqs[-1] + 1
+            if stage.is_first:
+                if world > 1 and k > 0:
+                    dist.recv(stage.tok_all[lo:hi], src=world - 1, group=token_group)      # the group's picks of the previous round
+            else:
+                dist.recv(stage.hid_in_all[lo:hi], src=prv, group=grp(prv))
+            if len(seqs) > 1:
+                stage.step_set(seqs)
+            else:
+                stage.step(seqs[0])
+            if not stage.is_last:
+                pending.append(dist.isend(stage.hid_out_all[lo:hi], dst=nxt, group=grp(rank)))
+            elif world > 1:
+                pending.append(dist.isend(stage.tok_out_all[lo:hi], dst=0, group=token_group))
+            reap(2 * len(groups))
+    if stage.is_first and world > 1 and rounds > 0:
+        for seqs in groups:
+            dist.recv(stage.tok_all[seqs[0]:seqs[-1] + 1], src=world - 1, group=token_group)
+    reap(0)
+
+
 def mailbox_decode(stage: Stage, n_seq: int, rounds: int, seqs: Optional[Sequence[int]] = None) -> None:
     """The decode loop with device-side mailboxes: `rounds` token steps for each sequence, enqueued back to back on the current
     stream.  No receive, no send, no ordering with the other ranks on the host or on a communicator: a stage's first kernel polls
@@ -315,246 +369,3 @@ def gather_traces(stage: Stage, rank: int, world: int, dist, torch, n_seq: int, 
         dist.broadcast(buf, src=world - 1)
         out = buf.cpu().numpy()
     return out, pos
-
-
-def _cpu_trace(path: str, prompt: np.ndarray, n_tokens: int, n_ctx: int, budget_s: float):
-    """Greedy tokens of the CPU path (the reference's ggml.c build when it travelled with the snapshot, else the restatement) for one
-    prompt: the parity gate of the multi-GPU line.  Bounded by `budget_s` seconds of decoding."""
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tests"))
-    import reflib
-    kind = "reference" if reflib.have_ref() else "port"
-    lib = reflib.RefLib() if kind == "reference" else reflib.OracleLib()
-    m = lib.load(path, n_ctx, 0)
-    m.eval(np.array([0, 1, 2, 3], np.int32), 0, 8)            # the bridge's scratch-sizing eval (.mm:820-822)
-    lg = m.eval(prompt, 0, 8)["logits"]
-    t, toks, n_past = int(np.argmax(lg)), [], len(prompt)
-    first = t
-    t0 = time.time()
-    while len(toks) < n_tokens and time.time() - t0 < budget_s:
-        lg = m.eval(np.array([t], np.int32), n_past, 8)["logits"]
-        t = int(np.argmax(lg)); toks.append(t); n_past += 1
-    m.close()
-    return kind, first, toks
-
-
-def bench_main(args, cfg, model_path_fn, log, models=None):
-    """`bench.py --gpus N` for N > 1 (launched by torch.distributed.run, one rank per GPU)."""
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with {args.gpus} ranks (WORLD_SIZE={world}); "
-                         f"use: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
-    # RCCL prints a version banner on STDOUT when it creates a communicator; the bench contract is ONE
-    # JSON line on stdout, so everything before that line goes to stderr at the file-descriptor level
-    import sys
-    import threading
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-
-    # a multi-rank run that stops making progress (a peer died, a hand-off never matched) must not hang the
-    # caller forever: every schedule call below runs under run_guarded (transport error -> PipelineError, silence ->
-    # exit code 3 after `limit` seconds), and the whole bench under one more timer of the same length
-    limit = float(os.environ.get("LLAMAHIP_PIPE_WATCHDOG_S", "900"))
-    headline = {}                                # rank 0: the finished JSON line of the headline model (printed by whoever ends the run)
-
-    def _emit_and_exit(code):
-        if rank == 0 and headline:
-            os.dup2(saved_stdout, 1)
-            os.write(1, (json.dumps(headline) + "\n").encode())
-        os._exit(code)
-
-    def _abort():
-        os.write(2, f"[bench] rank {rank}/{world}: no result after {limit:.0f} s -- PredictionFailed ({ERR_PREDICT}), aborting\n".encode())
-        _emit_and_exit(0 if headline else 3)     # (a stuck EXTRA leg must not cost the headline line that is already measured)
-
-    watchdog = threading.Timer(limit, _abort)
-    watchdog.daemon = True
-    watchdog.start()
-    guard = lambda fn, what: run_guarded(fn, rank, world, limit, what, on_timeout=(lambda msg: _emit_and_exit(0)) if headline else None)
-    # (smoke test of the multi-rank path on ONE GPU: LLAMAHIP_PIPE_ONE_GPU=1 puts every rank on cuda:0 and LLAMAHIP_PIPE_BACKEND=gloo
-    #  replaces RCCL, which refuses two ranks on one device; the mailboxes then run over HIP IPC between the processes)
-    if os.environ.get("LLAMAHIP_PIPE_ONE_GPU") == "1":
-        local = 0
-    backend = os.environ.get("LLAMAHIP_PIPE_BACKEND", "nccl")
-    torch.cuda.set_device(local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    else:
-        dist.init_process_group(backend)
-    token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
-    fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]   # forward edges by sender parity
-    sync_schedule = os.environ.get("LLAMAHIP_PIPELINE_SYNC", "0") == "1"
-    want_mailbox = os.environ.get("LLAMAHIP_PIPE_MAILBOX", "1") != "0" and not sync_schedule and world > 1
-
-    def run_model(model_name, mcfg, steps_req, warmup, parity_tokens):
-        if rank == 0:
-            model_path_fn(model_name, mcfg, args.seed)
-        dist.barrier()
-        path = model_path_fn(model_name, mcfg, args.seed)
-        # sequences in flight: two per stage (weak scaling).  With exactly one per stage every stage waits out
-        # the hand-off latency of its predecessor on every step; a second one keeps a ready item queued.
-        S = world * max(1, int(os.environ.get("LLAMAHIP_PIPE_SEQS_PER_STAGE", "2"))) if world > 1 else 1
-        stage = HipStage(path, args.n_ctx, rank, world, S, mcfg["n_layer"], local, args.threads)
-        rng = np.random.default_rng(1234)
-        prompts = [np.concatenate([[1], rng.integers(3, mcfg["n_vocab"], 7)]).astype(np.int32) for _ in range(S)]
-        n_single = 16                                          # single-stream latency leg: tokens of sequence 0 alone
-        steps = max(1, min(steps_req, args.n_ctx - 8 - warmup - 1 - n_single))
-        hand_off = "RCCL point-to-point per token (torch.distributed isend / recv, stream-ordered)"
-        if sync_schedule:
-            toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + warmup, token_group), "pipeline_rounds (prompt + warm-up)")
-            last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
-            dist.barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            toks2, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, last, n_past, steps, token_group), "pipeline_rounds (timed decode)")
-            dist.barrier(); torch.cuda.synchronize()
-            dt_loc = time.perf_counter() - t0
-            firsts = [int(toks[s, 0]) for s in range(S)]
-            traces = np.concatenate([toks[:, 1:], toks2], axis=1)
-            single = None
-        else:
-            toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt)")
-            firsts = [int(toks[s, -1]) for s in range(S)]
-            mailbox = False
-            if want_mailbox:
-                # device-side mailboxes: one object all-gather of IPC handles now, no collective per token afterwards.  Every rank
-                # must take the same branch: agree on the outcome.
-                ok = 1
-                try:
-                    stage.setup_mailboxes(dist, rank, world, S)
-                except Exception as e:                          # e.g. IPC not permitted on this box
-                    log(f"[bench] rank {rank}: mailboxes unavailable ({type(e).__name__}: {e}); RCCL hand-off")
-                    ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local}")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                mailbox = int(flag.item()) == 1
-                if not mailbox:
-                    stage.mailboxes = False
-            for s in range(S):
-                stage.bind(s, n_past[s], firsts[s])
-            lane = torch.cuda.Stream()               # the decode loop's own stream
-            if mailbox:
-                # handshake: ONE token of sequence 0 through every stage on the mailboxes, then every rank reads its fault word.  A
-                # row that does not arrive (peer mapping that does not carry stores, ...) costs one poll bound here, not one per step
-                # of the timed loop; all ranks agree on the outcome and fall back to the RCCL hand-off together.
-                ok = 1
-                try:
-                    with torch.cuda.stream(lane):
-                        stage.step(0)
-                    torch.cuda.synchronize()
-                    n_done, pos0, _ = stage.trace(0, 1)
-                    ok = int(n_done == 1 and pos0 == n_past[0] + 1)
-                except Exception as e:
-                    log(f"[bench] rank {rank}: mailbox handshake failed ({type(e).__name__}: {str(e)[:200]}); RCCL hand-off")
-                    ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local}")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) != 1:
-                    mailbox = False
-                    stage.mailboxes = False
-                    toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1, token_group), "pipeline_rounds (prompt, again)")
-                    firsts = [int(toks[s, -1]) for s in range(S)]
-                    for s in range(S):
-                        stage.bind(s, n_past[s], firsts[s])
-            handshake_tokens = 1 if mailbox else 0
-            if mailbox:
-                hand_off = "device-side mailboxes: position-tagged granules stored into the next stage's memory (HIP IPC / xGMI) by the last kernel of a stage step, polled by the first kernel of the next; no collective and no host call per token"
-
-            def decode(n, seqs=None):
-                with torch.cuda.stream(lane):
-                    if mailbox:
-                        mailbox_decode(stage, S, n, seqs)
-                    else:
-                        pipeline_decode(stage, rank, world, dist, S if seqs is None else len(seqs), n, fwd_groups, token_group)
-                torch.cuda.synchronize()
-            guard(lambda: decode(warmup), "decode (warm-up)")                                # untimed; captures the graphs
-            dist.barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            guard(lambda: decode(steps), "decode (timed)")
-            dist.barrier(); torch.cuda.synchronize()
-            dt_loc = time.perf_counter() - t0
-            # single-stream latency, measured: sequence 0 alone through all stages
-            single = None
-            if world > 1:
-                dist.barrier(); torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                guard(lambda: decode(n_single, [0]), "decode (single stream)")
-                dist.barrier(); torch.cuda.synchronize()
-                ds = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=f"cuda:{local}")
-                dist.all_reduce(ds, op=dist.ReduceOp.MAX)
-                single = {"tokens": n_single, "ms_per_token": float(ds.item()) * 1e3 / n_single, "tokens_per_s": n_single / float(ds.item()),
-                          "note": "sequence 0 alone: one token at a time through every stage (the latency a single user sees)"}
-            traces, _pos = guard(lambda: gather_traces(stage, rank, world, dist, torch, S, handshake_tokens + warmup + steps + (n_single if world > 1 else 0)), "gather_traces")
-        dt = torch.tensor([dt_loc], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        dt = float(dt.item())
-        # parity gate: sequence 0's prompt pick and first generated tokens against the CPU path (rank 0 computes it, bounded)
-        parity = {"checked": False}
-        if rank == 0 and parity_tokens > 0:
-            try:
-                kind, cfirst, ctoks = _cpu_trace(path, prompts[0], parity_tokens, args.n_ctx, float(os.environ.get("LLAMAHIP_PIPE_PARITY_S", "30")))
-                got = [int(t) for t in traces[0][:len(ctoks)]]
-                parity = {"checked": True, "against": f"{kind} CPU path, 8 threads, sequence 0", "prompt_pick_identical": cfirst == firsts[0],
-                          "tokens_compared": len(ctoks), "identical": cfirst == firsts[0] and got == ctoks,
-                          "first_divergence": next((i for i, (x, y) in enumerate(zip(got, ctoks)) if x != y), None)}
-            except Exception as e:                              # the checker must never take the measurement down
-                parity = {"checked": False, "error": repr(e)}
-        roof = None
-        try:
-            r = stage.model.bench_gemv(2, -1, 1, 10)
-            roof = {"bound": "hbm", "kernel": "lh::k_gemv PRE_QA / STORE probe variant on w1|w3 of rank 0's layers (stand-alone, not in situ)", "achieved": r["GBps"], "peak": 8000.0,
-                    "unit": "GB/s", "frac": r["GBps"] / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": r["algo_bytes"], "us_per_launch": r["us_per_launch"],
-                    "per_stage_weight_bytes": stage.model.stats()["weight_bytes_device"]}
-        except Exception as e:                       # measurement extras never cost the headline line
-            roof = {"error": repr(e)}
-        stage.model.close()
-        return dict(S=S, steps=steps, dt=dt, parity=parity, roof=roof, single=single, hand_off=hand_off, n_layer=mcfg["n_layer"])
-
-    r = run_model(args.model, cfg, args.steps, args.warmup, 8)
-    if rank == 0:
-        total = r["S"] * r["steps"]
-        headline.update({
-            "metric": f"decode tokens/sec LLaMA-{args.model} Q4_0 @{world} GPUs (layer pipeline, {r['S']} sequences in flight); % HBM-roofline on Q4_0 GEMV",
-            "value": total / r["dt"], "unit": "tokens/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
-            "ms_per_step": r["dt"] * 1e3 / r["steps"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "q4_0 x q4_0 -> int32 block sums, fp32 scales/accumulate",
-            "data": "synthetic (random-init weights in the reference file format, synthetic token ids)",
-            "config": {"workload": f"LLaMA-{args.model} Q4_0 greedy decode, {world}-stage layer pipeline "
-                                   f"({r['n_layer']} layers / {world}), {r['S']} independent sequences in flight, n_ctx {args.n_ctx}; "
-                                   f"a step = one token for every sequence",
-                       "parallelism": f"pp{world}", "hand_off": r["hand_off"],
-                       "sequences": r["S"], "tokens_timed": total},
-            "roofline": r["roof"],
-            "parity": r["parity"],
-            "cpu_baseline": None,
-            "cpu_baseline_note": "timed at N = 1 only (bench.py --gpus 1)",
-            "single_stream": r["single"],
-            "schedule": "host-synchronous" if sync_schedule else "stream-ordered (hipGraph stage steps, device-side greedy pick)",
-        })
-    # BASELINE.json configs[4]: the 65B model is what the 8-GPU pipeline is for.  A bounded extra leg (32 timed steps), reported next to
-    # the headline; whatever happens to it, the headline line above is printed.
-    if models and args.model != "65B" and os.environ.get("LLAMAHIP_BENCH_65B", "1") != "0" and "65B" in models:
-        try:
-            r65 = run_model("65B", models["65B"], 32, 4, 4)
-            if rank == 0:
-                t65 = r65["S"] * r65["steps"]
-                headline["config4_65B"] = {"workload": f"LLaMA-65B Q4_0, {r65['n_layer']} layers over {world} stages, {r65['S']} sequences in flight",
-                                           "tokens_per_s": t65 / r65["dt"], "ms_per_step": r65["dt"] * 1e3 / r65["steps"], "steps": r65["steps"],
-                                           "parity": r65["parity"], "single_stream": r65["single"], "hand_off": r65["hand_off"], "roofline": r65["roof"]}
-        except BaseException as e:                   # (SystemExit from a guard included: the headline survives)
-            if rank == 0:
-                headline["config4_65B"] = {"error": repr(e)}
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
-    if rank == 0:
-        print(json.dumps(headline), flush=True)
-    watchdog.cancel()
-    os.dup2(2, 1)                                # communicator teardown may print as well
-    dist.destroy_process_group()

@@ -56,10 +56,14 @@ class OracleStage:
         import torch
         if not hasattr(self, "tok_in"):
             S = len(self.models)
-            self.tok_in = [torch.zeros(1, dtype=torch.int32) for _ in range(S)]
-            self.tok_out = self.tok_in if (self.is_first and self.is_last) else [torch.zeros(1, dtype=torch.int32) for _ in range(S)]
-            self.hid_in = [None if self.is_first else torch.zeros(self.n_embd) for _ in range(S)]
-            self.hid_out = [None if self.is_last else torch.zeros(self.n_embd) for _ in range(S)]
+            self.tok_all = torch.zeros(S, dtype=torch.int32)
+            self.tok_out_all = self.tok_all if (self.is_first and self.is_last) else torch.zeros(S, dtype=torch.int32)
+            self.hid_in_all = None if self.is_first else torch.zeros(S, self.n_embd)
+            self.hid_out_all = None if self.is_last else torch.zeros(S, self.n_embd)
+            self.tok_in = [self.tok_all[s:s + 1] for s in range(S)]
+            self.tok_out = [self.tok_out_all[s:s + 1] for s in range(S)]
+            self.hid_in = [None if self.is_first else self.hid_in_all[s] for s in range(S)]
+            self.hid_out = [None if self.is_last else self.hid_out_all[s] for s in range(S)]
             self.pos, self.picked = [0] * S, [[] for _ in range(S)]
         self.tok_in[seq].fill_(int(first_token))
         self.pos[seq], self.picked[seq] = n_past, []
@@ -76,6 +80,10 @@ class OracleStage:
             self.tok_out[seq].fill_(t)
         else:
             self.hid_out[seq].copy_(torch.from_numpy(hout).reshape(-1))
+
+    def step_set(self, seqs):
+        for s in seqs:                              # (the CPU stand-in has nothing to batch: one eval per sequence is the definition)
+            self.step(s)
 
     def trace(self, seq, cap):
         return len(self.picked[seq]), self.pos[seq], np.array(self.picked[seq][:cap], np.int32)
@@ -99,8 +107,12 @@ def _worker(rank, world, path, n_layer, init_file, rounds, out_file):
         stage.bind(s, n_past[s], int(toks2[s, -1]))
     pipeline_decode(stage, rank, world, dist, S, 2, fwd_groups, token_group)
     pipeline_decode(stage, rank, world, dist, S, 3, fwd_groups, token_group)
-    toks3, pos = gather_traces(stage, rank, world, dist, torch, S, 5)
-    assert pos == [n + 5 for n in n_past], (rank, pos, n_past)
+    # ... and the micro-batched schedule (sets of consecutive slots, one message per set): 2 more rounds
+    from llama_swift_amd.pipeline import pipeline_decode_sets
+    groups = [list(range(0, 2)), list(range(2, S))]
+    pipeline_decode_sets(stage, rank, world, dist, groups, 2, fwd_groups, token_group)
+    toks3, pos = gather_traces(stage, rank, world, dist, torch, S, 7)
+    assert pos == [n + 7 for n in n_past], (rank, pos, n_past)
     if rank == 0:
         np.savez(out_file, toks=np.concatenate([toks, toks2, toks3], axis=1), n_past=np.array(pos))
     dist.barrier()
@@ -193,7 +205,7 @@ def _mailbox_wiring_worker(rank, world, init_file, n_seq, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_mailbox_handle_exchange_wires_every_stage_to_its_successor_gloo(tmp_path, world):
     """The one collective of the device-side hand-off (HipStage.setup_mailboxes: an object all-gather of the 64-byte IPC handles): for
     every sequence slot, stage r opens the hidden inbox of stage r + 1 and nothing else, the last stage also the first stage's token
@@ -230,12 +242,90 @@ def test_pipeline_schedule_gloo(built, tmp_path, world):
         prompt = synth.synth_prompt(5 + s, 96, seed=10 + s)
         lg = m.eval(prompt, 0, 8)["logits"]
         n_past, want = len(prompt), []
-        for _ in range(rounds + 3 + 5):
+        for _ in range(rounds + 3 + 7):
             t = int(np.argmax(lg)); want.append(t)
             lg = m.eval(np.array([t], np.int32), n_past, 8)["logits"]; n_past += 1
         assert got["toks"][s].tolist() == want, f"sequence {s}"
-        assert int(got["n_past"][s]) == len(prompt) + rounds - 1 + 3 + 5
+        assert int(got["n_past"][s]) == len(prompt) + rounds - 1 + 3 + 7
 
+
+
+# ---- the N > 1 bench leg's control flow at world 8 (bench.pipeline_bench_main) on the CPU: gloo + oracle stages ----
+class _CpuEnv:
+    """bench.CudaEnv's shape for the CPU: no streams, oracle stages (one llama_eval per sequence and token)."""
+    device = "cpu"
+
+    def sync(self):
+        pass
+
+    def lane(self):
+        return None
+
+    def on(self, lane):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def make_stage(self, path, n_ctx, rank, world, n_seq, n_layer, n_threads):
+        return OracleStage(path, n_ctx, rank, world, n_seq, n_layer)
+
+    def stage_roofline(self, *a, **k):
+        return {"note": "CPU control-flow test: no roofline"}
+
+    def close_stage(self, stage):
+        pass
+
+
+def _bench_main_worker(rank, world, init_file, out_dir, env_extra):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    import argparse
+    import json
+
+    import torch.distributed as dist
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "LLAMAHIP_PIPE_WATCHDOG_S": "600", "LLAMAHIP_PIPE_PARITY_S": "20"})
+    os.environ.update(env_extra)
+    import bench
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    cfgs = {"tiny8": dict(n_vocab=96, n_embd=64, n_mult=32, n_head=1, n_layer=8), "65B": dict(n_vocab=96, n_embd=64, n_mult=32, n_head=1, n_layer=80)}
+
+    def model_path(name, cfg, seed):
+        path = os.path.join(out_dir, f"{name}.bin")
+        if not os.path.exists(path):
+            hp = synth.HParams(**cfg)
+            synth.write_model(path + ".tmp", hp, synth.random_tensors(hp, seed=seed % 1000))
+            os.replace(path + ".tmp", path)
+        return path
+    args = argparse.Namespace(gpus=world, steps=3, warmup=1, model="tiny8", n_ctx=64, threads=8, seed=20230312)
+    def emit(line):                                 # (written at once: a failing extra leg ends the process right after emitting)
+        json.dump([line], open(os.path.join(out_dir, "line.json"), "w"))
+    bench.pipeline_bench_main(args, cfgs["tiny8"], model_path, lambda *a: None, cfgs, env=_CpuEnv(), emit=emit)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sets", "one_per_step"])
+def test_bench_pipeline_control_flow_at_world_8_gloo(built, tmp_path, mode):
+    """No 8-GPU node has ever run this code, so its control flow runs here: `bench.py --gpus 8` (bench.pipeline_bench_main) with eight
+    gloo ranks and oracle stages -- prompt rounds, (one_per_step: mailbox setup that fails on every rank -> the common fall-back to the
+    per-token hand-off; sets: groups of sequences per stage, one message per set), bind + barrier, warm-up, timed loop, the
+    single-stream leg, trace gather, the parity gate against the CPU path, then the 65B leg's layer_range(80, r, 8) partition with
+    its own parity gate -- and ONE line comes out on rank 0 with both legs parity-identical."""
+    import json
+
+    import torch.multiprocessing as mp
+    world = 8
+    env_extra = {"LLAMAHIP_PIPE_SEQS_PER_STAGE": "2", "LLAMAHIP_PIPE_SET": "1" if mode == "sets" else "0", "LLAMAHIP_PIPE_65B_STEPS": "2", "ORC_OMP_THREADS": "1"}
+    mp.spawn(_bench_main_worker, args=(world, str(tmp_path / "rdv"), str(tmp_path), env_extra), nprocs=world, join=True)
+    lines = json.load(open(tmp_path / "line.json"))
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["config"]["sequences"] == 16 and line["value"] > 0
+    assert line["parity"]["checked"] and line["parity"]["identical"], line["parity"]
+    assert ("one set" in line["config"]["workload"]) == (mode == "sets")
+    assert ("one message per set" in line["config"]["hand_off"]) == (mode == "sets")
+    leg = line["config4_65B"]
+    assert "error" not in leg, leg
+    assert "80 layers over 8 stages" in leg["workload"] and leg["parity"]["checked"] and leg["parity"]["identical"], leg
+    assert line["single_stream"]["tokens"] == 16
 
 @pytest.mark.gpu
 def test_hip_stage_in_the_pipeline_schedule_single_rank(L, tmp_path):
@@ -578,6 +668,7 @@ first = int(np.argmax(lg))
 print(json.dumps({"first": first}), flush=True)
 sys.stdin.readline()                                            # "go": the first stage is bound
 b.stage_bind(0, msg["n_prompt"])
+print(json.dumps({"bound": True}), flush=True)                  # binding clears this stage's inbox: the first stage steps only after this
 for _ in range(n_steps):
     b.stage_step(0, 8, 0)
 try:
@@ -623,6 +714,7 @@ def test_device_side_mailboxes_two_processes_over_hip_ipc(L, tmp_path):
         torch.cuda.synchronize()
         a.stage_bind(0, len(prompt), token_in=tokbuf.data_ptr())
         child.stdin.write("go\n"); child.stdin.flush()
+        assert json.loads(child.stdout.readline()).get("bound") is True
         for _ in range(n_steps):
             a.stage_step(0, 8, 0)
         res = json.loads(child.stdout.readline())
