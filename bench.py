@@ -645,9 +645,15 @@ def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, em
     #  replaces RCCL, which refuses two ranks on one device; the mailboxes then run over HIP IPC between the processes)
     if os.environ.get("LLAMAHIP_PIPE_ONE_GPU") == "1":
         local = 0
+    hsync = None
     if env is None:
+        for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):      # (LLAMAHIP_FORCE_PIPELINE: one rank without a launcher)
+            os.environ.setdefault(k_, v_)
         env = CudaEnv(local)
-        env.init_process_group(dist, os.environ.get("LLAMAHIP_PIPE_BACKEND", env.backend_default))
+        backend = os.environ.get("LLAMAHIP_PIPE_BACKEND", env.backend_default)
+        env.init_process_group(dist, backend)
+        if backend != "nccl":
+            hsync = env.sync                     # gloo moves CUDA tensors through the host, not in device-stream order: synchronise around it (smoke runs only)
     dev = env.device
     token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
     fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]   # forward edges by sender parity
@@ -745,9 +751,9 @@ def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, em
                     if mailbox:
                         mailbox_decode(stage, S, n, seqs)
                     elif set_mode and seqs is None:
-                        pipeline_decode_sets(stage, rank, world, dist, groups, n, fwd_groups, token_group)
+                        pipeline_decode_sets(stage, rank, world, dist, groups, n, fwd_groups, token_group, hsync)
                     else:
-                        pipeline_decode(stage, rank, world, dist, S if seqs is None else len(seqs), n, fwd_groups, token_group)
+                        pipeline_decode(stage, rank, world, dist, S if seqs is None else len(seqs), n, fwd_groups, token_group, hsync)
                 env.sync()
             guard(lambda: decode(warmup), "decode (warm-up)")                                # untimed; captures the graphs
             dist.barrier(); env.sync()

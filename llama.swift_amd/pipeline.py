@@ -275,7 +275,7 @@ def pipeline_rounds(stage: Stage, rank: int, world: int, dist, torch, tokens_per
 
 
 def pipeline_decode(stage: Stage, rank: int, world: int, dist, n_seq: int, rounds: int,
-                    fwd_groups=None, token_group=None):
+                    fwd_groups=None, token_group=None, host_sync=None):
     """`rounds` greedy tokens for each of `n_seq` bound sequences (stage.bind), one token per sequence
     per round, with no host synchronisation: every receive, stage step and send is enqueued in program
     order and ordered on the device.  Round 0 evaluates the token already in ``stage.tok_in`` (from
@@ -284,67 +284,84 @@ def pipeline_decode(stage: Stage, rank: int, world: int, dist, n_seq: int, round
     Returns nothing: read the picks with ``stage.trace`` on the last stage."""
     nxt, prv = (rank + 1) % world, (rank - 1) % world
     grp = (lambda sender: fwd_groups[sender % 2]) if fwd_groups else (lambda sender: None)
-    pending = []
+    sent = [None] * n_seq                         # a sequence's send is waited for before its next step rewrites the buffer (host_sync: see pipeline_decode_sets)
 
-    def reap(limit):
-        while len(pending) > limit:
-            pending.pop(0).wait()
+    def recv(t, src, group):
+        dist.recv(t, src=src, group=group)
+        if host_sync:
+            host_sync()
 
     for k in range(rounds):
         for s in range(n_seq):
             if stage.is_first:
                 if world > 1 and k > 0:
-                    dist.recv(stage.tok_in[s], src=world - 1, group=token_group)     # pick of the previous round
+                    recv(stage.tok_in[s], world - 1, token_group)     # pick of the previous round
             else:
-                dist.recv(stage.hid_in[s], src=prv, group=grp(prv))
+                recv(stage.hid_in[s], prv, grp(prv))
+            if sent[s] is not None:
+                sent[s].wait()
+                sent[s] = None
             stage.step(s)
+            if host_sync and world > 1:
+                host_sync()
             if not stage.is_last:
-                pending.append(dist.isend(stage.hid_out[s], dst=nxt, group=grp(rank)))
+                sent[s] = dist.isend(stage.hid_out[s], dst=nxt, group=grp(rank))
             elif world > 1:
-                pending.append(dist.isend(stage.tok_out[s], dst=0, group=token_group))
-            reap(2 * n_seq)
+                sent[s] = dist.isend(stage.tok_out[s], dst=0, group=token_group)
     if stage.is_first and world > 1 and rounds > 0:
         for s in range(n_seq):
-            dist.recv(stage.tok_in[s], src=world - 1, group=token_group)
-    reap(0)
+            recv(stage.tok_in[s], world - 1, token_group)
+    for w in sent:
+        if w is not None:
+            w.wait()
 
 
 def pipeline_decode_sets(stage: Stage, rank: int, world: int, dist, groups: Sequence[Sequence[int]], rounds: int,
-                         fwd_groups=None, token_group=None):
+                         fwd_groups=None, token_group=None, host_sync=None):
     """The micro-batched schedule: the bound sequences are split into `groups` (consecutive slots each); a stage takes
     a whole group per step -- ONE receive of the group's rows, ONE llamahip_stage_step_set (the stage's weights are streamed once for
     all of its sequences), ONE send -- so with as many groups as stages every stage is busy and every weight byte serves a group's
     worth of tokens.  Same contract as pipeline_decode: round 0 evaluates the tokens bound into ``stage.tok_in``, the call ends with
-    stage 0 having received the last round's picks; results through ``stage.trace``."""
+    stage 0 having received the last round's picks; results through ``stage.trace``.
+    A group's send is waited for (stream-side with RCCL) before the group's next step rewrites the buffer it reads.  `host_sync`: a
+    transport that is not ordered on the device stream (gloo moving CUDA tensors: the one-GPU smoke test) gets a host
+    synchronisation before every send and after every receive."""
     nxt, prv = (rank + 1) % world, (rank - 1) % world
     grp = (lambda sender: fwd_groups[sender % 2]) if fwd_groups else (lambda sender: None)
-    pending = []
+    sent = [None] * len(groups)
 
-    def reap(limit):
-        while len(pending) > limit:
-            pending.pop(0).wait()
+    def recv(t, src, group):
+        dist.recv(t, src=src, group=group)
+        if host_sync:
+            host_sync()
 
     for k in range(rounds):
-        for seqs in groups:
+        for gi, seqs in enumerate(groups):
             lo, hi = seqs[0], seqs[-1] + 1
             if stage.is_first:
                 if world > 1 and k > 0:
-                    dist.recv(stage.tok_all[lo:hi], src=world - 1, group=token_group)      # the group's picks of the previous round
+                    recv(stage.tok_all[lo:hi], world - 1, token_group)      # the group's picks of the previous round
             else:
-                dist.recv(stage.hid_in_all[lo:hi], src=prv, group=grp(prv))
+                recv(stage.hid_in_all[lo:hi], prv, grp(prv))
+            if sent[gi] is not None:
+                sent[gi].wait()
+                sent[gi] = None
             if len(seqs) > 1:
                 stage.step_set(seqs)
             else:
                 stage.step(seqs[0])
+            if host_sync and world > 1:
+                host_sync()
             if not stage.is_last:
-                pending.append(dist.isend(stage.hid_out_all[lo:hi], dst=nxt, group=grp(rank)))
+                sent[gi] = dist.isend(stage.hid_out_all[lo:hi], dst=nxt, group=grp(rank))
             elif world > 1:
-                pending.append(dist.isend(stage.tok_out_all[lo:hi], dst=0, group=token_group))
-            reap(2 * len(groups))
+                sent[gi] = dist.isend(stage.tok_out_all[lo:hi], dst=0, group=token_group)
     if stage.is_first and world > 1 and rounds > 0:
         for seqs in groups:
-            dist.recv(stage.tok_all[seqs[0]:seqs[-1] + 1], src=world - 1, group=token_group)
-    reap(0)
+            recv(stage.tok_all[seqs[0]:seqs[-1] + 1], world - 1, token_group)
+    for w in sent:
+        if w is not None:
+            w.wait()
 
 
 def mailbox_decode(stage: Stage, n_seq: int, rounds: int, seqs: Optional[Sequence[int]] = None) -> None:
