@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_fullsize.py: one CPU-side expectation (prompt logits, greedy tokens, final logits) written to an
 .npz, so that the expectations of the full-size tests -- minutes of host time each -- are computed side by side while the GPU tests run
 (the reference build keeps one static scratch buffer, .mm:529-547: two of its evals cannot share a process).
-usage: cpu_expect.py <kind> <model file> <n_ctx> <n_prompt> <n_gen> <nth> <seed> <out.npz>
+usage: cpu_expect.py <kind> <model file> <n_ctx> <n_prompt> <n_gen> <nth> <seed> <out.npz> [n_vocab = 32000]
   kind  decode   the reference path as the bridge drives it: 4-token scratch-sizing eval, ONE eval of the prompt, n_gen greedy tokens
         flow     the same with the prompt in the bridge's nine-token llama_eval calls (.mm:880-888)
         single   the standalone restatement (oracle.c): ONE eval of the prompt whatever its length (the reference's llama_eval cannot
@@ -16,7 +16,7 @@ import reflib  # noqa: E402
 import synth  # noqa: E402
 
 kind, path, n_ctx, n_prompt, n_gen, nth, seed, out = sys.argv[1], sys.argv[2], *map(int, sys.argv[3:8]), sys.argv[8]
-prompt = synth.synth_prompt(n_prompt, 32000, seed=seed)
+prompt = synth.synth_prompt(n_prompt, int(sys.argv[9]) if len(sys.argv) > 9 else 32000, seed=seed)
 if kind == "single":
     os.environ.setdefault("ORC_OMP_THREADS", str(min(os.cpu_count() or 8, 64)))
     cpu = reflib.OracleLib().load(path, n_ctx)

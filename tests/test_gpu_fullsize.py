@@ -43,6 +43,27 @@ def _model(preset: str) -> str:
     return path
 
 
+# 2-layer models of the 13B / 65B WIDTHS (n_embd, heads, n_ff; 2 / 8-part files as the reference derives from n_embd, .mm:33-38): the
+# decode step's attention schedule switches by POSITION at thresholds that depend on the width (llamahip.cpp attn_sched_at: 13B 544 and
+# 1600, 65B 448), far beyond what a full-depth CPU expectation can reach -- prompts in the bridge's nine-token evals up to just below a
+# threshold, then greedy tokens across it with NO environment override.  name -> (shape, n_ctx, prompt tokens, generated tokens)
+_WIDE = {
+    "13Bw_544": (dict(n_vocab=512, n_embd=5120, n_mult=256, n_head=40, n_layer=2), 640, 531, 24),       # positions 531 .. 554: fused launch -> three launches at 544
+    "13Bw_1600": (dict(n_vocab=512, n_embd=5120, n_mult=256, n_head=40, n_layer=2), 1664, 1593, 16),    # 1593 .. 1608: three launches -> streaming soft_max . V at 1600
+    "65Bw_448": (dict(n_vocab=512, n_embd=8192, n_mult=256, n_head=64, n_layer=2), 512, 441, 14),       # 441 .. 454: fused launch -> three launches at 448
+}
+
+
+def _wide_model(tag: str, kw: dict) -> str:
+    d = os.environ.get("LLAMAHIP_MODEL_DIR", "/tmp/llamahip_models")
+    path = os.path.join(d, f"{tag}-2layer-seed31", "ggml-model-q4_0.bin")
+    if not os.path.exists(path + ".done"):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        synth_tool(path, seed=31, **kw)
+        open(path + ".done", "w").close()
+    return path
+
+
 class _Expect:
     """The CPU expectations of this module, each computed by its own child process (tests/cpu_expect.py), all of them side by side
     from the first test on: the host time of the four full-size tests overlaps instead of adding up."""
@@ -50,14 +71,14 @@ class _Expect:
     def __init__(self, tmp):
         self.tmp, self.jobs = tmp, {}
 
-    def start(self, name, kind, path, n_ctx, n_prompt, n_gen, nth=8, seed=3):
+    def start(self, name, kind, path, n_ctx, n_prompt, n_gen, nth=8, seed=3, n_vocab=32000):
         import subprocess
         import sys
         if name in self.jobs:
             return
         out = os.path.join(self.tmp, name + ".npz")
         here = os.path.dirname(os.path.abspath(__file__))
-        p = subprocess.Popen([sys.executable, os.path.join(here, "cpu_expect.py"), kind, path, str(n_ctx), str(n_prompt), str(n_gen), str(nth), str(seed), out],
+        p = subprocess.Popen([sys.executable, os.path.join(here, "cpu_expect.py"), kind, path, str(n_ctx), str(n_prompt), str(n_gen), str(nth), str(seed), out, str(n_vocab)],
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         self.jobs[name] = (p, out)
 
@@ -76,6 +97,9 @@ def expect(tmp_path_factory):
     e.start("flow2048", "flow", p7, 2560, 2048, 3, seed=6)
     e.start("single2048", "single", p7, 2560, 2048, 3, seed=5)
     e.start("13B", "decode", _model("13B"), 64, 9, 5)
+    e.start("13B_128", "flow", _model("13B"), 256, 128, 32, seed=9)
+    for name, (kw, n_ctx, n_prompt, n_gen) in _WIDE.items():
+        e.start(name, "flow", _wide_model(name.split("_")[0], kw), n_ctx, n_prompt, n_gen, seed=12, n_vocab=kw["n_vocab"])
     if not os.environ.get("LLAMAHIP_SKIP_65B"):
         e.start("65B", "decode", _model("65B"), 64, 9, 4)                 # (writing the 40 GB file takes a minute or three: the 7B / 13B children run meanwhile)
     yield e
@@ -134,3 +158,32 @@ def test_7b_full_depth_2048_token_prompt_in_the_reference_flow_vs_reference(L, e
         assert same(a, lg), "logits after the 2048-token prompt: " + describe(a, lg)
         got, last = gm.decode_greedy(first, 2048, 3, 8, want_logits=True)
         assert got.tolist() == want and same(last, lo), (got.tolist(), want, describe(last, lo))
+
+
+def _flow_vs_cpu(L, expect, name, path, n_ctx, n_gen):
+    """the prompt in the bridge's nine-token evals (CPU: the reference's own llama_eval calls; device: ONE llamahip_eval_chunks pass),
+    then n_gen greedy tokens through the decode step's production schedule selection: tokens and final logits bit for bit."""
+    x = expect.get(name)
+    prompt, lg, first, want, lo = x["prompt"], x["lg"], int(x["first"]), x["want"].tolist(), x["lo"]
+    assert len(want) == n_gen
+    with L.Model(path, n_ctx=n_ctx) as gm:
+        gm.eval(np.array([0, 1, 2, 3], np.int32), 0, 8)
+        a = gm.eval_chunks(prompt, 0, 9, 8)
+        assert same(a, lg), "logits after the prompt: " + describe(a, lg)
+        got, last = gm.decode_greedy(first, len(prompt), n_gen, 8, want_logits=True)
+        assert got.tolist() == want, (name, got.tolist(), want)
+        assert same(last, lo), "final logits: " + describe(last, lo)
+
+
+def test_13b_full_depth_128_token_prompt_and_32_tokens_vs_reference(L, expect):
+    """configs[3] beyond position 14: all 40 layers, a 128-token prompt in the reference's flow (fifteen llama_eval calls of the
+    reference build) against one llamahip_eval_chunks pass, then 32 greedy tokens (positions 128 .. 159)."""
+    _flow_vs_cpu(L, expect, "13B_128", _model("13B"), 256, 32)
+
+
+@pytest.mark.parametrize("name", sorted(_WIDE))
+def test_wide_models_decode_across_their_default_attention_schedule_thresholds(L, expect, name):
+    """13B-width and 65B-width rows decoded ACROSS the positions where attn_sched_at switches the decode step's attention schedule
+    (no environment override: the thresholds the production build uses), against the reference build."""
+    kw, n_ctx, n_prompt, n_gen = _WIDE[name]
+    _flow_vs_cpu(L, expect, name, _wide_model(name.split("_")[0], kw), n_ctx, n_gen)
