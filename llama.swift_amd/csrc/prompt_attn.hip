@@ -259,7 +259,10 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
 // per pair of keys 2 loads of probabilities (lane = query) and 4 of values (lane = column), 8 MFMAs = 512 cycles of the matrix
 // pipe at the fp32 FMA peak, and no VALU work but the soft_max scale.  A chunk with an odd number of keys is padded with a zero
 // pair at the FRONT: fma(0, 0, +0) = +0 leaves the chain's start unchanged (a trailing pad could turn a -0 sum into +0).
+// PERROW: a chunked pass (split_keys, chunk > 0) gives the queries of a block different key ranges; a plain eval (one split for every
+// row) does not pay for the per-lane range tests (the 2 048-token eval: 200.4 -> see profiles/r04_*prefill*).
 typedef float f32x16v __attribute__((ext_vector_type(16)));
+template <bool PERROW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ part,
                 int n_past, int N, int nb0, int NB, int d, int T, int nth, int chunk) {
@@ -299,8 +302,8 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
         const float *sp_ = S + ((size_t) h * T + kc_) * NB + q0 + i;                                \
         const float *vp_ = Vc + (size_t) kc_ * d + h * 128 + i;                                     \
         const float s0_ = sp_[0], s1_ = sp_[32], v0_ = vp_[0], v1_ = vp_[32], v2_ = vp_[64], v3_ = vp_[96]; \
-        pa0[ST] = (real_ && key_ >= loA && key_ < hiA) ? s0_ * iv0 : 0.0f;          /* soft_max's final scale (ggml.c:7036-7041) */ \
-        pa1[ST] = (real_ && key_ >= loB && key_ < hiB) ? s1_ * iv1 : 0.0f;          \
+        pa0[ST] = (real_ && (!PERROW || (key_ >= loA && key_ < hiA))) ? s0_ * iv0 : 0.0f;          /* soft_max's final scale (ggml.c:7036-7041) */ \
+        pa1[ST] = (real_ && (!PERROW || (key_ >= loB && key_ < hiB))) ? s1_ * iv1 : 0.0f;          \
         pb0[ST] = real_ ? v0_ : 0.0f; pb1[ST] = real_ ? v1_ : 0.0f; pb2[ST] = real_ ? v2_ : 0.0f; pb3[ST] = real_ ? v3_ : 0.0f; \
     }
     if (nk > 0) {
@@ -371,7 +374,8 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_attnq_pv_mfma, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk);
+            if (chunk > 0) hipLaunchKernelGGL(k_attnq_pv_mfma<true>, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk);
+            else hipLaunchKernelGGL(k_attnq_pv_mfma<false>, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, 0);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_merge, dim3((nb + 1) / 2, H), dim3(256), 0, st, ws->part, merged, N, nb0, ws->NB, d, nth);
             LH_LAUNCH_CHECK();
