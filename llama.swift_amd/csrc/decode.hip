@@ -100,6 +100,7 @@ struct GemvArgs {
     const uint64_t *resid_t; int slot_resid;          // EPI_RESID_TAG: the residual row [M] arrives tagged (null: plain `resid`)
     uint64_t *out_t;        int slot_out;             // EPI_RESID_TAG: y [M] also leaves tagged (null: plain `y` only)
     const int32_t *pos_w;                             // mailbox tags are made from the sequence position, *pos_w + 1, not from the epoch (null: epoch)
+    PickIO pick;                                      // EPI_STORE_PICK (llamahip_internal.h)
     int patience;                                     // mailbox polls wait for ANOTHER process / device: their bounds are shifted left by this (3: ~20 s of
                                                       // looks at an uncached / remote granule -- legitimate waits are milliseconds, and a mapping that does not carry
                                                       // the stores must cost the bench's one-token handshake seconds, not minutes, before it falls back to RCCL)
@@ -542,6 +543,75 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
             }
             acc = acc + rv;
         }
+        if (EPI == EPI_STORE_PICK) {
+            if (live) y[m] = acc;
+            // order-preserving key {value, ~index}: the largest value wins, then the lower index; NaN (key 0) never does; -0 == +0
+            unsigned long long key = 0ull;
+            if (live && acc == acc) {
+                const uint32_t b = __builtin_bit_cast(uint32_t, acc == 0.0f ? 0.0f : acc);
+                const uint32_t ob = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                key = ((unsigned long long) ob << 32) | (unsigned long long) (0xFFFFFFFFu - (uint32_t) m);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint32_t lo_ = (uint32_t) __shfl_xor((int) (uint32_t) key, o), hi_ = (uint32_t) __shfl_xor((int) (uint32_t) (key >> 32), o);
+                const unsigned long long ok = ((unsigned long long) hi_ << 32) | lo_;
+                key = ok > key ? ok : key;
+            }
+            unsigned long long *wk = (unsigned long long *) red;      // [nw] wave keys, then [15] = "this workgroup finished last", [14] = the pick
+            __syncthreads();
+            if (lane == 0) wk[wave] = key;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long k2 = wk[0];
+                for (int w2_ = 1; w2_ < nw; w2_++) k2 = wk[w2_] > k2 ? wk[w2_] : k2;
+                atomicMax(ga.pick.key, k2);
+                __threadfence();
+                const uint32_t ticket = atomicAdd(ga.pick.count, 1u);
+                int lastwg = 0;
+                if (ticket == gridDim.x - 1) {
+                    __threadfence();
+                    const unsigned long long fin = __hip_atomic_load(ga.pick.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int r = (fin >> 32) == 0ull ? 0 : (int) (0xFFFFFFFFu - (uint32_t) fin);
+                    int32_t *st = ga.pick.state;
+                    ga.pick.out[st[1]] = r;
+                    if (ga.pick.next_token) *ga.pick.next_token = r;
+                    st[0] += 1; st[1] += 1;
+                    __hip_atomic_store(ga.pick.key, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ga.pick.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wk[14] = (unsigned long long) (r < ga.pick.n_vocab ? r : 0);
+                    lastwg = 1;
+                }
+                wk[15] = (unsigned long long) lastwg;
+            }
+            __syncthreads();
+            if (wk[15] != 0ull && ga.pick.emb) {
+                // the picked token's embedding row for the next step: k_embed_part's arithmetic, thread for thread (nw * 64 = 256 threads)
+                const int tok = (int) wk[14];
+                const int dE = K;
+                __syncthreads();
+                const uint8_t *row = ga.pick.emb + (size_t) tok * (dE / 32) * 20;
+                double s1 = 0.0, s2 = 0.0;
+                for (int i = tid; i < dE / 2; i += nw * 64) {
+                    const int b = i >> 4, j = i & 15;
+                    const uint8_t *blk_ = row + b * 20;
+                    const uint32_t bits = blk_[0] | (blk_[1] << 8) | (blk_[2] << 16) | ((uint32_t) blk_[3] << 24);
+                    const float dd = __builtin_bit_cast(float, bits);
+                    const uint32_t q = blk_[4 + j];
+                    const float v0 = (float) ((int) (q & 0xF) - 8) * dd, v1 = (float) ((int) (q >> 4) - 8) * dd;
+                    ga.pick.x_next[2 * i + 0] = v0;
+                    ga.pick.x_next[2 * i + 1] = v1;
+                    s1 += (double) v0; s1 += (double) v1;
+                    s2 += (double) v0 * (double) v0; s2 += (double) v1 * (double) v1;
+                }
+                s1 = block_sum_d(s1, red, 0);
+                s2 = block_sum_d(s2, red, 1);
+                if (tid == 0) {
+                    ((f64x2 *) ga.pick.part_next)[0] = f64x2{ s1, s2 };
+                    if (ga.pick.epoch) ga.pick.epoch[0] = next_epoch(ga.pick.epoch[0]);
+                }
+            }
+        } else
         if (EPI == EPI_STORE_TAG) {                     // ga.sync -> the epoch word, ga.sync_epoch = layer (k_qkv_attn)
             if (live) store_tagged((uint64_t *) y + m, acc, store_tag ^ ((ga.lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test -- a tag nobody waits for)
         } else if (EPI == EPI_RESID_TAG) {              // the row leaves for the next pipeline stage's mailbox (and / or plain)
@@ -1613,6 +1683,45 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
 }
 
 
+hipError_t launch_gemv_pick(const QMat &w, const float *in0, const float *in1, float *y, const uint16_t *T_silu, hipStream_t st,
+                            const NormPart *npp, const PickIO &pick) {
+    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;
+    NormPart np = npp ? *npp : NormPart();
+    const bool normp = norm_mode >= 2 && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX;
+    if (!normp) { np.in = nullptr; np.n_in = norm_mode == 0 ? -1 : 0; }
+    // the workgroup shape of launch_gemv_t's fp32 prologues; the embedding in the epilogue is written for 256 threads
+    int nw = pick_waves(w.ngroups);
+    const int need = w.K / 16;
+    while (nw < 4 && need > nw * 64) nw *= 2;
+    const int pg = need <= nw * 64 ? 1 : need <= 2 * nw * 64 ? 2 : 0;
+    if (nw != 4 || !pg || (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024))) return hipErrorInvalidValue;      // (the caller checks gemv_pick_applies)
+    const int D = pick_depth(w.nchunks, w.ngroups);
+    const int grid = (w.ngroups + nw - 1) / nw;
+    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
+    lds = ((lds + 15) & ~(size_t) 15) + (size_t) D * 288;
+    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, in0, in1, w.K, y, nullptr, T_silu, nullptr, nullptr,
+                    (const f64x2 *) np.in, np.n_in, nullptr, nullptr, 0, 0, g_lut_math };
+    ga.pick = pick;
+#define LH_GOP(PRE, DD, PG) hipLaunchKernelGGL((k_gemv<PRE, EPI_STORE_PICK, DD, true, PG>), dim3(grid), dim3(nw * 64), lds, st, ga)
+#define LH_GOPD(PRE, PG) { if (D == 4) LH_GOP(PRE, 4, PG); else if (D == 8) LH_GOP(PRE, 8, PG); else if (D == 10) LH_GOP(PRE, 10, PG); else return hipErrorInvalidValue; }
+    if (normp) { if (pg == 1) LH_GOPD(PREP_NORMP, 1) else LH_GOPD(PREP_NORMP, 2) }
+    else { if (pg == 1) LH_GOPD(PREP_NORM, 1) else LH_GOPD(PREP_NORM, 2) }
+#undef LH_GOPD
+#undef LH_GOP
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+// the shapes launch_gemv_pick is instantiated for (ring kernels with 4-wave workgroups: every LLaMA lm head)
+bool gemv_pick_applies(const QMat &w) {
+    int nw = pick_waves(w.ngroups);
+    const int need = w.K / 16;
+    while (nw < 4 && need > nw * 64) nw *= 2;
+    const int pg = need <= nw * 64 ? 1 : need <= 2 * nw * 64 ? 2 : 0;
+    if (nw != 4 || !pg || (w.nchunks <= 16 && !(w.nchunks == 16 && w.ngroups >= 1024))) return false;
+    const int D = pick_depth(w.nchunks, w.ngroups);
+    return D == 4 || D == 8 || D == 10;
+}
+
 // Short prompt chunk (see k_decn_scores): scores -> soft_max + V*P + ordered combine + Q4_0 quantization of the
 // merged rows straight into the QA operand of the wo mat-mul (no separate preparation launch).
 //   sc : scratch of N * H * n_ctx floats
@@ -1975,6 +2084,10 @@ hipError_t init_attrs_decode() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
     LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
     LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
+    LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 8, true, 1>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 10, true, 1>));
+    LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 4, true, 2>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 8, true, 2>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 10, true, 2>));
+    LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 8, true, 1>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 10, true, 1>));
+    LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 4, true, 2>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 8, true, 2>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 10, true, 2>));
     LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 1); LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 2); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 4); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 12);
 #undef LH_ATTR_G1
     LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_pv_stream<4>); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));

@@ -173,6 +173,7 @@ struct llamahip_model {
     uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
+    unsigned long long *d_pick = nullptr; // greedy loop: {64-bit atomic-max key, arrival counter} of the lm head's pick epilogue (EPI_STORE_PICK)
     uint64_t *d_pvx = nullptr;           // tagged partial sums of k_dec_pv_stream's split workgroups: [H dh/32][32 threads of the split][32]
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
     uint32_t *d_fault = nullptr;         //   ran out raises it; the host reads it (a plain load) after every synchronisation
@@ -242,6 +243,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
+    free_dev(d_pick);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_pvx);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
@@ -547,6 +549,10 @@ struct StepIO {
     const uint64_t *mb_in = nullptr;
     uint64_t *mb_out = nullptr;
     const uint64_t *mb_token = nullptr;
+    // the device-resident greedy loop: the lm head's launch also picks the token, advances the position and embeds the pick for the
+    // next step (EPI_STORE_PICK); the step then starts from the row the previous step (or the caller) left in x / npart_a
+    bool fold_pick = false;
+    int32_t *pick_out = nullptr, *pick_next = nullptr;
 };
 // The decode attention schedule by position (a host-side fact at every entry point: n_past, or the slot's next position; graphs are
 // captured per schedule):
@@ -606,6 +612,10 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     const bool use_epoch = use_qkvx || pv_split;
     if (use_epoch && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (io && fused && io->mb_token && m->first_stage && !use_part) { set_err(err, err_cap, "pipeline mailboxes need the default norm-statistics mode (LLAMAHIP_NORM_MODE unset)"); return LLAMAHIP_ERR_PREDICT; }
+    const bool fold = io && io->fold_pick && fused && use_part && m->first_stage && m->last_stage;
+    if (m->first_stage && fold) {
+        n_part_x = 1;               // x, npart_a and the epoch were left by the previous step's lm head (or by decode_greedy's first embedding launch)
+    } else
     if (m->first_stage) {
         if (use_part) {
             HIP_TRY(launch_embed_part((io && io->token) ? io->token : m->tok_src ? m->tok_src : m->d_tokens, m->tok_emb, m->x, d, m->npart_a, st, use_epoch ? m->d_epoch : nullptr, nullptr,
@@ -740,6 +750,11 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         if (fused) {
             NormPart np_out;
             if (n_part_x > 0 && m->l1 > m->l0) { np_out.in = m->npart_a; np_out.n_in = n_part_x; }      // (x_last is null on the last stage: the row is in m->x)
+            if (fold) {
+                const PickIO pk = { m->d_pick, (uint32_t *) (m->d_pick + 1), io->pick_out, io->pick_next, state, m->tok_emb, m->x, m->npart_a,
+                                    (m->d_attn_sync || m->d_pvx) ? m->d_epoch : nullptr, V };      // (the NEXT step's epoch: its schedule may use the tags even if this one does not)
+                HIP_TRY(launch_gemv_pick(m->output, m->x, m->norm_w, m->logits, m->T_silu, st, &np_out, pk), LLAMAHIP_ERR_PREDICT);
+            } else
             HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, nullptr, nullptr, st, &np_out), LLAMAHIP_ERR_PREDICT);
         } else if (want_all) {
             HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, N, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);
@@ -991,6 +1006,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         }
         HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->d_pick, 64), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->d_pick, 0, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->npart_a, 0, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
@@ -1218,17 +1235,29 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         // One decode step (embed -> layers -> lm head -> argmax) captured once per n_threads value.
         // Nothing in it depends on the step: position and token slots live in device memory and
         // k_argmax advances them, so the same executable graph is replayed n_steps times.
+        // Where the lm head's pick epilogue applies (EPI_STORE_PICK) the step is layers -> lm head alone: that launch picks the token,
+        // advances the position and embeds the pick for the next step; only the FIRST token of the call is embedded by a launch of its own.
+        static const bool no_fold = getenv("LLAMAHIP_NO_PICK_FOLD") != nullptr;
+        static const bool norm_default = !(getenv("LLAMAHIP_NORM_MODE") && atoi(getenv("LLAMAHIP_NORM_MODE")) < 2);
+        const bool fold = !no_fold && norm_default && !m->dense && !(m->flags & LLAMAHIP_FLAG_UNFUSED) && m->w13_interleaved && m->l1 > m->l0 && gemv_pick_applies(m->output);
+        StepIO pio;
+        pio.fold_pick = true; pio.pick_out = m->d_out_tokens; pio.pick_next = m->d_tokens;
+        if (fold) {
+            // the first token's row, statistics and epoch (what k_embed_part does at the head of an un-folded step)
+            const bool ep = m->d_attn_sync || m->d_pvx;
+            HIP_TRY(launch_embed_part(m->d_tokens, m->tok_emb, m->x, m->hp.n_embd, m->npart_a, m->stream, ep ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);
+        }
         for (int i = 0; i < n_steps; i++) {
             m->attn_sched = attn_sched_at(m, n_past + i);
-            const int gkey = nth * 4096 + m->cur_seq + (m->attn_sched << 24);
+            const int gkey = nth * 4096 + m->cur_seq + (m->attn_sched << 24) + (fold ? 1 << 27 : 0);
             auto it = m->decode_graphs.find(gkey);
             if (it == m->decode_graphs.end()) {
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
                 HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
                 HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal), LLAMAHIP_ERR_PREDICT);
-                rc = forward(m, nth, 0, 1, nullptr, true, false, -1, nullptr, err, err_cap);
-                hipError_t e1 = rc ? hipErrorUnknown : launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, 0, m->d_tokens, m->d_state, m->stream);
+                rc = forward(m, nth, 0, 1, nullptr, true, false, -1, nullptr, err, err_cap, fold ? &pio : nullptr);
+                hipError_t e1 = (rc || fold) ? (rc ? hipErrorUnknown : hipSuccess) : launch_argmax(m->logits, m->hp.n_vocab, m->d_out_tokens, 0, m->d_tokens, m->d_state, m->stream);
                 hipError_t e2 = hipStreamEndCapture(m->stream, &graph);
                 if (rc) return rc;
                 HIP_TRY(e1, LLAMAHIP_ERR_PREDICT);

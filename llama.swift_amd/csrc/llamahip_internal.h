@@ -13,7 +13,7 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 // (the *_TAG forms: the operand arrives / the result leaves as 8-byte {fp32 bits, tag} granules that the consumer polls -- the
 //  hand-offs inside k_qkv_attn, and the residual-stream row between pipeline stages through a device-side mailbox)
 enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PREP_NORM_TAG = 6 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5, EPI_STORE_PICK = 6 };
 // The rows of a BATCHED decode step (llamahip_stage_step_set): row b is the next token of sequence slot b' -- its own position (device
 // resident, so a captured step replays unchanged), its own KV cache, its own token / pick / residual-stream buffers.  Lives in device
 // memory; kernels that take a `const SeqSet *` treat null as "one sequence, consecutive positions" (the prompt-chunk meaning).
@@ -106,7 +106,19 @@ struct MailboxIO {
     uint32_t *epoch = nullptr, *fault = nullptr;
     int test_bits = 0;                   // 0x1000 short polls, 0x2000 wrong tag on out_t (fault-injection tests)
 };
+// EPI_STORE_PICK (the lm head of the device-resident greedy loop): the launch that writes the logits also picks the token (k_argmax's
+// rule: the largest value, the LOWEST index on ties, NaN never wins) -- every workgroup folds its rows into one 64-bit atomic max, the
+// last workgroup to finish records the pick, advances the position and embeds the picked token for the next step (k_embed_part's
+// arithmetic: row, {sum x, sum x^2}, epoch bump), so a decode step has no single-workgroup launches left.
+struct PickIO {
+    unsigned long long *key; uint32_t *count;       // zeroed once; the last workgroup re-zeroes them
+    int32_t *out; int32_t *next_token; int32_t *state;      // as launch_argmax: out[state[1]] = pick, *next_token = pick, state advances
+    const uint8_t *emb; float *x_next; double *part_next; uint32_t *epoch; int n_vocab;      // the next step's embedding row
+};
 int gemv_resid_parts(const QMat &w);
+bool gemv_pick_applies(const QMat &w);
+hipError_t launch_gemv_pick(const QMat &w, const float *in0, const float *in1, float *y, const uint16_t *T_silu, hipStream_t st,
+                            const NormPart *np, const PickIO &pick);
 hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, const float *qa_d,
                        const float *in0, const float *in1, float *y, const float *resid,
                        const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
