@@ -562,29 +562,51 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
             __syncthreads();
             if (lane == 0) wk[wave] = key;
             __syncthreads();
+            // Arrival: this workgroup's key goes to its own slot (write-through store, acknowledged before the ticket), tickets are
+            // taken per shard of 8 (block % 8: one atomic per workgroup on 8 different words -- a single counter costs ~12 ns per
+            // arrival, 1 000 workgroups = 12 us), the last of a shard takes a ticket of the top counter, the last of those reduces.
             if (tid == 0) {
                 unsigned long long k2 = wk[0];
                 for (int w2_ = 1; w2_ < nw; w2_++) k2 = wk[w2_] > k2 ? wk[w2_] : k2;
-                atomicMax(ga.pick.key, k2);
-                __threadfence();
-                const uint32_t ticket = atomicAdd(ga.pick.count, 1u);
+                __hip_atomic_store(ga.pick.key + blk, k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int nwg = (int) gridDim.x, shard = blk & 7, nsh = (nwg + 7 - shard) / 8, ntop = nwg < 8 ? nwg : 8;
                 int lastwg = 0;
-                if (ticket == gridDim.x - 1) {
-                    __threadfence();
-                    const unsigned long long fin = __hip_atomic_load(ga.pick.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicAdd(ga.pick.count + shard * 16, 1u) == (uint32_t) (nsh - 1))
+                    lastwg = atomicAdd(ga.pick.count + 128, 1u) == (uint32_t) (ntop - 1);
+                wk[15] = (unsigned long long) lastwg;
+            }
+            __syncthreads();
+            if (wk[15] != 0ull) {
+                // the last workgroup: every key is visible (each was acknowledged before its ticket); fold them in index order
+                unsigned long long best = 0ull;
+                for (int i = tid; i < (int) gridDim.x; i += nw * 64) {
+                    const unsigned long long kv = __hip_atomic_load(ga.pick.key + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    best = kv > best ? kv : best;
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const uint32_t lo_ = (uint32_t) __shfl_xor((int) (uint32_t) best, o), hi_ = (uint32_t) __shfl_xor((int) (uint32_t) (best >> 32), o);
+                    const unsigned long long ok = ((unsigned long long) hi_ << 32) | lo_;
+                    best = ok > best ? ok : best;
+                }
+                __syncthreads();
+                if (lane == 0) wk[wave] = best;
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned long long fin = wk[0];
+                    for (int w2_ = 1; w2_ < nw; w2_++) fin = wk[w2_] > fin ? wk[w2_] : fin;
                     const int r = (fin >> 32) == 0ull ? 0 : (int) (0xFFFFFFFFu - (uint32_t) fin);
                     int32_t *st = ga.pick.state;
                     ga.pick.out[st[1]] = r;
                     if (ga.pick.next_token) *ga.pick.next_token = r;
                     st[0] += 1; st[1] += 1;
-                    __hip_atomic_store(ga.pick.key, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ga.pick.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int sh = 0; sh < 8; sh++) __hip_atomic_store(ga.pick.count + sh * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ga.pick.count + 128, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     wk[14] = (unsigned long long) (r < ga.pick.n_vocab ? r : 0);
-                    lastwg = 1;
                 }
-                wk[15] = (unsigned long long) lastwg;
+                __syncthreads();
             }
-            __syncthreads();
             if (wk[15] != 0ull && ga.pick.emb) {
                 // the picked token's embedding row for the next step: k_embed_part's arithmetic, thread for thread (nw * 64 = 256 threads)
                 const int tok = (int) wk[14];

@@ -751,7 +751,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             NormPart np_out;
             if (n_part_x > 0 && m->l1 > m->l0) { np_out.in = m->npart_a; np_out.n_in = n_part_x; }      // (x_last is null on the last stage: the row is in m->x)
             if (fold) {
-                const PickIO pk = { m->d_pick, (uint32_t *) (m->d_pick + 1), io->pick_out, io->pick_next, state, m->tok_emb, m->x, m->npart_a,
+                const PickIO pk = { m->d_pick + 128, (uint32_t *) m->d_pick, io->pick_out, io->pick_next, state, m->tok_emb, m->x, m->npart_a,
                                     (m->d_attn_sync || m->d_pvx) ? m->d_epoch : nullptr, V };      // (the NEXT step's epoch: its schedule may use the tags even if this one does not)
                 HIP_TRY(launch_gemv_pick(m->output, m->x, m->norm_w, m->logits, m->T_silu, st, &np_out, pk), LLAMAHIP_ERR_PREDICT);
             } else
@@ -1006,8 +1006,11 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         }
         HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
-        HIP_TRY(hipMalloc((void **) &m->d_pick, 64), LLAMAHIP_ERR_LOAD);
-        HIP_TRY(hipMemset(m->d_pick, 0, 64), LLAMAHIP_ERR_LOAD);
+        {   // lm-head pick epilogue: [0, 1024) bytes tickets, then one 8-byte key per workgroup of the lm head's launch (<= n_vocab / 8 + 8)
+            const size_t pb = 1024 + ((size_t) V / 8 + 8) * 8;
+            HIP_TRY(hipMalloc((void **) &m->d_pick, pb), LLAMAHIP_ERR_LOAD);
+            HIP_TRY(hipMemset(m->d_pick, 0, pb), LLAMAHIP_ERR_LOAD);
+        }
         HIP_TRY(hipMalloc((void **) &m->npart_a, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->npart_b, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->npart_a, 0, NORM_PART_MAX * 2 * sizeof(double)), LLAMAHIP_ERR_LOAD);

@@ -111,7 +111,7 @@ struct MailboxIO {
 // last workgroup to finish records the pick, advances the position and embeds the picked token for the next step (k_embed_part's
 // arithmetic: row, {sum x, sum x^2}, epoch bump), so a decode step has no single-workgroup launches left.
 struct PickIO {
-    unsigned long long *key; uint32_t *count;       // zeroed once; the last workgroup re-zeroes them
+    unsigned long long *key; uint32_t *count;       // key: one slot per workgroup of the launch; count: 8 shard tickets (16 dwords apart) + the top ticket at [128]; zeroed once, re-zeroed by the last workgroup
     int32_t *out; int32_t *next_token; int32_t *state;      // as launch_argmax: out[state[1]] = pick, *next_token = pick, state advances
     const uint8_t *emb; float *x_next; double *part_next; uint32_t *epoch; int n_vocab;      // the next step's embedding row
 };
