@@ -23,6 +23,12 @@
  * build, so logits are expected to be bit-identical to that build for the same
  * `n_threads` (the reference's attention V*P product depends on its thread count,
  * Sources/cpp/ggml.c:5619-5665 / 5553-5577; `n_threads` selects the same split here).
+ * One operator is exact BY TEST, NOT BY CONSTRUCTION: the norm (ggml.c:5327-5385).  Its two double-precision sums are formed in a
+ * different association order than the reference's sequential loops, and the single-token decode kernels by default take the second
+ * moment from the producer's partial sums in one pass (sum x^2 - mean * sum x, guarded against cancellation) instead of the reference's
+ * two-pass form: both carry a few 2^-53 of rounding before the result is narrowed to fp32, where a difference survives with
+ * probability ~2^-29 per row.  No parity test (504-token full-depth traces, rows with a DC offset on both sides of the guard) has ever
+ * observed one; LLAMAHIP_NORM_MODE=0 selects the reference's two-pass formula in every decode prologue (prompt evals always use it).
  */
 #ifndef LLAMAHIP_H
 #define LLAMAHIP_H
