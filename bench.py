@@ -259,6 +259,30 @@ def parse_kernel_trace(outdir, cfg):
                 matched = True
                 break
         if not matched:
+            # the device-resident greedy loop since round 4: per layer launches, then the lm head's launch that also picks the token and
+            # embeds it (EPI_STORE_PICK) -- no k_embed_part / k_argmax in a token.  (The window cannot lock onto a layer boundary inside a
+            # token: the slot of its last layer's first launch would hold the lm head and the slot after it the NEXT token's first launch,
+            # which is never the second launch of a layer.)
+            for layer in layouts:
+                seq_len = nl * len(layer) + 1
+                if i + seq_len > len(rows) or "k_gemv" not in rows[i + seq_len - 1][2] or "k_embed" in rows[i][2]:
+                    continue
+                seg = rows[i:i + seq_len]
+                if not all(sub in seg[il * len(layer) + j][2] for il in range(nl) for j, (_, _, sub) in enumerate(layer)):
+                    continue
+                ntok += 1
+                for il in range(nl):
+                    for j, (role, _, _) in enumerate(layer):
+                        s_ = seg[il * len(layer) + j]
+                        dur.setdefault(role, []).append((s_[1] - s_[0]) * 1e-3)
+                        names[role] = s_[2]
+                dur.setdefault(out_role[0], []).append((seg[-1][1] - seg[-1][0]) * 1e-3)
+                names[out_role[0]] = seg[-1][2]
+                dur.setdefault("token_span", []).append((seg[-1][1] - seg[0][0]) * 1e-3)
+                i += seq_len
+                matched = True
+                break
+        if not matched:
             i += 1
     if ntok == 0:
         return None
