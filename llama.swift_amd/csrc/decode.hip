@@ -1184,17 +1184,46 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
             const int e = 2 * tid;
             const double cs = tab[e], sn = tab[e + 1];
             const uint64_t *q2 = aa.qkv2 + h * dh, *k2 = q2 + d, *v2 = q2 + 2 * d;
-            const double x0 = (double) (QKV_WAIT ? poll_tagged(q2 + e, tag, fault, nowait) : q[e]), x1 = (double) (QKV_WAIT ? poll_tagged(q2 + e + 1, tag, fault, nowait) : q[e + 1]);
+            // the granules this thread needs -- 2 (q) or, in the workgroup whose slice holds the new key, 6 (q, k, v) -- are polled TOGETHER:
+            // one look = all loads in flight at once, one L2 round trip (they used to be polled one after the other: six dependent
+            // round trips in the one workgroup every soft_max . V workgroup of the head waits for)
+            float gq0, gq1, gk0 = 0.0f, gk1 = 0.0f, gv0 = 0.0f, gv1 = 0.0f;
+            if (QKV_WAIT) {
+                uint64_t g_[6] = { 0, 0, 0, 0, 0, 0 };
+                int spins = 0;
+                for (;;) {
+                    g_[0] = __hip_atomic_load(q2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g_[1] = __hip_atomic_load(q2 + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (owns_new) {
+                        g_[2] = __hip_atomic_load(k2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g_[3] = __hip_atomic_load(k2 + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g_[4] = __hip_atomic_load(v2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g_[5] = __hip_atomic_load(v2 + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    bool ok = (uint32_t) (g_[0] >> 32) == tag && (uint32_t) (g_[1] >> 32) == tag;
+                    if (owns_new) ok = ok && (uint32_t) (g_[2] >> 32) == tag && (uint32_t) (g_[3] >> 32) == tag && (uint32_t) (g_[4] >> 32) == tag && (uint32_t) (g_[5] >> 32) == tag;
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (poll_give_up(spins, nowait ? (1 << 8) : (1 << 20), fault)) break;
+                }
+                gq0 = __builtin_bit_cast(float, (uint32_t) g_[0]); gq1 = __builtin_bit_cast(float, (uint32_t) g_[1]);
+                gk0 = __builtin_bit_cast(float, (uint32_t) g_[2]); gk1 = __builtin_bit_cast(float, (uint32_t) g_[3]);
+                gv0 = __builtin_bit_cast(float, (uint32_t) g_[4]); gv1 = __builtin_bit_cast(float, (uint32_t) g_[5]);
+            } else {
+                gq0 = q[e]; gq1 = q[e + 1];
+                if (owns_new) { gk0 = kk[e]; gk1 = kk[e + 1]; gv0 = vv[e]; gv1 = vv[e + 1]; }
+            }
+            const double x0 = (double) gq0, x1 = (double) gq1;
             qs[e] = (float) (x0 * cs - x1 * sn);
             qs[e + 1] = (float) (x0 * sn + x1 * cs);
             if (owns_new) {
-                const double k0 = (double) (QKV_WAIT ? poll_tagged(k2 + e, tag, fault, nowait) : kk[e]), k1 = (double) (QKV_WAIT ? poll_tagged(k2 + e + 1, tag, fault, nowait) : kk[e + 1]);
+                const double k0 = (double) gk0, k1 = (double) gk1;
                 const float r0 = (float) (k0 * cs - k1 * sn), r1 = (float) (k0 * sn + k1 * cs);
                 kn[e] = r0; kn[e + 1] = r1;
                 Kc[(size_t) n_past * d + h * dh + e] = r0;
                 Kc[(size_t) n_past * d + h * dh + e + 1] = r1;
-                Vc[(size_t) n_past * d + h * dh + e] = QKV_WAIT ? poll_tagged(v2 + e, tag, fault, nowait) : vv[e];
-                Vc[(size_t) n_past * d + h * dh + e + 1] = QKV_WAIT ? poll_tagged(v2 + e + 1, tag, fault, nowait) : vv[e + 1];
+                Vc[(size_t) n_past * d + h * dh + e] = gv0;
+                Vc[(size_t) n_past * d + h * dh + e + 1] = gv1;
                 // the new V row must be in the L2 before any score of this workgroup is (a soft_max . V workgroup reads it once it
                 // has seen the tagged scores): drain these stores on this side of the barrier
                 if (QKV_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1277,7 +1306,27 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
     if (QKV_WAIT) {
         const uint32_t tag = make_tag(aa.epoch[0], aa.layer + 1);
         const bool nowait = (lut_math & 0x1000) != 0;
-        for (int t = tid; t < T; t += nt) { const float v = poll_tagged(aa.sc2 + (size_t) h * n_ctx + t, tag, fault, nowait); p[t] = v; mx = fmaxf(mx, v); }
+        // (a thread's granules, up to four at a time, are polled together: one round trip per look instead of one per granule)
+        for (int t0 = tid; t0 < T; t0 += 4 * nt) {
+            uint64_t g_[4] = { 0, 0, 0, 0 };
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int t = t0 + i * nt;
+                    if (t < T) { g_[i] = __hip_atomic_load(aa.sc2 + (size_t) h * n_ctx + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && (uint32_t) (g_[i] >> 32) == tag; }
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (poll_give_up(spins, nowait ? (1 << 8) : (1 << 20), fault)) break;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = t0 + i * nt;
+                if (t < T) { const float v = __builtin_bit_cast(float, (uint32_t) g_[i]); p[t] = v; mx = fmaxf(mx, v); }
+            }
+        }
     } else
     for (int t = tid; t < T; t += nt) { const float v = load_f32_sc1(row + t); p[t] = v; mx = fmaxf(mx, v); }
     mx = block_max_f(mx, red, 0);
