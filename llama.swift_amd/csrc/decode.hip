@@ -1099,6 +1099,184 @@ k_dec_pv_stream(const float *__restrict__ sc, const float *__restrict__ Vc, int 
 #undef LH_PFLUSH
 
 // ------------------------------------------------------------------------------------------------
+// k_dec_pv_dma (round 4): k_dec_pv_stream with the V rows moved HBM -> LDS by LDS-DMA from ONE loader wave instead of through the
+// registers of all 1 024 threads.  In k_dec_pv_stream the soft_max took 6 us at 2 048 keys although it needs 1.8 us alone: every
+// thread was also issuing V loads, and a wave's exp / sum instructions queue behind its own load issue.  Here wave 0 does nothing but
+// global_load_lds_dwordx4 (1 KiB per instruction = 8 consecutive rows x 128 bytes of ONE chain, per-lane row addresses; no VGPR round
+// trip, no barrier per stage), starting when the score row is back (issued earlier, V would delay the row behind 15 MB of requests:
+// k_dec_pv_stream's timeline), into a ring of stages [chain][8 rows][32 floats]; waves 1 .. 7 run the soft_max (ggml.c:5619-5665) and
+// then the owners of the workgroup's chains (two 32-lane chains per wave) walk their rows in key order out of the ring -- the same fp32
+// FMA chains (ggml.c:5459-5480), so the sums are bit-identical to k_dec_pv_blk / k_dec_pv_stream.  Flow control: `landed` (stages whose
+// DMA has completed: the loader's own vmcnt) and one `done` word per consumer wave.  The chains of a (head, column block) are split
+// over workgroups and handed over as tagged granules exactly as in k_dec_pv_stream.  Workgroup barriers are raw s_barrier (a
+// __syncthreads would make the loader wait for its DMA).  grid H dh/32 x split, 512 threads; LDS = red + p[n_ctx] + part + flags + ring.
+// ------------------------------------------------------------------------------------------------
+constexpr int PVD_SR = 8;            // rows per chain and stage: one DMA instruction
+constexpr int PVD_F = 12;            // stages... DMA instructions that may be in flight behind the stage whose landing is awaited: PVD_F * nloc <= 60
+template <int N> __device__ __forceinline__ void pvd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void pvd_barrier() {      // LDS writes of this wave done, then the hardware barrier; nothing waits for VMEM
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// barrier of the 7 worker waves only (the loader wave takes part in the first hardware barrier and in nothing after it): an LDS counter
+__device__ __forceinline__ void pvd_worker_barrier(uint32_t *ctr, uint32_t &round, int lane, uint32_t *fault) {
+    round += 7;
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < round) { __builtin_amdgcn_s_sleep(0); if (poll_give_up(spins, 1 << 24, fault)) break; }
+}
+__global__ void __launch_bounds__(512)
+k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth, int NS,
+             float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
+             const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st, int lut_math,
+             int H, int split, uint64_t *__restrict__ xpart, const uint32_t *__restrict__ epoch, int layer, uint32_t *__restrict__ fault) {
+    extern __shared__ double smem_d[];
+    double *red = smem_d;                                               // [32]
+    float *p = (float *) (smem_d + 32);                                 // [n_ctx rounded to 4]
+    float *part = p + ((n_ctx + 3) & ~3);                               // [nth][32]
+    uint32_t *flags = (uint32_t *) (part + nth * 32);                   // [0] landed, [1 .. 7] done per consumer wave
+    float *ring = (float *) (flags + 16);                               // [NS][nloc][8][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x, z = (bid >> 3) % split, base = (bid / (8 * split)) * 8 + (bid & 7);
+    const int h = base % H, cb = base / H;
+    const int cpw = (nth + split - 1) / split, th_lo = z * cpw, nloc = min(nth, th_lo + cpw) - th_lo;      // this workgroup's chains
+    const int T = st[0] + 1;
+    const int dc = (T + nth - 1) / nth;
+    const int nstage = (dc + PVD_SR - 1) / PVD_SR;
+    const int col0 = h * dh + cb * 32;
+    const int ncw = (nloc + 1) / 2;                                     // consumer waves (1 .. ncw), two chains each
+    const int limit = (lut_math & 0x1000) ? (1 << 8) : (1 << 22);
+    if (tid < 16) flags[tid] = 0u;
+    // the head's score row: waves 1 .. 7 only (the loader wave must have no load of its own in flight next to its DMA)
+    constexpr int PV_ROW = 10;                                          // 448 threads x 10 cover n_ctx <= 4 096
+    const float *row = sc + (size_t) h * n_ctx;
+    float rv[PV_ROW];
+    const int wt = tid - 64;
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) rv[i] = row[min(i * 448 + wt, T - 1)];
+    }
+    float mx = -INFINITY;
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) if (i * 448 + wt < T) mx = fmaxf(mx, rv[i]);
+        mx = wave_max_f(mx);
+        if (lane == 0) ((float *) red)[wave] = mx;
+    }
+    pvd_barrier();                                                      // the row is back (and the flags are zero): the loader may start
+    if (wave == 0) {
+        // =========================================== loader ===========================================
+        const uint32_t ring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) ring;
+        const uint64_t vbase = (uint64_t) (uintptr_t) (Vc + col0);
+        const int u = lane >> 3, q = lane & 7;
+        uint32_t pub = 0;
+        int slot = 0;
+        auto min_done = [&]() { uint32_t m = 0xffffffffu; for (int w = 1; w <= ncw; w++) m = min(m, __hip_atomic_load(flags + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); return m; };
+        for (int s = 0; s < nstage; s++) {
+            if (s >= NS && min_done() < (uint32_t) (s - NS + 1)) {
+                pvd_wait_vmcnt<0>();                                    // the ring is full: everything issued has to land anyway
+                if ((uint32_t) s > pub) { pub = (uint32_t) s; __hip_atomic_store(flags, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                int spins = 0;
+                while (min_done() < (uint32_t) (s - NS + 1)) { __builtin_amdgcn_s_sleep(1); if (poll_give_up(spins, limit, fault)) break; }
+            }
+            for (int lc = 0; lc < nloc; lc++) {
+                const int th = th_lo + lc;
+                const int t = min(min(dc * th + s * PVD_SR + u, dc * th + dc - 1), T - 1);      // rows past the chain's end: clamped re-reads nobody consumes
+                const uint32_t voff = (uint32_t) ((size_t) t * d * 4 + q * 16);
+                const uint32_t dst = ring_lds + (uint32_t) ((slot * nloc + lc) * 1024);
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(dst), "s"(vbase) : "memory");
+            }
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            // at most 60 DMA instructions stay in flight: stage s + 1 - F has landed once only F stages' instructions are outstanding
+            const int F = 60 / nloc;                                    // (uniform; the waits below need immediates: nloc in 1 .. 14)
+            if (s + 1 > F) {
+                switch (nloc) {
+                    case 1: pvd_wait_vmcnt<60>(); break; case 2: pvd_wait_vmcnt<60>(); break; case 3: pvd_wait_vmcnt<60>(); break;
+                    case 4: pvd_wait_vmcnt<60>(); break; case 5: pvd_wait_vmcnt<60>(); break; case 6: pvd_wait_vmcnt<60>(); break;
+                    case 7: pvd_wait_vmcnt<56>(); break; case 8: pvd_wait_vmcnt<56>(); break; case 9: pvd_wait_vmcnt<54>(); break;
+                    case 10: pvd_wait_vmcnt<60>(); break; case 11: pvd_wait_vmcnt<55>(); break; case 12: pvd_wait_vmcnt<60>(); break;
+                    case 13: pvd_wait_vmcnt<52>(); break; default: pvd_wait_vmcnt<56>(); break;
+                }
+                if ((uint32_t) (s + 1 - F) > pub) { pub = (uint32_t) (s + 1 - F); __hip_atomic_store(flags, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            }
+        }
+        pvd_wait_vmcnt<0>();
+        __hip_atomic_store(flags, (uint32_t) nstage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;                                                         // the loader is done; the workers go on among themselves
+    }
+    uint32_t wround = 0;
+    {
+        // soft_max (pv_soft_max's arithmetic on the register copy): max, fp16-table exp, double sum, scale
+        float m2 = ((float *) red)[1];
+        for (int w = 2; w < 8; w++) m2 = fmaxf(m2, ((float *) red)[w]);
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) {
+            if (i * 448 + wt < T) {
+                const uint16_t xh = f2h_bits(rv[i] - m2);
+                rv[i] = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
+                sum += (double) rv[i];
+            }
+        }
+        sum = wave_sum_d(sum);
+        if (lane == 0) red[8 + wave] = sum;
+    }
+    pvd_worker_barrier(flags + 8, wround, lane, fault);
+    float acc = 0.0f;
+    const int lc = (tid - 64) >> 5, c = tid & 31, th = th_lo + lc;
+    const bool owner = lc < nloc;
+    {
+        double tot = red[9];
+        for (int w = 2; w < 8; w++) tot += red[8 + w];                  // (exact in any order: every term is a multiple of 2^-24, at most 2^12 terms)
+        const float inv = (float) (1.0 / tot);
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) if (i * 448 + wt < T) p[i * 448 + wt] = rv[i] * inv;
+    }
+    pvd_worker_barrier(flags + 8, wround, lane, fault);                 // p is complete
+    if (wave <= ncw) {
+        // ---- chain owners: rows t0 .. t1 - 1 of chain th in key order, from the ring
+        const int t0 = dc * th, t1 = min(t0 + dc, T);
+        uint32_t landed_seen = 0;
+        int slot = 0;
+        for (int s = 0; s < nstage; s++) {
+            if ((uint32_t) s >= landed_seen) {
+                int spins = 0;
+                while ((landed_seen = __hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= (uint32_t) s) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (poll_give_up(spins, limit, fault)) break;
+                }
+            }
+            if (owner) {
+                const float *vs = ring + (size_t) (slot * nloc + lc) * 256 + c;
+                const int tb = t0 + s * PVD_SR, n = min(PVD_SR, t1 - tb);
+                if (n == PVD_SR) {
+                    float v[PVD_SR], w[PVD_SR];
+#pragma unroll
+                    for (int k = 0; k < PVD_SR; k++) { v[k] = vs[k * 32]; w[k] = p[tb + k]; }
+#pragma unroll
+                    for (int k = 0; k < PVD_SR; k++) acc = fmaf(v[k], w[k], acc);
+                } else {
+                    for (int k = 0; k < n; k++) acc = fmaf(vs[k * 32], p[tb + k], acc);
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flags + wave, (uint32_t) (s + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+    }
+    if (z + 1 < split) {                                                // not the last workgroup of this column block: publish and leave
+        if (owner) store_tagged(xpart + ((size_t) base * nth + th) * 32 + c, acc, make_tag(epoch[0], layer + 1) ^ ((lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test)
+        return;
+    }
+    if (owner) part[th * 32 + c] = acc;
+    if (split > 1 && wt < th_lo * 32)                                   // the chains before this workgroup's, from their owners
+        part[wt] = poll_tagged(xpart + (size_t) base * nth * 32 + wt, make_tag(epoch[0], layer + 1), fault, (lut_math & 0x1000) != 0);
+    pvd_worker_barrier(flags + 8, wround, lane, fault);
+    if (wave == 1) pv_store_block(part, nth, lane, col0 + lane, h, dh, cb, merged, qa_A, qa_d);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_dec_attn_x: k_dec_scores + k_dec_pv_blk<false> in ONE launch with a hand-off that stays inside one XCD.
 // The scores -> soft_max . V seam is per head, and the workgroups of head h (grid (H, n_ctx / 32), linear id
 // h + H * y, H a multiple of 8) all sit on XCD h % 8 (round-robin dispatch, checked by the load-time self-test
@@ -1850,6 +2028,7 @@ bool xcd_selftest(int H, int Y, hipStream_t st) {
 // the score row in 4 registers per thread, 16-byte column quads
 // (LLAMAHIP_HANDOFF_FAULT_TEST=4: the polls of k_dec_pv_stream give up after 256 looks and its publishers use a tag nobody waits for)
 static const int g_pv_fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) == 4) ? 0x1000 : 0;
+static bool th_split_ok(int nth, int split, int cpw) { return split >= 1 && cpw >= 1 && (split - 1) * cpw < nth; }
 bool pv_stream_applies(int dh, int n_ctx, int nth) { return nth >= 1 && nth <= 32 && n_ctx <= 4096 && dh % 32 == 0; }
 
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,
@@ -1880,6 +2059,17 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
         static const int sr_cap = getenv("LLAMAHIP_PV_STAGE_ROWS") ? std::max(1, atoi(getenv("LLAMAHIP_PV_STAGE_ROWS"))) : 1 << 20;
         const int SR = std::min(nl * 128 / cpw, sr_cap);
         const size_t lds = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 32) * sizeof(float) + (size_t) 2 * cpw * SR * 128;
+        // the LDS-DMA variant (k_dec_pv_dma): a loader wave + the chains of at most 7 consumer waves per workgroup; LLAMAHIP_PV_DMA=0 keeps k_dec_pv_stream
+        static const bool no_dma = getenv("LLAMAHIP_PV_DMA") && atoi(getenv("LLAMAHIP_PV_DMA")) == 0;
+        if (!no_dma && cpw <= 14 && th_split_ok(nth, split, cpw) && !getenv("LLAMAHIP_PV_STAGE_ROWS")) {
+            const size_t fixed = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 32) * sizeof(float) + 64;
+            int NS = (int) (((size_t) 150 * 1024 - fixed) / ((size_t) cpw * 1024));
+            NS = std::max(2, std::min(NS, 64));
+            const size_t ldsd = fixed + (size_t) NS * cpw * 1024;
+            hipLaunchKernelGGL(k_dec_pv_dma, dim3(W * split), dim3(512), ldsd, st, sc, Vc, d, dh, n_ctx, nth, NS, merged, qa_A, qa_d, T_exp, state, g_lut_math | g_pv_fault_test, H, split, xpart, epoch, layer, fault);
+            LH_LAUNCH_CHECK();
+            return hipSuccess;
+        }
         hipLaunchKernelGGL(k_dec_pv_stream<4>, dim3(W * split), dim3(1024), lds, st, sc, Vc, d, dh, n_ctx, nth, SR, merged, qa_A, qa_d, T_exp, state, g_lut_math | g_pv_fault_test, H, split, xpart, epoch, layer, fault);
         LH_LAUNCH_CHECK();
         return hipSuccess;
@@ -2161,7 +2351,7 @@ hipError_t init_attrs_decode() {
     LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 4, true, 2>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 8, true, 2>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 10, true, 2>));
     LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 1); LH_ATTR_G1(PREP_NORM_TAG, EPI_STORE, 2); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 4); LH_ATTR_G1(PRE_QA, EPI_RESID_TAG, 12);
 #undef LH_ATTR_G1
-    LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_pv_stream<4>); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));
+    LH_ATTR(k_dec_pv_blk<false>); LH_ATTR(k_dec_pv_blk<true>); LH_ATTR(k_dec_pv_stream<4>); LH_ATTR(k_dec_pv_dma); LH_ATTR(k_dec_attn_x); LH_ATTR((k_qkv_attn<PREP_NORMP, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORMP, 4, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM, 4, 2>));
     LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 8, 1>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 10, 2>)); LH_ATTR((k_qkv_attn<PREP_NORM_TAG, 4, 2>));
 #undef LH_ATTR
     return hipSuccess;
