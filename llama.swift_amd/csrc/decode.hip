@@ -1117,9 +1117,9 @@ template <int N> __device__ __forceinline__ void pvd_wait_vmcnt() { asm volatile
 __device__ __forceinline__ void pvd_barrier() {      // LDS writes of this wave done, then the hardware barrier; nothing waits for VMEM
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// barrier of the 7 worker waves only (the loader wave takes part in the first hardware barrier and in nothing after it): an LDS counter
+// barrier of the 6 worker waves only (the two loader waves take part in the first hardware barrier and in nothing after it): an LDS counter
 __device__ __forceinline__ void pvd_worker_barrier(uint32_t *ctr, uint32_t &round, int lane, uint32_t *fault) {
-    round += 7;
+    round += 6;
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < round) { __builtin_amdgcn_s_sleep(0); if (poll_give_up(spins, 1 << 24, fault)) break; }
@@ -1133,7 +1133,7 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     double *red = smem_d;                                               // [32]
     float *p = (float *) (smem_d + 32);                                 // [n_ctx rounded to 4]
     float *part = p + ((n_ctx + 3) & ~3);                               // [nth][32]
-    uint32_t *flags = (uint32_t *) (part + nth * 32);                   // [0] landed, [1 .. 7] done per consumer wave
+    uint32_t *flags = (uint32_t *) (part + nth * 32);                   // [0], [1] stages landed per loader wave | [2 .. 7] done per consumer wave | [8] worker barrier
     float *ring = (float *) (flags + 16);                               // [NS][nloc][8][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x, z = (bid >> 3) % split, base = (bid / (8 * split)) * 8 + (bid & 7);
@@ -1143,77 +1143,80 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     const int dc = (T + nth - 1) / nth;
     const int nstage = (dc + PVD_SR - 1) / PVD_SR;
     const int col0 = h * dh + cb * 32;
-    const int ncw = (nloc + 1) / 2;                                     // consumer waves (1 .. ncw), two chains each
+    const int ncw = (nloc + 1) / 2;                                     // consumer waves (2 .. 1 + ncw), two chains each
     const int limit = (lut_math & 0x1000) ? (1 << 8) : (1 << 22);
     if (tid < 16) flags[tid] = 0u;
-    // the head's score row: waves 1 .. 7 only (the loader wave must have no load of its own in flight next to its DMA)
-    constexpr int PV_ROW = 10;                                          // 448 threads x 10 cover n_ctx <= 4 096
+    // the head's score row: the 6 worker waves only (a loader wave must have no load of its own in flight next to its DMA)
+    constexpr int PV_ROW = 11, NWT = 384;                               // 384 threads x 11 cover n_ctx <= 4 096
     const float *row = sc + (size_t) h * n_ctx;
     float rv[PV_ROW];
-    const int wt = tid - 64;
-    if (wave > 0) {
-#pragma unroll
-        for (int i = 0; i < PV_ROW; i++) rv[i] = row[min(i * 448 + wt, T - 1)];
-    }
+    const int wt = tid - 128;
     float mx = -INFINITY;
-    if (wave > 0) {
+    if (wave > 1) {
 #pragma unroll
-        for (int i = 0; i < PV_ROW; i++) if (i * 448 + wt < T) mx = fmaxf(mx, rv[i]);
+        for (int i = 0; i < PV_ROW; i++) rv[i] = row[min(i * NWT + wt, T - 1)];
+#pragma unroll
+        for (int i = 0; i < PV_ROW; i++) if (i * NWT + wt < T) mx = fmaxf(mx, rv[i]);
         mx = wave_max_f(mx);
         if (lane == 0) ((float *) red)[wave] = mx;
     }
-    pvd_barrier();                                                      // the row is back (and the flags are zero): the loader may start
-    if (wave == 0) {
-        // =========================================== loader ===========================================
+    pvd_barrier();                                                      // the row is back (and the flags are zero): the loaders may start
+    if (wave < 2) {
+        // =========================================== loaders: chains lc = wave, wave + 2, ... ===========================================
         const uint32_t ring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) ring;
         const uint64_t vbase = (uint64_t) (uintptr_t) (Vc + col0);
         const int u = lane >> 3, q = lane & 7;
+        const int nmine = (nloc - wave + 1) / 2;                        // my chains
+        if (nmine <= 0) return;
+        // per-lane byte offset of row u of stage 0 of my j-th chain; a stage further is PVD_SR rows further.  Rows beyond a chain's end are
+        // fetched and never consumed; only the cache's end bounds them.
+        uint32_t off[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) off[j] = (uint32_t) ((size_t) min(dc * (th_lo + min(wave + 2 * j, nloc - 1)) + u, n_ctx - 1) * d * 4 + q * 16);
+        const uint32_t step = (uint32_t) ((size_t) PVD_SR * d * 4);
+        const uint32_t off_max = (uint32_t) ((size_t) (n_ctx - 1) * d * 4 + q * 16);
         uint32_t pub = 0;
         int slot = 0;
-        auto min_done = [&]() { uint32_t m = 0xffffffffu; for (int w = 1; w <= ncw; w++) m = min(m, __hip_atomic_load(flags + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); return m; };
+        auto min_done = [&]() { uint32_t m = 0xffffffffu; for (int w = 0; w < ncw; w++) m = min(m, __hip_atomic_load(flags + 2 + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); return m; };
+        const int F = 60 / nmine;                                       // stages whose DMA instructions may be outstanding (nmine in 1 .. 7)
         for (int s = 0; s < nstage; s++) {
             if (s >= NS && min_done() < (uint32_t) (s - NS + 1)) {
                 pvd_wait_vmcnt<0>();                                    // the ring is full: everything issued has to land anyway
-                if ((uint32_t) s > pub) { pub = (uint32_t) s; __hip_atomic_store(flags, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                if ((uint32_t) s > pub) { pub = (uint32_t) s; __hip_atomic_store(flags + wave, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
                 int spins = 0;
                 while (min_done() < (uint32_t) (s - NS + 1)) { __builtin_amdgcn_s_sleep(1); if (poll_give_up(spins, limit, fault)) break; }
             }
-            for (int lc = 0; lc < nloc; lc++) {
-                const int th = th_lo + lc;
-                const int t = min(min(dc * th + s * PVD_SR + u, dc * th + dc - 1), T - 1);      // rows past the chain's end: clamped re-reads nobody consumes
-                const uint32_t voff = (uint32_t) ((size_t) t * d * 4 + q * 16);
-                const uint32_t dst = ring_lds + (uint32_t) ((slot * nloc + lc) * 1024);
-                uint32_t keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(voff), "s"(dst), "s"(vbase) : "memory");
+            const bool tail = (s + 2) * PVD_SR + dc * nth > n_ctx;      // (uniform) only the last stages of the last chains can run past the cache
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                if (j < nmine) {
+                    const uint32_t voff = tail ? min(off[j], off_max) : off[j];
+                    const uint32_t dst = ring_lds + (uint32_t) ((slot * nloc + wave + 2 * j) * 1024);
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(vbase) : "memory");
+                    off[j] += step;
+                }
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
-            // at most 60 DMA instructions stay in flight: stage s + 1 - F has landed once only F stages' instructions are outstanding
-            const int F = 60 / nloc;                                    // (uniform; the waits below need immediates: nloc in 1 .. 14)
             if (s + 1 > F) {
-                switch (nloc) {
-                    case 1: pvd_wait_vmcnt<60>(); break; case 2: pvd_wait_vmcnt<60>(); break; case 3: pvd_wait_vmcnt<60>(); break;
-                    case 4: pvd_wait_vmcnt<60>(); break; case 5: pvd_wait_vmcnt<60>(); break; case 6: pvd_wait_vmcnt<60>(); break;
-                    case 7: pvd_wait_vmcnt<56>(); break; case 8: pvd_wait_vmcnt<56>(); break; case 9: pvd_wait_vmcnt<54>(); break;
-                    case 10: pvd_wait_vmcnt<60>(); break; case 11: pvd_wait_vmcnt<55>(); break; case 12: pvd_wait_vmcnt<60>(); break;
-                    case 13: pvd_wait_vmcnt<52>(); break; default: pvd_wait_vmcnt<56>(); break;
-                }
-                if ((uint32_t) (s + 1 - F) > pub) { pub = (uint32_t) (s + 1 - F); __hip_atomic_store(flags, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                if (nmine == 7) pvd_wait_vmcnt<56>(); else pvd_wait_vmcnt<60>();        // F * nmine: 60 for 1 .. 6 chains, 56 for 7
+                if ((uint32_t) (s + 1 - F) > pub) { pub = (uint32_t) (s + 1 - F); __hip_atomic_store(flags + wave, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
             }
         }
         pvd_wait_vmcnt<0>();
-        __hip_atomic_store(flags, (uint32_t) nstage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return;                                                         // the loader is done; the workers go on among themselves
+        __hip_atomic_store(flags + wave, (uint32_t) nstage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;                                                         // the loaders are done; the workers go on among themselves
     }
     uint32_t wround = 0;
     {
         // soft_max (pv_soft_max's arithmetic on the register copy): max, fp16-table exp, double sum, scale
-        float m2 = ((float *) red)[1];
-        for (int w = 2; w < 8; w++) m2 = fmaxf(m2, ((float *) red)[w]);
+        float m2 = ((float *) red)[2];
+        for (int w = 3; w < 8; w++) m2 = fmaxf(m2, ((float *) red)[w]);
         double sum = 0.0;
 #pragma unroll
         for (int i = 0; i < PV_ROW; i++) {
-            if (i * 448 + wt < T) {
+            if (i * NWT + wt < T) {
                 const uint16_t xh = f2h_bits(rv[i] - m2);
                 rv[i] = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
                 sum += (double) rv[i];
@@ -1224,17 +1227,17 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     }
     pvd_worker_barrier(flags + 8, wround, lane, fault);
     float acc = 0.0f;
-    const int lc = (tid - 64) >> 5, c = tid & 31, th = th_lo + lc;
+    const int lc = (tid - 128) >> 5, c = tid & 31, th = th_lo + lc;
     const bool owner = lc < nloc;
     {
-        double tot = red[9];
-        for (int w = 2; w < 8; w++) tot += red[8 + w];                  // (exact in any order: every term is a multiple of 2^-24, at most 2^12 terms)
+        double tot = red[10];
+        for (int w = 3; w < 8; w++) tot += red[8 + w];                  // (exact in any order: every term is a multiple of 2^-24, at most 2^12 terms)
         const float inv = (float) (1.0 / tot);
 #pragma unroll
-        for (int i = 0; i < PV_ROW; i++) if (i * 448 + wt < T) p[i * 448 + wt] = rv[i] * inv;
+        for (int i = 0; i < PV_ROW; i++) if (i * NWT + wt < T) p[i * NWT + wt] = rv[i] * inv;
     }
     pvd_worker_barrier(flags + 8, wround, lane, fault);                 // p is complete
-    if (wave <= ncw) {
+    if (wave - 2 < ncw) {
         // ---- chain owners: rows t0 .. t1 - 1 of chain th in key order, from the ring
         const int t0 = dc * th, t1 = min(t0 + dc, T);
         uint32_t landed_seen = 0;
@@ -1242,7 +1245,10 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
         for (int s = 0; s < nstage; s++) {
             if ((uint32_t) s >= landed_seen) {
                 int spins = 0;
-                while ((landed_seen = __hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= (uint32_t) s) {
+                for (;;) {
+                    landed_seen = min(__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP),
+                                      nloc > 1 ? __hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xffffffffu);
+                    if (landed_seen > (uint32_t) s) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (poll_give_up(spins, limit, fault)) break;
                 }
@@ -1273,7 +1279,7 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     if (split > 1 && wt < th_lo * 32)                                   // the chains before this workgroup's, from their owners
         part[wt] = poll_tagged(xpart + (size_t) base * nth * 32 + wt, make_tag(epoch[0], layer + 1), fault, (lut_math & 0x1000) != 0);
     pvd_worker_barrier(flags + 8, wround, lane, fault);
-    if (wave == 1) pv_store_block(part, nth, lane, col0 + lane, h, dh, cb, merged, qa_A, qa_d);
+    if (wave == 2) pv_store_block(part, nth, lane, col0 + lane, h, dh, cb, merged, qa_A, qa_d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2061,7 +2067,7 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
         const size_t lds = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 32) * sizeof(float) + (size_t) 2 * cpw * SR * 128;
         // the LDS-DMA variant (k_dec_pv_dma): a loader wave + the chains of at most 7 consumer waves per workgroup; LLAMAHIP_PV_DMA=0 keeps k_dec_pv_stream
         static const bool no_dma = getenv("LLAMAHIP_PV_DMA") && atoi(getenv("LLAMAHIP_PV_DMA")) == 0;
-        if (!no_dma && cpw <= 14 && th_split_ok(nth, split, cpw) && !getenv("LLAMAHIP_PV_STAGE_ROWS")) {
+        if (!no_dma && cpw <= 12 && th_split_ok(nth, split, cpw) && !getenv("LLAMAHIP_PV_STAGE_ROWS")) {
             const size_t fixed = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 32) * sizeof(float) + 64;
             int NS = (int) (((size_t) 150 * 1024 - fixed) / ((size_t) cpw * 1024));
             NS = std::max(2, std::min(NS, 64));
