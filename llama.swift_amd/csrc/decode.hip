@@ -1099,20 +1099,23 @@ k_dec_pv_stream(const float *__restrict__ sc, const float *__restrict__ Vc, int 
 #undef LH_PFLUSH
 
 // ------------------------------------------------------------------------------------------------
-// k_dec_pv_dma (round 4): k_dec_pv_stream with the V rows moved HBM -> LDS by LDS-DMA from ONE loader wave instead of through the
-// registers of all 1 024 threads.  In k_dec_pv_stream the soft_max took 6 us at 2 048 keys although it needs 1.8 us alone: every
-// thread was also issuing V loads, and a wave's exp / sum instructions queue behind its own load issue.  Here wave 0 does nothing but
-// global_load_lds_dwordx4 (1 KiB per instruction = 8 consecutive rows x 128 bytes of ONE chain, per-lane row addresses; no VGPR round
-// trip, no barrier per stage), starting when the score row is back (issued earlier, V would delay the row behind 15 MB of requests:
-// k_dec_pv_stream's timeline), into a ring of stages [chain][8 rows][32 floats]; waves 1 .. 7 run the soft_max (ggml.c:5619-5665) and
-// then the owners of the workgroup's chains (two 32-lane chains per wave) walk their rows in key order out of the ring -- the same fp32
-// FMA chains (ggml.c:5459-5480), so the sums are bit-identical to k_dec_pv_blk / k_dec_pv_stream.  Flow control: `landed` (stages whose
-// DMA has completed: the loader's own vmcnt) and one `done` word per consumer wave.  The chains of a (head, column block) are split
-// over workgroups and handed over as tagged granules exactly as in k_dec_pv_stream.  Workgroup barriers are raw s_barrier (a
-// __syncthreads would make the loader wait for its DMA).  grid H dh/32 x split, 512 threads; LDS = red + p[n_ctx] + part + flags + ring.
+// k_dec_pv_dma (round 4): the long-context soft_max . V with the V rows moved HBM -> LDS by LDS-DMA from two loader waves instead of
+// through the registers of all 1 024 threads, and with a different decomposition: a workgroup owns `cpw` chunks of the reference's
+// n_threads-way key split for ALL 128 columns of a head (k_dec_pv_stream: 32 columns), so it reads 512 contiguous bytes of every V
+// row instead of 128.  In k_dec_pv_stream the soft_max took 6 us at 2 048 keys although it needs 1.8 us alone: every thread was also
+// issuing V loads, and a wave's exp / sum instructions queue behind its own load issue.  Here waves 0 and 1 do nothing but
+// global_load_lds_dwordx4 (1 KiB per instruction = 2 consecutive rows x 512 bytes of one chain, per-lane addresses; no VGPR round trip,
+// no barrier per stage; a lone wave issues ~one instruction per 8 cycles, hence two loaders and incremental addresses), starting when
+// the score row is back (issued earlier, V would delay the row behind megabytes of requests: k_dec_pv_stream's timeline), into a
+// ring of stages [chain][8 rows][128 floats]; waves 2 .. 7 run the soft_max (ggml.c:5619-5665) and then the owners of the workgroup's
+// chains (two waves per chain: 128 columns) walk their rows in key order out of the ring -- the same fp32 FMA chains
+// (ggml.c:5459-5480), so the sums are bit-identical to k_dec_pv_blk / k_dec_pv_stream.  Flow control: `landed` per loader wave (its own
+// vmcnt) and one `done` word per consumer wave.  The chunks of a head are split over `split` workgroups on one XCD; all but the last
+// leave their sums as tagged granules, the last adds all n_threads in thread order and quantizes the head's four Q4_0 blocks.
+// Workgroup barriers: one raw s_barrier before the loaders start (a __syncthreads would make them wait for their DMA), then an LDS
+// counter among the six worker waves.  grid H x split, 512 threads; LDS = red + p[n_ctx] + part[nth][128] + flags + ring.  dh = 128.
 // ------------------------------------------------------------------------------------------------
-constexpr int PVD_SR = 8;            // rows per chain and stage: one DMA instruction
-constexpr int PVD_F = 12;            // stages... DMA instructions that may be in flight behind the stage whose landing is awaited: PVD_F * nloc <= 60
+constexpr int PVD_SR = 8;            // rows per chain and stage: four DMA instructions of two rows
 template <int N> __device__ __forceinline__ void pvd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void pvd_barrier() {      // LDS writes of this wave done, then the hardware barrier; nothing waits for VMEM
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1125,25 +1128,25 @@ __device__ __forceinline__ void pvd_worker_barrier(uint32_t *ctr, uint32_t &roun
     while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < round) { __builtin_amdgcn_s_sleep(0); if (poll_give_up(spins, 1 << 24, fault)) break; }
 }
 __global__ void __launch_bounds__(512)
-k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int dh, int n_ctx, int nth, int NS,
+k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, int n_ctx, int nth, int NS,
              float *__restrict__ merged, uint32_t *__restrict__ qa_A, float *__restrict__ qa_d,
              const uint16_t *__restrict__ T_exp, const int32_t *__restrict__ st, int lut_math,
              int H, int split, uint64_t *__restrict__ xpart, const uint32_t *__restrict__ epoch, int layer, uint32_t *__restrict__ fault) {
+    constexpr int dh = 128;
     extern __shared__ double smem_d[];
     double *red = smem_d;                                               // [32]
     float *p = (float *) (smem_d + 32);                                 // [n_ctx rounded to 4]
-    float *part = p + ((n_ctx + 3) & ~3);                               // [nth][32]
-    uint32_t *flags = (uint32_t *) (part + nth * 32);                   // [0], [1] stages landed per loader wave | [2 .. 7] done per consumer wave | [8] worker barrier
-    float *ring = (float *) (flags + 16);                               // [NS][nloc][8][32]
+    float *part = p + ((n_ctx + 3) & ~3);                               // [nth][128]
+    uint32_t *flags = (uint32_t *) (part + nth * dh);                   // [0], [1] stages landed per loader wave | [2 .. 7] done per consumer wave | [8] worker barrier
+    float *ring = (float *) (flags + 16);                               // [NS][nloc][8][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x, z = (bid >> 3) % split, base = (bid / (8 * split)) * 8 + (bid & 7);
-    const int h = base % H, cb = base / H;
-    const int cpw = (nth + split - 1) / split, th_lo = z * cpw, nloc = min(nth, th_lo + cpw) - th_lo;      // this workgroup's chains
+    const int bid = blockIdx.x, z = (bid >> 3) % split, h = (bid / (8 * split)) * 8 + (bid & 7);      // the workgroups of a head are 8 apart: one XCD
+    const int cpw = (nth + split - 1) / split, th_lo = z * cpw, nloc = min(nth, th_lo + cpw) - th_lo;      // this workgroup's chunks (1 .. 3)
     const int T = st[0] + 1;
     const int dc = (T + nth - 1) / nth;
     const int nstage = (dc + PVD_SR - 1) / PVD_SR;
-    const int col0 = h * dh + cb * 32;
-    const int ncw = (nloc + 1) / 2;                                     // consumer waves (2 .. 1 + ncw), two chains each
+    const int col0 = h * dh;
+    const int ncw = 2 * nloc;                                           // consumer waves (2 .. 1 + ncw): two per chain
     const int limit = (lut_math & 0x1000) ? (1 << 8) : (1 << 22);
     if (tid < 16) flags[tid] = 0u;
     // the head's score row: the 6 worker waves only (a loader wave must have no load of its own in flight next to its DMA)
@@ -1162,23 +1165,21 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     }
     pvd_barrier();                                                      // the row is back (and the flags are zero): the loaders may start
     if (wave < 2) {
-        // =========================================== loaders: chains lc = wave, wave + 2, ... ===========================================
+        // ====== loaders: a chain-stage is 4 instructions (rows 0-1, 2-3, 4-5, 6-7); loader w issues instructions w and w + 2 of every chain ======
         const uint32_t ring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) ring;
         const uint64_t vbase = (uint64_t) (uintptr_t) (Vc + col0);
-        const int u = lane >> 3, q = lane & 7;
-        const int nmine = (nloc - wave + 1) / 2;                        // my chains
-        if (nmine <= 0) return;
-        // per-lane byte offset of row u of stage 0 of my j-th chain; a stage further is PVD_SR rows further.  Rows beyond a chain's end are
-        // fetched and never consumed; only the cache's end bounds them.
-        uint32_t off[7];
+        const int u = lane >> 5, q = lane & 31;
+        // per-lane byte offset of my first row of stage 0 of chain j (instruction w: rows 2 w + u; instruction w + 2: 4 rows further);
+        // a stage further is PVD_SR rows further.  Rows beyond a chain's end are fetched and never consumed; only the cache's end bounds them.
+        uint32_t off[3];
 #pragma unroll
-        for (int j = 0; j < 7; j++) off[j] = (uint32_t) ((size_t) min(dc * (th_lo + min(wave + 2 * j, nloc - 1)) + u, n_ctx - 1) * d * 4 + q * 16);
-        const uint32_t step = (uint32_t) ((size_t) PVD_SR * d * 4);
+        for (int j = 0; j < 3; j++) off[j] = (uint32_t) ((size_t) min(dc * (th_lo + min(j, nloc - 1)) + 2 * wave + u, n_ctx - 1) * d * 4 + q * 16);
+        const uint32_t step = (uint32_t) ((size_t) PVD_SR * d * 4), four = (uint32_t) ((size_t) 4 * d * 4);
         const uint32_t off_max = (uint32_t) ((size_t) (n_ctx - 1) * d * 4 + q * 16);
         uint32_t pub = 0;
         int slot = 0;
         auto min_done = [&]() { uint32_t m = 0xffffffffu; for (int w = 0; w < ncw; w++) m = min(m, __hip_atomic_load(flags + 2 + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); return m; };
-        const int F = 60 / nmine;                                       // stages whose DMA instructions may be outstanding (nmine in 1 .. 7)
+        const int F = 60 / (2 * nloc);                                  // stages whose DMA instructions (2 nloc per stage and loader) may be outstanding
         for (int s = 0; s < nstage; s++) {
             if (s >= NS && min_done() < (uint32_t) (s - NS + 1)) {
                 pvd_wait_vmcnt<0>();                                    // the ring is full: everything issued has to land anyway
@@ -1188,19 +1189,23 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
             }
             const bool tail = (s + 2) * PVD_SR + dc * nth > n_ctx;      // (uniform) only the last stages of the last chains can run past the cache
 #pragma unroll
-            for (int j = 0; j < 7; j++) {
-                if (j < nmine) {
-                    const uint32_t voff = tail ? min(off[j], off_max) : off[j];
-                    const uint32_t dst = ring_lds + (uint32_t) ((slot * nloc + wave + 2 * j) * 1024);
-                    uint32_t keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(vbase) : "memory");
+            for (int j = 0; j < 3; j++) {
+                if (j < nloc) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const uint32_t o = off[j] + (i ? four : 0u);
+                        const uint32_t voff = tail ? min(o, off_max) : o;
+                        const uint32_t dst = ring_lds + (uint32_t) ((slot * nloc + j) * 4096 + (wave + 2 * i) * 1024);
+                        uint32_t keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(vbase) : "memory");
+                    }
                     off[j] += step;
                 }
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
             if (s + 1 > F) {
-                if (nmine == 7) pvd_wait_vmcnt<56>(); else pvd_wait_vmcnt<60>();        // F * nmine: 60 for 1 .. 6 chains, 56 for 7
+                if (nloc == 1) pvd_wait_vmcnt<60>(); else if (nloc == 2) pvd_wait_vmcnt<60>(); else pvd_wait_vmcnt<60>();       // F * 2 nloc = 60 for 1, 2, 3 chains
                 if ((uint32_t) (s + 1 - F) > pub) { pub = (uint32_t) (s + 1 - F); __hip_atomic_store(flags + wave, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
             }
         }
@@ -1227,7 +1232,7 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     }
     pvd_worker_barrier(flags + 8, wround, lane, fault);
     float acc = 0.0f;
-    const int lc = (tid - 128) >> 5, c = tid & 31, th = th_lo + lc;
+    const int lc = (tid - 128) >> 7, c = (tid - 128) & 127, th = th_lo + lc;      // chain lc = worker threads [128 lc, 128 lc + 128): its 128 columns
     const bool owner = lc < nloc;
     {
         double tot = red[10];
@@ -1238,7 +1243,7 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
     }
     pvd_worker_barrier(flags + 8, wround, lane, fault);                 // p is complete
     if (wave - 2 < ncw) {
-        // ---- chain owners: rows t0 .. t1 - 1 of chain th in key order, from the ring
+        // ---- chain owners: rows t0 .. t1 - 1 of chunk th in key order, from the ring
         const int t0 = dc * th, t1 = min(t0 + dc, T);
         uint32_t landed_seen = 0;
         int slot = 0;
@@ -1246,24 +1251,23 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
             if ((uint32_t) s >= landed_seen) {
                 int spins = 0;
                 for (;;) {
-                    landed_seen = min(__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP),
-                                      nloc > 1 ? __hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xffffffffu);
+                    landed_seen = min(__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP), __hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                     if (landed_seen > (uint32_t) s) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (poll_give_up(spins, limit, fault)) break;
                 }
             }
-            if (owner) {
-                const float *vs = ring + (size_t) (slot * nloc + lc) * 256 + c;
+            {
+                const float *vs = ring + (size_t) (slot * nloc + lc) * 1024 + c;
                 const int tb = t0 + s * PVD_SR, n = min(PVD_SR, t1 - tb);
                 if (n == PVD_SR) {
                     float v[PVD_SR], w[PVD_SR];
 #pragma unroll
-                    for (int k = 0; k < PVD_SR; k++) { v[k] = vs[k * 32]; w[k] = p[tb + k]; }
+                    for (int k = 0; k < PVD_SR; k++) { v[k] = vs[k * dh]; w[k] = p[tb + k]; }
 #pragma unroll
                     for (int k = 0; k < PVD_SR; k++) acc = fmaf(v[k], w[k], acc);
                 } else {
-                    for (int k = 0; k < n; k++) acc = fmaf(vs[k * 32], p[tb + k], acc);
+                    for (int k = 0; k < n; k++) acc = fmaf(vs[k * dh], p[tb + k], acc);
                 }
             }
             asm volatile("" ::: "memory");
@@ -1271,15 +1275,33 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
     }
-    if (z + 1 < split) {                                                // not the last workgroup of this column block: publish and leave
-        if (owner) store_tagged(xpart + ((size_t) base * nth + th) * 32 + c, acc, make_tag(epoch[0], layer + 1) ^ ((lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test)
+    const uint32_t ptag = make_tag(epoch[0], layer + 1);
+    if (z + 1 < split) {                                                // not the last workgroup of this head: publish and leave
+        if (owner) store_tagged(xpart + ((size_t) h * nth + th) * dh + c, acc, ptag ^ ((lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test)
         return;
     }
-    if (owner) part[th * 32 + c] = acc;
-    if (split > 1 && wt < th_lo * 32)                                   // the chains before this workgroup's, from their owners
-        part[wt] = poll_tagged(xpart + (size_t) base * nth * 32 + wt, make_tag(epoch[0], layer + 1), fault, (lut_math & 0x1000) != 0);
+    if (owner) part[th * dh + c] = acc;
+    for (int i = wt; i < th_lo * dh; i += NWT)                          // the chunks before this workgroup's, from their owners
+        part[i] = poll_tagged(xpart + (size_t) h * nth * dh + i, ptag, fault, (lut_math & 0x1000) != 0);
     pvd_worker_barrier(flags + 8, wround, lane, fault);
-    if (wave == 2) pv_store_block(part, nth, lane, col0 + lane, h, dh, cb, merged, qa_A, qa_d);
+    // the head's four 32-column blocks: partial sums added in thread order, quantized (pv_store_block, one block per wave 2 .. 5)
+    if (wave >= 2 && wave < 6 && lane < 32) {
+        const int cb = wave - 2, cc0 = cb * 32 + lane;
+        float s_ = part[cc0];
+        for (int t2 = 1; t2 < nth; t2++) s_ += part[t2 * dh + cc0];         // thread order (ggml.c:5553-5577)
+        if (merged) merged[col0 + cc0] = s_;
+        float amax = fabsf(s_);
+        amax = max_lanes_0_31(amax);
+        const float dd = amax / 7.0f;
+        const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+        const uint32_t nib = (uint32_t) ((int) __builtin_rintf(s_ * id)) & 0xF;
+        const int kk = lane & 7;
+        const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+        const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+        const int b = h * (dh / 32) + cb, cc = b >> 3, j = b & 7;
+        if (lane < 8) qa_A[(cc * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+        if (lane == 0) qa_d[b] = dd;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2065,16 +2087,23 @@ hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, c
         static const int sr_cap = getenv("LLAMAHIP_PV_STAGE_ROWS") ? std::max(1, atoi(getenv("LLAMAHIP_PV_STAGE_ROWS"))) : 1 << 20;
         const int SR = std::min(nl * 128 / cpw, sr_cap);
         const size_t lds = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 32) * sizeof(float) + (size_t) 2 * cpw * SR * 128;
-        // the LDS-DMA variant (k_dec_pv_dma): a loader wave + the chains of at most 7 consumer waves per workgroup; LLAMAHIP_PV_DMA=0 keeps k_dec_pv_stream
+        // the LDS-DMA variant (k_dec_pv_dma): head size 128, a workgroup = (head, up to 3 chunks of the key split) over all 128 columns,
+        // the heads' chunks split over as many workgroups as fill the chip once; LLAMAHIP_PV_DMA=0 keeps k_dec_pv_stream
         static const bool no_dma = getenv("LLAMAHIP_PV_DMA") && atoi(getenv("LLAMAHIP_PV_DMA")) == 0;
-        if (!no_dma && cpw <= 12 && th_split_ok(nth, split, cpw) && !getenv("LLAMAHIP_PV_STAGE_ROWS")) {
-            const size_t fixed = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 32) * sizeof(float) + 64;
-            int NS = (int) (((size_t) 150 * 1024 - fixed) / ((size_t) cpw * 1024));
-            NS = std::max(2, std::min(NS, 64));
-            const size_t ldsd = fixed + (size_t) NS * cpw * 1024;
-            hipLaunchKernelGGL(k_dec_pv_dma, dim3(W * split), dim3(512), ldsd, st, sc, Vc, d, dh, n_ctx, nth, NS, merged, qa_A, qa_d, T_exp, state, g_lut_math | g_pv_fault_test, H, split, xpart, epoch, layer, fault);
-            LH_LAUNCH_CHECK();
-            return hipSuccess;
+        if (!no_dma && dh == 128 && xpart && epoch && fault && H % 8 == 0 && !getenv("LLAMAHIP_PV_STAGE_ROWS")) {
+            int sp = 1;
+            if (split_env > 0 && valid(split_env)) sp = split_env;
+            else while (H * sp * 2 <= 256 && valid(sp * 2)) sp *= 2;
+            const int cpwd = (nth + sp - 1) / sp;
+            if (cpwd <= 3) {
+                const size_t fixed = 32 * sizeof(double) + ((size_t) ((n_ctx + 3) & ~3) + (size_t) nth * 128) * sizeof(float) + 64;
+                int NS = (int) (((size_t) 156 * 1024 - fixed) / ((size_t) cpwd * 4096));
+                NS = std::max(2, std::min(NS, 256));
+                const size_t ldsd = fixed + (size_t) NS * cpwd * 4096;
+                hipLaunchKernelGGL(k_dec_pv_dma, dim3(H * sp), dim3(512), ldsd, st, sc, Vc, d, n_ctx, nth, NS, merged, qa_A, qa_d, T_exp, state, g_lut_math | g_pv_fault_test, H, sp, xpart, epoch, layer, fault);
+                LH_LAUNCH_CHECK();
+                return hipSuccess;
+            }
         }
         hipLaunchKernelGGL(k_dec_pv_stream<4>, dim3(W * split), dim3(1024), lds, st, sc, Vc, d, dh, n_ctx, nth, SR, merged, qa_A, qa_d, T_exp, state, g_lut_math | g_pv_fault_test, H, split, xpart, epoch, layer, fault);
         LH_LAUNCH_CHECK();

@@ -289,10 +289,11 @@ _SMALL = "wider_models or tiny_model_golden or prompt_continuation or thread_spl
 @pytest.mark.parametrize("switch,select", [
     ({"LLAMAHIP_NO_QKV_ATTN": "1"}, _FULL), ({"LLAMAHIP_NO_ATTN_X": "1"}, _FULL),
     ({"LLAMAHIP_ATTN_TWO_FROM": "0", "LLAMAHIP_ATTN_LONG_FROM": "-1"}, _SMALL),
-    ({"LLAMAHIP_ATTN_LONG_FROM": "0"}, _SMALL),          # (on the real 7B: tests/test_gpu_fullsize.py decodes behind 2048-token prompts)
+    ({"LLAMAHIP_ATTN_LONG_FROM": "0"}, _SMALL + " or ragged_contexts"),          # (on the real 7B: tests/test_gpu_fullsize.py decodes behind 2048-token prompts)
+    ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_DMA": "0"}, "ragged_contexts or thread_splits"),
     ({"LLAMAHIP_ATTN_TWO_FROM": "33", "LLAMAHIP_ATTN_LONG_FROM": "50", "LLAMAHIP_PV_STAGE_ROWS": "3"}, _SMALL),
     ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_STAGE_ROWS": "2", "LLAMAHIP_PV_SPLIT": "1"}, _SMALL)],
-    ids=["no_qkv_attn", "no_attn_x", "two_launch_everywhere", "stream_everywhere", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
+    ids=["no_qkv_attn", "no_attn_x", "two_launch_everywhere", "stream_everywhere", "stream_everywhere_without_dma", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
 def test_decode_attention_fallback_paths(switch, select):
     """The decode step runs wq|wk|wv + attention as one launch with in-launch hand-offs (k_qkv_attn) where the shapes allow;
     the paths it replaces stay in the library for every other shape: the single-launch attention with per-head counters
@@ -309,6 +310,30 @@ def test_decode_attention_fallback_paths(switch, select):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", select],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+
+@pytest.mark.parametrize("nth", [8, 3, 5])
+def test_7b_width_decode_at_ragged_contexts_thread_splits(L, oracle, tmp_path, nth):
+    """7B-width rows (n_embd 4096, 32 heads of 128: the shapes every decode attention schedule is instantiated for -- the fused launch,
+    and with LLAMAHIP_ATTN_LONG_FROM=0 the LDS-DMA soft_max . V, k_dec_pv_dma: head size 128, chunks split over 8 / 2 / 2 workgroups
+    of a head) decoded from position 137 to 185 with n_threads 8 / 3 / 5: chunk lengths that are not multiples of the 8-row stages, a
+    last chunk shorter than the others, the ring wrapping never / the tail clamp at the cache's end (n_ctx 192)."""
+    kw = dict(n_vocab=256, n_embd=4096, n_mult=256, n_head=32, n_layer=2)
+    path = synth_tool(tmp_path / "w7b.bin", seed=29, **kw)
+    prompt = synth.synth_prompt(137, kw["n_vocab"], seed=2)
+    om = oracle.load(path, 192)
+    lo = om.eval(prompt, 0, nth)["logits"]
+    with L.Model(path, n_ctx=192) as gm:
+        a = gm.eval(prompt, 0, nth)
+        assert same(a, lo), describe(a, lo)
+        t = int(np.argmax(lo)); first, want = t, []
+        for i in range(48):
+            lo = om.eval(np.array([t], np.int32), 137 + i, nth)["logits"]
+            t = int(np.argmax(lo)); want.append(t)
+        got, last = gm.decode_greedy(first, 137, 48, nth, want_logits=True)
+        assert got.tolist() == want and same(last, lo), (got.tolist(), want)
+    om.close()
 
 
 @pytest.mark.parametrize("shape", ["small", "7b_width"])
