@@ -325,10 +325,9 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
             if (k == 0) gu[n * 64 + wave * 8 + (lane >> 3)] = acc;
         }
         __syncthreads();
-        for (int cn = wave; cn < NC; cn += NW)               // (wide column groups: more columns than waves)
-        if (n0 + cn < ncols && wgi * 8 < ngroups) {
+        if (wave < NC && n0 + wave < ncols && wgi * 8 < ngroups) {
             const int i = lane & 31;
-            const float act = h2f_bits(T_silu[f2h_bits(gu[cn * 64 + i])]) * gu[cn * 64 + 32 + i];
+            const float act = h2f_bits(T_silu[f2h_bits(gu[wave * 64 + i])]) * gu[wave * 64 + 32 + i];
             const float amax = max_lanes_0_31(fabsf(act));
             const float dd = amax / 7.0f;
             const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
@@ -337,8 +336,8 @@ k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, i
             const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
             const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
             const int bb = wgi, c = bb >> 3, j = bb & 7;
-            uint32_t *oA = out_A + (size_t) (n0 + cn) * out_strideA;
-            float *oD = out_d + (size_t) (n0 + cn) * out_strideD;
+            uint32_t *oA = out_A + (size_t) (n0 + wave) * out_strideA;
+            float *oD = out_d + (size_t) (n0 + wave) * out_strideD;
             if (lane < 8) oA[(c * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
             if (lane == 0) oD[bb] = dd;
         }
@@ -1098,26 +1097,13 @@ static int skinny_pick_nc(const QMat &w, int N) {
     return (N + ncg - 1) / ncg;                            // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
 }
 
-// Matrices with >= 1 536 row-groups (wq|wk|wv, w1|w3 of the 7B and larger) fill the chip with ONE column group: 5 .. 9 columns then
-// go through a single group of that width (round 4) -- the weights are read once instead of once per group of 3 or 4 columns (the
-// reference's 9-token prompt evals: three groups).  LLAMAHIP_SKINNY_WIDE_MIN overrides the row-group threshold (tests: small models).
-static int skinny_pick_nc_wide(const QMat &w, int N) {
-    static const int wide_min = getenv("LLAMAHIP_SKINNY_WIDE_MIN") ? atoi(getenv("LLAMAHIP_SKINNY_WIDE_MIN")) : 1536;
-    if (N >= 5 && N <= 9 && w.ngroups >= wide_min && (size_t) N * (w.nchunks + 4) * 288 <= 150 * 1024) return N;
-    return skinny_pick_nc(w, N);
-}
 // Short evals, wq|wk|wv: mat-mul + RoPE + KV append in one launch (k_gemm_skinny<EPI_ROPE_KV>)
 bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
     return N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
 }
 hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
-    const int nc = skinny_pick_nc_wide(wqkv, N), ncg = (N + nc - 1) / nc;
+    const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
-    case 9:  return launch_gemm_skinny_rope_t<9>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    case 8:  return launch_gemm_skinny_rope_t<8>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    case 7:  return launch_gemm_skinny_rope_t<7>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    case 6:  return launch_gemm_skinny_rope_t<6>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    case 5:  return launch_gemm_skinny_rope_t<5>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 4:  return launch_gemm_skinny_rope_t<4>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 3:  return launch_gemm_skinny_rope_t<3>(wqkv, qa_A, qa_d, N, ncg, ra, st);
     case 2:  return launch_gemm_skinny_rope_t<2>(wqkv, qa_A, qa_d, N, ncg, ra, st);
@@ -1132,13 +1118,8 @@ bool gemm_silu_qa_applies(const QMat &w13, int N) {
 }
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
-    const int nc = skinny_pick_nc_wide(w13, N), ncg = (N + nc - 1) / nc;
+    const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
-    case 9:  return launch_gemm_skinny_silu_t<9>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    case 8:  return launch_gemm_skinny_silu_t<8>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    case 7:  return launch_gemm_skinny_silu_t<7>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    case 6:  return launch_gemm_skinny_silu_t<6>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    case 5:  return launch_gemm_skinny_silu_t<5>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 3:  return launch_gemm_skinny_silu_t<3>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
     case 2:  return launch_gemm_skinny_silu_t<2>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
@@ -1300,8 +1281,6 @@ hipError_t init_attrs_prompt_gemm() {
 #define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
     LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
     LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
-    LH_ATTR((k_gemm_skinny<5, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<6, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<7, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<8, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<9, 1, EPI_ROPE_KV>));
-    LH_ATTR((k_gemm_skinny<5, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<6, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<7, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<8, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<9, 1, EPI_SILU_QA>));
 #undef LH_ATTR
     return hipSuccess;
 }

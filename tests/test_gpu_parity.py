@@ -368,21 +368,19 @@ def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape
 
 @pytest.mark.parametrize("env", [{"LLAMAHIP_NO_LUT_MATH": "1"}, {"LLAMAHIP_NORM_MODE": "0"}, {"LLAMAHIP_NORM_MODE": "1"},
                                  {"LLAMAHIP_NO_HOST_IO": "1", "LLAMAHIP_HOST_SAMPLER": "1"},
-                                 {"LLAMAHIP_MFMA_I8": "1", "LLAMAHIP_MFMA_MIN": "32"}, {"LLAMAHIP_EAGER_PREFILL_COPY": "1"},
-                                 {"LLAMAHIP_SKINNY_WIDE_MIN": "1"}])
+                                 {"LLAMAHIP_MFMA_I8": "1", "LLAMAHIP_MFMA_MIN": "32"}, {"LLAMAHIP_EAGER_PREFILL_COPY": "1"}])
 def test_production_fallbacks_and_selectable_variants(env):
     """Arithmetic that ships in libllamahip.so but that the default configuration of this box never selects:
     NO_LUT_MATH -- the SiLU / exp fp16 tables GATHERED (ggml.c:1956-1963, 7024-7036) instead of evaluated, what a device whose
     double-precision exp failed the exhaustive load-time check would run; NORM_MODE 0 / 1 -- the reference's two-pass statistics /
     the one-pass statistics reduced inside every prologue instead of handed over by the producer; NO_HOST_IO + HOST_SAMPLER -- blit
     copies and the host-side candidate selection; MFMA_I8 -- the int8 matrix-core prompt GEMM of round 1; EAGER_PREFILL_COPY -- the
-    prompt-only weight copies built at load; SKINNY_WIDE_MIN=1 -- evals of 5 .. 9 rows through ONE column group of that width in the
-    wq|wk|wv and w1|w3 launches (what the 7B and larger models take by their row-group count) on the small models.  Switches are read once
+    prompt-only weight copies built at load.  Switches are read once
     per process, hence the subprocess; same parity tests, same oracle."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "dc_offset or thread_splits or tiny_model_golden or wider_models or prompt_continuation or short_chunks or runner_event or topk_candidates"],
+                        "dc_offset or thread_splits or tiny_model_golden or wider_models or prompt_continuation or runner_event or topk_candidates"],
                        env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
