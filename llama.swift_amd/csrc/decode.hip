@@ -116,7 +116,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     uint32_t *__restrict__ out_A = ga.out_A; float *__restrict__ out_d = ga.out_d;
     const f64x2 *__restrict__ part_in = ga.part_in; f64x2 *__restrict__ part_out = ga.part_out;
     // (EPI_STORE_TAG: the tag of this launch's output granules, read up front -- not a dependent load at the tail)
-    constexpr bool TAGGED = (EPI == EPI_STORE_TAG || PRE == PREP_NORM_TAG || EPI == EPI_RESID_TAG);
+    constexpr bool TAGGED = (EPI == EPI_STORE_TAG || PRE == PREP_NORM_TAG || EPI == EPI_RESID_TAG || EPI == EPI_SILU_QAH);
     const uint32_t epoch_ = TAGGED ? __builtin_nontemporal_load(ga.sync) : 0u;
     const uint32_t store_tag = make_tag(epoch_, ga.sync_epoch + 1);        // EPI_STORE_TAG output of layer ga.sync_epoch
     // (mailbox rows between pipeline stages: the tag is the sequence position both sides know, st[0] + 1 -- the stages' epochs differ)
@@ -132,7 +132,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     //  weight load is `global_load ... v_off, s[base]` with a constant per-lane offset -- measured slower here)
     const int tid = threadIdx.x, lane = tid & 63, wave = LH_GEMV_SADDR ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     constexpr bool active = true;
-    const int g = blk * nw + wave;
+    // (EPI_SILU_QAH: workgroup blk = half `(blk >> 3) & 1` of activation block `(blk >> 4) * 8 + (blk & 7)` -- the two halves of a block
+    //  are 8 apart in the grid, i.e. on one XCD; waves 0, 1 own the half's two gate row-groups, waves 2, 3 the matching up row-groups
+    //  of the interleaved tile order)
+    const int qah_block = (blk >> 4) * 8 + (blk & 7), qah_half = (blk >> 3) & 1;
+    const int g = EPI == EPI_SILU_QAH ? qah_block * 8 + (wave >> 1) * 4 + qah_half * 2 + (wave & 1) : blk * nw + wave;
     const bool valid = active && g < ngroups;
     const uint8_t *wbase = wt + (size_t) (valid ? g : 0) * (nchunks + 1) * TILE_BYTES;
     const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + (lane & 3) * 2) * 4u;
@@ -496,6 +500,37 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     int lg = g;
     if (gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : gmapF8 + b8 * 4 + (w8 - 4); }
     const int m = lg * 8 + (lane >> 3);
+    if (EPI == EPI_SILU_QAH) {
+        // 4 waves: waves 0, 1 hold gate rows 16 half .. + 15 of the block, waves 2, 3 the matching up rows
+        float *gu = (float *) red;                      // prologue scratch is free again
+        __syncthreads();
+        if (k == 0) gu[wave * 8 + (lane >> 3)] = acc;
+        __syncthreads();
+        if (wave == 0 && valid) {
+            const int i = lane & 15;
+            const uint16_t gh = f2h_bits(gu[i]);
+            const float act = h2f_bits((ga.lut_math & 1) ? silu_math_bits(gh) : T_silu[gh]) * gu[16 + i];
+            float amax = wave_max_f(lane < 16 ? fabsf(act) : 0.0f);
+            // the other half's partial amax: one tagged granule each way inside this XCD's L2
+            uint64_t *at = (uint64_t *) ga.out_t;
+            const int hb = qah_block * 2 + qah_half;
+            float other = 0.0f;
+            if (lane == 0) {
+                store_tagged(at + hb, amax, store_tag ^ ((ga.lut_math & 0x1000) ? 1u : 0u));      // (0x1000: fault-injection test)
+                other = poll_tagged(at + (hb ^ 1), store_tag, ga.fault, (ga.lut_math & 0x1000) != 0);
+            }
+            other = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, other)));
+            amax = fmaxf(amax, other);
+            const float dd = amax / 7.0f;
+            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
+            const uint32_t nib = (uint32_t) ((int) __builtin_rintf(act * id)) & 0xF;           // signed nibble of (q - 8)
+            const int kk = lane & 7;
+            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+            const int b = qah_block, c = b >> 3, j = b & 7;
+            if (lane < 8) ((uint16_t *) (out_A + (c * 8 + kk) * 8 + j))[qah_half] = (uint16_t) ((e0 | (e1 << 8)) << (4 * (j & 1)));
+            if (lane == 0 && qah_half == 0) out_d[b] = dd;
+        }
+    } else
     if (EPI == EPI_SILU_QA) {
         // 8 waves: waves 0-3 hold gate rows b*32 .. b*32+31, waves 4-7 the matching up rows (b = blockIdx.x)
         float *gu = (float *) red;                      // prologue scratch is free again
@@ -1988,6 +2023,33 @@ hipError_t launch_gemv_pick(const QMat &w, const float *in0, const float *in1, f
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
+// w1|w3 in half-block workgroups (EPI_SILU_QAH, llamahip_internal.h)
+bool gemv_silu_half_applies(const QMat &w) {
+    static const bool off = getenv("LLAMAHIP_NO_W13_HALF") != nullptr;
+    return !off && w.gmapF8 && w.ngroups % 8 == 0 && w.K / 16 <= 512 && w.nchunks > 4 && pick_depth(w.nchunks, w.ngroups) == 4 && w.ngroups >= 2048;
+}
+hipError_t launch_gemv_silu_half(const QMat &w, const float *in0, const float *in1, const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
+                                 const NormPart *npp, uint64_t *amax_t, uint32_t *epoch, int layer, uint32_t *fault) {
+    static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;
+    static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) == 6) ? 0x1000 : 0;
+    NormPart np = npp ? *npp : NormPart();
+    const bool normp = norm_mode >= 2 && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX;
+    if (!normp) { np.in = nullptr; np.n_in = norm_mode == 0 ? -1 : 0; }
+    const int nblocks = w.ngroups / 8, grid = (nblocks + 7) / 8 * 16;       // two halves per block, blocks of one XCD 16 apart
+    const int need = w.K / 16, pg = need <= 256 ? 1 : 2;
+    size_t lds = (size_t) w.nchunks * 64 * 4 + (size_t) w.nchunks * 8 * 4 + 32 * sizeof(double);
+    lds = ((lds + 15) & ~(size_t) 15) + (size_t) 4 * 288;
+    GemvArgs ga = { w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, nullptr, nullptr, in0, in1, w.K, nullptr, nullptr, T_silu, out_A, out_d,
+                    (const f64x2 *) np.in, np.n_in, nullptr, epoch, 0, layer, g_lut_math | fault_test, fault };
+    ga.out_t = amax_t;
+#define LH_GOH(PRE, PG) hipLaunchKernelGGL((k_gemv<PRE, EPI_SILU_QAH, 4, true, PG>), dim3(grid), dim3(256), lds, st, ga)
+    if (normp) { if (pg == 1) LH_GOH(PREP_NORMP, 1); else LH_GOH(PREP_NORMP, 2); }
+    else { if (pg == 1) LH_GOH(PREP_NORM, 1); else LH_GOH(PREP_NORM, 2); }
+#undef LH_GOH
+    LH_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 // the shapes launch_gemv_pick is instantiated for (ring kernels with 4-wave workgroups: every LLaMA lm head)
 bool gemv_pick_applies(const QMat &w) {
     int nw = pick_waves(w.ngroups);
@@ -2380,6 +2442,7 @@ hipError_t init_attrs_decode() {
     LH_ATTR_G1(PREP_SILU_MUL, EPI_RESID, 1); LH_ATTR_G1(PREP_NORM, EPI_SILU_QA, 1);
     LH_ATTR_G1(PREP_NORMP, EPI_STORE, 1); LH_ATTR_G1(PREP_NORMP, EPI_STORE, 2); LH_ATTR_G1(PREP_NORMP, EPI_SILU_QA, 1);
     LH_ATTR_G1(PRE_QA, EPI_SILU_QA, 1);
+    LH_ATTR((k_gemv<PREP_NORMP, EPI_SILU_QAH, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_SILU_QAH, 4, true, 2>)); LH_ATTR((k_gemv<PREP_NORM, EPI_SILU_QAH, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORM, EPI_SILU_QAH, 4, true, 2>));
     LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 8, true, 1>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 10, true, 1>));
     LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 4, true, 2>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 8, true, 2>)); LH_ATTR((k_gemv<PREP_NORMP, EPI_STORE_PICK, 10, true, 2>));
     LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 4, true, 1>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 8, true, 1>)); LH_ATTR((k_gemv<PREP_NORM, EPI_STORE_PICK, 10, true, 1>));

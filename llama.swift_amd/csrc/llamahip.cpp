@@ -173,6 +173,7 @@ struct llamahip_model {
     uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
+    uint64_t *d_w13_amax = nullptr;      // partial amaxes exchanged by the half-block workgroups of the w1|w3 decode mat-vec (EPI_SILU_QAH): [F / 16] granules
     unsigned long long *d_pick = nullptr; // greedy loop: {64-bit atomic-max key, arrival counter} of the lm head's pick epilogue (EPI_STORE_PICK)
     uint64_t *d_pvx = nullptr;           // tagged partial sums of k_dec_pv_stream's split workgroups: [H dh/32][32 threads of the split][32]
     uint32_t *h_fault = nullptr;         // sticky fault word in pinned, device-mapped host memory: a bounded in-launch spin that
@@ -243,7 +244,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    free_dev(d_pick);
+    free_dev(d_pick); free_dev(d_w13_amax);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_pvx);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
@@ -609,7 +610,10 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     const bool two_attn = fused && (m->attn_sched == 1 || (m->attn_sched == 2 && !long_attn));
     const bool use_qkvx = !long_attn && !two_attn && fused && m->d_attn_sync && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS && qkv_attn_applies(m->layers[0].qkv, d, H, nth);
     const bool pv_split = long_attn && m->d_pvx && m->l1 - m->l0 <= TAG_MAX_LAYERS;          // (its tags are (epoch, layer) too)
-    const bool use_epoch = use_qkvx || pv_split;
+    // w1|w3 in half-block workgroups (balanced over the CUs; the halves of a block exchange their amax inside one XCD): needs the XCD
+    // placement the load-time self-test confirmed (d_attn_sync) and the epoch for its tags
+    const bool use_w13h = fused && m->w13_interleaved && m->d_attn_sync && m->d_w13_amax && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS && gemv_silu_half_applies(m->layers[0].w13);
+    const bool use_epoch = use_qkvx || pv_split || use_w13h;
     if (use_epoch && !(m->first_stage && use_part)) HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
     if (io && fused && io->mb_token && m->first_stage && !use_part) { set_err(err, err_cap, "pipeline mailboxes need the default norm-statistics mode (LLAMAHIP_NORM_MODE unset)"); return LLAMAHIP_ERR_PREDICT; }
     const bool fold = io && io->fold_pick && fused && use_part && m->first_stage && m->last_stage;
@@ -665,6 +669,8 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             }
             HIP_TRY(launch_gemv(L.wo, PRE_QA, EPI_RESID, m->qa1_A, m->qa1_d, nullptr, nullptr, m->x1, xa, m->T_silu, nullptr, nullptr, st, &np_wo, mbi), LLAMAHIP_ERR_PREDICT);
             if (m->w13_interleaved) {
+                if (use_w13h) HIP_TRY(launch_gemv_silu_half(L.w13, m->x1, L.ffn_norm, m->T_silu, m->qa2_A, m->qa2_d, st, &np_w13, m->d_w13_amax, m->d_epoch, il - m->l0, m->d_fault), LLAMAHIP_ERR_PREDICT);
+                else
                 HIP_TRY(launch_gemv(L.w13, PREP_NORM, EPI_SILU_QA, nullptr, nullptr, m->x1, L.ffn_norm, nullptr, nullptr, m->T_silu, m->qa2_A, m->qa2_d, st, &np_w13), LLAMAHIP_ERR_PREDICT);
                 HIP_TRY(launch_gemv(L.w2, PRE_QA, EPI_RESID, m->qa2_A, m->qa2_d, nullptr, nullptr, mbo ? nullptr : xo, m->x1, m->T_silu, nullptr, nullptr, st, &np_w2, mbo), LLAMAHIP_ERR_PREDICT);
             } else {
@@ -752,7 +758,7 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
             if (n_part_x > 0 && m->l1 > m->l0) { np_out.in = m->npart_a; np_out.n_in = n_part_x; }      // (x_last is null on the last stage: the row is in m->x)
             if (fold) {
                 const PickIO pk = { m->d_pick + 128, (uint32_t *) m->d_pick, io->pick_out, io->pick_next, state, m->tok_emb, m->x, m->npart_a,
-                                    (m->d_attn_sync || m->d_pvx) ? m->d_epoch : nullptr, V };      // (the NEXT step's epoch: its schedule may use the tags even if this one does not)
+                                    (m->d_attn_sync || m->d_pvx || m->d_w13_amax) ? m->d_epoch : nullptr, V };      // (the NEXT step's epoch: its schedule may use the tags even if this one does not)
                 HIP_TRY(launch_gemv_pick(m->output, m->x, m->norm_w, m->logits, m->T_silu, st, &np_out, pk), LLAMAHIP_ERR_PREDICT);
             } else
             HIP_TRY(launch_gemv(m->output, PREP_NORM, EPI_STORE, nullptr, nullptr, m->x, m->norm_w, m->logits, nullptr, m->T_silu, nullptr, nullptr, st, &np_out), LLAMAHIP_ERR_PREDICT);
@@ -1006,6 +1012,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         }
         HIP_TRY(hipMalloc((void **) &m->d_epoch, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->d_w13_amax, ((size_t) F / 16 + 16) * 8), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->d_w13_amax, 0, ((size_t) F / 16 + 16) * 8), LLAMAHIP_ERR_LOAD);
         {   // lm-head pick epilogue: [0, 1024) bytes tickets, then one 8-byte key per workgroup of the lm head's launch (<= n_vocab / 8 + 8)
             const size_t pb = 1024 + ((size_t) V / 8 + 8) * 8;
             HIP_TRY(hipMalloc((void **) &m->d_pick, pb), LLAMAHIP_ERR_LOAD);
@@ -1247,7 +1255,7 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         pio.fold_pick = true; pio.pick_out = m->d_out_tokens; pio.pick_next = m->d_tokens;
         if (fold) {
             // the first token's row, statistics and epoch (what k_embed_part does at the head of an un-folded step)
-            const bool ep = m->d_attn_sync || m->d_pvx;
+            const bool ep = m->d_attn_sync || m->d_pvx || m->d_w13_amax;
             HIP_TRY(launch_embed_part(m->d_tokens, m->tok_emb, m->x, m->hp.n_embd, m->npart_a, m->stream, ep ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);
         }
         for (int i = 0; i < n_steps; i++) {

@@ -13,7 +13,7 @@ constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 6
 // (the *_TAG forms: the operand arrives / the result leaves as 8-byte {fp32 bits, tag} granules that the consumer polls -- the
 //  hand-offs inside k_qkv_attn, and the residual-stream row between pipeline stages through a device-side mailbox)
 enum { PRE_QA = 0, PREP_PLAIN = 1, PREP_NORM = 2, PREP_SILU_MUL = 3, PREP_NORMP = 4, PREP_NORM_TAG = 6 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5, EPI_STORE_PICK = 6 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_QA = 2, EPI_ROPE_KV = 3, EPI_STORE_TAG = 4, EPI_RESID_TAG = 5, EPI_STORE_PICK = 6, EPI_SILU_QAH = 7 };
 // The rows of a BATCHED decode step (llamahip_stage_step_set): row b is the next token of sequence slot b' -- its own position (device
 // resident, so a captured step replays unchanged), its own KV cache, its own token / pick / residual-stream buffers.  Lives in device
 // memory; kernels that take a `const SeqSet *` treat null as "one sequence, consecutive positions" (the prompt-chunk meaning).
@@ -116,6 +116,14 @@ struct PickIO {
     const uint8_t *emb; float *x_next; double *part_next; uint32_t *epoch; int n_vocab;      // the next step's embedding row
 };
 int gemv_resid_parts(const QMat &w);
+// EPI_SILU_QAH: the w1|w3 decode mat-vec in HALF-block workgroups (4 waves: 16 gate rows + the same 16 up rows).  The 8-wave workgroups of
+// EPI_SILU_QA are F / 32 = 344 on 256 CUs at 7B: 88 CUs stream two workgroups' weights, the others one, and a CU's load path bounds what
+// it can pull -- the launch ends with a third of the chip streaming alone.  688 half-block workgroups spread 3 / 2 per CU.  The two halves
+// of a Q4_0 activation block sit 8 blocks apart in the grid (one XCD: xcd_selftest) and exchange their partial amax as one tagged granule
+// each way (fmaxf is exact in any order), then each writes its 16-bit halves of the block's eight QA dwords.
+bool gemv_silu_half_applies(const QMat &w);
+hipError_t launch_gemv_silu_half(const QMat &w, const float *in0, const float *in1, const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
+                                 const NormPart *np, uint64_t *amax_t, uint32_t *epoch, int layer, uint32_t *fault);
 bool gemv_pick_applies(const QMat &w);
 hipError_t launch_gemv_pick(const QMat &w, const float *in0, const float *in1, float *y, const uint16_t *T_silu, hipStream_t st,
                             const NormPart *np, const PickIO &pick);

@@ -287,13 +287,13 @@ _SMALL = "wider_models or tiny_model_golden or prompt_continuation or thread_spl
 
 
 @pytest.mark.parametrize("switch,select", [
-    ({"LLAMAHIP_NO_QKV_ATTN": "1"}, _FULL), ({"LLAMAHIP_NO_ATTN_X": "1"}, _FULL),
+    ({"LLAMAHIP_NO_QKV_ATTN": "1"}, _FULL), ({"LLAMAHIP_NO_ATTN_X": "1"}, _FULL), ({"LLAMAHIP_NO_W13_HALF": "1"}, "wider_models or greedy_trace_128 or ragged_contexts"),
     ({"LLAMAHIP_ATTN_TWO_FROM": "0", "LLAMAHIP_ATTN_LONG_FROM": "-1"}, _SMALL),
     ({"LLAMAHIP_ATTN_LONG_FROM": "0"}, _SMALL + " or ragged_contexts"),          # (on the real 7B: tests/test_gpu_fullsize.py decodes behind 2048-token prompts)
     ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_DMA": "0"}, "ragged_contexts or thread_splits"),
     ({"LLAMAHIP_ATTN_TWO_FROM": "33", "LLAMAHIP_ATTN_LONG_FROM": "50", "LLAMAHIP_PV_STAGE_ROWS": "3"}, _SMALL),
     ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_STAGE_ROWS": "2", "LLAMAHIP_PV_SPLIT": "1"}, _SMALL)],
-    ids=["no_qkv_attn", "no_attn_x", "two_launch_everywhere", "stream_everywhere", "stream_everywhere_without_dma", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
+    ids=["no_qkv_attn", "no_attn_x", "w13_block_workgroups", "two_launch_everywhere", "stream_everywhere", "stream_everywhere_without_dma", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
 def test_decode_attention_fallback_paths(switch, select):
     """The decode step runs wq|wk|wv + attention as one launch with in-launch hand-offs (k_qkv_attn) where the shapes allow;
     the paths it replaces stay in the library for every other shape: the single-launch attention with per-head counters
@@ -385,12 +385,14 @@ def test_production_fallbacks_and_selectable_variants(env):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("which", [{"LLAMAHIP_HANDOFF_FAULT_TEST": "1"}, {"LLAMAHIP_HANDOFF_FAULT_TEST": "4", "LLAMAHIP_ATTN_LONG_FROM": "0"}])
+@pytest.mark.parametrize("which", [{"LLAMAHIP_HANDOFF_FAULT_TEST": "1"}, {"LLAMAHIP_HANDOFF_FAULT_TEST": "4", "LLAMAHIP_ATTN_LONG_FROM": "0"},
+                                   {"LLAMAHIP_HANDOFF_FAULT_TEST": "6"}])
 def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b, which):
     """The tagged hand-offs of the decode step are bounded polls; one that runs out raises a sticky fault word in
     pinned host memory and the next synchronisation returns PredictionFailed.  LLAMAHIP_HANDOFF_FAULT_TEST=1 makes the
     mat-vec role of k_qkv_attn publish a tag nobody waits for and shortens the polls (read once per process: subprocess);
-    =4 does the same to the split workgroups of the long-context soft_max . V (k_dec_pv_stream), run here from position 0."""
+    =4 does the same to the split workgroups of the long-context soft_max . V (k_dec_pv_stream / k_dec_pv_dma), run here from position 0;
+    =6 to the half-block workgroups of the w1|w3 mat-vec (EPI_SILU_QAH: a partial amax published under a tag its partner does not wait for)."""
     import subprocess
     import sys
     code = (
