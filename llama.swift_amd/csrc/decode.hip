@@ -105,9 +105,8 @@ struct GemvArgs {
                                                       // looks at an uncached / remote granule -- legitimate waits are milliseconds, and a mapping that does not carry
                                                       // the stores must cost the bench's one-token handshake seconds, not minutes, before it falls back to RCCL)
 };
-constexpr int GEMV_G_AUTO = -2, GEMV_G_NONE = -1;      // g_explicit of gemv_body: row-group blk * nw + wave | this wave has no row-group (it only helps the prologue)
 template <int PRE, int EPI, int D, bool RING, int PG>
-__device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, const int nw, double *smem_d, const int g_explicit = GEMV_G_AUTO) {
+__device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, const int nw, double *smem_d) {
     const uint8_t *__restrict__ wt = ga.wt;
     const int ngroups = ga.ngroups, nchunks = ga.nchunks, M = ga.M, gmapF8 = ga.gmapF8, K = ga.K, npart = ga.npart;
     const uint32_t *__restrict__ qa_A = ga.qa_A; const float *__restrict__ qa_d = ga.qa_d;
@@ -137,12 +136,8 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     //  are 8 apart in the grid, i.e. on one XCD; waves 0, 1 own the half's two gate row-groups, waves 2, 3 the matching up row-groups
     //  of the interleaved tile order)
     const int qah_block = (blk >> 4) * 8 + (blk & 7), qah_half = (blk >> 3) & 1;
-    const int g = g_explicit != GEMV_G_AUTO ? (g_explicit == GEMV_G_NONE ? ngroups : g_explicit)
-                : EPI == EPI_SILU_QAH ? qah_block * 8 + (wave >> 1) * 4 + qah_half * 2 + (wave & 1) : blk * nw + wave;
+    const int g = EPI == EPI_SILU_QAH ? qah_block * 8 + (wave >> 1) * 4 + qah_half * 2 + (wave & 1) : blk * nw + wave;
     const bool valid = active && g < ngroups;
-    // a wave without a row-group streams nothing: all its chunk loads go to the (L2-resident) zero tile of row-group 0 -- no branch
-    // around the loads, so the counted waits of the ring stay counted
-    const int ch_min = (g_explicit == GEMV_G_NONE) ? nchunks : 0;
     const uint8_t *wbase = wt + (size_t) (valid ? g : 0) * (nchunks + 1) * TILE_BYTES;
     const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + (lane & 3) * 2) * 4u;
     // (an empty asm per loop trip keeps the 32 -> 64-bit extension of these lane offsets inside the loop
@@ -166,7 +161,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs &ga, const int blk, con
     f32x2 ws[D];
 #define LH_LOADW(SLOT, CH)                                                                                   \
     {                                                                                                        \
-        const int ch_ = max(min((CH), nchunks), ch_min);   /* tile `nchunks` of every row-group is the zero tile */      \
+        const int ch_ = min((CH), nchunks);   /* tile `nchunks` of every row-group is the zero tile */      \
         const uint8_t *tp_ = wbase + (size_t) ch_ * TILE_BYTES;                                              \
         if (LH_GEMV_SADDR) {                                                                                 \
             wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + (size_t) vw_));                     \
@@ -1664,20 +1659,10 @@ k_dec_attn_x(const AttnXArgs aa) {
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
 template <int PRE, int D, int PG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG == 1 ? 4 : 3)))
-k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H, const int rg3) {
+k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
     extern __shared__ double smem_d[];
     const int b = blockIdx.x;
     if (b < gridA) {
-        if (rg3) {
-            // THREE row-groups per workgroup -- one of q, one of k, one of v of the same head (the fourth wave has none: it only helps the
-            // prologue) -- where that spreads the mat-vec evenly: 7B: d / 8 = 512 workgroups = exactly two per CU (the four-row-group
-            // shape gives 384: half of the CUs stream two workgroups' weights, the other half one, and the launch waits for the former)
-            const int wph = aa.dh / 8;                          // workgroups per head
-            const int xcd = b & 7, slot = b >> 3, j = slot / wph, i = slot % wph, h = xcd + 8 * j;
-            const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-            gemv_body<PRE, EPI_STORE_TAG, D, true, PG>(ga, 0, 4, smem_d, wave < 3 ? wave * (aa.d / 8) + h * wph + i : GEMV_G_NONE);
-            return;
-        }
         const int ncb = aa.dh / 32, wph = 3 * ncb;
         const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
         const int h = xcd + 8 * j;
@@ -2241,11 +2226,7 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
                            const MailboxIO *mb) {
     const uint64_t *x_t = mb ? mb->in_t : nullptr;
     // x_t (first layer of a pipeline stage fed through a device-side mailbox): the input row arrives as tagged granules, slot 0
-    // mat-vec workgroups of 4 or of 3 row-groups: whichever leaves the busiest CU less to stream (the chip has 256 CUs)
-    static const int rg3_env = getenv("LLAMAHIP_QKV_RG3") ? atoi(getenv("LLAMAHIP_QKV_RG3")) : -1;
-    const int n4 = w.ngroups / 4, n3 = w.ngroups / 3;
-    const int rg3 = rg3_env >= 0 ? rg3_env : (((n3 + 255) / 256) * 3 < ((n4 + 255) / 256) * 4 && (d / H) % 8 == 0) ? 1 : 0;
-    const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = rg3 ? n3 : n4;
+    const int dh = d / H, nsl = (n_ctx + DEC_TS - 1) / DEC_TS, gridA = w.ngroups / 4;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     static const int norm_mode = getenv("LLAMAHIP_NORM_MODE") ? atoi(getenv("LLAMAHIP_NORM_MODE")) : 2;      // as launch_gemv
     const bool normp = norm_mode >= 2 && np.in && np.n_in > 0 && np.n_in <= NORM_PART_MAX;
@@ -2263,9 +2244,9 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
     const AttnXArgs aa = { nullptr, d, dh, tab, Kc, Vc, nullptr, n_ctx, nth, kq_scale, merged, qa_A, qa_d, T_exp, state, nullptr, fault, g_lut_math | fault_test,
                            qkv2, sc2, epoch, layer };
     const int grid = gridA + H * (nsl + dh / 32);
-#define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, rg3); \
-                        else if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, rg3); \
-                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H, rg3); }
+#define LH_GOX(D, PG) { if (x_t) hipLaunchKernelGGL((k_qkv_attn<PREP_NORM_TAG, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
+                        else if (normp) hipLaunchKernelGGL((k_qkv_attn<PREP_NORMP, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); \
+                        else hipLaunchKernelGGL((k_qkv_attn<PREP_NORM, D, PG>), dim3(grid), dim3(256), lds, st, ga, aa, gridA, H); }
     if (variant == 1) LH_GOX(8, 1) else if (variant == 2) LH_GOX(10, 2) else if (variant == 3) LH_GOX(4, 2) else return hipErrorInvalidValue;
 #undef LH_GOX
     LH_LAUNCH_CHECK();
