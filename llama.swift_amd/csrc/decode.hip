@@ -33,6 +33,8 @@
 //   launchers: set_phase_probe, launch_gemv (+ kernel selection rules), launch_attn_short, xcd_selftest, launch_dec_attn,
 //              launch_qkv_attn, launch_bump_epoch, launch_topk_candidates, launch_argmax, launch_advance, init_kernel_attrs
 #define LH_DEFINE_PHASE_PROBE 1
+#include <cmath>
+
 #include "kcommon.hip.h"
 
 namespace lh {
@@ -2026,7 +2028,15 @@ hipError_t launch_gemv_pick(const QMat &w, const float *in0, const float *in1, f
 // w1|w3 in half-block workgroups (EPI_SILU_QAH, llamahip_internal.h)
 bool gemv_silu_half_applies(const QMat &w) {
     static const bool off = getenv("LLAMAHIP_NO_W13_HALF") != nullptr;
-    return !off && w.gmapF8 && w.ngroups % 8 == 0 && w.K / 16 <= 512 && w.nchunks > 4 && pick_depth(w.nchunks, w.ngroups) == 4 && w.ngroups >= 2048;
+    static const bool force = getenv("LLAMAHIP_W13_HALF") && atoi(getenv("LLAMAHIP_W13_HALF")) == 1;      // tests: shapes the balance rule leaves with block workgroups
+    static const int ncu = [] { int dev = 0; hipDeviceProp_t p; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    if (off || !w.gmapF8 || w.ngroups % 8 != 0 || w.K / 16 > 512 || w.nchunks <= 4 || pick_depth(w.nchunks, w.ngroups) != 4 || w.ngroups < 2048) return false;
+    if (force) return true;
+    // halves only where they leave the busiest CU relatively less to stream than whole blocks do: max / mean workgroups per CU
+    // (7B: 344 blocks 2 / 1.34 = 1.49 against 688 halves 3 / 2.69 = 1.12; 13B 432 / 864 and 65B 688 / 1 376: equal, blocks stay)
+    const double nb = w.ngroups / 8.0;
+    const double r_blocks = std::ceil(nb / ncu) / (nb / ncu), r_halves = std::ceil(2.0 * nb / ncu) / (2.0 * nb / ncu);
+    return r_halves < r_blocks - 0.02;
 }
 hipError_t launch_gemv_silu_half(const QMat &w, const float *in0, const float *in1, const uint16_t *T_silu, uint32_t *out_A, float *out_d, hipStream_t st,
                                  const NormPart *npp, uint64_t *amax_t, uint32_t *epoch, int layer, uint32_t *fault) {

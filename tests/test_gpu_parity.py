@@ -288,12 +288,13 @@ _SMALL = "wider_models or tiny_model_golden or prompt_continuation or thread_spl
 
 @pytest.mark.parametrize("switch,select", [
     ({"LLAMAHIP_NO_QKV_ATTN": "1"}, _FULL), ({"LLAMAHIP_NO_ATTN_X": "1"}, _FULL), ({"LLAMAHIP_NO_W13_HALF": "1"}, "wider_models or greedy_trace_128 or ragged_contexts"),
+    ({"LLAMAHIP_W13_HALF": "1"}, "wider_models"),
     ({"LLAMAHIP_ATTN_TWO_FROM": "0", "LLAMAHIP_ATTN_LONG_FROM": "-1"}, _SMALL),
     ({"LLAMAHIP_ATTN_LONG_FROM": "0"}, _SMALL + " or ragged_contexts"),          # (on the real 7B: tests/test_gpu_fullsize.py decodes behind 2048-token prompts)
     ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_DMA": "0"}, "ragged_contexts or thread_splits"),
     ({"LLAMAHIP_ATTN_TWO_FROM": "33", "LLAMAHIP_ATTN_LONG_FROM": "50", "LLAMAHIP_PV_STAGE_ROWS": "3"}, _SMALL),
     ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_STAGE_ROWS": "2", "LLAMAHIP_PV_SPLIT": "1"}, _SMALL)],
-    ids=["no_qkv_attn", "no_attn_x", "w13_block_workgroups", "two_launch_everywhere", "stream_everywhere", "stream_everywhere_without_dma", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
+    ids=["no_qkv_attn", "no_attn_x", "w13_block_workgroups", "w13_half_workgroups_13b_65b_widths", "two_launch_everywhere", "stream_everywhere", "stream_everywhere_without_dma", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
 def test_decode_attention_fallback_paths(switch, select):
     """The decode step runs wq|wk|wv + attention as one launch with in-launch hand-offs (k_qkv_attn) where the shapes allow;
     the paths it replaces stay in the library for every other shape: the single-launch attention with per-head counters
@@ -303,6 +304,9 @@ def test_decode_attention_fallback_paths(switch, select):
     workgroups with tagged partial sums) from LLAMAHIP_ATTN_LONG_FROM -- run here from position 0, and with both switch points
     inside the thread-split test's one decode call (27 -> 71: three captured graphs replayed in turn), with stages of 3 / 2 rows per
     chain so that these small contexts walk the whole load / LDS pipeline (many stages, both buffers, ragged last stage).
+    The w1|w3 mat-vec runs in half-block workgroups where that balances the CUs (7B; EPI_SILU_QAH: the halves of a Q4_0 activation block
+    exchange their partial amax inside one XCD) -- LLAMAHIP_NO_W13_HALF keeps the 8-wave block workgroups everywhere, LLAMAHIP_W13_HALF=1
+    forces the halves onto the 13B / 65B widths (their two-granule prologue variant).
     The switches are read once per process, hence the subprocess; same parity tests, same oracle."""
     import subprocess
     import sys
