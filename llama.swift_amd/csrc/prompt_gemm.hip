@@ -1036,19 +1036,23 @@ k_gemm_mfma16(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
 // k_gemm_mfma16 keeps 128 accumulators per lane, so two waves share a SIMD -- and tools/valu_rate_probe.hip /
 // tools/chain_probe.hip show what that costs: a wave alone on its SIMD issues one VALU instruction per ~8 cycles, so whenever one of
 // the two waits (for its MFMA result, for the barrier) the other runs at half rate; the kernel sat at 94 ns per MFMA issue and SIMD
-// against 60 ns of VALU work.  Here a wave owns HALF the chains of a 32 x 32 output tile -- chains {h, 4 + h, 2 + h, 6 + h}: one side
-// of the reference's final add tree (ggml.c:872-887), so the two halves meet in ONE addition per output at the very end -- on
-// v_mfma_f32_16x16x4_4b_f16 (four 16 x 16 x 4 products per issue = the wave's four chains of a 16 x 16 sub-tile; 16 result
-// registers): 64 accumulators + 16 results, <= 128 registers, 8 waves per workgroup, two workgroups per CU.  The operands of the next
-// quad go global -> LDS by DMA (global_load_lds_dwordx4: no staging registers, no ds_write), the activation columns XOR-swizzled by
-// the loader so that the 256-byte column stride reads conflict-free.
+// against 60 ns of VALU work.  Here a wave owns a 16-row x 32-column output tile with all 8 chains on v_mfma_f32_16x16x4_4b_f16 (four
+// 16 x 16 x 4 products per issue = four chains of a 16 x 16 sub-tile; 16 result registers; a lane holds 4 rows x 1 column of every
+// sub-tile, so the 8 scale products d_w * d_a of a block serve all 8 chains): 64 accumulators + 16 results, <= 128 registers, 8 waves
+// per workgroup (64 x 64 outputs), two workgroups per CU.  The operands of the next quad go global -> LDS by DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write), the activation columns XOR-swizzled by the loader so that the
+// 256-byte column stride reads conflict-free.  What bounds it (tools/mfma_overlap_probe.hip, profiles/r04_p_mfma_overlap.txt): on
+// gfx950 an MFMA and the VALU instructions of OTHER waves of the same SIMD do not run side by side -- an 8-pass MFMA keeps the VALU
+// out for its 14 ns, whatever the instruction type -- so a block of a sub-tile costs the MFMA's 14 ns PLUS its 16 FMAs and their
+// operand preparation.
 // Weight copy "mt4" (same size and tiling as mt16, replaces it): tile (row-block of 32, quad of 4 blocks) = 2560 B:
-//   [h 0..1][lane 0..63][16 B]   lane = i + 16 b: dword j = block 4 q + j, chain CH(h, b) = h + {0, 4, 2, 6}[b], rows i (sub-tile 0)
-//                                and 16 + i (sub-tile 1): BIASED nibbles (q = n + 8) at bit 8 s + 16 (e & 1) + 4 (e >> 1), so that
+//   [s 0..1][lane 0..63][16 B]   lane = i + 16 b, row 16 s + i: dword j = block 4 q + j, chains CH(h, b) = h + {0, 4, 2, 6}[b], h = 0, 1:
+//                                BIASED nibbles (q = n + 8) at bit 8 h + 16 (e & 1) + 4 (e >> 1), so that
 //                                `(x >> 4 u) & 0x000F000F | 0x64006400`, u = 0 .. 3, are the fp16 pairs (1024 + q): (e0, e1), (e2, e3) of
-//                                sub-tile 0, then of sub-tile 1
+//                                the h = 0 operand, then of the h = 1 operand
 //   [j][32 rows] fp32 scales
-// Activation operand "QB4" (k_qa_to_qb4): per column and quad 256 B = [h][b][j 0..3][4 fp16], exact integers -8..7.
+// Activation operand "QB4" (k_qa_to_qb4): per column and quad 256 B = [b][j 0..3][h][4 fp16], exact integers -8..7.
+// The chains of an operand, {h, 4 + h, 2 + h, 6 + h}, are one side of the reference's final add tree (ggml.c:872-887).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int mt4_chain(int h, int b) { return h + 2 * (((b & 1) << 1) | (b >> 1)); }
@@ -1059,10 +1063,10 @@ __global__ void k_tiles_to_mt4(const uint8_t *__restrict__ tiles, uint8_t *__res
     const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long) nrb32 * nq * 2 * 64;
     if (gid >= total) return;
-    const int lane = (int) (gid & 63), h = (int) ((gid >> 6) & 1);
+    const int lane = (int) (gid & 63), s = (int) ((gid >> 6) & 1);
     const long t = gid >> 7;
     const int q = (int) (t % nq), rb = (int) (t / nq);
-    const int i = lane & 15, b = lane >> 4, kc = mt4_chain(h, b);
+    const int i = lane & 15, b = lane >> 4;
     auto tile_of = [&](int row, int c) -> const uint8_t * {
         const int lg = row >> 3;
         if (lg >= ngroups) return nullptr;
@@ -1070,33 +1074,34 @@ __global__ void k_tiles_to_mt4(const uint8_t *__restrict__ tiles, uint8_t *__res
         if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
         return tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
     };
+    const int row = rb * 32 + 16 * s + i, r = row & 7;
     uint32_t x[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int bk = q * 4 + j, c = bk >> 3, jj = bk & 7, i2 = jj >> 1, half = jj & 1;
+        const uint8_t *tp = tile_of(row, c);
         uint32_t v = 0u;
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int row = rb * 32 + 16 * s + i, r = row & 7;
-            const uint8_t *tp = tile_of(row, c);
+        for (int h = 0; h < 2; h++) {
+            const int kc = mt4_chain(h, b);
             const uint32_t dw = tp ? ((const uint32_t *) (tp + (r * 8 + kc) * 16))[i2] : 0u;     // chain kc, blocks (2 i2, 2 i2 + 1): byte p = element e_p
 #pragma unroll
             for (int pp = 0; pp < 4; pp++) {
                 const uint32_t e = tp ? (((dw >> (8 * pp + 4 * half)) & 0xFu) ^ 8u) : 8u;       // signed nibble -> biased q (padding rows: 8 = zero)
-                v |= e << (8 * s + 16 * (pp & 1) + 4 * (pp >> 1));
+                v |= e << (8 * h + 16 * (pp & 1) + 4 * (pp >> 1));
             }
         }
         x[j] = v;
     }
     uint8_t *o = mt + ((size_t) rb * nq + q) * MTILE_BYTES;
-    *(u32x4 *) (o + h * 1024 + lane * 16) = u32x4{ x[0], x[1], x[2], x[3] };
-    if (h == 0) {
+    *(u32x4 *) (o + s * 1024 + lane * 16) = u32x4{ x[0], x[1], x[2], x[3] };
+    if (s == 0) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int idx = lane + 64 * u, j = idx >> 5, m = idx & 31;
-            const int bk = q * 4 + j, c = bk >> 3, jj = bk & 7, row = rb * 32 + m;
-            const uint8_t *tp = tile_of(row, c);
-            ((float *) (o + 2048))[idx] = tp ? ((const float *) (tp + 1024 + (row & 7) * 32))[(jj & 3) * 2 + (jj >> 2)] : 0.0f;
+            const int bk = q * 4 + j, c = bk >> 3, jj = bk & 7, row2 = rb * 32 + m;
+            const uint8_t *tp = tile_of(row2, c);
+            ((float *) (o + 2048))[idx] = tp ? ((const float *) (tp + 1024 + (row2 & 7) * 32))[(jj & 3) * 2 + (jj >> 2)] : 0.0f;
         }
     }
 }
@@ -1120,7 +1125,7 @@ __global__ void k_qa_to_qb4(const uint32_t *__restrict__ qa_A, uint8_t *__restri
     }
     const int h = kc & 1, k2 = kc >> 1, b = ((k2 & 1) << 1) | (k2 >> 1);          // mt4_chain(h, b) == kc
     const int q = bk >> 2, j = bk & 3;
-    *(h4v *) (qb + ((size_t) n * nbp + q * 4) * 64 + (h * 8 + b * 2 + (j >> 1)) * 16 + (j & 1) * 8) = v;
+    *(h4v *) (qb + ((size_t) n * nbp + q * 4) * 64 + (b * 4 + j) * 16 + h * 8) = v;
 }
 
 // one wave instruction: lane l's 16 bytes at `base + voff` land in LDS at `lds_dst + 16 l` (lds_dst, base: wave-uniform)
@@ -1130,7 +1135,7 @@ __device__ __forceinline__ void gemm4_dma16(uint32_t lds_dst, uint64_t base, uin
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
 }
 
-template <int EPI, bool PK>
+template <int EPI>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
              const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
@@ -1142,7 +1147,7 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
     const int ct = qq % nct, rp = (qq / nct) * 8 + xcd;
     if (rp * 2 >= nrb32) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = wave & 1, wr = (wave >> 1) & 1, wc = wave >> 2;
+    const int s = wave & 1, wr = (wave >> 1) & 1, wc = wave >> 2;             // rows 32 wr + 16 s .. + 15, columns 32 wc .. + 31 of the 64 x 64 tile
     const int n0 = ct * 64;
     const int nbp = nq * 4;
     const int cc = lane & 15, b = lane >> 4;
@@ -1169,12 +1174,9 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
         if (wave == 5) gemm4_dma16(ldsD + buf * 1024, (uint64_t) (uintptr_t) qa_d, offD + (uint32_t) q * 16u);
     };
 
-    float acc[2][2][4][4];                                  // [row sub-tile s][column sub-tile t][chain slot][row r]
-    f32x2 acc2[2][2][4][2];                                 // the same as register pairs (rows 0-1, 2-3) for the packed variant
+    float acc[2][2][4][4];                                  // [column sub-tile t][operand h][chain slot b][row r]: chain CH(h, b)
 #pragma unroll
     for (int i = 0; i < 64; i++) (&acc[0][0][0][0])[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; i++) (&acc2[0][0][0][0])[i] = f32x2{ 0.0f, 0.0f };
     f32x16v zero16;
 #pragma unroll
     for (int r = 0; r < 16; r++) zero16[r] = 0.0f;
@@ -1188,115 +1190,67 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
         const int buf = q & 1;
         if (q + 1 < nq) issue(q + 1, buf ^ 1);              // that buffer was last read in quad q - 1: every wave is past its closing barrier
         const uint8_t *wt_ = &sW[buf][wr * MTILE_BYTES];
-        const u32x4 x = *(const u32x4 *) (wt_ + h * 1024 + lane * 16);
+        const u32x4 x = *(const u32x4 *) (wt_ + s * 1024 + lane * 16);
         const uint8_t *bc0 = &sB[buf][(wc * 32 + cc) * 256], *bc1 = bc0 + 16 * 256;
         const float *dc0 = &sDa[buf][(wc * 32 + cc) * 4], *dc1 = dc0 + 16 * 4;
 #pragma unroll
-        for (int jp = 0; jp < 2; jp++) {
-            const int g = ((h * 8 + b * 2 + jp) ^ cc) * 16;
-            const u32x4 Bt0 = *(const u32x4 *) (bc0 + g), Bt1 = *(const u32x4 *) (bc1 + g);
+        for (int j = 0; j < 4; j++) {
+            const int g = ((b * 4 + j) ^ cc) * 16;
+            const u32x4 Bt0 = *(const u32x4 *) (bc0 + g), Bt1 = *(const u32x4 *) (bc1 + g);        // (h = 0 | h = 1) operands of column sub-tiles 0, 1
+            const uint32_t xs = x[j];
+            uint32_t pa[4];
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                const int j = 2 * jp + jj;
-                const uint32_t xs = x[j];
-                uint32_t pa[4];
+            for (int u = 0; u < 4; u++) {
+                uint32_t pu;
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pu) : "v"(xs >> (4 * u)), "v"(0x000F000Fu), "v"(0x64006400u));
+                pa[u] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2v, pu) - bias);      // 1024 + q - 1032: the signed nibble, exact
+            }
+            const float da0 = dc0[j], da1 = dc1[j];
+            const f32x4 dw = *(const f32x4 *) (wt_ + 2048 + (j * 32 + 16 * s + 4 * b) * 4);
+            const float sc[2][4] = { { dw.x * da0, dw.y * da0, dw.z * da0, dw.w * da0 }, { dw.x * da1, dw.y * da1, dw.z * da1, dw.w * da1 } };
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    uint32_t pu;
-                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pu) : "v"(xs >> (4 * u)), "v"(0x000F000Fu), "v"(0x64006400u));
-                    pa[u] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2v, pu) - bias);      // 1024 + q - 1032: the signed nibble, exact
-                }
-                const float da0 = dc0[j], da1 = dc1[j];
-                const f32x2 dapair = { da0, da1 };
+            for (int h = 0; h < 2; h++) {
+                struct { uint32_t a, b; } aw = { pa[2 * h], pa[2 * h + 1] };
 #pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    const f32x4 dw = *(const f32x4 *) (wt_ + 2048 + (j * 32 + 16 * s + 4 * b) * 4);
-                    struct { uint32_t a, b; } aw = { pa[2 * s], pa[2 * s + 1] };
+                for (int t = 0; t < 2; t++) {
+                    const u32x4 Bq = t ? Bt1 : Bt0;
+                    struct { uint32_t a, b; } bw = { h ? Bq.z : Bq.x, h ? Bq.w : Bq.y };
+                    const f32x16v D = __builtin_amdgcn_mfma_f32_16x16x4f16(__builtin_bit_cast(h4v, aw), __builtin_bit_cast(h4v, bw), zero16, 0, 0, 0);
+                    // (volatile asm FMAs in this order with one result set live; the first one is a plain FMA so that the compiler
+                    // inserts the MFMA -> VALU wait states, and its result is a dummy input of the second: see k_gemm_mfma16.
+                    // Packed FMAs -- v_pk_fma_f32 + v_pk_mul_f32 with op_sel broadcasts, no register copies -- measured SLOWER
+                    // here, 184.8 -> 192.0 ms for 2048 tokens: profiles/r04_q_gemm4_pk_ab.txt)
+                    float (&a)[4][4] = acc[t][h];
+                    const float first = __builtin_fmaf(sc[t][0], D[0], a[0][0]);
+                    a[0][0] = first;
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[0][1]) : "v"(sc[t][1]), "v"(D[1]), "v"(first));
 #pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        const u32x4 Bq = t ? Bt1 : Bt0;
-                        struct { uint32_t a, b; } bw = { jj ? Bq.z : Bq.x, jj ? Bq.w : Bq.y };
-                        const f32x16v D = __builtin_amdgcn_mfma_f32_16x16x4f16(__builtin_bit_cast(h4v, aw), __builtin_bit_cast(h4v, bw), zero16, 0, 0, 0);
-                        const float da = t ? da1 : da0;
-                        // (volatile asm FMAs in this order with one result set live; the first one is a plain FMA so that the compiler
-                        // inserts the MFMA -> VALU wait states, and its result is a dummy input of the second: see k_gemm_mfma16)
-                        float (&a)[4][4] = acc[s][t];
-                        if constexpr (PK) {
-                            // packed: at four waves per SIMD v_pk_fma_f32 costs 1.96 ns against 2 x 1.18 for two v_fma_f32
-                            // (profiles/r02_e_valu_rate.txt; at two waves it is the other way round) -- the same IEEE FMA per component.
-                            // The column's scale is broadcast by op_sel out of the pair (da0, da1): no register copies.
-                            f32x2 sc01, sc23;
-                            const f32x2 dw01 = { dw.x, dw.y }, dw23 = { dw.z, dw.w };
-                            if (t == 0) {
-                                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sc01) : "v"(dw01), "v"(dapair));
-                                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sc23) : "v"(dw23), "v"(dapair));
-                            } else {
-                                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(sc01) : "v"(dw01), "v"(dapair));
-                                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(sc23) : "v"(dw23), "v"(dapair));
-                            }
-                            f32x2 (&ap)[4][2] = acc2[s][t];
-                            const float first = __builtin_fmaf(sc01.x, D[0], ap[0][0].x);
-                            ap[0][0].x = first;
-                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ap[0][0].y) : "v"(sc01.y), "v"(D[1]), "v"(first));
-#pragma unroll
-                            for (int e = 2; e < 16; e += 2) {
-                                const f32x2 dp = { D[e], D[e + 1] };
-                                if (e & 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ap[e >> 2][1]) : "v"(sc23), "v"(dp));
-                                else       asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ap[e >> 2][0]) : "v"(sc01), "v"(dp));
-                            }
-                        } else {
-                            float sc[4] = { dw.x * da, dw.y * da, dw.z * da, dw.w * da };
-                            const float first = __builtin_fmaf(sc[0], D[0], a[0][0]);
-                            a[0][0] = first;
-                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[0][1]) : "v"(sc[1]), "v"(D[1]), "v"(first));
-#pragma unroll
-                            for (int e = 2; e < 16; e++)
-                                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[e >> 2][e & 3]) : "v"(sc[e & 3]), "v"(D[e]));
-                        }
-                    }
+                    for (int e = 2; e < 16; e++)
+                        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[e >> 2][e & 3]) : "v"(sc[t][e & 3]), "v"(D[e]));
                 }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my DMA instructions for quad q + 1 have landed
         __syncthreads();
     }
-    // ---- each wave folds its side of the tree, (A_h + A_{4+h}) + (A_{2+h} + A_{6+h}); the odd side crosses to the even wave through LDS
-    float part[2][2][4];
+    // ---- fold the 8 chains (ggml.c:872-887 tree: ((A0 + A4) + (A2 + A6)) + ((A1 + A5) + (A3 + A7))) and store: lane = column, 4 rows
+    if (rp * 2 + wr >= nrb32) return;
 #pragma unroll
-    for (int s = 0; s < 2; s++)
+    for (int t = 0; t < 2; t++) {
+        const int n = n0 + wc * 32 + 16 * t + cc;
+        const int m0 = (rp * 2 + wr) * 32 + 16 * s + 4 * b;
+        if (n >= ncols) continue;
 #pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-#define LH_A4(B) (PK ? ((r & 1) ? acc2[s][t][B][r >> 1].y : acc2[s][t][B][r >> 1].x) : acc[s][t][B][r])
-                part[s][t][r] = (LH_A4(0) + LH_A4(1)) + (LH_A4(2) + LH_A4(3));
-#undef LH_A4
-            }
-    float *xch = (float *) &sB[0][0] + (wave >> 1) * (16 * 64);           // (every wave is past the last quad's closing barrier)
-    if (h == 1) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) xch[i * 64 + lane] = (&part[0][0][0])[i];
-    }
-    __syncthreads();
-    if (h == 1 || rp * 2 + wr >= nrb32) return;
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int n = n0 + wc * 32 + 16 * t + cc;
-            const int m0 = (rp * 2 + wr) * 32 + 16 * s + 4 * b;
-            if (n >= ncols) continue;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = part[s][t][r] + xch[((s * 2 + t) * 4 + r) * 64 + lane];
-                if (m0 + r < M) {
-                    if (EPI == EPI_RESID) v = v + resid[(size_t) n * resid_stride + m0 + r];
-                    y[(size_t) n * y_stride + m0 + r] = v;
-                }
+        for (int r = 0; r < 4; r++) {
+            float v = ((acc[t][0][0][r] + acc[t][0][1][r]) + (acc[t][0][2][r] + acc[t][0][3][r]))
+                    + ((acc[t][1][0][r] + acc[t][1][1][r]) + (acc[t][1][2][r] + acc[t][1][3][r]));
+            if (m0 + r < M) {
+                if (EPI == EPI_RESID) v = v + resid[(size_t) n * resid_stride + m0 + r];
+                y[(size_t) n * y_stride + m0 + r] = v;
             }
         }
+    }
 }
-
 
 template <int NC>
 static hipError_t launch_gemm_lds_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols,
@@ -1461,11 +1415,8 @@ static hipError_t launch_gemm_mfma16(const QMat &w, int epi, const uint32_t *qa_
     if (gemm4_mode()) {
         hipLaunchKernelGGL(k_qa_to_qb4, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, qa_A, qb16, w.nchunks, ncols);
         LH_LAUNCH_CHECK();
-        static const bool pk = !(getenv("LLAMAHIP_GEMM4_PK") && atoi(getenv("LLAMAHIP_GEMM4_PK")) == 0);
-#define LH_G4(E, P) hipLaunchKernelGGL((k_gemm_mfma4<E, P>), dim3(grid), dim3(512), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride)
-        if (epi == EPI_RESID) { if (pk) LH_G4(EPI_RESID, true); else LH_G4(EPI_RESID, false); }
-        else                  { if (pk) LH_G4(EPI_STORE, true); else LH_G4(EPI_STORE, false); }
-#undef LH_G4
+        if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_mfma4<EPI_RESID>), dim3(grid), dim3(512), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+        else                  hipLaunchKernelGGL((k_gemm_mfma4<EPI_STORE>), dim3(grid), dim3(512), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
         LH_LAUNCH_CHECK();
         return hipSuccess;
     }

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round-4 pass Q: k_gemm_mfma4 with packed FMAs: A/B (parity of the packed variant: gpurun_out/r04q_pytest.txt)
+# Round-4 pass Q2: k_gemm_mfma4 as 16-row x 32-column wave tiles with all 8 chains (scale products shared): parity + A/B against k_gemm_mfma16
 O=gpurun_out; mkdir -p $O
 bash tools/ensure_7b.sh
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "matrix_core_prompt_gemm or 2048_token_prefill or long_prompt or multipart" > $O/r04q2_pytest.txt 2>&1; tail -4 $O/r04q2_pytest.txt
 {
-echo "== k_gemm_mfma4, plain v_fma_f32   [LLAMAHIP_GEMM4_PK=0]"; LLAMAHIP_GEMM4_PK=0 timeout 300 python tools/prefill_probe.py 2>&1 | grep -v amdgpu.ids
-echo "== k_gemm_mfma4, v_pk_fma_f32 / v_pk_mul_f32"; timeout 300 python tools/prefill_probe.py 2>&1 | grep -v amdgpu.ids
-} > $O/r04q_gemm4_pk_ab.txt 2>&1; cat $O/r04q_gemm4_pk_ab.txt
+echo "== k_gemm_mfma16 (two waves per SIMD)   [LLAMAHIP_GEMM4=0]"; LLAMAHIP_GEMM4=0 timeout 300 python tools/prefill_probe.py 2>&1 | grep -v amdgpu.ids
+echo "== k_gemm_mfma4 (four waves per SIMD, wave = 16 x 32 outputs x 8 chains)"; timeout 300 python tools/prefill_probe.py 2>&1 | grep -v amdgpu.ids
+} > $O/r04q2_gemm4_ab.txt 2>&1; cat $O/r04q2_gemm4_ab.txt
