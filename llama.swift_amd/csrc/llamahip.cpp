@@ -359,7 +359,7 @@ int make_rows(QMat &q, llamahip_model *m) {
     q.nrb32 = (q.M + 31) / 32;
     if ((m->flags & LLAMAHIP_FLAG_FAST_PREFILL) || want_i8) {
         if (!build(&q.mt, q.mt_bytes(), [&]() { return launch_tiles_to_mtiles(q, m->stream); })) return 1;
-    } else if (!build(&q.mt16, q.mt_bytes(), [&]() { return launch_tiles_to_mt16(q, m->stream); })) return 1;
+    } else if (!build(&q.mt16, gemm_mt16_bytes(q), [&]() { return launch_tiles_to_mt16(q, m->stream); })) return 1;
     return 0;
 }
 constexpr int PROMPT_COPY_MIN_ROWS = 61;       // evals up to 60 rows take k_gemm_skinny on the decode tiles

@@ -86,6 +86,7 @@ hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int
 hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st);   // w.rows / w.nrb set by the caller
 hipError_t launch_tiles_to_mtiles(const QMat &w, hipStream_t st); // w.mt / w.nrb32 set by the caller
 hipError_t launch_tiles_to_mt16(const QMat &w, hipStream_t st);   // w.mt16 / w.nrb32 set by the caller
+size_t gemm_mt16_bytes(const QMat &w);                            // size of that copy (depends on the kernel generation in use)
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st);
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,

@@ -1045,11 +1045,11 @@ k_gemm_mfma16(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
 // gfx950 an MFMA and the VALU instructions of OTHER waves of the same SIMD do not run side by side -- an 8-pass MFMA keeps the VALU
 // out for its 14 ns, whatever the instruction type -- so a block of a sub-tile costs the MFMA's 14 ns PLUS its 16 FMAs and their
 // operand preparation.
-// Weight copy "mt4" (same size and tiling as mt16, replaces it): tile (row-block of 32, quad of 4 blocks) = 2560 B:
-//   [s 0..1][lane 0..63][16 B]   lane = i + 16 b, row 16 s + i: dword j = block 4 q + j, chains CH(h, b) = h + {0, 4, 2, 6}[b], h = 0, 1:
-//                                BIASED nibbles (q = n + 8) at bit 8 h + 16 (e & 1) + 4 (e >> 1), so that
-//                                `(x >> 4 u) & 0x000F000F | 0x64006400`, u = 0 .. 3, are the fp16 pairs (1024 + q): (e0, e1), (e2, e3) of
-//                                the h = 0 operand, then of the h = 1 operand
+// Weight copy "mt4" (replaces mt16; ONE BYTE per weight, 1.8 x the size): tile (row-block of 32, quad of 4 blocks) = MT4_BYTES = 4608 B:
+//   [s 0..1][lane 0..63][32 B]   lane = i + 16 b, row 16 s + i: dword 2 j + h = block 4 q + j, chain CH(h, b) = h + {0, 4, 2, 6}[b]: its four
+//                                weights as the HIGH BYTES of their fp16 values (every integer -8..7 has an fp16 low byte of zero), so
+//                                that two v_perm_b32 (bytes {0, w0, 0, w1} and {0, w2, 0, w3}) ARE the MFMA operand -- no bias, no
+//                                masks, no shifts (the nibble form cost 11 VALU instructions per block and lane, this one 4)
 //   [j][32 rows] fp32 scales
 // Activation operand "QB4" (k_qa_to_qb4): per column and quad 256 B = [b][j 0..3][h][4 fp16], exact integers -8..7.
 // The chains of an operand, {h, 4 + h, 2 + h, 6 + h}, are one side of the reference's final add tree (ggml.c:872-887).
@@ -1057,6 +1057,7 @@ k_gemm_mfma16(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int mt4_chain(int h, int b) { return h + 2 * (((b & 1) << 1) | (b >> 1)); }
 
+constexpr int MT4_BYTES = 4608;
 __global__ void k_tiles_to_mt4(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ mt,
                                int ngroups, int nchunks, int nrb32, int gmapF8) {
     const int nq = nchunks * 2;
@@ -1075,33 +1076,35 @@ __global__ void k_tiles_to_mt4(const uint8_t *__restrict__ tiles, uint8_t *__res
         return tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
     };
     const int row = rb * 32 + 16 * s + i, r = row & 7;
-    uint32_t x[4];
+    uint32_t x[8];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int bk = q * 4 + j, c = bk >> 3, jj = bk & 7, i2 = jj >> 1, half = jj & 1;
         const uint8_t *tp = tile_of(row, c);
-        uint32_t v = 0u;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int kc = mt4_chain(h, b);
             const uint32_t dw = tp ? ((const uint32_t *) (tp + (r * 8 + kc) * 16))[i2] : 0u;     // chain kc, blocks (2 i2, 2 i2 + 1): byte p = element e_p
+            uint32_t v = 0u;
 #pragma unroll
             for (int pp = 0; pp < 4; pp++) {
-                const uint32_t e = tp ? (((dw >> (8 * pp + 4 * half)) & 0xFu) ^ 8u) : 8u;       // signed nibble -> biased q (padding rows: 8 = zero)
-                v |= e << (8 * h + 16 * (pp & 1) + 4 * (pp >> 1));
+                const int n = (int) (((dw >> (8 * pp + 4 * half)) & 0xFu) ^ 8u) - 8;           // the weight, -8..7 (padding rows: 0)
+                const uint32_t hb = (uint32_t) (__builtin_bit_cast(uint16_t, (_Float16) (float) n) >> 8);
+                v |= hb << (8 * pp);
             }
+            x[2 * j + h] = v;
         }
-        x[j] = v;
     }
-    uint8_t *o = mt + ((size_t) rb * nq + q) * MTILE_BYTES;
-    *(u32x4 *) (o + s * 1024 + lane * 16) = u32x4{ x[0], x[1], x[2], x[3] };
+    uint8_t *o = mt + ((size_t) rb * nq + q) * MT4_BYTES;
+    *(u32x4 *) (o + s * 2048 + lane * 32) = u32x4{ x[0], x[1], x[2], x[3] };
+    *(u32x4 *) (o + s * 2048 + lane * 32 + 16) = u32x4{ x[4], x[5], x[6], x[7] };
     if (s == 0) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int idx = lane + 64 * u, j = idx >> 5, m = idx & 31;
             const int bk = q * 4 + j, c = bk >> 3, jj = bk & 7, row2 = rb * 32 + m;
             const uint8_t *tp = tile_of(row2, c);
-            ((float *) (o + 2048))[idx] = tp ? ((const float *) (tp + 1024 + (row2 & 7) * 32))[(jj & 3) * 2 + (jj >> 2)] : 0.0f;
+            ((float *) (o + 4096))[idx] = tp ? ((const float *) (tp + 1024 + (row2 & 7) * 32))[(jj & 3) * 2 + (jj >> 2)] : 0.0f;
         }
     }
 }
@@ -1141,7 +1144,7 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
              const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
     __shared__ __attribute__((aligned(1024))) uint8_t sB[2][64 * 256];          // [column][16 granules, XOR-swizzled by column & 15]
-    __shared__ __attribute__((aligned(1024))) uint8_t sW[2][2 * MTILE_BYTES];
+    __shared__ __attribute__((aligned(1024))) uint8_t sW[2][2 * MT4_BYTES];
     __shared__ __attribute__((aligned(1024))) float sDa[2][64 * 4];
     const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
     const int ct = qq % nct, rp = (qq / nct) * 8 + xcd;
@@ -1156,22 +1159,23 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
     const uint32_t ldsB = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) &sB[0][0];
     const uint32_t ldsW = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) &sW[0][0];
     const uint32_t ldsD = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) &sDa[0][0];
-    uint32_t offB[2], offW = 0u, offD = 0u;
+    // (weights: two tiles = 9 instructions of 1 KiB: instruction w by wave w, the ninth by wave 6; the columns' scales: wave 5)
+    uint32_t offB[2], offW, offX = 0u;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int col = 4 * (2 * wave + u) + (lane >> 4), p = (lane & 15) ^ (col & 15);
         offB[u] = (uint32_t) ((size_t) min(n0 + col, ncols - 1) * nbp * 64 + p * 16);
     }
-    if (wave < 5) {
-        const int g = wave * 64 + lane, tile = g / 160;
-        offW = (uint32_t) ((size_t) min(rp * 2 + tile, nrb32 - 1) * nq * MTILE_BYTES + (g % 160) * 16);
-    }
-    if (wave == 5) offD = (uint32_t) ((size_t) min(n0 + lane, ncols - 1) * nbp * 4);
+    auto w_off = [&](int g) { return (uint32_t) ((size_t) min(rp * 2 + g / 288, nrb32 - 1) * nq * MT4_BYTES + (g % 288) * 16); };
+    offW = w_off(wave * 64 + lane);
+    if (wave == 6) offX = w_off(8 * 64 + lane);
+    if (wave == 5) offX = (uint32_t) ((size_t) min(n0 + lane, ncols - 1) * nbp * 4);
     auto issue = [&](int q, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; u++) gemm4_dma16(ldsB + buf * 16384 + (2 * wave + u) * 1024, (uint64_t) (uintptr_t) qb, offB[u] + (uint32_t) q * 256u);
-        if (wave < 5) gemm4_dma16(ldsW + buf * (2 * MTILE_BYTES) + wave * 1024, (uint64_t) (uintptr_t) mt, offW + (uint32_t) q * MTILE_BYTES);
-        if (wave == 5) gemm4_dma16(ldsD + buf * 1024, (uint64_t) (uintptr_t) qa_d, offD + (uint32_t) q * 16u);
+        gemm4_dma16(ldsW + buf * (2 * MT4_BYTES) + wave * 1024, (uint64_t) (uintptr_t) mt, offW + (uint32_t) q * MT4_BYTES);
+        if (wave == 6) gemm4_dma16(ldsW + buf * (2 * MT4_BYTES) + 8 * 1024, (uint64_t) (uintptr_t) mt, offX + (uint32_t) q * MT4_BYTES);
+        if (wave == 5) gemm4_dma16(ldsD + buf * 1024, (uint64_t) (uintptr_t) qa_d, offX + (uint32_t) q * 16u);
     };
 
     float acc[2][2][4][4];                                  // [column sub-tile t][operand h][chain slot b][row r]: chain CH(h, b)
@@ -1180,8 +1184,6 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
     f32x16v zero16;
 #pragma unroll
     for (int r = 0; r < 16; r++) zero16[r] = 0.0f;
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    const h2v bias = { (_Float16) 1032.0f, (_Float16) 1032.0f };
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1189,24 +1191,24 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
     for (int q = 0; q < nq; q++) {
         const int buf = q & 1;
         if (q + 1 < nq) issue(q + 1, buf ^ 1);              // that buffer was last read in quad q - 1: every wave is past its closing barrier
-        const uint8_t *wt_ = &sW[buf][wr * MTILE_BYTES];
-        const u32x4 x = *(const u32x4 *) (wt_ + s * 1024 + lane * 16);
+        const uint8_t *wt_ = &sW[buf][wr * MT4_BYTES];
+        const u32x4 x01 = *(const u32x4 *) (wt_ + s * 2048 + lane * 32), x23 = *(const u32x4 *) (wt_ + s * 2048 + lane * 32 + 16);
         const uint8_t *bc0 = &sB[buf][(wc * 32 + cc) * 256], *bc1 = bc0 + 16 * 256;
         const float *dc0 = &sDa[buf][(wc * 32 + cc) * 4], *dc1 = dc0 + 16 * 4;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int g = ((b * 4 + j) ^ cc) * 16;
             const u32x4 Bt0 = *(const u32x4 *) (bc0 + g), Bt1 = *(const u32x4 *) (bc1 + g);        // (h = 0 | h = 1) operands of column sub-tiles 0, 1
-            const uint32_t xs = x[j];
-            uint32_t pa[4];
+            const u32x4 xq = j < 2 ? x01 : x23;
+            uint32_t pa[4];                                 // operand h = (pa[2 h], pa[2 h + 1]): the chain's four fp16 weights
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t pu;
-                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pu) : "v"(xs >> (4 * u)), "v"(0x000F000Fu), "v"(0x64006400u));
-                pa[u] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2v, pu) - bias);      // 1024 + q - 1032: the signed nibble, exact
+            for (int h = 0; h < 2; h++) {
+                const uint32_t xd = (j & 1) ? (h ? xq.w : xq.z) : (h ? xq.y : xq.x);
+                pa[2 * h] = __builtin_amdgcn_perm(0u, xd, 0x010C000Cu);
+                pa[2 * h + 1] = __builtin_amdgcn_perm(0u, xd, 0x030C020Cu);
             }
             const float da0 = dc0[j], da1 = dc1[j];
-            const f32x4 dw = *(const f32x4 *) (wt_ + 2048 + (j * 32 + 16 * s + 4 * b) * 4);
+            const f32x4 dw = *(const f32x4 *) (wt_ + 4096 + (j * 32 + 16 * s + 4 * b) * 4);
             const float sc[2][4] = { { dw.x * da0, dw.y * da0, dw.z * da0, dw.w * da0 }, { dw.x * da1, dw.y * da1, dw.z * da1, dw.w * da1 } };
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -1310,8 +1312,9 @@ static int skinny_max_rows() {
 }
 // column-group width of k_gemm_skinny for N rows: the widest (<= 4) that still leaves ~1500 waves, balanced
 static int skinny_pick_nc(const QMat &w, int N) {
+    static const long min_waves = getenv("LLAMAHIP_SKINNY_WAVES") ? atol(getenv("LLAMAHIP_SKINNY_WAVES")) : 1536;     // measurement override
     int nc = 4;
-    while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
+    while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < min_waves) nc--;
     if (nc > N) nc = N;
     while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
     const int ncg = (N + nc - 1) / nc;
@@ -1394,6 +1397,7 @@ static bool gemm4_mode() {
     static const bool on = !(getenv("LLAMAHIP_GEMM4") && atoi(getenv("LLAMAHIP_GEMM4")) == 0);
     return on;
 }
+size_t gemm_mt16_bytes(const QMat &w) { return gemm4_mode() ? (size_t) w.nrb32 * w.nchunks * 2 * MT4_BYTES : w.mt_bytes(); }
 hipError_t launch_tiles_to_mt16(const QMat &w, hipStream_t st) {
     if (gemm4_mode()) {
         const long tot4 = (long) w.nrb32 * w.nchunks * 2 * 2 * 64;
