@@ -151,7 +151,9 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 // 16 queries (registers, loaded once) against its key slice, 16 keys per step = 32 independent MFMAs (C = 0) + the reduction tree
 // (ggml.c:872-887) on the VALU, 31 additions per pair.  Result registers: lane holds key n = lane % 16, queries 4 kk + r.
 // 100 us per launch at 2 048 tokens, logits bit-identical; requesting the next step's key rows a step ahead (+32 registers) measured 109 us:
-// two waves per SIMD already cover the load.
+// two waves per SIMD already cover the load.  Four waves per SIMD (the MFMAs four at a time as inline asm, partial sums folded as they
+// arrive, <= 128 registers) measured SLOWER, 102 -> 126 us per launch (profiles/r04_u_attn_ab.txt): each group of four waits for its own
+// results where this version has all 32 MFMAs in the pipe before the first addition.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
@@ -262,11 +264,14 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
 // PERROW: a chunked pass (split_keys, chunk > 0) gives the queries of a block different key ranges; a plain eval (one split for every
 // row) does not pay for the per-lane range tests (the 2 048-token eval: 200.4 -> see profiles/r04_*prefill*).
 typedef float f32x16v __attribute__((ext_vector_type(16)));
-template <bool PERROW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
+// NCB = 32-column tiles per wave: 2 (grid z = 2 nth: the head's columns in two halves, 64 accumulators, four waves per SIMD) puts twice the
+// waves on the chip -- profiles/r04_t_prefill_pmc.txt: with one wave per (64 queries, head, chunk) a CU held 1.4 waves on average, each
+// alone on its SIMD waiting for its own loads, the matrix pipe 41 % busy.
+template <bool PERROW, int NCB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCB == 4 ? 3 : 4)))
 k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, const float *__restrict__ Vc, float *__restrict__ part,
                 int n_past, int N, int nb0, int NB, int d, int T, int nth, int chunk) {
-    const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5, h = blockIdx.y, th = blockIdx.z;
+    const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5, h = blockIdx.y, th = blockIdx.z % nth, c0 = (blockIdx.z / nth) * (NCB * 32);
     const int q0 = blockIdx.x * 64;
     const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
     const int Tb = n_past + nb_end;
@@ -280,11 +285,11 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
     const int t1 = hi_of(qlast);
     const int nA = min(nb0 + q0 + i, N - 1), nB = min(nb0 + q0 + 32 + i, N - 1);
     const int loA = lo_of(nA), hiA = hi_of(nA), loB = lo_of(nB), hiB = hi_of(nB);
-    f32x16v D[2][4];
+    f32x16v D[2][NCB];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++)
+        for (int b = 0; b < NCB; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) D[a][b][r] = 0.0f;
     const float iv0 = inv[(size_t) h * NB + q0 + i], iv1 = inv[(size_t) h * NB + q0 + 32 + i];
@@ -292,7 +297,7 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
     // operands of PF pair-steps in flight: a step is 512 matrix-pipe cycles, a load round trip several times that (8 and 12 steps at two
     // waves per SIMD measured the same 2 048-token eval: 191.9 / 191.0 / 190.8 ms)
     constexpr int PF = 4;
-    float pa0[PF], pa1[PF], pb0[PF], pb1[PF], pb2[PF], pb3[PF];
+    float pa0[PF], pa1[PF], pb[PF][NCB];
     const int tstart = t0 - (nk > 0 ? (nk & 1) : 0);          // (an even number of steps; the extra front key is outside every range)
 #define LH_PVLOAD(ST, TP)                                                                           \
     {                                                                                               \
@@ -300,11 +305,13 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
         const bool real_ = key_ >= t0 && key_ < t1;      /* (the front pad, and steps past the end) */ \
         const int kc_ = min(max(key_, t0), max(t1 - 1, t0));                                        \
         const float *sp_ = S + ((size_t) h * T + kc_) * NB + q0 + i;                                \
-        const float *vp_ = Vc + (size_t) kc_ * d + h * 128 + i;                                     \
-        const float s0_ = sp_[0], s1_ = sp_[32], v0_ = vp_[0], v1_ = vp_[32], v2_ = vp_[64], v3_ = vp_[96]; \
+        const float *vp_ = Vc + (size_t) kc_ * d + h * 128 + c0 + i;                                \
+        const float s0_ = sp_[0], s1_ = sp_[32];                                                    \
+        float v_[NCB];                                                                              \
+        _Pragma("unroll") for (int b = 0; b < NCB; b++) v_[b] = vp_[32 * b];                        \
         pa0[ST] = (real_ && (!PERROW || (key_ >= loA && key_ < hiA))) ? s0_ * iv0 : 0.0f;          /* soft_max's final scale (ggml.c:7036-7041) */ \
         pa1[ST] = (real_ && (!PERROW || (key_ >= loB && key_ < hiB))) ? s1_ * iv1 : 0.0f;          \
-        pb0[ST] = real_ ? v0_ : 0.0f; pb1[ST] = real_ ? v1_ : 0.0f; pb2[ST] = real_ ? v2_ : 0.0f; pb3[ST] = real_ ? v3_ : 0.0f; \
+        _Pragma("unroll") for (int b = 0; b < NCB; b++) pb[ST][b] = real_ ? v_[b] : 0.0f;           \
     }
     if (nk > 0) {
 #pragma unroll
@@ -313,16 +320,15 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
 #pragma unroll
             for (int st = 0; st < PF; st++) {
                 if (tp + 2 * st < t1) {
-                    const float a0 = pa0[st], a1 = pa1[st], b0 = pb0[st], b1 = pb1[st], b2 = pb2[st], b3 = pb3[st];
+                    const float a0 = pa0[st], a1 = pa1[st];
+                    float bv[NCB];
+#pragma unroll
+                    for (int b = 0; b < NCB; b++) bv[b] = pb[st][b];
                     LH_PVLOAD(st, tp + 2 * (st + PF))
-                    D[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, D[0][0], 0, 0, 0);
-                    D[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, D[0][1], 0, 0, 0);
-                    D[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, D[0][2], 0, 0, 0);
-                    D[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, D[0][3], 0, 0, 0);
-                    D[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, D[1][0], 0, 0, 0);
-                    D[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, D[1][1], 0, 0, 0);
-                    D[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, D[1][2], 0, 0, 0);
-                    D[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, D[1][3], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < NCB; b++) D[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[b], D[0][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < NCB; b++) D[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[b], D[1][b], 0, 0, 0);
                 }
             }
         }
@@ -334,9 +340,9 @@ k_attnq_pv_mfma(const float *__restrict__ S, const float *__restrict__ inv, cons
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int nl = q0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            float *o = part + (((size_t) th * gridDim.y + h) * NB + nl) * 128 + i;
+            float *o = part + (((size_t) th * gridDim.y + h) * NB + nl) * 128 + c0 + i;
 #pragma unroll
-            for (int b = 0; b < 4; b++) o[32 * b] = D[a][b][r];
+            for (int b = 0; b < NCB; b++) o[32 * b] = D[a][b][r];
         }
 }
 
@@ -368,14 +374,18 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
             // scores: 16 queries per wave, ~4 waves per SIMD over key slices
             const int qt = (nb + 15) / 16;
-            int KS = (4096 + qt * H - 1) / (qt * H);
+            static const int ks_waves = getenv("LLAMAHIP_SCORES_WAVES") ? atoi(getenv("LLAMAHIP_SCORES_WAVES")) : 4096;      // measurement override
+            int KS = (ks_waves + qt * H - 1) / (qt * H);
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
             hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
-            if (chunk > 0) hipLaunchKernelGGL(k_attnq_pv_mfma<true>, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk);
-            else hipLaunchKernelGGL(k_attnq_pv_mfma<false>, dim3(qb, H, nth), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, 0);
+            static const int ncb = getenv("LLAMAHIP_PV_NCB") ? atoi(getenv("LLAMAHIP_PV_NCB")) : 2;        // (4: one wave per head's 128 columns, the round-3 shape)
+#define LH_PV(P, C) hipLaunchKernelGGL((k_attnq_pv_mfma<P, C>), dim3(qb, H, nth * (4 / C)), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk)
+            if (chunk > 0) { if (ncb == 4) LH_PV(true, 4); else LH_PV(true, 2); }
+            else           { if (ncb == 4) LH_PV(false, 4); else LH_PV(false, 2); }
+#undef LH_PV
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_merge, dim3((nb + 1) / 2, H), dim3(256), 0, st, ws->part, merged, N, nb0, ws->NB, d, nth);
             LH_LAUNCH_CHECK();

@@ -103,6 +103,7 @@ template <> struct Acc<5> { typedef f32x4v type; };
 template <> struct Acc<6> { typedef f32x4v type; };
 template <> struct Acc<7> { typedef i32x16v type; };
 template <> struct Acc<8> { typedef i32x16v type; };
+template <> struct Acc<10> { typedef f32x4v type; };
 template <int T, typename C> __device__ __forceinline__ C mf(h4 a, h4 b, h8 a8, h8 b8, C c) {
     if constexpr (T == 0) return __builtin_amdgcn_mfma_f32_16x16x4f16(a, b, c, 0, 0, 0);
     else if constexpr (T == 1) return __builtin_amdgcn_mfma_f32_32x32x4f16(a, b, c, 0, 0, 0);
@@ -112,6 +113,8 @@ template <int T, typename C> __device__ __forceinline__ C mf(h4 a, h4 b, h8 a8, 
     else if constexpr (T == 5) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
     else if constexpr (T == 6) return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0);
     else if constexpr (T == 7) return __builtin_amdgcn_mfma_i32_32x32x16_i8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+    else if constexpr (T == 9) return __builtin_amdgcn_mfma_f32_32x32x2f32((float) a[0], (float) b[0], c, 0, 0, 0);
+    else if constexpr (T == 10) return __builtin_amdgcn_mfma_f32_16x16x4f32((float) a[0], (float) b[0], c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a8), __builtin_bit_cast(i32x4v, b8), c, 0, 0, 0);
 }
 template <int T>
@@ -186,5 +189,7 @@ int main() {
     run_split<6>("v_mfma_f32_4x4x4_16b_f16", sink, p.multiProcessorCount);
     run_split<7>("v_mfma_i32_32x32x16_i8", sink, p.multiProcessorCount);
     run_split<8>("v_mfma_i32_32x32x32_i8", sink, p.multiProcessorCount);
+    run_split<9>("v_mfma_f32_32x32x2_f32", sink, p.multiProcessorCount);
+    run_split<10>("v_mfma_f32_16x16x4_f32", sink, p.multiProcessorCount);
     return 0;
 }
