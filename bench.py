@@ -937,9 +937,12 @@ def prefill_2048(args, cfg, path):
                          "frac_of_fp32_valu_peak": fma_flops / best / 1e12 / FP32_VALU_PEAK_TFLOPS,
                          "bound": "fp32 VALU issue: the reference's arithmetic needs 8 separately rounded fp32 FMA chains per Q4_0 block and "
                                   "output (ggml.c:1415-1466), 3.3e12 plain v_fma_f32 for this eval.  Only the 4-element integer sums of a chain "
-                                  "run on the matrix cores (exact in fp16 -> fp32: v_mfma_f32_32x32x4_2b_f16, two chains per issue, "
-                                  "lh::k_gemm_mfma16), which keeps that pipe 30% busy while the VALU is active 81% of the SIMD cycles (profiles/r02_i_prefill_pmc.txt); the whole eval (attention, "
-                                  "norms, quantizers included) is divided by the peaks here"}}
+                                  "run on the matrix cores (exact in fp16 -> fp32: v_mfma_f32_16x16x4_4b_f16, four chains per issue, "
+                                  "lh::k_gemm_mfma4 at four waves per SIMD).  On gfx950 an MFMA and the VALU instructions of other waves of the same SIMD "
+                                  "do not run side by side (tools/mfma_overlap_probe.hip, profiles/r04_p_mfma_overlap.txt): per Q4_0 block and 16 x 16 "
+                                  "sub-tile the SIMD spends the MFMA's 14 ns PLUS 16 FMAs (19 ns) and their operand preparation -- 39 ns measured, so "
+                                  "the fp32 FMA rate the path can reach is about half the VALU peak; the whole eval (attention, norms, quantizers "
+                                  "included) is divided by the peaks here"}}
 
 
 def main():

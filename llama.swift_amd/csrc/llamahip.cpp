@@ -235,7 +235,7 @@ llamahip_model::~llamahip_model() {
         free_dev(l.qkv.tiles); free_dev(l.wo.tiles); free_dev(l.w13.tiles); free_dev(l.w2.tiles);
         free_dev(l.qkv.rows); free_dev(l.wo.rows); free_dev(l.w13.rows); free_dev(l.w2.rows);
         free_dev(l.qkv.mt); free_dev(l.wo.mt); free_dev(l.w13.mt); free_dev(l.w2.mt);
-        free_dev(l.qkv.mt16); free_dev(l.wo.mt16); free_dev(l.w13.mt16); free_dev(l.w2.mt16);
+        free_dev(l.qkv.mt4); free_dev(l.wo.mt4); free_dev(l.w13.mt4); free_dev(l.w2.mt4);
         free_dev(l.dqkv.w); free_dev(l.dwo.w); free_dev(l.dw13.w); free_dev(l.dw2.w);
         free_dev(l.dqkv.w2); free_dev(l.dwo.w2); free_dev(l.dw13.w2); free_dev(l.dw2.w2);
     }
@@ -353,13 +353,13 @@ int make_rows(QMat &q, llamahip_model *m) {
     };
     q.nrb = (q.M + 63) / 64;
     if (!build(&q.rows, q.rows_bytes(), [&]() { return launch_tiles_to_rows(q, m->stream); })) return 1;
-    // matrix-core tiles: fp16 two-chain order for the exact path; the int8 order only for a handle opened with
-    // LLAMAHIP_FLAG_FAST_PREFILL (or LLAMAHIP_MFMA_I8=1: the round-1 exact kernel, for A/B) -- one of the two, same size
+    // matrix-core tiles: one byte per weight in four-chain operand order for the exact path (k_gemm_mfma4); the int8 order only for a
+    // handle opened with LLAMAHIP_FLAG_FAST_PREFILL (or LLAMAHIP_MFMA_I8=1: the round-1 exact kernel, for A/B) -- one of the two
     static const bool want_i8 = getenv("LLAMAHIP_MFMA_I8") != nullptr;
     q.nrb32 = (q.M + 31) / 32;
     if ((m->flags & LLAMAHIP_FLAG_FAST_PREFILL) || want_i8) {
         if (!build(&q.mt, q.mt_bytes(), [&]() { return launch_tiles_to_mtiles(q, m->stream); })) return 1;
-    } else if (!build(&q.mt16, gemm_mt16_bytes(q), [&]() { return launch_tiles_to_mt16(q, m->stream); })) return 1;
+    } else if (!build(&q.mt4, q.mt4_bytes(), [&]() { return launch_tiles_to_mt4(q, m->stream); })) return 1;
     return 0;
 }
 constexpr int PROMPT_COPY_MIN_ROWS = 61;       // evals up to 60 rows take k_gemm_skinny on the decode tiles

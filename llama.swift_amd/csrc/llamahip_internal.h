@@ -6,6 +6,7 @@
 
 namespace lh {
 
+constexpr int MT4_TILE_BYTES = 4608;   // k_gemm_mfma4's weight tile: 32 rows x 4 Q4_0 blocks, one byte per weight + 128 fp32 scales
 constexpr int TILE_BYTES = 1280;   // 8 rows x 8 Q4_0 blocks: 1024 B nibbles + 64 fp32 scales
 
 // activation-preparation modes (also the fused-prologue selector of k_gemv)
@@ -45,9 +46,10 @@ struct QMat {
     int nrb = 0;                // ceil(M / 64)
     // optional third copy for long prompts: MFMA tiles, nrb32 * (2 * nchunks) * 2560 B (see k_gemm_mfma)
     uint8_t *mt = nullptr;      // int8 operand order (the opt-in fast path and LLAMAHIP_MFMA_I8)
-    uint8_t *mt16 = nullptr;    // fp16 two-chain operand order (k_gemm_mfma16: the exact path); same size and tiling
+    uint8_t *mt4 = nullptr;     // one byte per weight, four-chain operand order (k_gemm_mfma4: the exact path): nrb32 * (2 * nchunks) * 4608 B
     int nrb32 = 0;              // ceil(M / 32)
     size_t mt_bytes() const { return (size_t) nrb32 * nchunks * 2 * 2560; }
+    size_t mt4_bytes() const { return (size_t) nrb32 * nchunks * 2 * MT4_TILE_BYTES; }
     size_t rows_bytes() const { return (size_t) nrb * (nchunks + 1) * 10240; }
     size_t bytes() const { return (size_t) ngroups * (nchunks + 1) * TILE_BYTES; }
     int Kp() const { return nchunks * 256; }
@@ -85,8 +87,7 @@ hipError_t launch_add(const float *a, const float *b, float *c, long n, hipStrea
 hipError_t launch_repack(const uint8_t *src_aos, uint8_t *dst, int M, int K, int gmap, int goff, hipStream_t st);
 hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st);   // w.rows / w.nrb set by the caller
 hipError_t launch_tiles_to_mtiles(const QMat &w, hipStream_t st); // w.mt / w.nrb32 set by the caller
-hipError_t launch_tiles_to_mt16(const QMat &w, hipStream_t st);   // w.mt16 / w.nrb32 set by the caller
-size_t gemm_mt16_bytes(const QMat &w);                            // size of that copy (depends on the kernel generation in use)
+hipError_t launch_tiles_to_mt4(const QMat &w, hipStream_t st);    // w.mt4 / w.nrb32 set by the caller
 hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int d, int N, hipStream_t st);
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,

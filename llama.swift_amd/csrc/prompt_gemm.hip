@@ -1,6 +1,6 @@
 // prompt_gemm.hip -- the Q4_0 x Q4_0 mat-mul for MULTI-ROW evals (prompt chunks), bit-exact with ggml_compute_forward_mul_mat_q4_0_f32
 // (ggml.c:5987-6285, vec_dot :1415-1466): k_gemm_lds (decode tiles, QA in LDS), k_gemm_skinny (2..60 rows, epilogues with RoPE + KV append /
-// SiLU*up -> Q4_0), k_gemm_rows (row-lane tiles), k_gemm_mfma / k_gemm_mfma16 (integer sums on the matrix cores), the tile converters,
+// SiLU*up -> Q4_0), k_gemm_rows (row-lane tiles), k_gemm_mfma / k_gemm_mfma4 (integer sums on the matrix cores), the tile converters,
 // and launch_gemm with its kernel selection rules.  Conventions and layouts: decode.hip / DESIGN.md.
 #include "kcommon.hip.h"
 
@@ -806,246 +806,35 @@ k_gemm_mfma(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same exact product on v_mfma_f32_32x32x4_2b_f16: K = 4 is exactly one chain of a Q4_0 block (the 4 elements
-// {2k, 2k+1, 16+2k, 17+2k} that one lane of the reference's _mm256_madd_epi16 sums), the instruction carries TWO
-// independent 32 x 32 x 4 products ("blocks" = lane halves on the operand side, result registers 0-15 / 16-31 --
-// checked on the hardware, tools/mfma_layout_probe.hip), so one issue returns two chains' sums for a 32 x 32 tile:
-//   * nothing is masked (the int8 kernel above issues one 32 x 32 x 32 MFMA per chain with 7/8 of its operand zeroed);
-//   * the sums arrive as FLOATS (small integers are exact in fp16 operands and fp32 accumulation), so the
-//     integer -> float conversion of the int8 kernel (one packed subtraction per pair of outputs, as many VALU issues
-//     as the FMAs themselves) disappears: what is left per output and chain is the one FMA the reference defines.
-// Matrix-pipe time per Q4_0 block and 32 x 32 tile is the same (4 issues of 16 passes = 8 of 8), VALU work drops from
-// ~190 to ~110 instructions.
-// Weight copy "mt16" (same size as the int8 tiles, replaces them): tile (row-block of 32, quad of 4 blocks) = 2560 B:
-//   [j 0..3][lane 0..63][8 B]   lane = m + 32 * g: the 16 nibbles of chains {g, 2 + g, 4 + g, 6 + g} of block 4q + j, row m,
-//                               BIASED (q = n + 8, 0..15) and placed so that `(x >> 4s) & 0x000F000F | 0x64006400` is the
-//                               fp16 pair (1024 + q_lo, 1024 + q_hi): dword 0 serves issues 0, 1 (chains g, 2 + g), dword 1
-//                               issues 2, 3; within a dword s = 0: (e0, e1) of the even issue, s = 1: (e2, e3), s = 2, 3: odd issue
-//   [j][32 rows] fp32 scales
-// Activation operand "QB16" (k_qa_to_qb16): per column [block][g][issue 0..3][4 fp16] = 64 B, exact integers -8..7.
-// Workgroup = 4 waves = 64 rows x 64 columns, operands of one quad staged in LDS (double-buffered), as above.
-// ------------------------------------------------------------------------------------------------
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-typedef float f32x32v __attribute__((ext_vector_type(32)));
-
-__global__ void k_tiles_to_mt16(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ mt,
-                                int ngroups, int nchunks, int nrb32, int gmapF8) {
-    const int nq = nchunks * 2;
-    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long) nrb32 * nq * 4 * 64;
-    if (gid >= total) return;
-    const int lane = (int) (gid & 63), j = (int) ((gid >> 6) & 3);
-    const long t = gid >> 8;
-    const int q = (int) (t % nq), rb = (int) (t / nq);
-    const int m = lane & 31, g = lane >> 5;
-    const int row = rb * 32 + m, lg = row >> 3, r = row & 7;
-    const int b = q * 4 + j, c = b >> 3, jj = b & 7, i = jj >> 1, half = jj & 1;
-    uint32_t x[2] = { 0x88888888u ^ 0x88888888u, 0u };     // biased zero is 8: padding rows get q = 8 everywhere below
-    x[0] = 0x88888888u; x[1] = 0x88888888u;
-    float d = 0.0f;
-    if (lg < ngroups) {
-        int tg = lg;
-        if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
-        const uint8_t *tp = tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
-        x[0] = x[1] = 0u;
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            const int kc = 2 * ii + g;
-            const uint32_t dw = ((const uint32_t *) (tp + (r * 8 + kc) * 16))[i];       // chain kc, blocks (2i, 2i+1): byte p = element e_p
-            uint32_t e[4];
-#pragma unroll
-            for (int pp = 0; pp < 4; pp++) e[pp] = (((dw >> (8 * pp + 4 * half)) & 0xFu) ^ 8u);     // signed nibble -> biased q
-            const int sh = (ii & 1) * 8;
-            x[ii >> 1] |= (e[0] << sh) | (e[1] << (16 + sh)) | (e[2] << (4 + sh)) | (e[3] << (20 + sh));
-        }
-        d = ((const float *) (tp + 1024 + r * 32))[(jj & 3) * 2 + (jj >> 2)];
-    }
-    uint8_t *o = mt + ((size_t) rb * nq + q) * MTILE_BYTES;
-    ((uint32_t *) (o + j * 512 + lane * 8))[0] = x[0];
-    ((uint32_t *) (o + j * 512 + lane * 8))[1] = x[1];
-    if (g == 0) ((float *) (o + 2048))[j * 32 + m] = d;
-}
-
-// QA (chain-major signed nibbles) -> QB16.  One thread per (column, block, chain).
-__global__ void k_qa_to_qb16(const uint32_t *__restrict__ qa_A, uint8_t *__restrict__ qb, int nchunks, int N) {
-    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    const int nbp = nchunks * 8;
-    const long total = (long) N * nbp * 8;
-    if (gid >= total) return;
-    const int kc = (int) (gid & 7);
-    const long t = gid >> 3;
-    const int b = (int) (t % nbp), n = (int) (t / nbp);
-    const int c = b >> 3, jj = b & 7;
-    const uint32_t dw = qa_A[(size_t) n * nchunks * 64 + c * 64 + kc * 8 + jj];
-    h4v v;
-#pragma unroll
-    for (int pp = 0; pp < 4; pp++) {
-        const int nib = (int) ((dw >> (8 * pp + 4 * (jj & 1))) & 0xF);
-        v[pp] = (_Float16) (float) ((nib ^ 8) - 8);
-    }
-    const int g = kc & 1, ii = kc >> 1;
-    *(h4v *) (qb + ((size_t) n * nbp + b) * 64 + g * 32 + ii * 8) = v;
-}
-
-template <int EPI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_gemm_mfma16(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
-              const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
-              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
-    constexpr int CS = 272;                                 // 256 B of a column's quad + 16 B pad: conflict-free b128 reads
-    __shared__ __attribute__((aligned(16))) uint8_t sW[2][2][MTILE_BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t sB[2][64 * CS];
-    __shared__ __attribute__((aligned(16))) float sDa[2][64 * 4];
-    const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
-    const int ct = qq % nct, rp = (qq / nct) * 8 + xcd;
-    if (rp * 2 >= nrb32) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave & 1, wc = wave >> 1;
-    const int n0 = ct * 64;
-    const int nbp = nq * 4;
-    const long strideD = (long) nq * 4;
-
-    u32x4 gw[2], gb[4];
-    f32x4 gd;
-    auto fetch = [&](int q) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int g = tid + u * 256;                   // 320 granules of weights (2 tiles x 160)
-            const int tile = min(g / 160, 1), off = (g % 160) * 16;
-            const int rb = min(rp * 2 + tile, nrb32 - 1);
-            gw[u] = *(const u32x4 *) (mt + ((size_t) rb * nq + q) * MTILE_BYTES + off);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int g = tid + u * 256;                   // 1024 granules of activations: 64 columns x 16
-            const int col = min(n0 + (g >> 4), ncols - 1), part = g & 15;
-            gb[u] = *(const u32x4 *) (qb + ((size_t) col * nbp + q * 4) * 64 + part * 16);
-        }
-        gd = *(const f32x4 *) (qa_d + (size_t) min(n0 + (tid & 63), ncols - 1) * strideD + q * 4);
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int g = tid + u * 256;
-            if (g < 320) *(u32x4 *) (&sW[buf][g / 160][(g % 160) * 16]) = gw[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int g = tid + u * 256;
-            *(u32x4 *) (&sB[buf][(g >> 4) * CS + (g & 15) * 16]) = gb[u];
-        }
-        if (tid < 64) *(f32x4 *) (&sDa[buf][tid * 4]) = gd;
-    };
-
-    f32x2 acc[8][8];                                        // [chain][pair of adjacent C/D registers]
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-#pragma unroll
-        for (int r = 0; r < 8; r++) acc[k][r] = f32x2{ 0.0f, 0.0f };
-    f32x32v zero32;
-#pragma unroll
-    for (int r = 0; r < 32; r++) zero32[r] = 0.0f;
-
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int q = 0; q < nq; q++) {
-        const int buf = q & 1;
-        if (q + 1 < nq) fetch(q + 1);
-        const uint8_t *wt_ = sW[buf][wr];
-        const uint8_t *bt_ = &sB[buf][(wc * 32 + (lane & 31)) * CS + (lane >> 5) * 32];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t x0 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[0];
-            const uint32_t x1 = ((const uint32_t *) (wt_ + j * 512 + lane * 8))[1];
-            const u32x4 B0 = *(const u32x4 *) (bt_ + j * 64), B1 = *(const u32x4 *) (bt_ + j * 64 + 16);      // issues 0,1 | 2,3
-            const float da = sDa[buf][(wc * 32 + (lane & 31)) * 4 + j];
-            f32x2 sc[8];
-            const f32x2 da2 = { da, da };
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 dw = *(const f32x4 *) (wt_ + 2048 + (j * 32 + 8 * g + 4 * (lane >> 5)) * 4);
-                sc[2 * g + 0] = f32x2{ dw.x, dw.y } * da2;
-                sc[2 * g + 1] = f32x2{ dw.z, dw.w } * da2;
-            }
-            // Two waves per SIMD (256 registers each: 128 accumulators + one result set + operands + the next quad's
-            // staging): while one wave's issue is in the matrix pipe the other runs its FMA chains.  Measured alternatives,
-            // one wave per SIMD owning the whole file with two or four result sets in flight: 334 ms against 236 ms for
-            // 2048 tokens of the 7B -- the in-order wave stalls on every MFMA result, and above 256 registers the compiler
-            // parks results in AGPRs (+128 v_accvgpr_read per block).
-            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-            const h2v bias = { (_Float16) 1032.0f, (_Float16) 1032.0f };
-#pragma unroll
-            for (int ii = 0; ii < 4; ii++) {
-                const uint32_t xs = (ii < 2 ? x0 : x1) >> ((ii & 1) * 8);
-                uint32_t p0, p1;                                // biased nibbles -> fp16 1024 + q (exact), then - 1032
-                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(p0) : "v"(xs), "v"(0x000F000Fu), "v"(0x64006400u));
-                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(p1) : "v"(xs >> 4), "v"(0x000F000Fu), "v"(0x64006400u));
-                const h2v a01 = __builtin_bit_cast(h2v, p0) - bias, a23 = __builtin_bit_cast(h2v, p1) - bias;
-                const h4v A = { a01.x, a01.y, a23.x, a23.y };
-                const u32x4 Bq = ii < 2 ? B0 : B1;
-                struct { uint32_t a, b; } bw = { (ii & 1) ? Bq.z : Bq.x, (ii & 1) ? Bq.w : Bq.y };
-                const f32x32v D = __builtin_amdgcn_mfma_f32_32x32x4f16(A, __builtin_bit_cast(h4v, bw), zero32, 0, 0, 0);
-                // The FMA chains are volatile asm so that they stay in this order with one result set live (written as plain
-                // C++ the compiler sinks them below later MFMAs and spills 2 KB per lane).  The MFMA -> VALU read needs software
-                // wait states which the compiler only inserts for instructions it can see: the first FMA of the issue is a
-                // visible one, and its result is a (dummy) input of the first asm FMA, which orders every asm FMA after it.
-                const float first = __builtin_fmaf(sc[0].x, D[0], acc[2 * ii][0].x);
-#pragma unroll
-                for (int hb = 0; hb < 2; hb++) {
-                    const int k = 2 * ii + hb;                 // result registers 16 hb .. 16 hb + 15 = chain k (lane halves carried chains 2 ii, 2 ii + 1)
-#pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        const float d0 = D[16 * hb + 2 * r], d1 = D[16 * hb + 2 * r + 1];
-                        // (two plain FMAs issue faster than one packed one: tools/mfma_rate_probe.hip)
-                        if (hb == 0 && r == 0) {
-                            acc[k][r].x = first;
-                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r].y) : "v"(sc[r].y), "v"(d1), "v"(first));
-                        } else {
-                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r].x) : "v"(sc[r].x), "v"(d0));
-                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k][r].y) : "v"(sc[r].y), "v"(d1));
-                        }
-                    }
-                }
-            }
-        }
-        if (q + 1 < nq) stash(buf ^ 1);
-        __syncthreads();
-    }
-    // ---- fold the 8 chains (ggml.c:872-887 tree) and store: lane = column, 16 rows (C/D layout)
-    const int n = n0 + wc * 32 + (lane & 31);
-    const int mb = (rp * 2 + wr) * 32 + 4 * (lane >> 5);
-    if (n < ncols && rp * 2 + wr < nrb32) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = mb + (r & 3) + 8 * (r >> 2);
-#define LH_A(K) ((r & 1) ? acc[K][r >> 1].y : acc[K][r >> 1].x)
-            float v = ((LH_A(0) + LH_A(4)) + (LH_A(2) + LH_A(6))) + ((LH_A(1) + LH_A(5)) + (LH_A(3) + LH_A(7)));
-#undef LH_A
-            if (m < M) {
-                if (EPI == EPI_RESID) v = v + resid[(size_t) n * resid_stride + m];
-                y[(size_t) n * y_stride + m] = v;
-            }
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
-// k_gemm_mfma4: the same exact arithmetic at FOUR waves per SIMD.
-// k_gemm_mfma16 keeps 128 accumulators per lane, so two waves share a SIMD -- and tools/valu_rate_probe.hip /
-// tools/chain_probe.hip show what that costs: a wave alone on its SIMD issues one VALU instruction per ~8 cycles, so whenever one of
-// the two waits (for its MFMA result, for the barrier) the other runs at half rate; the kernel sat at 94 ns per MFMA issue and SIMD
-// against 60 ns of VALU work.  Here a wave owns a 16-row x 32-column output tile with all 8 chains on v_mfma_f32_16x16x4_4b_f16 (four
-// 16 x 16 x 4 products per issue = four chains of a 16 x 16 sub-tile; 16 result registers; a lane holds 4 rows x 1 column of every
-// sub-tile, so the 8 scale products d_w * d_a of a block serve all 8 chains): 64 accumulators + 16 results, <= 128 registers, 8 waves
-// per workgroup (64 x 64 outputs), two workgroups per CU.  The operands of the next quad go global -> LDS by DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write), the activation columns XOR-swizzled by the loader so that the
-// 256-byte column stride reads conflict-free.  What bounds it (tools/mfma_overlap_probe.hip, profiles/r04_p_mfma_overlap.txt): on
-// gfx950 an MFMA and the VALU instructions of OTHER waves of the same SIMD do not run side by side -- an 8-pass MFMA keeps the VALU
-// out for its 14 ns, whatever the instruction type -- so a block of a sub-tile costs the MFMA's 14 ns PLUS its 16 FMAs and their
-// operand preparation.
-// Weight copy "mt4" (replaces mt16; ONE BYTE per weight, 1.8 x the size): tile (row-block of 32, quad of 4 blocks) = MT4_BYTES = 4608 B:
+// k_gemm_mfma4 -- the long-prompt kernel: the same exact product on the fp16 K = 4 matrix instructions.
+// K = 4 is exactly one chain of a Q4_0 block (the 4 elements {2k, 2k+1, 16+2k, 17+2k} that one lane of the reference's
+// _mm256_madd_epi16 sums), and v_mfma_f32_16x16x4_4b_f16 carries FOUR independent 16 x 16 x 4 products ("blocks" = groups of 16
+// lanes on the operand side, result registers 4 b .. 4 b + 3; checked on the hardware, tools/mfma_layout_probe4.hip), so one issue
+// returns four chains' sums for a 16 x 16 sub-tile:
+//   * nothing is masked (the int8 kernel above issues one 32 x 32 x 32 MFMA per chain with 7/8 of its operand zeroed);
+//   * the sums arrive as FLOATS (small integers are exact in fp16 operands and fp32 accumulation), so the integer -> float
+//     conversion of the int8 kernel disappears: what is left per output and chain is the one FMA the reference defines.
+// Rounds 2-3 ran this on v_mfma_f32_32x32x4_2b_f16 with 128 accumulators per lane (k_gemm_mfma16: a 32 x 32 tile x 8 chains per
+// wave), i.e. two waves per SIMD -- and tools/valu_rate_probe.hip / tools/chain_probe.hip show what that costs: a wave alone on its
+// SIMD issues one VALU instruction per ~12 cycles, so whenever one of the two waits (for its MFMA result, for the barrier) the other
+// runs at half rate; it sat at 94 ns per MFMA issue and SIMD against 60 ns of VALU work (2 048 tokens of the 7B: 192 ms; removed in
+// round 4, profiles/r04_p_gemm4_ab.txt .. r04_s_*).  Here a wave owns a 16-row x 32-column output tile with all 8 chains (a lane holds
+// 4 rows x 1 column of each of its two sub-tiles, so the 8 scale products d_w * d_a of a block serve all 8 chains): 64 accumulators +
+// 16 results, <= 128 registers, FOUR waves per SIMD, 8 waves per workgroup (64 x 64 outputs), two workgroups per CU.  The operands of
+// the next quad go global -> LDS by DMA (global_load_lds_dwordx4: no staging registers, no ds_write), the activation columns
+// XOR-swizzled by the loader so that the 256-byte column stride reads conflict-free.
+// The FMA chains are volatile asm so that they stay in this order with one result set live (written as plain C++ the compiler sinks
+// them below later MFMAs and spills).  The MFMA -> VALU read needs software wait states which the compiler only inserts for
+// instructions it can see: the first FMA of a result set is a visible one, and its result is a (dummy) input of the first asm FMA,
+// which orders every asm FMA after it (without it: wrong logits, 5 % faster).
+// What bounds it (tools/mfma_overlap_probe.hip, profiles/r04_p_mfma_overlap.txt): on gfx950 an MFMA and the VALU instructions of
+// OTHER waves of the same SIMD do not run side by side -- an 8-pass MFMA keeps the VALU out for its 14 ns, whatever the instruction
+// type (f16, i8, f32; only the 16-pass 32x32x4_2b lets the VALU in for its second half) -- so a block of a sub-tile costs the MFMA's
+// 14 ns PLUS its 16 FMAs (19 ns) and their operand preparation: 39 ns measured per block, sub-tile and SIMD.
+// Weight copy "mt4" (ONE BYTE per weight, 1.8 x the size of the int8 tiles): tile (row-block of 32, quad of 4 blocks) = MT4_BYTES = 4608 B:
 //   [s 0..1][lane 0..63][32 B]   lane = i + 16 b, row 16 s + i: dword 2 j + h = block 4 q + j, chain CH(h, b) = h + {0, 4, 2, 6}[b]: its four
 //                                weights as the HIGH BYTES of their fp16 values (every integer -8..7 has an fp16 low byte of zero), so
 //                                that two v_perm_b32 (bytes {0, w0, 0, w1} and {0, w2, 0, w3}) ARE the MFMA operand -- no bias, no
@@ -1057,7 +846,7 @@ k_gemm_mfma16(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int mt4_chain(int h, int b) { return h + 2 * (((b & 1) << 1) | (b >> 1)); }
 
-constexpr int MT4_BYTES = 4608;
+constexpr int MT4_BYTES = MT4_TILE_BYTES;
 __global__ void k_tiles_to_mt4(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ mt,
                                int ngroups, int nchunks, int nrb32, int gmapF8) {
     const int nq = nchunks * 2;
@@ -1219,7 +1008,7 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
                     struct { uint32_t a, b; } bw = { h ? Bq.z : Bq.x, h ? Bq.w : Bq.y };
                     const f32x16v D = __builtin_amdgcn_mfma_f32_16x16x4f16(__builtin_bit_cast(h4v, aw), __builtin_bit_cast(h4v, bw), zero16, 0, 0, 0);
                     // (volatile asm FMAs in this order with one result set live; the first one is a plain FMA so that the compiler
-                    // inserts the MFMA -> VALU wait states, and its result is a dummy input of the second: see k_gemm_mfma16.
+                    // inserts the MFMA -> VALU wait states, and its result is a dummy input of the second: see the header.
                     // Packed FMAs -- v_pk_fma_f32 + v_pk_mul_f32 with op_sel broadcasts, no register copies -- measured SLOWER
                     // here, 184.8 -> 192.0 ms for 2048 tokens: profiles/r04_q_gemm4_pk_ab.txt)
                     float (&a)[4][4] = acc[t][h];
@@ -1392,42 +1181,23 @@ static hipError_t launch_gemm_mfma(const QMat &w, int epi, const uint8_t *qb, co
     return hipSuccess;
 }
 
-// LLAMAHIP_GEMM4=0: the two-waves-per-SIMD kernel (k_gemm_mfma16) and its operand orders; read once, before the first weight copy is built
-static bool gemm4_mode() {
-    static const bool on = !(getenv("LLAMAHIP_GEMM4") && atoi(getenv("LLAMAHIP_GEMM4")) == 0);
-    return on;
-}
-size_t gemm_mt16_bytes(const QMat &w) { return gemm4_mode() ? (size_t) w.nrb32 * w.nchunks * 2 * MT4_BYTES : w.mt_bytes(); }
-hipError_t launch_tiles_to_mt16(const QMat &w, hipStream_t st) {
-    if (gemm4_mode()) {
-        const long tot4 = (long) w.nrb32 * w.nchunks * 2 * 2 * 64;
-        hipLaunchKernelGGL(k_tiles_to_mt4, dim3((unsigned) ((tot4 + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt16, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
-    const long total = (long) w.nrb32 * w.nchunks * 2 * 4 * 64;
-    hipLaunchKernelGGL(k_tiles_to_mt16, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt16, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
+hipError_t launch_tiles_to_mt4(const QMat &w, hipStream_t st) {
+    static_assert(MT4_BYTES == MT4_TILE_BYTES, "QMat::mt4_bytes() sizes the copy");
+    const long tot4 = (long) w.nrb32 * w.nchunks * 2 * 2 * 64;
+    hipLaunchKernelGGL(k_tiles_to_mt4, dim3((unsigned) ((tot4 + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt4, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
-static hipError_t launch_gemm_mfma16(const QMat &w, int epi, const uint32_t *qa_A, uint8_t *qb16, const float *qa_d, int ncols,
-                                     float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
+static hipError_t launch_gemm_mfma4(const QMat &w, int epi, const uint32_t *qa_A, uint8_t *qb4, const float *qa_d, int ncols,
+                                    float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     const long tot = (long) ncols * w.nchunks * 8 * 8;
     const int nct = (ncols + 63) / 64, nq = w.nchunks * 2;
     const int nrp = (w.nrb32 + 1) / 2;
     const int grid = ((nrp + 7) / 8) * nct * 8;
-    if (gemm4_mode()) {
-        hipLaunchKernelGGL(k_qa_to_qb4, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, qa_A, qb16, w.nchunks, ncols);
-        LH_LAUNCH_CHECK();
-        if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_mfma4<EPI_RESID>), dim3(grid), dim3(512), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
-        else                  hipLaunchKernelGGL((k_gemm_mfma4<EPI_STORE>), dim3(grid), dim3(512), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
-    hipLaunchKernelGGL(k_qa_to_qb16, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, qa_A, qb16, w.nchunks, ncols);
+    hipLaunchKernelGGL(k_qa_to_qb4, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, qa_A, qb4, w.nchunks, ncols);
     LH_LAUNCH_CHECK();
-    if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_mfma16<EPI_RESID>), dim3(grid), dim3(256), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
-    else                  hipLaunchKernelGGL((k_gemm_mfma16<EPI_STORE>), dim3(grid), dim3(256), 0, st, w.mt16, w.nrb32, nq, w.M, qb16, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+    if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_mfma4<EPI_RESID>), dim3(grid), dim3(512), 0, st, w.mt4, w.nrb32, nq, w.M, qb4, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
+    else                  hipLaunchKernelGGL((k_gemm_mfma4<EPI_STORE>), dim3(grid), dim3(512), 0, st, w.mt4, w.nrb32, nq, w.M, qb4, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1452,10 +1222,10 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
     // against the row-per-lane kernel on MI355X: N ~ 256 for the 7B matrices; 1.25x faster at N = 1024).
     static const int mfma_min = getenv("LLAMAHIP_MFMA_MIN") ? atoi(getenv("LLAMAHIP_MFMA_MIN")) : 0;     // measurement override
     const long mfma_wgs = (long) ((w.nrb32 + 1) / 2) * ((N + 63) / 64);
-    if (w.mt16 && !fast && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
-        // matrix-core path, exact: fp16 operands (QB16: 2 bytes per element of these N activation rows), two chains per MFMA
+    if (w.mt4 && !fast && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
+        // matrix-core path, exact: fp16 operands (QB4: 2 bytes per element of these N activation rows), four chains per MFMA
         g_gemm_path_counts[GEMM_PATH_MFMA]++;
-        return launch_gemm_mfma16(w, epi, qa_A, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
+        return launch_gemm_mfma4(w, epi, qa_A, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
     }
     if (w.mt && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
         // matrix-core path on the int8 tiles (the opt-in fast path; LLAMAHIP_MFMA_I8: the round-1 exact kernel): needs the int8 operand (QB)

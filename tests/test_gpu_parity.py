@@ -270,9 +270,10 @@ def test_other_head_sizes_vs_oracle(L, oracle, tmp_path, n_embd, n_head):
 
 
 def test_matrix_core_prompt_gemm_forced_on_small_models():
-    """k_gemm_mfma (masked int8 MFMA per chain, bit-exact) is only selected when its workgroups fill the chip,
-    which the small test models never do: re-run the prompt tests with LLAMAHIP_MFMA_MIN=32 (read once per
-    process, hence the subprocess) so that every eval of >= 32 rows goes through the matrix cores."""
+    """k_gemm_mfma4 (the exact long-prompt kernel: fp16 K = 4 matrix instructions, four chains per issue, four waves per SIMD,
+    DMA-staged operands) is only selected when its workgroups fill the chip, which the small test models never do: re-run the
+    prompt tests with LLAMAHIP_MFMA_MIN=32 (read once per process, hence the subprocess) so that every eval of >= 32 rows
+    goes through the matrix cores -- ragged row and column counts, odd numbers of 32-row blocks, the wider models' shapes."""
     import subprocess
     import sys
     env = dict(os.environ, LLAMAHIP_MFMA_MIN="32")
