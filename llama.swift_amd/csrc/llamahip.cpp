@@ -441,7 +441,8 @@ int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
 }
 
 // the score workspace of the multi-row prompt attention: [n_head][n_ctx][NB] fp32, NB = 512 query rows
-// (a 2 048-token 7B eval with NB = 256 / 512 / 1 024 / 2 048: 225.9 / 201.8 / 200.3 / 212.4 ms on one box -- 512 keeps the workspace at a quarter)
+// (a 2 048-token 7B eval with NB = 256 / 512 / 1 024 / 2 048: 225.9 / 201.8 / 200.3 / 212.4 ms on one box in round 3, 183.3 / 161.6 / 162.6 / 175.9 in
+// round 4 (profiles/r04_v_attn_shapes_ab.txt) -- 512 keeps the workspace at a quarter and inside the Infinity Cache)
 // per batch (7B, n_ctx 2560: 168 MB), allocated with the first multi-token eval
 int ensure_attn_ws(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N < 2 || m->attn_ws.S) return 0;

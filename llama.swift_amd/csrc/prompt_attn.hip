@@ -264,8 +264,8 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
 // PERROW: a chunked pass (split_keys, chunk > 0) gives the queries of a block different key ranges; a plain eval (one split for every
 // row) does not pay for the per-lane range tests (the 2 048-token eval: 200.4 -> see profiles/r04_*prefill*).
 typedef float f32x16v __attribute__((ext_vector_type(16)));
-// NCB = 32-column tiles per wave: 2 (grid z = 2 nth: the head's columns in two halves, 64 accumulators, four waves per SIMD) puts twice the
-// waves on the chip -- profiles/r04_t_prefill_pmc.txt: with one wave per (64 queries, head, chunk) a CU held 1.4 waves on average, each
+// NCB = 32-column tiles per wave: 2 (grid z = 2 nth: the head's columns in two halves, 64 accumulators, four waves per SIMD; rounds 2-3: 4)
+// puts twice the waves on the chip -- profiles/r04_t_prefill_pmc.txt: with one wave per (64 queries, head, chunk) a CU held 1.4 waves on average, each
 // alone on its SIMD waiting for its own loads, the matrix pipe 41 % busy.
 template <bool PERROW, int NCB>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCB == 4 ? 3 : 4)))
@@ -374,18 +374,15 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             const int nb = min(ws->NB, N - nb0), qb = (nb + 63) / 64;
             // scores: 16 queries per wave, ~4 waves per SIMD over key slices
             const int qt = (nb + 15) / 16;
-            static const int ks_waves = getenv("LLAMAHIP_SCORES_WAVES") ? atoi(getenv("LLAMAHIP_SCORES_WAVES")) : 4096;      // measurement override
-            int KS = (ks_waves + qt * H - 1) / (qt * H);
+            int KS = (4096 + qt * H - 1) / (qt * H);         // (8 192 / 16 384 waves per launch measured the same: profiles/r04_u_attn_ab.txt)
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
             hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
-            static const int ncb = getenv("LLAMAHIP_PV_NCB") ? atoi(getenv("LLAMAHIP_PV_NCB")) : 2;        // (4: one wave per head's 128 columns, the round-3 shape)
-#define LH_PV(P, C) hipLaunchKernelGGL((k_attnq_pv_mfma<P, C>), dim3(qb, H, nth * (4 / C)), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk)
-            if (chunk > 0) { if (ncb == 4) LH_PV(true, 4); else LH_PV(true, 2); }
-            else           { if (ncb == 4) LH_PV(false, 4); else LH_PV(false, 2); }
-#undef LH_PV
+            // (column quarters, and 1 024 / 2 048 queries per launch: measured level / slower, profiles/r04_v_attn_shapes_ab.txt)
+            if (chunk > 0) hipLaunchKernelGGL((k_attnq_pv_mfma<true, 2>), dim3(qb, H, nth * 2), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk);
+            else hipLaunchKernelGGL((k_attnq_pv_mfma<false, 2>), dim3(qb, H, nth * 2), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, 0);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_merge, dim3((nb + 1) / 2, H), dim3(256), 0, st, ws->part, merged, N, nb0, ws->NB, d, nth);
             LH_LAUNCH_CHECK();

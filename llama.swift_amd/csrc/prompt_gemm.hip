@@ -1101,9 +1101,8 @@ static int skinny_max_rows() {
 }
 // column-group width of k_gemm_skinny for N rows: the widest (<= 4) that still leaves ~1500 waves, balanced
 static int skinny_pick_nc(const QMat &w, int N) {
-    static const long min_waves = getenv("LLAMAHIP_SKINNY_WAVES") ? atol(getenv("LLAMAHIP_SKINNY_WAVES")) : 1536;     // measurement override
-    int nc = 4;
-    while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < min_waves) nc--;
+    int nc = 4;                                              // (3 072 / 6 144 waves: 5-8 % slower at 9 columns, profiles/r04_r_skinny_waves_ab.txt)
+    while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
     if (nc > N) nc = N;
     while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
     const int ncg = (N + nc - 1) / nc;
