@@ -27,7 +27,7 @@ timeout 1200 bash tools/run_config4.sh 13B > $O/${tag}_cfg4.log 2>&1; { grep -h 
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pf1
 LLAMAHIP_WITH_TORCH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf1 -o p -- python $R/tools/prefill_one.py 2048 2 > /tmp/pf1.log 2>&1
 cd $R
-python tools/prof_summary.py $(find /tmp/pf1 -name "*kernel_stats.csv") "rocprofv3 --kernel-trace --stats -- python tools/prefill_one.py 2048 2   (MI355X, synthetic LLaMA-7B Q4_0: model load, building the prompt copies, three 2048-token evals at n_ctx 2560; exact path, k_gemm_mfma16)" > $O/${tag}_prefill_2048_kernel_stats.txt
+python tools/prof_summary.py $(find /tmp/pf1 -name "*kernel_stats.csv") "rocprofv3 --kernel-trace --stats -- python tools/prefill_one.py 2048 2   (MI355X, synthetic LLaMA-7B Q4_0: model load, building the prompt copies, three 2048-token evals at n_ctx 2560; exact path, k_gemm_mfma4)" > $O/${tag}_prefill_2048_kernel_stats.txt
 timeout 300 python tools/prefill_probe.py > $O/${tag}_prefill_probe.txt 2>&1; tail -6 $O/${tag}_prefill_probe.txt
 timeout 300 python tools/chunk_probe.py > $O/${tag}_chunk_probe.txt 2>&1; tail -4 $O/${tag}_chunk_probe.txt
 timeout 300 python tools/runner_probe.py > $O/${tag}_runner_probe.txt 2>&1; tail -3 $O/${tag}_runner_probe.txt
