@@ -150,14 +150,28 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 // CONSECUTIVE floats [32 kk, 32 kk + 32) of its query / key row -- loaded straight into registers, no LDS, no scalar loads.  One wave =
 // 16 queries (registers, loaded once) against its key slice, 16 keys per step = 32 independent MFMAs (C = 0) + the reduction tree
 // (ggml.c:872-887) on the VALU, 31 additions per pair.  Result registers: lane holds key n = lane % 16, queries 4 kk + r.
-// 100 us per launch at 2 048 tokens, logits bit-identical; requesting the next step's key rows a step ahead (+32 registers) measured 109 us:
-// two waves per SIMD already cover the load.  Four waves per SIMD (the MFMAs four at a time as inline asm, partial sums folded as they
-// arrive, <= 128 registers) measured SLOWER, 102 -> 126 us per launch (profiles/r04_u_attn_ab.txt): each group of four waits for its own
-// results where this version has all 32 MFMAs in the pipe before the first addition.
+// Requesting the next step's key rows a step ahead (+32 registers) measured slower.  FOUR waves per SIMD (the MFMAs four at a time, <= 128
+// registers, spills) measured slower too, 102 -> 126 us per launch (profiles/r04_u_attn_ab.txt): each group of four waits for its own results.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+// THREE waves per SIMD: the 32 MFMAs of a step go in four groups of eight (inline asm: the builtin's results go to
+// AGPRs and the scheduler issues all 32 first -- 122 + 128 registers), every group folded into the tree's first levels before the next
+// one's results arrive: 32 + 32 operands, 32 results, 32 partial sums.  Group order (hf 0, j 0-3), (hf 1, j 0-3), (hf 0, j 4-7),
+// (hf 1, j 4-7): r1[hf][j] = D[j] + D[j + 8], u[j] = r1[0][j] + r1[1][j], then v = u[j] + u[j + 4] -- the tree (ggml.c:872-887) level by level.
+// (Rounds 2-3: all 32 MFMAs first, 186 registers, two waves per SIMD: 2 048-token eval 162.5 -> 160.5 ms, profiles/r04_w_scores3_ab.txt.)
+// An 8-pass MFMA result may be read by the VALU 11 wait states after its issue; only the compiler's own MFMAs get those automatically.
+#define LH_SC_GROUP(D, HF, J0)                                                                                                     \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %8, %16, 0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %17, 0\n\t"                            \
+                 "v_mfma_f32_16x16x4_f32 %2, %10, %18, 0\n\tv_mfma_f32_16x16x4_f32 %3, %11, %19, 0\n\t"                          \
+                 "v_mfma_f32_16x16x4_f32 %4, %12, %20, 0\n\tv_mfma_f32_16x16x4_f32 %5, %13, %21, 0\n\t"                          \
+                 "v_mfma_f32_16x16x4_f32 %6, %14, %22, 0\n\tv_mfma_f32_16x16x4_f32 %7, %15, %23, 0\n\ts_nop 11"                 \
+                 : "=&v"(D[0]), "=&v"(D[1]), "=&v"(D[2]), "=&v"(D[3]), "=&v"(D[4]), "=&v"(D[5]), "=&v"(D[6]), "=&v"(D[7])          \
+                 : "v"(aq[16 * (HF) + (J0)]), "v"(aq[16 * (HF) + (J0) + 1]), "v"(aq[16 * (HF) + (J0) + 2]), "v"(aq[16 * (HF) + (J0) + 3]),   \
+                   "v"(aq[16 * (HF) + (J0) + 8]), "v"(aq[16 * (HF) + (J0) + 9]), "v"(aq[16 * (HF) + (J0) + 10]), "v"(aq[16 * (HF) + (J0) + 11]), \
+                   "v"(bk[16 * (HF) + (J0)]), "v"(bk[16 * (HF) + (J0) + 1]), "v"(bk[16 * (HF) + (J0) + 2]), "v"(bk[16 * (HF) + (J0) + 3]),   \
+                   "v"(bk[16 * (HF) + (J0) + 8]), "v"(bk[16 * (HF) + (J0) + 9]), "v"(bk[16 * (HF) + (J0) + 10]), "v"(bk[16 * (HF) + (J0) + 11]))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
-                    int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
+                     int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
     const int lane = threadIdx.x, m = lane & 15, kk = lane >> 4, h = blockIdx.y, ks = blockIdx.z;
     const int nl0 = blockIdx.x * 16;
     const int Tb = n_past + min(nb0 + nl0 + 16, N);                    // keys any query of this tile can see
@@ -171,48 +185,48 @@ k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, 
 #pragma unroll
             for (int j = 0; j < 8; j++) { const f32x4 v = qp[j]; aq[4 * j] = v.x; aq[4 * j + 1] = v.y; aq[4 * j + 2] = v.z; aq[4 * j + 3] = v.w; }
         }
-        int tq[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) tq[r] = n_past + min(nb0 + nl0 + 4 * kk + r, N - 1);      // last key query 4 kk + r sees
-        const f32x4v zero4 = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const int tq0 = n_past + nb0 + nl0 + 4 * kk, tqmax = n_past + N - 1;                 // last key query 4 kk + r sees: min(tq0 + r, tqmax)
+        const float *kbase = Kc + h * 128;
+        float *sbase = S + (size_t) h * T * NB + nl0;
         for (int tb = t0; tb < t1; tb += 16) {
             float bk[32];
             {
-                const f32x4 *kp = (const f32x4 *) (Kc + (size_t) min(tb + m, t1 - 1) * d + h * 128 + 32 * kk);
+                const f32x4 *kp = (const f32x4 *) (kbase + (uint32_t) (min(tb + m, t1 - 1) * d + 32 * kk));
 #pragma unroll
                 for (int j = 0; j < 8; j++) { const f32x4 v = kp[j]; bk[4 * j] = v.x; bk[4 * j + 1] = v.y; bk[4 * j + 2] = v.z; bk[4 * j + 3] = v.w; }
             }
-            float r1[2][8][4];
+            f32x4v D[8];
+            float ra[4][4], u[4][4], vsum[4][4];
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                f32x4v D[16];
+            for (int half = 0; half < 2; half++) {                       // j 0-3, then j 4-7
+                LH_SC_GROUP(D, 0, 4 * half);
 #pragma unroll
-                for (int l = 0; l < 16; l++) D[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[16 * hf + l], bk[16 * hf + l], zero4, 0, 0, 0);
+                for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int j = 0; j < 8; j++)
+                    for (int r = 0; r < 4; r++) ra[j][r] = D[j][r] + D[j + 4][r];              // r1[0][4 half + j]
+                LH_SC_GROUP(D, 1, 4 * half);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) r1[hf][j][r] = D[j][r] + D[j + 8][r];
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float uj = ra[j][r] + (D[j][r] + D[j + 4][r]);                   // u[4 half + j] = r1[0][.] + r1[1][.]
+                        if (half == 0) u[j][r] = uj; else vsum[j][r] = u[j][r] + uj;            // v_j = u_j + u_{j+4}
+                    }
             }
-            f32x4 out;
             float scv[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float u[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) u[j] = r1[0][j][r] + r1[1][j][r];
-                const float v0 = u[0] + u[4], v1 = u[1] + u[5], v2 = u[2] + u[6], v3 = u[3] + u[7];
-                scv[r] = ((v0 + v1) + (v2 + v3)) * kq_scale;
-            }
+            for (int r = 0; r < 4; r++) scv[r] = ((vsum[0][r] + vsum[1][r]) + (vsum[2][r] + vsum[3][r])) * kq_scale;
             const int t = tb + m;                                       // this lane's key
-            if (t < t1) {
+            // (the running maximum is taken unconditionally so that the additions cannot sink into the store's branch and keep results live)
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (t <= tq[r]) mx[r] = fmaxf(mx[r], scv[r]);
+            for (int r = 0; r < 4; r++) mx[r] = fmaxf(mx[r], (t < t1 && t <= min(tq0 + r, tqmax)) ? scv[r] : -INFINITY);
+            if (t < t1) {
+                f32x4 out;
                 out.x = scv[0]; out.y = scv[1]; out.z = scv[2]; out.w = scv[3];
-                *(f32x4 *) (S + ((size_t) h * T + t) * NB + nl0 + 4 * kk) = out;
+                *(f32x4 *) (sbase + (uint32_t) (t * NB + 4 * kk)) = out;
             }
         }
     }
-    // running maximum of each query over this key slice: across the 16 lanes (keys) of a DPP row
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         float v = mx[r];
@@ -223,6 +237,8 @@ k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, 
         if (m == 0) pmax[((size_t) h * KS + ks) * NB + nl0 + 4 * kk + r] = v;
     }
 }
+#undef LH_SC_GROUP
+
 
 __global__ void __launch_bounds__(1024)
 k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__restrict__ inv,
