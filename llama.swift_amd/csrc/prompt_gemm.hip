@@ -1217,11 +1217,13 @@ long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0 };
 
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws, bool fast) {
-    // Matrix-core path when its 64 x 64-output workgroups fill the chip twice over (measured crossover
-    // against the row-per-lane kernel on MI355X: N ~ 256 for the 7B matrices; 1.25x faster at N = 1024).
-    static const int mfma_min = getenv("LLAMAHIP_MFMA_MIN") ? atoi(getenv("LLAMAHIP_MFMA_MIN")) : 0;     // measurement override
+    // Matrix-core path when its 64 x 64-output workgroups fill the chip twice over, or from 128 rows when the last 64-column tile is
+    // not mostly padding (measured against the row-per-lane kernel, 7B, every matrix on one kernel, profiles/r04_y_midN_ab.txt: 64 rows
+    // -3 %, 96 -7 %, 128 +19 %, 192 +10 %, 240 +32 %; 1.5x at 1 024).
+    static const int mfma_min = getenv("LLAMAHIP_MFMA_MIN") ? atoi(getenv("LLAMAHIP_MFMA_MIN")) : 0;     // tests: the small models through this kernel
     const long mfma_wgs = (long) ((w.nrb32 + 1) / 2) * ((N + 63) / 64);
-    if (w.mt4 && !fast && qb_ws && (mfma_min ? N >= mfma_min : (N >= 64 && mfma_wgs >= 512))) {
+    const bool mfma_rows = N >= 128 && N * 10 >= (N + 63) / 64 * 64 * 7;
+    if (w.mt4 && !fast && qb_ws && (mfma_min ? N >= mfma_min : (mfma_rows || (N >= 64 && mfma_wgs >= 512)))) {
         // matrix-core path, exact: fp16 operands (QB4: 2 bytes per element of these N activation rows), four chains per MFMA
         g_gemm_path_counts[GEMM_PATH_MFMA]++;
         return launch_gemm_mfma4(w, epi, qa_A, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
