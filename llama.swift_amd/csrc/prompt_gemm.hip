@@ -1223,7 +1223,9 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
     static const int mfma_min = getenv("LLAMAHIP_MFMA_MIN") ? atoi(getenv("LLAMAHIP_MFMA_MIN")) : 0;     // tests: the small models through this kernel
     const long mfma_wgs = (long) ((w.nrb32 + 1) / 2) * ((N + 63) / 64);
     const bool mfma_rows = N >= 128 && N * 10 >= (N + 63) / 64 * 64 * 7;
-    if (w.mt4 && !fast && qb_ws && (mfma_min ? N >= mfma_min : (mfma_rows || (N >= 64 && mfma_wgs >= 512)))) {
+    // (k_gemm_mfma4 addresses its operands as base + 32-bit byte offset)
+    const bool mfma_fits = w.mt4_bytes() < ((size_t) 1 << 32) && (size_t) N * w.nchunks * 8 * 64 < ((size_t) 1 << 32);
+    if (w.mt4 && !fast && qb_ws && mfma_fits && (mfma_min ? N >= mfma_min : (mfma_rows || (N >= 64 && mfma_wgs >= 512)))) {
         // matrix-core path, exact: fp16 operands (QB4: 2 bytes per element of these N activation rows), four chains per MFMA
         g_gemm_path_counts[GEMM_PATH_MFMA]++;
         return launch_gemm_mfma4(w, epi, qa_A, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st);
