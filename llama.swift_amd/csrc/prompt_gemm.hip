@@ -833,7 +833,9 @@ typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 // What bounds it (tools/mfma_overlap_probe.hip, profiles/r04_p_mfma_overlap.txt): on gfx950 an MFMA and the VALU instructions of
 // OTHER waves of the same SIMD do not run side by side -- an 8-pass MFMA keeps the VALU out for its 14 ns, whatever the instruction
 // type (f16, i8, f32; only the 16-pass 32x32x4_2b lets the VALU in for its second half) -- so a block of a sub-tile costs the MFMA's
-// 14 ns PLUS its 16 FMAs (19 ns) and their operand preparation: 39 ns measured per block, sub-tile and SIMD.
+// 14 ns PLUS its 16 FMAs (19 ns) and their operand preparation: 39 ns measured per block, sub-tile and SIMD.  (That 16-pass form at three
+// waves per SIMD -- a wave = 32 x 32 outputs x one side of the tree, 4-wave workgroups -- was built and measured: bit-identical, 190.5
+// against 167.1 ms for 2 048 tokens, profiles/r04_z_gemm2b_ab.txt; a wave waits 28 ns for each of its results and three do not cover that.)
 // Weight copy "mt4" (ONE BYTE per weight, 1.8 x the size of the int8 tiles): tile (row-block of 32, quad of 4 blocks) = MT4_BYTES = 4608 B:
 //   [s 0..1][lane 0..63][32 B]   lane = i + 16 b, row 16 s + i: dword 2 j + h = block 4 q + j, chain CH(h, b) = h + {0, 4, 2, 6}[b]: its four
 //                                weights as the HIGH BYTES of their fp16 values (every integer -8..7 has an fp16 low byte of zero), so
@@ -1043,200 +1045,6 @@ k_gemm_mfma4(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_gemm_mfma2b (experiment, LLAMAHIP_GEMM2B=1): the same product on v_mfma_f32_32x32x4_2b_f16 -- the one K = 4 instruction with 16
-// passes, of which only the first half keeps the VALU out (tools/mfma_overlap_probe.hip): 16 ns of blocked VALU per 2 048 chain sums
-// against 2 x 14 ns on the 4b form.  A wave = 32 x 32 outputs x the 4 chains of one side of the final add tree (two issues per block),
-// 64 accumulators + 32 results + the 16 scale products of a block: three waves per SIMD; workgroup = 4 waves = 32 rows x 64 columns
-// (2 column tiles x 2 chain halves), three workgroups per CU; the two halves of a tile meet through LDS at the end.
-// Weight copy (same size as mt4): tile = [h][lane = m + 32 g][j][p] dwords: the four weights (fp16 high bytes) of row m, block 4 q + j,
-// chain CH(h, 2 p + g); + [j][32 rows] scales.  Activation operand: per column and quad [h][g][j][p][4 fp16].
-// ------------------------------------------------------------------------------------------------
-typedef float f32x32v __attribute__((ext_vector_type(32)));
-__global__ void k_tiles_to_mt2b(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ mt,
-                                int ngroups, int nchunks, int nrb32, int gmapF8) {
-    const int nq = nchunks * 2;
-    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long) nrb32 * nq * 2 * 64;
-    if (gid >= total) return;
-    const int lane = (int) (gid & 63), h = (int) ((gid >> 6) & 1);
-    const long t = gid >> 7;
-    const int q = (int) (t % nq), rb = (int) (t / nq);
-    const int m = lane & 31, g = lane >> 5;
-    auto tile_of = [&](int row, int c) -> const uint8_t * {
-        const int lg = row >> 3;
-        if (lg >= ngroups) return nullptr;
-        int tg = lg;
-        if (gmapF8) tg = lg < gmapF8 ? (lg >> 2) * 8 + (lg & 3) : ((lg - gmapF8) >> 2) * 8 + 4 + ((lg - gmapF8) & 3);
-        return tiles + ((size_t) tg * (nchunks + 1) + c) * TILE_BYTES;
-    };
-    const int row = rb * 32 + m, r = row & 7;
-    uint32_t x[8];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int bk = q * 4 + j, c = bk >> 3, jj = bk & 7, i2 = jj >> 1, half = jj & 1;
-        const uint8_t *tp = tile_of(row, c);
-#pragma unroll
-        for (int pi = 0; pi < 2; pi++) {
-            const int kc = mt4_chain(h, 2 * pi + g);
-            const uint32_t dw = tp ? ((const uint32_t *) (tp + (r * 8 + kc) * 16))[i2] : 0u;
-            uint32_t v = 0u;
-#pragma unroll
-            for (int pp = 0; pp < 4; pp++) {
-                const int n = (int) (((dw >> (8 * pp + 4 * half)) & 0xFu) ^ 8u) - 8;
-                v |= (uint32_t) (__builtin_bit_cast(uint16_t, (_Float16) (float) n) >> 8) << (8 * pp);
-            }
-            x[2 * j + pi] = v;
-        }
-    }
-    uint8_t *o = mt + ((size_t) rb * nq + q) * MT4_BYTES;
-    *(u32x4 *) (o + h * 2048 + lane * 32) = u32x4{ x[0], x[1], x[2], x[3] };
-    *(u32x4 *) (o + h * 2048 + lane * 32 + 16) = u32x4{ x[4], x[5], x[6], x[7] };
-    if (h == 0) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int idx = lane + 64 * u, j = idx >> 5, mm = idx & 31;
-            const int bk = q * 4 + j, c = bk >> 3, jj = bk & 7, row2 = rb * 32 + mm;
-            const uint8_t *tp = tile_of(row2, c);
-            ((float *) (o + 4096))[idx] = tp ? ((const float *) (tp + 1024 + (row2 & 7) * 32))[(jj & 3) * 2 + (jj >> 2)] : 0.0f;
-        }
-    }
-}
-__global__ void k_qa_to_qb2b(const uint32_t *__restrict__ qa_A, uint8_t *__restrict__ qb, int nchunks, int N) {
-    const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    const int nbp = nchunks * 8;
-    const long total = (long) N * nbp * 8;
-    if (gid >= total) return;
-    const int kc = (int) (gid & 7);
-    const long t = gid >> 3;
-    const int bk = (int) (t % nbp), n = (int) (t / nbp);
-    const int c = bk >> 3, jj = bk & 7;
-    const uint32_t dw = qa_A[(size_t) n * nchunks * 64 + c * 64 + kc * 8 + jj];
-    h4v v;
-#pragma unroll
-    for (int pp = 0; pp < 4; pp++) {
-        const int nib = (int) ((dw >> (8 * pp + 4 * (jj & 1))) & 0xF);
-        v[pp] = (_Float16) (float) ((nib ^ 8) - 8);
-    }
-    const int h = kc & 1, k2 = kc >> 1, b = ((k2 & 1) << 1) | (k2 >> 1);          // mt4_chain(h, b) == kc
-    const int pi = b >> 1, g = b & 1, q = bk >> 2, j = bk & 3;
-    *(h4v *) (qb + ((size_t) n * nbp + q * 4) * 64 + ((h * 2 + g) * 4 + j) * 16 + pi * 8) = v;
-}
-
-template <int EPI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_gemm_mfma2b(const uint8_t *__restrict__ mt, int nrb32, int nq, int M,
-              const uint8_t *__restrict__ qb, const float *__restrict__ qa_d, int ncols, int nct,
-              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride) {
-    // (a workgroup must be a multiple of four waves: six -- 32 x 96 outputs -- land 2, 2, 1, 1 on the SIMDs and a second workgroup no
-    // longer fits next to them at 143 registers: 265 ms for 2 048 tokens)
-    __shared__ __attribute__((aligned(1024))) uint8_t sB[2][64 * 256];           // [column][16 granules, XOR-swizzled by column & 15]
-    __shared__ __attribute__((aligned(1024))) uint8_t sW[2][5 * 1024];           // one tile (4 608 B) + the tail of the fifth DMA instruction
-    __shared__ __attribute__((aligned(1024))) float sDa[2][64 * 4];
-    const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
-    const int ct0 = qq % nct, rb = (qq / nct) * 8 + xcd;
-    if (rb >= nrb32) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = wave & 1, ct = wave >> 1;                                      // chain half, 32-column tile of the 64
-    const int n0 = ct0 * 64;
-    const int nbp = nq * 4;
-    const int cn = lane & 31, g = lane >> 5;
-
-    // ---- loader role: activation instructions 4 wave .. 4 wave + 3 (4 columns each); weights: one instruction per wave, the fifth by wave 0;
-    // the columns' scales: wave 1
-    const uint32_t ldsB = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) &sB[0][0];
-    const uint32_t ldsW = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) &sW[0][0];
-    const uint32_t ldsD = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) &sDa[0][0];
-    uint32_t offB[4], offW, offX = 0u;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int col = 4 * (4 * wave + u) + (lane >> 4), p = (lane & 15) ^ (col & 15);
-        offB[u] = (uint32_t) ((size_t) min(n0 + col, ncols - 1) * nbp * 64 + p * 16);
-    }
-    offW = (uint32_t) ((size_t) rb * nq * MT4_BYTES + (wave * 64 + lane) * 16);
-    if (wave == 0) offX = (uint32_t) ((size_t) rb * nq * MT4_BYTES + min(256 + lane, 287) * 16);
-    if (wave == 1) offX = (uint32_t) ((size_t) min(n0 + lane, ncols - 1) * nbp * 4);
-    auto issue = [&](int q, int buf) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) gemm4_dma16(ldsB + buf * (64 * 256) + (4 * wave + u) * 1024, (uint64_t) (uintptr_t) qb, offB[u] + (uint32_t) q * 256u);
-        gemm4_dma16(ldsW + buf * 5120 + wave * 1024, (uint64_t) (uintptr_t) mt, offW + (uint32_t) q * MT4_BYTES);
-        if (wave == 0) gemm4_dma16(ldsW + buf * 5120 + 4 * 1024, (uint64_t) (uintptr_t) mt, offX + (uint32_t) q * MT4_BYTES);
-        if (wave == 1) gemm4_dma16(ldsD + buf * 1024, (uint64_t) (uintptr_t) qa_d, offX + (uint32_t) q * 16u);
-    };
-
-    float acc[2][2][16];                                    // [issue p][result half hb][row v]: chain CH(h, 2 p + hb)
-#pragma unroll
-    for (int i = 0; i < 64; i++) (&acc[0][0][0])[i] = 0.0f;
-    f32x32v zero32;
-#pragma unroll
-    for (int r = 0; r < 32; r++) zero32[r] = 0.0f;
-
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int q = 0; q < nq; q++) {
-        const int buf = q & 1;
-        if (q + 1 < nq) issue(q + 1, buf ^ 1);
-        const uint8_t *wt_ = &sW[buf][0];
-        const uint8_t *bc = &sB[buf][(ct * 32 + cn) * 256];
-        const float *dc = &sDa[buf][(ct * 32 + cn) * 4];
-#pragma unroll
-        for (int jp = 0; jp < 2; jp++) {
-            const u32x4 xq = *(const u32x4 *) (wt_ + h * 2048 + lane * 32 + 16 * jp);      // dwords (j, p) = (2 jp, 0), (2 jp, 1), (2 jp + 1, 0), (2 jp + 1, 1)
-#pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                const int j = 2 * jp + jj;
-                const u32x4 Bq = *(const u32x4 *) (bc + ((((h * 2 + g) * 4 + j) ^ (cn & 15)) * 16));       // issues p = 0 | 1
-                const float da = dc[j];
-                float sc[16];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const f32x4 dw = *(const f32x4 *) (wt_ + 4096 + (j * 32 + 8 * i + 4 * g) * 4);
-                    sc[4 * i] = dw.x * da; sc[4 * i + 1] = dw.y * da; sc[4 * i + 2] = dw.z * da; sc[4 * i + 3] = dw.w * da;
-                }
-#pragma unroll
-                for (int pi = 0; pi < 2; pi++) {
-                    const uint32_t xd = jj ? (pi ? xq.w : xq.z) : (pi ? xq.y : xq.x);
-                    struct { uint32_t a, b; } aw = { __builtin_amdgcn_perm(0u, xd, 0x010C000Cu), __builtin_amdgcn_perm(0u, xd, 0x030C020Cu) };
-                    struct { uint32_t a, b; } bw = { pi ? Bq.z : Bq.x, pi ? Bq.w : Bq.y };
-                    const f32x32v D = __builtin_amdgcn_mfma_f32_32x32x4f16(__builtin_bit_cast(h4v, aw), __builtin_bit_cast(h4v, bw), zero32, 0, 0, 0);
-                    // (volatile asm FMAs, the first one visible to the compiler: see k_gemm_mfma4)
-                    const float first = __builtin_fmaf(sc[0], D[0], acc[pi][0][0]);
-                    acc[pi][0][0] = first;
-                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[pi][0][1]) : "v"(sc[1]), "v"(D[1]), "v"(first));
-#pragma unroll
-                    for (int e = 2; e < 32; e++)
-                        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[pi][e >> 4][e & 15]) : "v"(sc[e & 15]), "v"(D[e]));
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    // ---- each wave folds its side of the tree, (A_h + A_{4+h}) + (A_{2+h} + A_{6+h}); the odd side crosses to the even wave through LDS
-    float part[16];
-#pragma unroll
-    for (int v = 0; v < 16; v++) part[v] = (acc[0][0][v] + acc[0][1][v]) + (acc[1][0][v] + acc[1][1][v]);
-    float *xch = (float *) &sB[0][0] + ct * (16 * 64);                  // (every wave is past the last quad's closing barrier)
-    if (h == 1) {
-#pragma unroll
-        for (int v = 0; v < 16; v++) xch[v * 64 + lane] = part[v];
-    }
-    __syncthreads();
-    if (h == 1) return;
-    const int n = n0 + ct * 32 + cn;
-    if (n >= ncols) return;
-#pragma unroll
-    for (int v = 0; v < 16; v++) {
-        const int m = rb * 32 + 8 * (v >> 2) + 4 * g + (v & 3);
-        float val = part[v] + xch[v * 64 + lane];
-        if (m < M) {
-            if (EPI == EPI_RESID) val = val + resid[(size_t) n * resid_stride + m];
-            y[(size_t) n * y_stride + m] = val;
-        }
-    }
-}
-
 template <int NC>
 static hipError_t launch_gemm_lds_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols,
                                     float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
@@ -1374,18 +1182,9 @@ static hipError_t launch_gemm_mfma(const QMat &w, int epi, const uint8_t *qb, co
     return hipSuccess;
 }
 
-static bool gemm2b_mode() {
-    static const bool on = getenv("LLAMAHIP_GEMM2B") && atoi(getenv("LLAMAHIP_GEMM2B")) == 1;
-    return on;
-}
 hipError_t launch_tiles_to_mt4(const QMat &w, hipStream_t st) {
     static_assert(MT4_BYTES == MT4_TILE_BYTES, "QMat::mt4_bytes() sizes the copy");
     const long tot4 = (long) w.nrb32 * w.nchunks * 2 * 2 * 64;
-    if (gemm2b_mode()) {
-        hipLaunchKernelGGL(k_tiles_to_mt2b, dim3((unsigned) ((tot4 + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt4, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
     hipLaunchKernelGGL(k_tiles_to_mt4, dim3((unsigned) ((tot4 + 255) / 256)), dim3(256), 0, st, w.tiles, w.mt4, w.ngroups, w.nchunks, w.nrb32, w.gmapF8);
     LH_LAUNCH_CHECK();
     return hipSuccess;
@@ -1396,15 +1195,6 @@ static hipError_t launch_gemm_mfma4(const QMat &w, int epi, const uint32_t *qa_A
     const int nct = (ncols + 63) / 64, nq = w.nchunks * 2;
     const int nrp = (w.nrb32 + 1) / 2;
     const int grid = ((nrp + 7) / 8) * nct * 8;
-    if (gemm2b_mode()) {
-        const int nct96 = (ncols + 63) / 64, grid2 = ((w.nrb32 + 7) / 8) * nct96 * 8;
-        hipLaunchKernelGGL(k_qa_to_qb2b, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, qa_A, qb4, w.nchunks, ncols);
-        LH_LAUNCH_CHECK();
-        if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_mfma2b<EPI_RESID>), dim3(grid2), dim3(256), 0, st, w.mt4, w.nrb32, nq, w.M, qb4, qa_d, ncols, nct96, y, y_stride, resid, resid_stride);
-        else                  hipLaunchKernelGGL((k_gemm_mfma2b<EPI_STORE>), dim3(grid2), dim3(256), 0, st, w.mt4, w.nrb32, nq, w.M, qb4, qa_d, ncols, nct96, y, y_stride, resid, resid_stride);
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
     hipLaunchKernelGGL(k_qa_to_qb4, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, qa_A, qb4, w.nchunks, ncols);
     LH_LAUNCH_CHECK();
     if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_mfma4<EPI_RESID>), dim3(grid), dim3(512), 0, st, w.mt4, w.nrb32, nq, w.M, qb4, qa_d, ncols, nct, y, y_stride, resid, resid_stride);
