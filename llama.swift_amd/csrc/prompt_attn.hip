@@ -244,7 +244,13 @@ __global__ void __launch_bounds__(1024)
 k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__restrict__ inv,
                 int n_past, int N, int nb0, int NB, int T, int KS, const uint16_t *__restrict__ T_exp) {
     constexpr int PH = 16;                                // key phases: a thread takes every 16th key of its query
-    __shared__ double part[PH][64];
+    // the exp table's negative half (score - max <= 0: 64 KB of the 128) in LDS: a wave's 64 table reads are 64 different cache lines
+    // for the texture path, a few bank conflicts for LDS
+    extern __shared__ double smem_d[];
+    double (*part)[64] = (double (*)[64]) smem_d;         // [PH][64]
+    uint16_t *lut = (uint16_t *) (smem_d + PH * 64);      // [32768]: lut[i] = T_exp[0x8000 | i]
+    for (int i = threadIdx.x; i < 32768 / 8; i += 1024) ((u32x4 *) lut)[i] = ((const u32x4 *) (T_exp + 0x8000))[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6, h = blockIdx.y;
     const int nl = blockIdx.x * 64 + lane, n = nb0 + nl;
     const int nb_end = min(nb0 + (int) (blockIdx.x + 1) * 64, N);
@@ -256,7 +262,11 @@ k_attnq_softmax(float *__restrict__ S, const float *__restrict__ pmax, float *__
     for (int t = ph; t < Tb; t += PH) {
         float *sp = S + ((size_t) h * T + t) * NB + nl;
         float e = 0.0f;                                   // masked keys (-inf in the reference) contribute 0
-        if (t <= tq) { e = h2f_bits(T_exp[f2h_bits(*sp - mx)]); sum += (double) e; }
+        if (t <= tq) {
+            const uint16_t xh = f2h_bits(*sp - mx);       // (exp(+0) = exp(-0): the row's maximum itself reads entry 0 of the negative half)
+            e = h2f_bits(((xh & 0x8000) || xh == 0) ? lut[xh & 0x7FFF] : T_exp[xh]);
+            sum += (double) e;
+        }
         *sp = e;
     }
     part[ph][lane] = sum;
@@ -394,7 +404,7 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
             hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 0, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
+            hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 16 * 64 * sizeof(double) + 65536, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();
             // (column quarters, and 1 024 / 2 048 queries per launch: measured level / slower, profiles/r04_v_attn_shapes_ab.txt)
             if (chunk > 0) hipLaunchKernelGGL((k_attnq_pv_mfma<true, 2>), dim3(qb, H, nth * 2), dim3(64), 0, st, ws->S, ws->inv, Vc, ws->part, n_past, N, nb0, ws->NB, d, T, nth, chunk);
@@ -416,6 +426,7 @@ hipError_t init_attrs_prompt_attn() {
     const int cap = 160 * 1024;          // fused prologues / wide rows need more than the default 64 KB of dynamic LDS
 #define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
     LH_ATTR(k_attn);
+    LH_ATTR(k_attnq_softmax);
 #undef LH_ATTR
     return hipSuccess;
 }
