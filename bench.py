@@ -626,7 +626,7 @@ def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, em
     import torch
     import torch.distributed as dist
 
-    from llama_swift_amd.pipeline import ERR_PREDICT, gather_traces, layer_range, mailbox_decode, pipeline_decode, pipeline_decode_sets, pipeline_rounds, run_guarded
+    from llama_swift_amd.pipeline import ERR_PREDICT, gather_traces, layer_range, mailbox_decode, make_groups, pipeline_decode, pipeline_decode_sets, pipeline_rounds, run_guarded, transport_selfcheck
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -679,8 +679,12 @@ def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, em
         if backend != "nccl":
             hsync = env.sync                     # gloo moves CUDA tensors through the host, not in device-stream order: synchronise around it (smoke runs only)
     dev = env.device
-    token_group = dist.new_group(list(range(world)))          # separate communicator for the feedback edge
-    fwd_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]   # forward edges by sender parity
+    backend_ran = dist.get_backend()
+    transport = "RCCL" if backend_ran == "nccl" else f"{backend_ran} (smoke transport, host-synchronised around every message)"
+    # the token feedback edge on its own communicator, the forward edges on two by sender parity (pipeline.make_groups: the same function
+    # under gloo in the CPU tests), then one barrier / object all-gather / all-reduce per communicator before anything is timed
+    token_group, fwd_groups, topology = make_groups(dist, world)
+    selfcheck = transport_selfcheck(dist, torch, rank, world, dev, backend_ran, token_group, fwd_groups, log)
     sync_schedule = os.environ.get("LLAMAHIP_PIPELINE_SYNC", "0") == "1"
     # sequences per stage: a stage steps them as ONE set (llamahip_stage_step_set: its weights are streamed once per step for all of
     # them) and the set's rows cross to the next stage in one message.  LLAMAHIP_PIPE_SET=0: one sequence per step, device-side
@@ -705,9 +709,9 @@ def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, em
         prompts = [np.concatenate([[1], rng.integers(3, mcfg["n_vocab"], 7 + (s % 3 if set_mode else 0))]).astype(np.int32) for s in range(S)]   # (set mode: rows of a set at different positions)
         n_single = 16                                          # single-stream latency leg: tokens of sequence 0 alone
         steps = max(1, min(steps_req, args.n_ctx - 11 - warmup - 1 - n_single))
-        hand_off = "RCCL point-to-point per token (torch.distributed isend / recv, stream-ordered)"
+        hand_off = f"{transport} point-to-point per token (torch.distributed isend / recv, stream-ordered)"
         if set_mode:
-            hand_off = f"RCCL point-to-point, one message per set of {per_stage} sequences and step (torch.distributed isend / recv, stream-ordered)"
+            hand_off = f"{transport} point-to-point, one message per set of {per_stage} sequences and step (torch.distributed isend / recv, stream-ordered)"
         if sync_schedule:
             toks, n_past = guard(lambda: pipeline_rounds(stage, rank, world, dist, torch, prompts, [0] * S, 1 + warmup, token_group), "pipeline_rounds (prompt + warm-up)")
             last = [np.array([toks[s, -1]], np.int32) for s in range(S)]
@@ -839,7 +843,9 @@ def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, em
                                    f"({r['n_layer']} layers / {world}), {r['S']} independent sequences in flight"
                                    + (f" ({per_stage} per stage, stepped as one set: llamahip_stage_step_set)" if r["set_mode"] else "") + f", n_ctx {args.n_ctx}; "
                                    f"a step = one token for every sequence",
-                       "parallelism": f"pp{world}", "hand_off": r["hand_off"],
+                       "parallelism": f"pp{world}", "hand_off": r["hand_off"], "backend": backend_ran,
+                       "transport_selfcheck": f"barrier + all_gather_object + all_reduce on 3 communicators ok on {len(selfcheck)} rank(s)",
+                       "group_topology": topology,
                        "sequences": r["S"], "tokens_timed": total},
             "roofline": r["roof"],
             "parity": r["parity"],

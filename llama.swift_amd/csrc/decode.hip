@@ -2439,6 +2439,7 @@ hipError_t init_kernel_attrs() {
     if ((e = init_attrs_prep()) != hipSuccess) return e;
     if ((e = init_attrs_decode()) != hipSuccess) return e;
     if ((e = init_attrs_prompt_gemm()) != hipSuccess) return e;
+    if ((e = init_attrs_gemv_set()) != hipSuccess) return e;
     return init_attrs_prompt_attn();
 }
 

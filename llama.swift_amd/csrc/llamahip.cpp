@@ -173,6 +173,7 @@ struct llamahip_model {
     uint32_t *d_attn_sync = nullptr;     // per-head hand-off counters of k_dec_attn_x ([H][32] dwords); null: two-launch attention
     uint64_t *d_qkv2 = nullptr, *d_sc2 = nullptr;   // tagged hand-off buffers of k_qkv_attn: [3 d] and [H][n_ctx] {fp32 bits, tag} granules
     uint32_t *d_epoch = nullptr;         // ... and the epoch word their tags are made from (bumped once per decode forward pass)
+    uint64_t *d_set_amax = nullptr;      // the same for the rows of a short eval / a batched decode step (k_gemv_set): [SET_MAX][F / 16 + 16] granules
     uint64_t *d_w13_amax = nullptr;      // partial amaxes exchanged by the half-block workgroups of the w1|w3 decode mat-vec (EPI_SILU_QAH): [F / 16] granules
     unsigned long long *d_pick = nullptr; // greedy loop: {64-bit atomic-max key, arrival counter} of the lm head's pick epilogue (EPI_STORE_PICK)
     uint64_t *d_pvx = nullptr;           // tagged partial sums of k_dec_pv_stream's split workgroups: [H dh/32][32 threads of the split][32]
@@ -229,6 +230,7 @@ static hipError_t malloc_mailbox(void **p, size_t bytes) {
 llamahip_model::~llamahip_model() {
     if (host_only) return;
     (void) hipSetDevice(device);
+    (void) hipDeviceSynchronize();      // captured steps may still run on a caller's stream: nothing is freed or destroyed under them
     free_dev(tok_emb); free_dev(norm_w); free_dev(output.tiles); free_dev(doutput.w); free_dev(doutput.w2);
     for (auto &l : layers) {
         free_dev(l.attention_norm); free_dev(l.ffn_norm);
@@ -244,7 +246,7 @@ llamahip_model::~llamahip_model() {
     free_dev(tmp); free_dev(logits); free_dev(qa_A); free_dev(qa_d); free_dev(qb_ws); free_dev(dbg_y); free_dev(dbg_p); free_dev(dbg_kqv);
     free_dev(qaF_A); free_dev(qaF_d);
     free_dev(d_out_tokens); free_dev(d_topk);
-    free_dev(d_pick); free_dev(d_w13_amax);
+    free_dev(d_pick); free_dev(d_w13_amax); free_dev(d_set_amax);
     free_dev(npart_a); free_dev(npart_b); free_dev(d_attn_sync); free_dev(d_qkv2); free_dev(d_sc2); free_dev(d_epoch); free_dev(d_pvx);
     if (h_fault) { (void) hipHostFree(h_fault); h_fault = nullptr; }
     if (h_io) { (void) hipHostFree(h_io); h_io = nullptr; }
@@ -395,8 +397,9 @@ void drop_set_graphs(llamahip_model *m) {
 }
 int ensure_workspace(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N <= m->ws_cap) return 0;
-    // captured graphs hold the old workspace pointers
-    HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    // captured graphs hold the old workspace pointers -- and they are launched on the CALLER's stream (llamahip_stage_step /
+    // _step_set), so the handle's own stream says nothing about them: wait for the device before an exec or a buffer goes
+    HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);
     drop_set_graphs(m);
     for (auto &kv : m->decode_graphs) (void) hipGraphExecDestroy(kv.second);
     m->decode_graphs.clear();
@@ -596,6 +599,13 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
     // the decode-shaped attention
     constexpr int short_max = 60;
     const bool short_chunk = N >= 2 && N <= short_max && m->attn_ws.S && N <= m->attn_ws.NB && dh % 32 == 0 && dh <= 256;
+    // short evals (2 .. 16 rows): the w1|w3 launch of k_gemv_set runs half-block workgroups whose halves exchange their amax as tagged
+    // granules -- needs the XCD placement the load-time self-test confirmed and one epoch per pass
+    SiluHalfIO set_hx;
+    if (short_chunk && !debug && N <= SET_MAX && m->d_attn_sync && m->d_set_amax && m->l1 > m->l0 && m->l1 - m->l0 <= TAG_MAX_LAYERS) {
+        set_hx.amax_t = m->d_set_amax; set_hx.epoch = m->d_epoch; set_hx.fault = m->d_fault;
+        HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
+    }
     int32_t *state = (io && io->state) ? io->state : m->d_state;
     const float *x_first = (io && fused && m->l1 > m->l0) ? io->x_first : nullptr;
     float *x_last = (io && fused && m->l1 > m->l0) ? io->x_last : nullptr;
@@ -727,7 +737,8 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         if (short_chunk && !dmp && m->w13_interleaved && N <= 64 && gemm_silu_qa_applies(L.w13, N)) {
             // short evals: w1 | w3, SiLU * up and the quantization for w2 in one launch (.mm:668-680)
             const long KpF = ((long) F + 255) / 256 * 256;
-            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, N, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st), LLAMAHIP_ERR_PREDICT);
+            set_hx.layer = il - m->l0;
+            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, N, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st, &set_hx), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, N, m->x, d, m->x1, d, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);      // .mm:682-687
             continue;
         }
@@ -1015,6 +1026,8 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
         HIP_TRY(hipMemset(m->d_epoch, 0, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &m->d_w13_amax, ((size_t) F / 16 + 16) * 8), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMemset(m->d_w13_amax, 0, ((size_t) F / 16 + 16) * 8), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &m->d_set_amax, (size_t) SET_MAX * set_amax_granules(F) * 8), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(m->d_set_amax, 0, (size_t) SET_MAX * set_amax_granules(F) * 8), LLAMAHIP_ERR_LOAD);
         {   // lm-head pick epilogue: [0, 1024) bytes tickets, then one 8-byte key per workgroup of the lm head's launch (<= n_vocab / 8 + 8)
             const size_t pb = 1024 + ((size_t) V / 8 + 8) * 8;
             HIP_TRY(hipMalloc((void **) &m->d_pick, pb), LLAMAHIP_ERR_LOAD);
@@ -1324,8 +1337,8 @@ int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
     }
     auto &sl = m->slots[seq];
     const bool same = sl.bound && sl.token_in == token_in && sl.token_out == token_out && sl.hidden_in == hidden_in && sl.hidden_out == hidden_out;
-    if (!same) {                 // captured graphs hold the old pointers
-        HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
+    if (!same) {                 // captured graphs hold the old pointers (and may still run on a caller stream: device-wide wait)
+        HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);
         for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
         sl.graphs.clear();
         drop_set_graphs(m);
@@ -1521,8 +1534,14 @@ int forward_set(llamahip_model *m, int nth, const SeqSet *d_set, int B, char *er
     if (m->first_stage) HIP_TRY(launch_embed_set(d_set, B, m->tok_emb, m->x, d, st), LLAMAHIP_ERR_PREDICT);                // .mm:558-561
     else HIP_TRY(launch_rows_set(d_set, B, m->x, d, true, st), LLAMAHIP_ERR_PREDICT);
     const long KpF = ((long) F + 255) / 256 * 256;
+    SiluHalfIO set_hx;          // (see forward(): the half-block w1|w3 launch of k_gemv_set)
+    if (m->d_attn_sync && m->d_set_amax && m->l1 - m->l0 <= TAG_MAX_LAYERS) {
+        set_hx.amax_t = m->d_set_amax; set_hx.epoch = m->d_epoch; set_hx.fault = m->d_fault;
+        HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
+    }
     for (int il = m->l0; il < m->l1; il++) {
         const Layer &L = m->layers[il - m->l0];
+        set_hx.layer = il - m->l0;
         float *Kl = m->Kc + (size_t) (il - m->l0) * C * d, *Vl = m->Vc + (size_t) (il - m->l0) * C * d;      // slot 0's cache of this layer; rows add their slot's offset
         HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
         RopeKvArgs ra = { m->sincos, m->qr, Kl, Vl, 0, d, dh };
@@ -1532,7 +1551,7 @@ int forward_set(llamahip_model *m, int nth, const SeqSet *d_set, int B, char *er
         HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, B, m->x1, d, m->x, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);  // .mm:649-654
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (m->w13_interleaved && gemm_silu_qa_applies(L.w13, B)) {
-            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, B, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st), LLAMAHIP_ERR_PREDICT);       // .mm:668-680
+            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, B, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st, &set_hx), LLAMAHIP_ERR_PREDICT);       // .mm:668-680
             HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, B, m->x, d, m->x1, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);                 // .mm:682-687
         } else {
             HIP_TRY(launch_gemm(L.w13, EPI_STORE, m->qa_A, m->qa_d, B, m->gu, 2L * F, nullptr, 0, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);

@@ -32,6 +32,8 @@ struct SeqSet {
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
 // (set: row n is at position set->state[n][0] of the cache at Kc / Vc + set->kv_off[n] instead of n_past + n)
 struct RopeKvArgs { const double *tab; float *qr, *Kc, *Vc; int n_past, d, dh; const SeqSet *set = nullptr; };
+// what the half-block w1|w3 epilogue of k_gemv_set needs (EPI_SILU_QAH): granules for the partial amaxes, the epoch word its tags are made from
+struct SiluHalfIO { uint64_t *amax_t = nullptr; const uint32_t *epoch = nullptr; int layer = 0; uint32_t *fault = nullptr; };
 
 // a Q4_0 weight matrix resident in HBM in chain-major tile layout
 struct QMat {
@@ -136,7 +138,7 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
 hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr, uint64_t *xt = nullptr,
                              const uint64_t *token_mb = nullptr, const int32_t *state = nullptr, uint32_t *fault = nullptr, int n_vocab = 0);      // token_mb: the token arrives as a mailbox granule
-enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_COUNT = 5 };
+enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_SET = 5, GEMM_PATH_COUNT = 6 };
 extern long g_gemm_path_counts[GEMM_PATH_COUNT];     // launches per kernel family of launch_gemm (process-wide; tests)
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
@@ -159,7 +161,21 @@ bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d);
 hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st);
 bool gemm_silu_qa_applies(const QMat &w13, int N);
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
-                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st);
+                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st,
+                               const SiluHalfIO *hx = nullptr);      // hx: the half-block exchange of k_gemv_set may be used (2 .. 16 rows)
+// k_gemv_set (gemv_set.hip): the mat-mul for 2 .. 16 activation rows -- a batched decode step's rows, the reference's 9-token evals.  The waves
+// that share a row-group share its weight bytes through LDS, so every weight byte crosses a CU's load path once per launch.
+//   gemv_set_applies(w, N, epi): EPI_STORE / EPI_RESID (launch_gemv_set), EPI_ROPE_KV (launch_gemv_set_rope_kv), EPI_SILU_QAH (launch_gemv_set_silu:
+//   interleaved w1|w3 in half-block workgroups whose halves exchange their partial amax per column as tagged granules -- needs the XCD
+//   placement xcd_selftest confirmed, the epoch word and SET_AMAX_GRANULES(F) * 16 zeroed granules)
+inline size_t set_amax_granules(int F) { return (size_t) F / 16 + 16; }      // per column
+bool gemv_set_applies(const QMat &w, int N, int epi);
+hipError_t launch_gemv_set(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
+                           float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st);
+hipError_t launch_gemv_set_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st);
+hipError_t launch_gemv_set_silu(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
+                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, const SiluHalfIO &hx, hipStream_t st);
+hipError_t init_attrs_gemv_set();
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
                              const uint16_t *T_exp, hipStream_t st, int chunk = 0, const SeqSet *set = nullptr);      // set: N independent single-row evals (batched decode step)

@@ -1116,6 +1116,7 @@ bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
     return N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
 }
 hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
+    if (gemv_set_applies(wqkv, N, EPI_ROPE_KV)) { g_gemm_path_counts[GEMM_PATH_SET]++; return launch_gemv_set_rope_kv(wqkv, qa_A, qa_d, N, ra, st); }
     const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
     case 4:  return launch_gemm_skinny_rope_t<4>(wqkv, qa_A, qa_d, N, ncg, ra, st);
@@ -1131,7 +1132,11 @@ bool gemm_silu_qa_applies(const QMat &w13, int N) {
     return N >= 2 && N <= skinny_max_rows() && w13.gmapF8 != 0 && w13.ngroups % 8 == 0;
 }
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
-                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
+                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st, const SiluHalfIO *hx) {
+    if (hx && hx->amax_t && hx->epoch && gemv_set_applies(w13, N, EPI_SILU_QAH)) {
+        g_gemm_path_counts[GEMM_PATH_SET]++;
+        return launch_gemv_set_silu(w13, qa_A, qa_d, N, T_silu, out_A, out_d, out_strideA, out_strideD, *hx, st);
+    }
     const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
     case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
@@ -1215,7 +1220,7 @@ hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
 //   else: LDS-staged column tiles of 16 (the last one clamped), small remainders as 8 / 4 columns
 //   a single row always goes through the decode GEMV
 // which kernel family served a mat-mul (tests assert that the full-size shapes take the path they are meant to)
-long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0 };
+long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0, 0 };
 
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws, bool fast) {
@@ -1240,6 +1245,11 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st, fast);
     }
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
+    // a few rows (a batched decode step, the reference's 9-token evals): the waves of a row-group share its weights through LDS
+    if ((epi == EPI_STORE || epi == EPI_RESID) && gemv_set_applies(w, N, epi)) {
+        g_gemm_path_counts[GEMM_PATH_SET]++;
+        return launch_gemv_set(w, epi, qa_A, qa_d, N, y, y_stride, resid, resid_stride, st);
+    }
     // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put
     // ~1500 waves on the chip
     if (N >= 2 && N <= skinny_max_rows()) {

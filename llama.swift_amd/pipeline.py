@@ -115,6 +115,49 @@ def run_guarded(fn, rank: int, world: int, limit_s: float, what: str, on_timeout
         timer.cancel()
 
 
+def make_groups(dist, world: int):
+    """The process groups of the decode schedules (module docstring), for ANY backend -- the `nccl` (RCCL) branch of the bench and the
+    `gloo` branch of the CPU tests call this one function, so they differ in the transport only:
+      token     one communicator over all ranks for the feedback edge (last stage -> stage 0), apart from the forward edges
+      fwd[p]    the forward edge r -> r + 1 travels on fwd[r % 2]: a rank's receive (sender r - 1) and its send (sender r) never share
+                a communicator
+    Returns (token_group, [fwd_even, fwd_odd], topology) where `topology` is a plain description (ranks per group, the parity rule as a
+    table edge -> group index) that tests compare across backends."""
+    ranks = list(range(world))
+    token_group = dist.new_group(ranks)
+    fwd_groups = [dist.new_group(ranks), dist.new_group(ranks)]
+    topology = {"world": world, "token": {"ranks": ranks, "edge": [world - 1, 0]},
+                "fwd": [{"ranks": ranks, "edges": [[r, r + 1] for r in range(world - 1) if r % 2 == p]} for p in (0, 1)]}
+    return token_group, fwd_groups, topology
+
+
+def fwd_group_of(sender: int) -> int:
+    """Index into make_groups' fwd list for the edge sender -> sender + 1 (the parity rule, in one place)."""
+    return sender % 2
+
+
+def transport_selfcheck(dist, torch, rank: int, world: int, device: str, backend: str, token_group, fwd_groups, log=None):
+    """What the first multi-GPU run should not be the first to execute: one barrier, one object all-gather, and one tensor all-reduce on
+    EACH of the three communicators (creates them: RCCL builds a communicator at its first collective).  Returns the gathered
+    (rank, device, backend) records; raises what the transport raises."""
+    dist.barrier()
+    recs = [None] * world
+    dist.all_gather_object(recs, {"rank": rank, "device": device, "backend": backend})
+    for name, g in (("token", token_group), ("fwd_even", fwd_groups[0]), ("fwd_odd", fwd_groups[1])):
+        t = torch.full((1,), rank + 1, dtype=torch.int32, device=device)
+        dist.all_reduce(t, group=g)
+        if device != "cpu":
+            torch.cuda.synchronize()
+        want = world * (world + 1) // 2
+        if int(t.item()) != want:
+            raise RuntimeError(f"transport self-check: all_reduce on group {name} gave {int(t.item())}, expected {want}")
+        if log:
+            log(f"[pipeline] rank {rank}/{world}: backend {backend}: communicator '{name}' up (all_reduce ok)")
+    if log:
+        log(f"[pipeline] rank {rank}/{world}: backend {backend}: barrier + all_gather_object ok: {recs}")
+    return recs
+
+
 def layer_range(n_layer: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous, as even as possible; earlier stages take the remainder."""
     base, rem = divmod(n_layer, world)
@@ -283,7 +326,7 @@ def pipeline_decode(stage: Stage, rank: int, world: int, dist, n_seq: int, round
     round's picks into ``tok_in``, so calls can be chained and no send is left unmatched.
     Returns nothing: read the picks with ``stage.trace`` on the last stage."""
     nxt, prv = (rank + 1) % world, (rank - 1) % world
-    grp = (lambda sender: fwd_groups[sender % 2]) if fwd_groups else (lambda sender: None)
+    grp = (lambda sender: fwd_groups[fwd_group_of(sender)]) if fwd_groups else (lambda sender: None)
     sent = [None] * n_seq                         # a sequence's send is waited for before its next step rewrites the buffer (host_sync: see pipeline_decode_sets)
 
     def recv(t, src, group):
@@ -327,7 +370,7 @@ def pipeline_decode_sets(stage: Stage, rank: int, world: int, dist, groups: Sequ
     transport that is not ordered on the device stream (gloo moving CUDA tensors: the one-GPU smoke test) gets a host
     synchronisation before every send and after every receive."""
     nxt, prv = (rank + 1) % world, (rank - 1) % world
-    grp = (lambda sender: fwd_groups[sender % 2]) if fwd_groups else (lambda sender: None)
+    grp = (lambda sender: fwd_groups[fwd_group_of(sender)]) if fwd_groups else (lambda sender: None)
     sent = [None] * len(groups)
 
     def recv(t, src, group):

@@ -302,6 +302,48 @@ def _bench_main_worker(rank, world, init_file, out_dir, env_extra):
     dist.destroy_process_group()
 
 
+def _expected_topology(world):
+    """The communicators of the decode schedules, written down independently of pipeline.make_groups: one over all ranks for the token
+    feedback edge (last -> 0), two over all ranks for the forward edges r -> r + 1 by parity of the SENDER."""
+    ranks = list(range(world))
+    return {"world": world, "token": {"ranks": ranks, "edge": [world - 1, 0]},
+            "fwd": [{"ranks": ranks, "edges": [[r, r + 1] for r in range(0, world - 1, 2)]}, {"ranks": ranks, "edges": [[r, r + 1] for r in range(1, world - 1, 2)]}]}
+
+
+def test_nccl_and_gloo_branches_build_the_same_process_groups(built):
+    """bench.pipeline_bench_main creates its communicators through pipeline.make_groups whatever the backend, so the RCCL branch (never
+    run on more than one GPU so far) differs from the gloo branch the CPU tests run in the transport only: the function issues exactly
+    three new_group calls over all ranks in a fixed order on ANY `dist`, its topology is the independent specification above, the
+    schedules pick a forward group through the same parity rule, and the bench leg has no new_group call of its own."""
+    import inspect
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from llama_swift_amd import pipeline
+
+    class RecordingDist:
+        def __init__(self):
+            self.calls = []
+
+        def new_group(self, ranks):
+            self.calls.append(list(ranks))
+            return ("group", len(self.calls) - 1)
+
+    for world in (1, 2, 3, 8):
+        d = RecordingDist()
+        tok, fwd, topo = pipeline.make_groups(d, world)
+        assert d.calls == [list(range(world))] * 3 and tok == ("group", 0) and fwd == [("group", 1), ("group", 2)]
+        assert topo == _expected_topology(world)
+        for r in range(world - 1):
+            assert [r, r + 1] in topo["fwd"][pipeline.fwd_group_of(r)]["edges"]
+            # a rank's receive (sender r - 1) and its send (sender r) never share a communicator
+            assert r == 0 or pipeline.fwd_group_of(r - 1) != pipeline.fwd_group_of(r)
+    src = inspect.getsource(bench.pipeline_bench_main)
+    assert "make_groups(dist, world)" in src and "new_group(" not in src and "transport_selfcheck(" in src
+    for fn in (pipeline.pipeline_decode, pipeline.pipeline_decode_sets):
+        assert "fwd_group_of(sender)" in inspect.getsource(fn)
+
+
 @pytest.mark.parametrize("mode", ["sets", "one_per_step"])
 def test_bench_pipeline_control_flow_at_world_8_gloo(built, tmp_path, mode):
     """No 8-GPU node has ever run this code, so its control flow runs here: `bench.py --gpus 8` (bench.pipeline_bench_main) with eight
@@ -322,6 +364,9 @@ def test_bench_pipeline_control_flow_at_world_8_gloo(built, tmp_path, mode):
     assert line["parity"]["checked"] and line["parity"]["identical"], line["parity"]
     assert ("one set" in line["config"]["workload"]) == (mode == "sets")
     assert ("one message per set" in line["config"]["hand_off"]) == (mode == "sets")
+    # the line names the transport that actually ran, and the communicators are the ones every backend gets (next test)
+    assert line["config"]["backend"] == "gloo" and "gloo" in line["config"]["hand_off"] and "RCCL" not in line["config"]["hand_off"]
+    assert line["config"]["group_topology"] == _expected_topology(8) and "ok on 8 rank(s)" in line["config"]["transport_selfcheck"]
     leg = line["config4_65B"]
     assert "error" not in leg, leg
     assert "80 layers over 8 stages" in leg["workload"] and leg["parity"]["checked"] and leg["parity"]["identical"], leg
@@ -783,7 +828,8 @@ def test_device_side_mailbox_silent_peer_costs_seconds_with_the_production_poll_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S,shape,nth", [(2, "d512", 8), (4, "d256", 3), (8, "d512", 5), (16, "d256", 8), (5, "7b_width", 8)])
+@pytest.mark.parametrize("S,shape,nth", [(2, "d512", 8), (4, "d256", 3), (8, "d512", 5), (16, "d256", 8), (5, "7b_width", 8), (9, "7b_width", 5), (3, "d512", 8),
+                                          (4, "13b_width", 8), (8, "13b_width", 5), (4, "65b_width", 5), (8, "65b_width", 8)])
 def test_batched_set_steps_equal_one_eval_per_sequence_on_the_oracle(L, oracle, tmp_path, S, shape, nth):
     """llamahip_stage_step_set: ONE decode step for S sequences at DIFFERENT positions (the weights are streamed once per step for
     all of them).  Every sequence's picked tokens, the logits of its last step and the KV rows of every layer must be bit for bit
@@ -791,11 +837,16 @@ def test_batched_set_steps_equal_one_eval_per_sequence_on_the_oracle(L, oracle, 
     eval, ggml.c:5459-5480, n_threads 8 / 3 / 5).  Sets and single steps are interchangeable on the same slots (a few single
     steps in between, then a smaller set), captured graphs replay as the positions grow."""
     import torch
+    # (the 13B / 65B widths: n_embd 5120 / 8192, 40 / 64 heads, n_ff 13824 / 22016, two- / eight-part files -- the shapes the 8-GPU
+    #  pipeline's default schedule steps in sets of 4, .mm:33-38)
     kw = {"d512": dict(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=3), "d256": dict(n_vocab=96, n_embd=256, n_mult=64, n_head=2, n_layer=2),
-          "7b_width": dict(n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2)}[shape]
-    hp = synth.HParams(**kw)
+          "7b_width": dict(n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2),
+          "13b_width": dict(n_vocab=512, n_embd=5120, n_mult=256, n_head=40, n_layer=2, parts=2),
+          "65b_width": dict(n_vocab=512, n_embd=8192, n_mult=256, n_head=64, n_layer=2, parts=8)}[shape]
+    hp = synth.HParams(**{k: v for k, v in kw.items() if k != "parts"})
     path = str(tmp_path / "m.bin")
-    if shape == "7b_width":
+    paths_before = L.gemm_paths()
+    if shape.endswith("_width"):
         from conftest import synth_tool
         path = synth_tool(tmp_path / "m.bin", seed=23, **kw)
     else:
@@ -849,6 +900,9 @@ def test_batched_set_steps_equal_one_eval_per_sequence_on_the_oracle(L, oracle, 
             om.close()
         with pytest.raises(L.LlamaHipError, match="twice"):
             gm.stage_step_set([0, 1, 0], nth, st)
+    if not os.environ.get("LLAMAHIP_NO_GEMV_SET"):
+        # the set steps ran on the few-row kernel (k_gemv_set), not on a fall-back
+        assert L.gemm_paths()["set"] > paths_before["set"], (paths_before, L.gemm_paths())
 
 
 @pytest.mark.gpu
@@ -885,3 +939,62 @@ def test_batched_set_steps_through_two_stage_handles(L, tmp_path):
         n, pos, got = b.stage_trace(s, K)
         assert n == K and got.tolist() == wants[s], f"sequence {s}"
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,S,nth", [("65b_width", 4, 8), ("13b_width", 8, 5)])
+def test_batched_set_steps_through_two_stage_handles_vs_the_oracle(L, oracle, tmp_path, shape, S, nth):
+    """The 8-GPU pipeline's default schedule in miniature, against the CPU path and not against the whole-model HIP path: a 2-layer model
+    of the 65B / 13B width (eight- / two-part file) split into two one-layer stage handles, S sequences at different positions stepped
+    as ONE set per stage and step (llamahip_stage_step_set; rows gathered from / scattered to the slots' hidden buffers).  Every
+    sequence's tokens, the logits of its last step and the KV rows of both layers equal one llama_eval per token and sequence on the
+    oracle (.mm:563-705 row by row, the V*P key split of each row's own eval, ggml.c:5459-5480)."""
+    import torch
+    from conftest import synth_tool
+    kw = {"13b_width": dict(n_vocab=512, n_embd=5120, n_mult=256, n_head=40, n_layer=2, parts=2),
+          "65b_width": dict(n_vocab=512, n_embd=8192, n_mult=256, n_head=64, n_layer=2, parts=8)}[shape]
+    hp = synth.HParams(**{k: v for k, v in kw.items() if k != "parts"})
+    path = synth_tool(tmp_path / "m.bin", seed=37, **kw)
+    n_ctx, K = 64, 6
+    prompts = [synth.synth_prompt(3 + (7 * s) % 19, hp.n_vocab, seed=90 + s) for s in range(S)]
+    a = L.Model(path, n_ctx=n_ctx, layer_begin=0, layer_end=1, n_seq=S)
+    b = L.Model(path, n_ctx=n_ctx, layer_begin=1, layer_end=2, n_seq=S)
+    try:
+        firsts = []
+        hid = [torch.zeros(hp.n_embd, dtype=torch.float32, device="cuda") for _ in range(S)]
+        for s in range(S):
+            a.set_seq(s); b.set_seq(s)
+            h = torch.zeros(len(prompts[s]) * hp.n_embd, dtype=torch.float32, device="cuda")
+            a.eval_stage(0, tokens=prompts[s], hidden_out=h.data_ptr(), n_threads=nth)
+            lg = b.eval_stage(0, n_tokens=len(prompts[s]), hidden_in=h.data_ptr(), want_logits=True, n_threads=nth)
+            firsts.append(int(np.argmax(lg)))
+        tok = [torch.tensor([firsts[s]], dtype=torch.int32, device="cuda") for s in range(S)]
+        for s in range(S):
+            a.stage_bind(s, len(prompts[s]), token_in=tok[s].data_ptr(), hidden_out=hid[s].data_ptr())
+            b.stage_bind(s, len(prompts[s]), hidden_in=hid[s].data_ptr(), token_out=tok[s].data_ptr())
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(K):
+            a.stage_step_set(list(range(S)), nth, st)
+            b.stage_step_set(list(range(S)), nth, st)
+        last = [b.stage_logits(s) for s in range(S)]
+        for s in range(S):
+            n, pos, got = b.stage_trace(s, K)
+            assert n == K and pos == len(prompts[s]) + K
+            om = oracle.load(path, n_ctx)
+            lo = om.eval(prompts[s], 0, nth)["logits"]
+            t = int(np.argmax(lo))
+            assert t == firsts[s], f"sequence {s}: prompt pick"
+            want = []
+            for i in range(K):
+                lo = om.eval(np.array([t], np.int32), len(prompts[s]) + i, nth)["logits"]
+                t = int(np.argmax(lo)); want.append(t)
+            assert got.tolist() == want, f"sequence {s}: {got.tolist()} vs {want}"
+            assert same(last[s], lo), f"sequence {s}: logits of the last step"
+            for il, stage in ((0, a), (1, b)):
+                stage.set_seq(s)
+                gk, gv = stage.kv(il, len(prompts[s]) + K)
+                ok, ov = om.kv(il, len(prompts[s]) + K)
+                assert same(gk, ok) and same(gv, ov), f"sequence {s}: KV cache layer {il}"
+            om.close()
+    finally:
+        a.close(); b.close()
