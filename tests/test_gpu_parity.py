@@ -72,7 +72,11 @@ def test_tiny_model_golden(L, tmp_path, nth, flags):
 # ------------------------------------------------------------------------------------------------ oracle, seeded inputs
 @pytest.mark.parametrize("M,K,N", [(8, 64, 1), (40, 256, 1), (64, 704, 2), (256, 4096, 1), (256, 4096, 9), (64, 11008, 1),
                                    (64, 11008, 5), (24, 5120, 3), (16, 8192, 1), (100, 4096, 17), (8, 13824, 1), (8, 22016, 2),
-                                   (520, 4096, 32), (72, 11008, 13), (40, 22016, 4), (2056, 4096, 8)])
+                                   (520, 4096, 32), (72, 11008, 13), (40, 22016, 4), (2056, 4096, 8),
+                                   # every (columns per wave, waves per row-group) plan of the few-row kernel (k_gemv_set): small matrices ...
+                                   (264, 4096, 3), (264, 4096, 4), (264, 4096, 6), (264, 4096, 7), (264, 4096, 11), (264, 4096, 16), (200, 11008, 9), (136, 1280, 12),
+                                   # ... and matrices with >= 1 024 row-groups (two columns per wave up to four rows)
+                                   (8200, 512, 2), (8200, 512, 3), (8200, 768, 4)])
 def test_mul_mat_vs_oracle(L, oracle, M, K, N):
     rng = np.random.default_rng(M + K + N)
     w = synth.quantize_q4_0_offline((0.02 * rng.standard_normal((M, K))).astype(np.float32))

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-5 GPU passes (one parameterised script; the per-round r0N_pass_*.sh scripts of rounds 3-4 are gone).
+# usage (on the GPU box, repo root):  bash tools/gpu_pass.sh <pass> [tag]
+#   a      first pass of the few-row kernel (k_gemv_set): quick parity, A/B against k_gemm_skinny with per-kernel tables, plan sweep,
+#          the nccl world-1 dry run of the pipeline bench
+#   final  everything profiles/<tag>_* is made from (see the case below)
+pass=${1:-a}; tag=${2:-r05_$pass}
+O=gpurun_out; mkdir -p $O; R=$PWD
+bash tools/ensure_7b.sh
+case $pass in
+a)
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or tiny_model_golden or multipart or prompt_continuation or short_chunks or other_head or batched_set" --durations=5 > $O/${tag}_quick.txt 2>&1
+  tail -25 $O/${tag}_quick.txt
+  cat > /tmp/v.txt <<EOV
+set|
+skinny|LLAMAHIP_NO_GEMV_SET=1
+EOV
+  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=2,4,8 EVALS=4,9,16 timeout 900 bash tools/set_ab.sh /tmp/v.txt > $O/${tag}_ab.txt 2>&1
+  cat $O/${tag}_ab.txt
+  cat > /tmp/v2.txt <<EOV
+p41|LLAMAHIP_SET_PLAN=4,1
+p22|LLAMAHIP_SET_PLAN=2,2
+p14|LLAMAHIP_SET_PLAN=1,4
+EOV
+  PROF=1 PROF_SEQS="4" SEQS=4 EVALS= timeout 600 bash tools/set_ab.sh /tmp/v2.txt > $O/${tag}_plans4.txt 2>&1
+  cat $O/${tag}_plans4.txt
+  cat > /tmp/v3.txt <<EOV
+p24|LLAMAHIP_SET_PLAN=2,4
+p42|LLAMAHIP_SET_PLAN=4,2
+p33|LLAMAHIP_SET_PLAN=3,3
+p34|LLAMAHIP_SET_PLAN=3,4
+EOV
+  PROF=1 PROF_SEQS="8" SEQS=8 EVALS=9 timeout 700 bash tools/set_ab.sh /tmp/v3.txt > $O/${tag}_plans8.txt 2>&1
+  cat $O/${tag}_plans8.txt
+  # the RCCL branch of the pipeline bench at world 1: init_process_group("nccl", device_id), the three communicators, barrier, object
+  # all-gather, the forced one-rank schedule in set mode
+  LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_BENCH_65B=0 LLAMAHIP_PIPE_NO_INSITU=1 timeout 600 python bench.py --steps 48 --warmup 4 > $O/${tag}_nccl_world1.json 2> $O/${tag}_nccl_world1.log
+  grep -v "^$" $O/${tag}_nccl_world1.log | tail -25; head -c 1500 $O/${tag}_nccl_world1.json; echo
+  ;;
+esac
