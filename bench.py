@@ -1160,8 +1160,28 @@ def main():
         result["roofline"]["full_context_tokens_per_s"] = result["full_context"]["tokens_per_s"]
         result["roofline"]["full_context_end_to_end_frac"] = result["full_context"]["end_to_end_frac"]
         result["config"]["full_context_tokens_per_s"] = result["full_context"]["tokens_per_s"]
+    # (scalars only: nested objects of config / roofline do not survive such a reader)
     if isinstance(result.get("batched_sequences"), list):
-        result["config"]["batched_sequences_aggregate_tokens_per_s"] = {str(b["sequences"]): round(b["aggregate_tokens_per_s"], 1) for b in result["batched_sequences"]}
+        for b in result["batched_sequences"]:
+            result["config"][f"batched_sequences_aggregate_tokens_per_s_{b['sequences']}_seq"] = round(b["aggregate_tokens_per_s"], 1)
+            result["config"][f"batched_sequences_ms_per_step_{b['sequences']}_seq"] = round(b["ms_per_step"], 4)
+        result["config"]["batched_sequences_tokens_equal_single_stream"] = all(b["tokens_equal_single_stream"] for b in result["batched_sequences"])
+    result["config"]["parity_checked"] = bool(parity.get("checked"))
+    result["config"]["parity_identical"] = parity.get("identical")
+    result["config"]["parity_tokens_compared"] = parity.get("tokens_compared")
+    result["config"]["parity_against"] = parity.get("against")
+    dbt_ = result["roofline"].get("dominant_by_time")
+    if isinstance(dbt_, dict):
+        result["roofline"]["dominant_by_time_kernel"] = dbt_.get("kernel")
+        result["roofline"]["dominant_by_time_us"] = dbt_.get("us")
+        result["roofline"]["dominant_by_time_frac"] = dbt_.get("frac")
+        result["roofline"]["dominant_by_time_share"] = dbt_.get("share_of_gpu_time")
+    p9 = result["prefill"].get("reference_9_token_chunks") if isinstance(result.get("prefill"), dict) else None
+    if isinstance(p9, dict):
+        result["config"]["reference_9_token_evals_tokens_per_s"] = round(p9["tokens_per_s"], 1)
+    p2k = result["prefill"].get("configs2_2048_tokens_one_eval") if isinstance(result.get("prefill"), dict) else None
+    if isinstance(p2k, dict) and "tokens_per_s" in p2k:
+        result["config"]["prefill_2048_tokens_per_s"] = round(p2k["tokens_per_s"], 1)
     # the reference's user-facing flow (LlamaRunner.run: load once, 8-token prompt batches, one llama_eval and one
     # host-side top-k / top-p sample per token, token text through the event callback) -- not the headline metric
     try:

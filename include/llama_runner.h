@@ -21,6 +21,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations of this header are its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define LLAMA_ERROR_DOMAIN "com.alexrozanski.llama.error"   /* LlamaError.m:10 */
 
@@ -67,6 +71,9 @@ int32_t llama_runner_bridge_run(llama_runner_bridge *b, const char *prompt, cons
 
 void llama_runner_config_default(llama_runner_config *c);                       /* Config.default */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

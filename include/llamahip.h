@@ -39,6 +39,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations of this header are its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define LLAMAHIP_OK            0
 #define LLAMAHIP_ERR_UNKNOWN   (-1)      /* LlamaErrorCodeUnknown            (LlamaError.h:15) */
@@ -287,6 +291,8 @@ int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t 
  * {matrix-core (k_gemm_mfma), short-eval (k_gemm_skinny), row-per-lane (k_gemm_rows), LDS-staged, mat-vec}:
  * lets a test assert that a shape took the path it is meant to.  Returns the number of families. */
 int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap);
+/* in-kernel phase records of the few-row mat-mul (measurement builds only; 0 records in the product build) */
+int64_t llamahip_debug_set_probe(uint64_t *records, int64_t cap, int32_t reset);
 
 /* Bit 0 / bit 1: the decode kernels evaluate the reference's SiLU / exp fp16 tables with device arithmetic instead of
  * gathering them -- enabled only after a load-time check that all 65 536 entries are reproduced.  0 before any load. */
@@ -304,6 +310,9 @@ int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out);
 
 const char *llamahip_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -52,14 +52,65 @@ __device__ __forceinline__ void set_store_tagged(uint64_t *p, float v, uint32_t 
 struct GemvSetArgs {
     const uint8_t *wt; int ngroups, nchunks, M, gmapF8;
     const uint32_t *qa_A; const float *qa_d;        // [ncols] operand rows: nchunks * 64 dwords / nchunks * 8 floats apart
-    int ncols, rgw;                                  // rgw: row-groups per workgroup (waves = rgw * CW)
+    int ncols, rgw, ncg;                             // rgw: row-groups per workgroup (waves = rgw * CW); ncg: column groups of NC * CW columns (grid level)
     float *y; long y_stride; const float *resid; long resid_stride;
     const uint16_t *T_silu; uint32_t *out_A; float *out_d; long out_strideA, out_strideD;
     RopeKvArgs ra;
     uint64_t *amax_t; const uint32_t *epoch; int layer; uint32_t *fault; int lut_math;      // EPI_SILU_QAH (lut_math as GemvArgs: bit 0 SiLU evaluated, 0x1000 fault-injection test)
+    unsigned long long *probe;                      // LH_SET_PROBE builds: [0] record counter, [1] capacity, records of 32 words from [32]
 };
 
-constexpr int SET_DR = 4;                            // register ring of a wave: chunks in flight (2 loads each)
+// LH_SET_ABLATE (measurement builds only, tools/build_set_variants.sh; results are wrong): 1 = no arithmetic (what the launch shape streams),
+// 2 = no weight loads inside the loop (arithmetic, LDS traffic and barriers alone)
+#ifndef LH_SET_ABLATE
+#define LH_SET_ABLATE 0
+#endif
+// LH_SET_PROBE (measurement build, tools/set_timeline.py): wave 0 of every workgroup stamps s_memtime at the phase boundaries and inside its
+// first steps into a record of 32 words: [0] wall clock at entry | [1] entry | [2] loads issued | [3] operands staged | [4 + 3 s + {0, 1, 2}] step s
+// (s < 4): start, its chunk has landed, behind the barrier (the items end where the next step starts) | [24] loop done | [25] exit | [26] wall clock at exit | [27] id
+#ifndef LH_SET_PROBE
+#define LH_SET_PROBE 0
+#endif
+#if LH_SET_PROBE
+#define LH_PSTAMP(IDX) do { if (probe_on) probe_t[IDX] = __builtin_readcyclecounter(); } while (0)      /* probe_t: LDS, behind the ring */
+#else
+#define LH_PSTAMP(IDX) do { } while (0)
+#endif
+// The weight ring lives in LDS and is filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB of LDS, no VGPRs, no ds_write):
+// SET_DR slots of CW chunks per row-group, SET_DR - 1 steps in flight.  (The first version kept the ring in registers and published
+// every chunk with a ds_write.  Its in-kernel timeline, profiles/r05_t_timeline.txt: 3.0 - 6.5 us between "ring issued" and the first
+// step -- the operand rows were requested BEHIND the ring and vmcnt retires in order, and the register copies the compiler places in
+// front of a loop that carries a ring made every wave wait for ALL of its prefill, i.e. for the far end of its rows, before step 0.)
+#ifndef LH_SET_DR
+#define LH_SET_DR 4
+#endif
+constexpr int SET_DR = LH_SET_DR;
+// LDS operands of an item (chunk, column) are requested SET_PF items ahead into a ring of SET_PF + 1 register buffers.
+#ifndef LH_SET_PF
+#define LH_SET_PF 3
+#endif
+constexpr int SET_PF = LH_SET_PF, SET_NB = SET_PF + 1;
+static_assert((SET_DR % SET_NB) == 0 || SET_NB == 2, "the operand-buffer index is the item's position in the unrolled block of SET_DR steps");
+
+// one wave instruction of LDS-DMA: lane l's 16 (4) bytes at `base + voff` land in LDS at `lds_dst + 16 l` (`+ 4 l`); lds_dst, base wave-uniform
+__device__ __forceinline__ void set_dma16(uint32_t lds_dst, uint64_t base, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+}
+__device__ __forceinline__ void set_dma16_cached(uint32_t lds_dst, uint64_t base, uint32_t voff) {      // operand rows: every workgroup reads them
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+}
+__device__ __forceinline__ void set_dma4(uint32_t lds_dst, uint64_t base, uint32_t voff, bool nt) {
+    uint32_t keep;
+    if (nt) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                      : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+}
+template <int N> __device__ __forceinline__ void set_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // threads a launch may ask for: half-block workgroups are 4 row-groups x CW waves, the others at most 8 waves
 template <int CW, int EPI> constexpr int set_max_threads() { return EPI == EPI_SILU_QAH ? (CW * 256 > 512 ? CW * 256 : 512) : 512; }
@@ -69,74 +120,100 @@ __global__ void __launch_bounds__((set_max_threads<CW, EPI>()))
 k_gemv_set(const GemvSetArgs a) {
     constexpr int DR = SET_DR, NCW = NC * CW;
     constexpr bool SHARE = CW > 1;
-    static_assert((DR & 1) == 0, "stage parity and operand-buffer parity are taken from the unrolled step index");
     extern __shared__ double smem_d[];
-    const int nchunks = a.nchunks, ncols = a.ncols, rgw = a.rgw;
+    // grid: blockIdx -> (row block `blk`, column group `cg`); the column groups of a row block sit on one XCD, 8 apart in dispatch order
+    // (their weight tiles meet in that XCD's L2), as in k_gemm_skinny.  One group (ncg = 1): blk = blockIdx.
+    const int bid = blockIdx.x, cg = (bid >> 3) % a.ncg, blk = ((bid >> 3) / a.ncg) * 8 + (bid & 7);
+    const int col0 = cg * NCW;
+    const int nchunks = a.nchunks, ncols = min(NCW, a.ncols - col0), rgw = a.rgw;      // this group's columns: col0 .. col0 + ncols - 1
+    const uint32_t *qa_A = a.qa_A + (size_t) col0 * nchunks * 64;
+    const float *qa_d = a.qa_d + (size_t) col0 * nchunks * 8;
     const int steps = (nchunks + CW - 1) / CW;
-    const int npad = steps * CW + 1;                                // chunks per column in LDS: the step grid + the one-ahead operand fetch
-    u32x4 *sA = (u32x4 *) smem_d;                                   // [ncols][npad][16]
+    const int npad = steps * CW + SET_PF;                           // chunks per column in LDS: the step grid + the operand fetches SET_PF items ahead
+    u32x4 *sA = (u32x4 *) smem_d;                                   // [ncols][npad][16]: a chunk is [half][chain] (the eight chains' 16-byte reads of one half are 128 contiguous bytes: all 32 banks once)
     f32x2 *sD = (f32x2 *) (sA + (size_t) ncols * npad * 16);        // [ncols][npad][4]: {d[t], d[t + 4]} -- lane t of a quad owns blocks t and t + 4
-    uint8_t *stage = (uint8_t *) (sD + (size_t) ncols * npad * 4);  // [2][rgw][CW][TILE_BYTES]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nt = (int) blockDim.x;
+    uint8_t *ring = (uint8_t *) (sD + (size_t) ncols * npad * 4);   // [rgw][DR][CW][TILE_BYTES]: slot s % DR of a row-group holds the CW chunks of step s
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int) (blockDim.x >> 6), nt = (int) blockDim.x;
     const int rgi = wave / CW, ci = wave - rgi * CW;
-    const int blk = blockIdx.x;
     // (EPI_SILU_QAH: workgroup blk = half `(blk >> 3) & 1` of activation block `(blk >> 4) * 8 + (blk & 7)` -- the halves of a block are 8
     //  apart in the grid, one XCD; rgi 0, 1 = the half's two gate row-groups, rgi 2, 3 = the matching up row-groups of the interleaved order)
     const int qah_block = (blk >> 4) * 8 + (blk & 7), qah_half = (blk >> 3) & 1;
     const int g = EPI == EPI_SILU_QAH ? qah_block * 8 + (rgi >> 1) * 4 + qah_half * 2 + (rgi & 1) : blk * rgw + rgi;
     const bool valid = g < a.ngroups;
-    const uint8_t *wbase = a.wt + (size_t) (valid ? g : a.ngroups - 1) * (nchunks + 1) * TILE_BYTES;
+    const uint64_t wbase = (uint64_t) (uintptr_t) (a.wt + (size_t) (valid ? g : a.ngroups - 1) * (nchunks + 1) * TILE_BYTES);
     const int k = lane & 7, t = lane & 3;
     const int woff = lane * 16, soff = 1024 + ((lane >> 3) * 8 + t * 2) * 4;
     const uint32_t store_tag = EPI == EPI_SILU_QAH ? make_tag(__builtin_nontemporal_load(a.epoch), a.layer + 1) : 0u;
-
-    u32x4 wq[DR];
-    f32x2 ws[DR];
-#define LH_LOADW(SLOT, CH)                                                                         \
+    const uint32_t ring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) ring + (uint32_t) rgi * (DR * CW * TILE_BYTES);
+    const uint8_t *ring_rg = ring + (size_t) rgi * (DR * CW * TILE_BYTES);
+#if LH_SET_PROBE
+    const bool probe_on = a.probe != nullptr && tid == 0;
+    unsigned long long *probe_t = (unsigned long long *) (ring + (size_t) rgw * DR * CW * TILE_BYTES);
+    if (probe_on) { for (int i = 0; i < 28; i++) probe_t[i] = 0; probe_t[0] = wall_clock64(); }
+#endif
+    LH_PSTAMP(1);
+    // this wave's chunk of step S goes into slot (S % DR, ci): two DMA instructions (1 KiB of nibbles, 256 B of scales); chunks past the row
+    // end read the zero tile that closes every row-group (scale 0 -> fma(0 * d_a, p, acc) == acc)
+#define LH_DMAW(SLOTI, S)                                                                          \
     {                                                                                              \
-        const uint8_t *tp_ = wbase + (size_t) min((CH), nchunks) * TILE_BYTES;   /* tile `nchunks` is the zero tile */ \
-        wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + woff));                       \
-        ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + soff));                       \
+        const uint64_t tp_ = wbase + (uint64_t) min((S) * CW + ci, nchunks) * TILE_BYTES;          \
+        const uint32_t dst_ = ring_lds + (uint32_t) (((SLOTI) * CW + ci) * TILE_BYTES);            \
+        set_dma16(dst_, tp_, (uint32_t) woff);                                                     \
+        set_dma4(dst_ + 1024u, tp_ + 1024u, (uint32_t) lane * 4u, true);                           \
     }
-    // this wave's chunks are ci, ci + CW, ci + 2 CW, ...: the first DR of them go out before anything else
+    // ---- prologue.  vmcnt retires in order, so the order of issue is the order of arrival: the epilogue's operands (residual values, the
+    // rows' positions) first, then the operand rows of all columns (LDS-DMA, permuted into the LDS layout by per-lane source addresses),
+    // then the first DR - 1 steps of the weight ring; ONE counted wait leaves the ring in flight and the loop starts on the first chunk.
+    float resid_v[NC];
+    int rope_pos[NC];
+    long rope_kvo[NC];
 #pragma unroll
-    for (int i = 0; i < DR; i++) LH_LOADW(i, i * CW + ci)
-    __builtin_amdgcn_sched_barrier(0);
-    // stage the columns' operands
+    for (int n = 0; n < NC; n++) { resid_v[n] = 0.0f; rope_pos[n] = 0; rope_kvo[n] = 0; }
     {
-        constexpr int LB = 8;
-        const int perA = nchunks * 16, perD = nchunks * 2;        // granules of 16 bytes per operand row
-        const int totA = ncols * perA, totD = ncols * perD;
-        for (int base = tid; base < totA; base += nt * LB) {
-            u32x4 v[LB];
+        int lg0 = g;
+        if (a.gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : a.gmapF8 + b8 * 4 + (w8 - 4); }
+        const int m0 = min(lg0 * 8 + (lane >> 3), a.M - 1);
 #pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = min(base + u * nt, totA - 1), n = i / perA, r = i - n * perA;
-                v[u] = ((const u32x4 *) a.qa_A)[(long) n * perA + r];
-            }
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = base + u * nt, n = i / perA, r = i - n * perA;
-                if (i < totA) sA[(size_t) n * npad * 16 + r] = v[u];
+        for (int n = 0; n < NC; n++) {
+            const int col = col0 + min(ci * NC + n, ncols - 1);
+            if (EPI == EPI_RESID) resid_v[n] = a.resid[(size_t) col * a.resid_stride + m0];
+            if (EPI == EPI_ROPE_KV) {
+                // (batched decode step: the row's own position -- gathered into the descriptor by the step's first launch -- and cache)
+                rope_pos[n] = a.ra.set ? a.ra.set->pos[col] : a.ra.n_past + col;      // (col: the global column)
+                rope_kvo[n] = a.ra.set ? a.ra.set->kv_off[col] : 0L;
             }
         }
-        float *sDf = (float *) sD;
-        for (int base = tid; base < totD; base += nt * LB) {
-            f32x4 v[LB];
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = min(base + u * nt, totD - 1), n = i / perD, r = i - n * perD;
-                v[u] = ((const f32x4 *) a.qa_d)[(long) n * perD + r];
-            }
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = base + u * nt, n = i / perD, r = i - n * perD;
-                if (i < totD) {                                   // granule r = blocks 4 (r & 1) .. + 3 of chunk r >> 1
-                    float *o = sDf + ((size_t) n * npad + (r >> 1)) * 8 + (r & 1);
-                    o[0] = v[u].x; o[2] = v[u].y; o[4] = v[u].z; o[6] = v[u].w;
-                }
-            }
+    }
+    {
+        // operand rows: LDS granule L of a column = (chunk L >> 4, half (L >> 3) & 1, chain L & 7)  <-  QA granule (chunk, chain, half);
+        // d pairs: LDS float f of a chunk = (t = f >> 1, h = f & 1)  <-  d[4 h + t].  A wave instruction fills 64 consecutive LDS granules
+        // (floats) of one column: the permutation is a per-lane constant, everything else is wave-uniform (scalar); the instructions are
+        // dealt to the waves round-robin (lanes past a row's end are masked).
+        const int perA = nchunks * 16, perDf = nchunks * 8;
+        const int ipcA = (perA + 63) >> 6, ipcD = (perDf + 63) >> 6;
+        const uint32_t sA_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) (uint8_t *) sA;
+        const uint32_t sD_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) (uint8_t *) sD;
+        const uint32_t laneA = (uint32_t) (((lane & ~15) + (lane & 7) * 2 + ((lane >> 3) & 1)) * 16);
+        const uint32_t laneD = (uint32_t) (((lane & ~7) + (lane & 1) * 4 + ((lane >> 1) & 3)) * 4);
+        int n = wave / ipcA, b = wave - n * ipcA;
+        for (int q = wave; q < ncols * ipcA; q += nw) {
+            if (b * 64 + lane < perA)
+                set_dma16_cached(sA_lds + (uint32_t) ((n * npad * 16 + b * 64) * 16), (uint64_t) (uintptr_t) qa_A + ((uint64_t) n * perA + (uint64_t) b * 64) * 16, laneA);
+            b += nw;
+            while (b >= ipcA) { b -= ipcA; n++; }
         }
+        n = wave / ipcD; b = wave - n * ipcD;
+        for (int q = wave; q < ncols * ipcD; q += nw) {
+            if (b * 64 + lane < perDf)
+                set_dma4(sD_lds + (uint32_t) ((n * npad * 8 + b * 64) * 4), (uint64_t) (uintptr_t) qa_d + ((uint64_t) n * perDf + (uint64_t) b * 64) * 4, laneD, false);
+            b += nw;
+            while (b >= ipcD) { b -= ipcD; n++; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DR - 1; i++) LH_DMAW(i, i)
+    LH_PSTAMP(2);
+    {
         const int zc = npad - nchunks;                             // zeroed chunks behind every column: A 16 granules, d 8 floats each
         for (int i = tid; i < ncols * zc * 18; i += nt) {
             const int n = i / (zc * 18), r = i - n * (zc * 18);
@@ -144,11 +221,9 @@ k_gemv_set(const GemvSetArgs a) {
             else ((f32x4 *) sD)[((size_t) n * npad + nchunks) * 2 + (r - zc * 16)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
     }
-    // (see k_gemm_skinny: after loops with run-time trip counts the compiler no longer knows the age of the ring loads; draining here
-    //  makes the loop's entry state exact and the waits inside become the counted ones of the back edge.  The staging loads were
-    //  issued behind the ring's and vmcnt retires in order, so this waits for nothing the first step would not wait for.)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), nothing else
-    __syncthreads();
+    set_wait_vmcnt<2 * (DR - 1)>();                                // everything older than the ring: this wave's share of the operand rows
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and everybody else's (a __syncthreads() would wait for the ring as well)
+    LH_PSTAMP(3);
 
     float accs[NC];
 #pragma unroll
@@ -158,19 +233,17 @@ k_gemv_set(const GemvSetArgs a) {
     int colofs[NC];
 #pragma unroll
     for (int n = 0; n < NC; n++) colofs[n] = min(ncol0 + n, ncols - 1) * npad;
-    // operands of item (chunk, column) are fetched one item ahead into the other half of a two-entry register buffer; the weights of
-    // chunk c + 1 of a step while chunk c is consumed
-    u32x4 la0[2], la1[2], wb[2];
-    f32x2 ldd[2], wsb[2];
+    u32x4 la0[SET_NB], la1[SET_NB], wb[2];
+    f32x2 ldd[SET_NB], wsb[2];
 #define LH_LDSA(BUF, N, CH)                                                                        \
     {                                                                                              \
-        const u32x4 *pa_ = sA + (colofs[N] + (CH)) * 16 + k * 2;                                   \
-        la0[BUF] = pa_[0]; la1[BUF] = pa_[1];                                                      \
+        const u32x4 *pa_ = sA + (colofs[N] + (CH)) * 16 + k;                                       \
+        la0[BUF] = pa_[0]; la1[BUF] = pa_[8];                                                      \
         ldd[BUF] = sD[(colofs[N] + (CH)) * 4 + t];                                                 \
     }
-#define LH_LDSW(BUF, PAR, C)                                                                       \
+#define LH_LDSW(BUF, SLOTI, C)                                                                     \
     {                                                                                              \
-        const uint8_t *sp_ = stage + (size_t) ((((PAR) * rgw + rgi) * CW) + (C)) * TILE_BYTES;     \
+        const uint8_t *sp_ = ring_rg + (size_t) (((SLOTI) * CW) + (C)) * TILE_BYTES;               \
         wb[BUF] = *(const u32x4 *) (sp_ + woff); wsb[BUF] = *(const f32x2 *) (sp_ + soff);         \
     }
     // one (chunk, column) item: 8 integer dots onto the bits of 1.5 * 2^23, 4 packed subtractions, 2 scale products, the block-ordered
@@ -192,40 +265,37 @@ k_gemv_set(const GemvSetArgs a) {
         const f32x2 q23_ = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
         const f32x2 q45_ = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
         const f32x2 q67_ = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
-        LH_FMAC8_DPP(ACC, plo_, phi_, q01_, q23_, q45_, q67_);                                     \
+        if (LH_SET_ABLATE != 1) LH_FMAC8_DPP(ACC, plo_, phi_, q01_, q23_, q45_, q67_);              \
     }
-    // step S (I = S % DR, compile time): this wave's chunk of the step sits in ring slot I.  Publish it, refill the slot with this wave's
-    // chunk of step S + DR, barrier, then the CW chunks of the step in block order against this wave's NC columns.  The stage has
-    // two parities: step S + 1 writes the other one, and a wave reaches the barrier of step S + 1 only after it has read everything of
-    // step S, so the writes of step S + 2 (behind that barrier) cannot overtake a reader.
-#define LH_SSTEP(I, S)                                                                              \
+    // step S (I = S % DR, compile time).  This wave's chunk of the step is DR - 1 steps old: wait for it (counted: the DR - 2 younger steps
+    // stay in flight), then -- CW > 1 -- one workgroup barrier: every wave's chunk of step S has landed AND every wave is done reading
+    // step S - 1, whose slot the DMA for step S + DR - 1 may now overwrite.  Then the CW chunks of the step in block order against this
+    // wave's NC columns.  (CW = 1: the wave shares its ring with nobody; its own reads of step S - 1 have returned, no barrier.)
+#define LH_SSTEP(I, S)                                                                             \
     {                                                                                              \
-        const int par_ = (I) & 1;                                                                  \
-        if (SHARE) {                                                                               \
-            uint8_t *sp_ = stage + (size_t) (((par_ * rgw + rgi) * CW) + ci) * TILE_BYTES;         \
-            *(u32x4 *) (sp_ + woff) = wq[I]; *(f32x2 *) (sp_ + soff) = ws[I];                      \
-            LH_LOADW(I, ((S) + DR) * CW + ci)                                                      \
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
-            LH_LDSW(0, par_, 0)                                                                    \
-        }                                                                                          \
+        if (s0 == 0) LH_PSTAMP(4 + 3 * (I));                                                       \
+        set_wait_vmcnt<2 * (DR - 2)>();                                                            \
+        if (s0 == 0) LH_PSTAMP(5 + 3 * (I));                                                       \
+        if (SHARE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 \
+        if (s0 == 0) LH_PSTAMP(6 + 3 * (I));                                                       \
+        if (LH_SET_ABLATE != 2) LH_DMAW(((I) + DR - 1) % DR, (S) + DR - 1)                         \
+        LH_LDSW(0, (I), 0)                                                                         \
         _Pragma("unroll")                                                                          \
         for (int c = 0; c < CW; c++) {                                                             \
-            if (SHARE && c + 1 < CW) LH_LDSW((c + 1) & 1, par_, c + 1)                             \
+            if (c + 1 < CW) LH_LDSW((c + 1) & 1, (I), c + 1)                                       \
             _Pragma("unroll")                                                                      \
             for (int n = 0; n < NC; n++) {                                                         \
-                const int pb_ = ((I) * NCW + c * NC + n) & 1;                                      \
-                if (n + 1 < NC) LH_LDSA(pb_ ^ 1, n + 1, (S) * CW + c)                              \
-                else LH_LDSA(pb_ ^ 1, 0, (S) * CW + c + 1)                                         \
-                __builtin_amdgcn_sched_barrier(0);      /* the reads for the next item go out before this item's arithmetic */ \
-                if (SHARE) LH_ITEM(wb[c & 1], wsb[c & 1], pb_, accs[n])                            \
-                else LH_ITEM(wq[I], ws[I], pb_, accs[n])                                           \
+                const int it_ = (I) * NCW + c * NC + n;        /* item index in the unrolled block */   \
+                const int pb_ = it_ % SET_NB;                                                      \
+                LH_LDSA((it_ + SET_PF) % SET_NB, (n + SET_PF) % NC, (S) * CW + c + (n + SET_PF) / NC) \
+                __builtin_amdgcn_sched_barrier(0);      /* the reads for the items ahead go out before this item's arithmetic */ \
+                LH_ITEM(wb[c & 1], wsb[c & 1], pb_, accs[n])                                       \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
             }                                                                                      \
         }                                                                                          \
-        if (!SHARE) LH_LOADW(I, ((S) + DR) * CW + ci)                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
     }
-    LH_LDSA(0, 0, 0)
+#pragma unroll
+    for (int i = 0; i < SET_PF; i++) LH_LDSA(i, i % NC, i / NC)
     int s0 = 0;
     for (; s0 + DR <= steps; s0 += DR) {
 #pragma unroll
@@ -235,17 +305,27 @@ k_gemv_set(const GemvSetArgs a) {
 #pragma unroll
     for (int i = 0; i < DR - 1; i++)
         if (s0 + i < steps) LH_SSTEP(i, s0 + i)
+    set_wait_vmcnt<0>();                                           // (the ring's last requests are zero tiles: nothing may still be landing in LDS below)
+    LH_PSTAMP(24);
 #undef LH_SSTEP
 #undef LH_ITEM
 #undef LH_LDSW
 #undef LH_LDSA
-#undef LH_LOADW
+#undef LH_DMAW
 
+#if LH_SET_PROBE
+#define LH_PFLUSH() do { if (probe_on) { probe_t[25] = __builtin_readcyclecounter(); probe_t[26] = wall_clock64();                       \
+        probe_t[27] = ((unsigned long long) NC << 56) | ((unsigned long long) CW << 48) | ((unsigned long long) EPI << 40) | ((unsigned long long) nchunks << 24) | (unsigned) blk; \
+        const unsigned long long slot_ = atomicAdd(a.probe, 1ull);                                                                      \
+        if (slot_ < a.probe[1]) { unsigned long long *e_ = a.probe + 32 * (1 + slot_); for (int i_ = 0; i_ < 28; i_++) e_[i_] = probe_t[i_]; } } } while (0)
+#else
+#define LH_PFLUSH() do { } while (0)
+#endif
     int lg = g;
     if (a.gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : a.gmapF8 + b8 * 4 + (w8 - 4); }
     const int m = lg * 8 + (lane >> 3);
     if (EPI == EPI_SILU_QAH) {
-        // the workgroup's 32 outputs per column: gu[column][gate 0 .. 15 | up 0 .. 15]; the operand staging area is free again
+        // the workgroup's 32 outputs per column: gu[column][gate 0 .. 15 | up 0 .. 15]; the operand area is free again
         float *gu = (float *) smem_d;
         __syncthreads();
 #pragma unroll
@@ -255,14 +335,15 @@ k_gemv_set(const GemvSetArgs a) {
         }
         __syncthreads();
         const bool inject = (a.lut_math & 0x1000) != 0;                       // fault-injection test: a tag nobody waits for, short polls
-        for (int col = wave; col < NCW; col += (int) (blockDim.x >> 6)) {
+        for (int col = wave; col < NCW; col += nw) {
             if (col >= ncols || qah_block * 8 >= a.ngroups) continue;
             const int i = lane & 15;
             const uint16_t gh = f2h_bits(gu[col * 32 + i]);
             const float act = h2f_bits((a.lut_math & 1) ? silu_math_bits(gh) : a.T_silu[gh]) * gu[col * 32 + 16 + i];
             float amax = wave_max_f(lane < 16 ? fabsf(act) : 0.0f);
             // the other half's partial amax of this column: one tagged granule each way inside this XCD's L2
-            uint64_t *at = a.amax_t + (size_t) col * ((size_t) (a.ngroups / 8) * 2 + 16);
+            const int gcol = col0 + col;
+            uint64_t *at = a.amax_t + (size_t) gcol * ((size_t) (a.ngroups / 8) * 2 + 16);
             const int hb = qah_block * 2 + qah_half;
             float other = 0.0f;
             if (lane == 0) {
@@ -277,80 +358,106 @@ k_gemv_set(const GemvSetArgs a) {
             const int kk = lane & 7;
             const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
             const int b = qah_block, c = b >> 3, j = b & 7;
-            uint32_t *oA = a.out_A + (size_t) col * a.out_strideA;
+            uint32_t *oA = a.out_A + (size_t) gcol * a.out_strideA;
             if (lane < 8) ((uint16_t *) (oA + (c * 8 + kk) * 8 + j))[qah_half] = (uint16_t) ((e0 | (e1 << 8)) << (4 * (j & 1)));
-            if (lane == 0 && qah_half == 0) a.out_d[(size_t) col * a.out_strideD + b] = dd;
+            if (lane == 0 && qah_half == 0) a.out_d[(size_t) gcol * a.out_strideD + b] = dd;
         }
+        LH_PFLUSH();
+        return;
+    }
+    if (EPI == EPI_ROPE_KV) {
+        // (ggml.c:7076-7131, .mm:586-611; k_rope_kv) rows m, m ^ 1 = lanes 8 apart; m is even iff the lane's row is.  The table entries of
+        // all columns are requested together (one round trip), then the rotations
+        const RopeKvArgs &ra = a.ra;
+        const int which = m / ra.d, c = m - which * ra.d, pe = (c % ra.dh) & ~1;
+        const bool live = valid && k == 0 && m < a.M;
+        double cs[NC], sn[NC];
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            cs[n] = 1.0; sn[n] = 0.0;
+            if (live && which != 2) { cs[n] = ra.tab[(size_t) rope_pos[n] * ra.dh + pe]; sn[n] = ra.tab[(size_t) rope_pos[n] * ra.dh + pe + 1]; }
+        }
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float acc = fold8(accs[n]);
+            const int col = ncol0 + n;
+            const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
+            if (live && col < ncols) {
+                const int pos = rope_pos[n];
+                const long kvo = rope_kvo[n];
+                if (which == 2) {
+                    ra.Vc[kvo + (size_t) pos * ra.d + c] = acc;
+                } else {
+                    const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
+                    const float val = (c & 1) ? (float) (x0 * sn[n] + x1 * cs[n]) : (float) (x0 * cs[n] - x1 * sn[n]);
+                    if (which == 0) ra.qr[(size_t) (col0 + col) * ra.d + c] = val;
+                    else ra.Kc[kvo + (size_t) pos * ra.d + c] = val;
+                }
+            }
+        }
+        LH_PFLUSH();
         return;
     }
 #pragma unroll
     for (int n = 0; n < NC; n++) {
         float acc = fold8(accs[n]);
         const int col = ncol0 + n;
-        if (EPI == EPI_ROPE_KV) {
-            // (ggml.c:7076-7131, .mm:586-611; k_rope_kv) rows m, m ^ 1 = lanes 8 apart; m is even iff the lane's row is
-            const RopeKvArgs &ra = a.ra;
-            const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
-            if (valid && k == 0 && m < a.M && col < ncols) {
-                const int which = m / ra.d, c = m - which * ra.d;
-                // (batched decode step: the row's own position and cache)
-                const int pos = ra.set ? ra.set->state[col][0] : ra.n_past + col;
-                const long kvo = ra.set ? ra.set->kv_off[col] : 0L;
-                if (which == 2) {
-                    ra.Vc[kvo + (size_t) pos * ra.d + c] = acc;
-                } else {
-                    const int pe = (c % ra.dh) & ~1;
-                    const double cs = ra.tab[(size_t) pos * ra.dh + pe], sn = ra.tab[(size_t) pos * ra.dh + pe + 1];
-                    const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
-                    const float val = (c & 1) ? (float) (x0 * sn + x1 * cs) : (float) (x0 * cs - x1 * sn);
-                    if (which == 0) ra.qr[(size_t) col * ra.d + c] = val;
-                    else ra.Kc[kvo + (size_t) pos * ra.d + c] = val;
-                }
-            }
-            continue;
-        }
         if (valid && k == 0 && m < a.M && col < ncols) {
-            if (EPI == EPI_RESID) acc = acc + a.resid[(size_t) col * a.resid_stride + m];
-            a.y[(size_t) col * a.y_stride + m] = acc;
+            if (EPI == EPI_RESID) acc = acc + resid_v[n];
+            a.y[(size_t) (col0 + col) * a.y_stride + m] = acc;
         }
     }
+    LH_PFLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side: the (NC, CW) plan per row count, launchers
 // ------------------------------------------------------------------------------------------------
-struct SetPlan { int nc = 0, cw = 0, rgw = 0; size_t lds = 0; };
+struct SetPlan { int nc = 0, cw = 0, rgw = 0, ncg = 1; size_t lds = 0; };
 
-static size_t set_lds_bytes(const QMat &w, int N, int nc, int cw, int rgw) {
-    const int steps = (w.nchunks + cw - 1) / cw, npad = steps * cw + 1;
-    size_t lds = (size_t) N * npad * 288 + (cw > 1 ? (size_t) 2 * rgw * cw * TILE_BYTES : 0);
+static size_t set_lds_bytes(const QMat &w, int ncols_group, int nc, int cw, int rgw) {
+    const int steps = (w.nchunks + cw - 1) / cw, npad = steps * cw + SET_PF;
+    size_t lds = (size_t) ncols_group * npad * 288 + (size_t) rgw * SET_DR * cw * TILE_BYTES + (LH_SET_PROBE ? 256 : 0);
     return std::max(lds, (size_t) nc * cw * 64 * 4);
 }
 
-// Columns per wave and waves per row-group for N rows.  Small matrices (512 row-groups at 7B: wo, w2) need CW waves per row-group to put
-// two waves on every SIMD; on the large ones (wq|wk|wv, w1|w3, the lm head) the row-groups alone do that and wider waves save LDS reads
-// of the weights.  LLAMAHIP_SET_PLAN="nc,cw[,rgw]" overrides (measurement).
+// Columns per wave (nc), waves per row-group (cw) and column groups (ncg) for N rows.  What the in-kernel timelines say (profiles/r05_*):
+// a wave spends ~0.07 - 0.09 us per (chunk, column) item whatever shares its SIMD, a step of a shared ring costs a barrier (~0.3 us in a
+// 16-wave workgroup), and a launch ends when its longest wave does.  So: matrices with few row-groups (wo, w2: 512 at 7B) take cw waves per
+// row-group with one or two columns each (items per wave = chunks x nc); matrices with >= 1 024 row-groups (wq|wk|wv, w1|w3, the lm head)
+// have waves enough: up to four columns per wave, no sharing, and for more than four rows column GROUPS at grid level (the groups of a
+// row block run side by side on one XCD; the second read of a tile is an L2 hit hidden behind arithmetic -- at 8 rows these launches
+// are VALU bound).  LLAMAHIP_SET_PLAN[_BIG|_SMALL]="nc,cw[,ncg[,rgw]]" overrides (measurement).
+static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int &ncg, int &rgw) {
+    const char *env = getenv(name);
+    if (!env) return false;
+    int e_nc = 0, e_cw = 0, e_ncg = 0, e_rgw = 0;
+    const int got = sscanf(env, "%d,%d,%d,%d", &e_nc, &e_cw, &e_ncg, &e_rgw);
+    if (got < 2 || e_nc < 1 || e_nc > 4 || e_cw < 1 || e_cw > 4) return false;
+    if (got < 3 || e_ncg < 1) e_ncg = (N + e_nc * e_cw - 1) / (e_nc * e_cw);
+    if (e_nc * e_cw * e_ncg < N || (e_ncg - 1) * e_nc * e_cw >= N) return false;
+    nc = e_nc; cw = e_cw; ncg = e_ncg;
+    if (got >= 4 && e_rgw >= 1 && e_rgw <= 8 && epi != EPI_SILU_QAH) rgw = e_rgw;
+    return true;
+}
 static SetPlan set_plan(const QMat &w, int N, int epi) {
-    static const char *env = getenv("LLAMAHIP_SET_PLAN");
     SetPlan p;
-    int nc, cw;
+    int nc, cw, ncg = 1, rgw = 0;
     const bool big = w.ngroups >= 1024;
-    if (N <= 4) { if (big) { nc = N <= 2 ? N : 2; cw = (N + nc - 1) / nc; } else { nc = 1; cw = N; } }
+    if (big) { ncg = (N + 3) / 4; nc = (N + ncg - 1) / ncg; cw = 1; }            // balanced groups of <= 4 columns (9 rows: 3 + 3 + 3)
+    else if (N <= 4) { nc = 1; cw = N; }
     else if (N <= 6) { nc = 2; cw = 3; }
     else if (N <= 8) { nc = 2; cw = 4; }
     else if (N == 9) { nc = 3; cw = 3; }
     else if (N <= 12) { nc = 3; cw = 4; }
     else { nc = 4; cw = 4; }
-    int rgw = epi == EPI_SILU_QAH ? 4 : (cw >= 3 ? 2 : 4);
-    if (env) {
-        int e_nc = 0, e_cw = 0, e_rgw = 0;
-        const int got = sscanf(env, "%d,%d,%d", &e_nc, &e_cw, &e_rgw);
-        if (got >= 2 && e_nc >= 1 && e_nc <= 4 && e_cw >= 1 && e_cw <= 4 && e_nc * e_cw >= N) { nc = e_nc; cw = e_cw; }
-        if (got >= 3 && e_rgw >= 1 && e_rgw <= 8 && epi != EPI_SILU_QAH) rgw = e_rgw;
-    }
-    if (epi != EPI_SILU_QAH && rgw * cw > 8) rgw = 8 / cw;            // (set_max_threads)
-    p.nc = nc; p.cw = cw; p.rgw = rgw;
-    p.lds = set_lds_bytes(w, N, nc, cw, rgw);
+    if (!set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw)) set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
+    if (nc == 1 && cw == 1) { nc = 2; }                               // (no <1, 1> instantiation)
+    if (!rgw) rgw = epi == EPI_SILU_QAH ? 4 : (cw >= 3 ? 2 : 4);
+    if (epi == EPI_SILU_QAH) rgw = 4;
+    else if (rgw * cw > 8) rgw = 8 / cw;                              // (set_max_threads)
+    p.nc = nc; p.cw = cw; p.rgw = rgw; p.ncg = ncg;
+    p.lds = set_lds_bytes(w, std::min(N, nc * cw), nc, cw, rgw);
     return p;
 }
 
@@ -382,11 +489,32 @@ static hipError_t launch_set_t(const GemvSetArgs &a, int epi, int grid, int nthr
     return hipSuccess;
 }
 
+// LH_SET_PROBE builds: LLAMAHIP_SET_PROBE=<records> allocates the record buffer at the first launch; llamahip_debug_set_probe reads it
+static unsigned long long *g_set_probe = nullptr;
+static long g_set_probe_cap = 0;
+long set_probe_dump(unsigned long long *out, long cap_records, bool reset) {
+    if (!g_set_probe) return 0;
+    unsigned long long hdr[2] = { 0, 0 };
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(hdr, g_set_probe, sizeof(hdr), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const long n = (long) std::min<unsigned long long>(hdr[0], (unsigned long long) std::min(cap_records, g_set_probe_cap));
+    if (out && n > 0 && hipMemcpy(out, g_set_probe + 32, (size_t) n * 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset) { hdr[0] = 0; hdr[1] = (unsigned long long) g_set_probe_cap; (void) hipMemcpy(g_set_probe, hdr, sizeof(hdr), hipMemcpyHostToDevice); }
+    return n;
+}
 static hipError_t launch_set_any(const QMat &w, GemvSetArgs a, int epi, hipStream_t st) {
+#if LH_SET_PROBE
+    if (!g_set_probe && getenv("LLAMAHIP_SET_PROBE")) {
+        g_set_probe_cap = std::max(1L, atol(getenv("LLAMAHIP_SET_PROBE")));
+        if (hipMalloc((void **) &g_set_probe, (size_t) (g_set_probe_cap + 1) * 32 * 8) != hipSuccess) { g_set_probe = nullptr; g_set_probe_cap = 0; }
+        else { const unsigned long long hdr[2] = { 0, (unsigned long long) g_set_probe_cap }; (void) hipMemset(g_set_probe, 0, (size_t) (g_set_probe_cap + 1) * 32 * 8); (void) hipMemcpy(g_set_probe, hdr, sizeof(hdr), hipMemcpyHostToDevice); }
+    }
+    a.probe = g_set_probe;
+#endif
     const SetPlan p = set_plan(w, a.ncols, epi);
     if (p.lds > SET_LDS_CAP) return hipErrorInvalidValue;
-    a.rgw = p.rgw;
-    const int grid = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;
+    a.rgw = p.rgw; a.ncg = p.ncg;
+    const int nwg = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;
+    const int grid = p.ncg == 1 ? nwg : (nwg + 7) / 8 * 8 * p.ncg;
     const int nthreads = p.rgw * p.cw * 64;
 #define LH_SP(NCV, CWV) if (p.nc == NCV && p.cw == CWV) return launch_set_t<NCV, CWV>(a, epi, grid, nthreads, p.lds, st)
     LH_SP(1, 2); LH_SP(1, 3); LH_SP(1, 4);

@@ -1362,7 +1362,7 @@ int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
 }
 
 namespace {
-int ensure_slots(llamahip_model *m, char *err, size_t err_cap) {
+static int ensure_slots(llamahip_model *m, char *err, size_t err_cap) {
     if (!m->d_slot_state) {
         HIP_TRY(hipMalloc((void **) &m->d_slot_state, (size_t) m->n_seq * 2 * sizeof(int32_t)), LLAMAHIP_ERR_PREDICT);
         HIP_TRY(hipMalloc((void **) &m->d_slot_trace, (size_t) m->n_seq * m->hp.n_ctx * sizeof(int32_t)), LLAMAHIP_ERR_PREDICT);
@@ -1370,7 +1370,7 @@ int ensure_slots(llamahip_model *m, char *err, size_t err_cap) {
     }
     return 0;
 }
-int drop_slot_graphs(llamahip_model *m, int seq, char *err, size_t err_cap) {
+static int drop_slot_graphs(llamahip_model *m, int seq, char *err, size_t err_cap) {
     auto &sl = m->slots[seq];
     HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);
     for (auto &kv : sl.graphs) (void) hipGraphExecDestroy(kv.second);
@@ -1448,7 +1448,7 @@ int llamahip_stage_mailbox_connect(llamahip_model *m, int32_t seq, const void *n
 
 namespace {
 // the launches of one stage step, issued on m->stream (directly or under capture)
-int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, size_t err_cap) {
+static int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, size_t err_cap) {
     auto &sl = m->slots[seq];
     int32_t *state = m->d_slot_state + 2 * seq;
     StepIO io;
@@ -1527,18 +1527,15 @@ namespace {
 // llama_eval's graph works row by row (.mm:563-705), so row b is bit for bit a single-token llama_eval of its sequence: its own
 // position in RoPE / the KV append / the causal range, its own cache, and the V*P key split of ITS eval, n_past_b + 1 keys over
 // n_threads (ggml.c:5459-5480).  The weights are streamed once per step for all rows.
-int forward_set(llamahip_model *m, int nth, const SeqSet *d_set, int B, char *err, size_t err_cap) {
+static int forward_set(llamahip_model *m, int nth, SeqSet *d_set, int B, char *err, size_t err_cap) {
     const HParams &hp = m->hp;
     const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx, V = hp.n_vocab;
     hipStream_t st = m->stream;
-    if (m->first_stage) HIP_TRY(launch_embed_set(d_set, B, m->tok_emb, m->x, d, st), LLAMAHIP_ERR_PREDICT);                // .mm:558-561
-    else HIP_TRY(launch_rows_set(d_set, B, m->x, d, true, st), LLAMAHIP_ERR_PREDICT);
     const long KpF = ((long) F + 255) / 256 * 256;
-    SiluHalfIO set_hx;          // (see forward(): the half-block w1|w3 launch of k_gemv_set)
-    if (m->d_attn_sync && m->d_set_amax && m->l1 - m->l0 <= TAG_MAX_LAYERS) {
-        set_hx.amax_t = m->d_set_amax; set_hx.epoch = m->d_epoch; set_hx.fault = m->d_fault;
-        HIP_TRY(launch_bump_epoch(m->d_epoch, st), LLAMAHIP_ERR_PREDICT);
-    }
+    SiluHalfIO set_hx;          // (see forward(): the half-block w1|w3 launch of k_gemv_set; the step's first launch opens the epoch)
+    if (m->d_attn_sync && m->d_set_amax && m->l1 - m->l0 <= TAG_MAX_LAYERS) { set_hx.amax_t = m->d_set_amax; set_hx.epoch = m->d_epoch; set_hx.fault = m->d_fault; }
+    if (m->first_stage) HIP_TRY(launch_embed_set(d_set, B, m->tok_emb, m->x, d, st, set_hx.amax_t ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);                // .mm:558-561
+    else HIP_TRY(launch_rows_set(d_set, B, m->x, d, true, st, set_hx.amax_t ? m->d_epoch : nullptr), LLAMAHIP_ERR_PREDICT);
     for (int il = m->l0; il < m->l1; il++) {
         const Layer &L = m->layers[il - m->l0];
         set_hx.layer = il - m->l0;
@@ -1729,6 +1726,12 @@ int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t 
 }
 
 int32_t llamahip_debug_lut_math(void) { return g_lut_math; }
+
+// Phase records of the few-row kernel (k_gemv_set; libllamahip_setprobe.so built with -DLH_SET_PROBE=1 and LLAMAHIP_SET_PROBE=<capacity>):
+// copies up to `cap` records of 32 words and optionally clears the buffer.  Returns the number of records.  Measurement tooling only.
+int64_t llamahip_debug_set_probe(uint64_t *records, int64_t cap, int32_t reset) {
+    return (int64_t) set_probe_dump((unsigned long long *) records, (long) cap, reset != 0);
+}
 
 int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap) {
     for (int i = 0; out && i < cap && i < GEMM_PATH_COUNT; i++) out[i] = g_gemm_path_counts[i];

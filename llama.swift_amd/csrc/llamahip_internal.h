@@ -27,6 +27,8 @@ struct SeqSet {
     const float *hid_in[SET_MAX];       // stages after the first: the row of the residual stream coming in
     float *hid_out[SET_MAX];            // stages before the last: ... going out
     long kv_off[SET_MAX];               // elements from slot 0's KV cache to the row's slot's
+    int32_t pos[SET_MAX];               // the rows' positions of THIS step (= *state[i]), gathered by the step's first launch (k_embed_set / k_rows_set): one
+                                        // load instead of a pointer chase at the tail of the wq|wk|wv launch (written by the device, every step)
     int n;
 };
 // operands of the EPI_ROPE_KV epilogue (short evals, wq|wk|wv): rotate q / k, append k / v to the cache
@@ -176,12 +178,14 @@ hipError_t launch_gemv_set_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const
 hipError_t launch_gemv_set_silu(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
                                 uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, const SiluHalfIO &hx, hipStream_t st);
 hipError_t init_attrs_gemv_set();
+long set_probe_dump(unsigned long long *out, long cap_records, bool reset);      // LH_SET_PROBE builds (tools/set_timeline.py): records of 32 words
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
                              const uint16_t *T_exp, hipStream_t st, int chunk = 0, const SeqSet *set = nullptr);      // set: N independent single-row evals (batched decode step)
 // batched decode step: embedding rows / residual rows in and out / greedy picks of the set's rows
-hipError_t launch_embed_set(const SeqSet *set, int n, const uint8_t *emb, float *x, int d, hipStream_t st);
-hipError_t launch_rows_set(const SeqSet *set, int n, float *x, int d, bool gather, hipStream_t st);      // gather: hid_in -> x rows; else x rows -> hid_out
+// (the step's FIRST launch -- embed, or rows with gather -- also writes set->pos and, given the epoch word, opens the step's epoch)
+hipError_t launch_embed_set(SeqSet *set, int n, const uint8_t *emb, float *x, int d, hipStream_t st, uint32_t *epoch = nullptr);
+hipError_t launch_rows_set(SeqSet *set, int n, float *x, int d, bool gather, hipStream_t st, uint32_t *epoch = nullptr);      // gather: hid_in -> x rows; else x rows -> hid_out
 hipError_t launch_argmax_set(const float *logits, int V, const SeqSet *set, int n, hipStream_t st);   // + trace, tok_out, position advance
 hipError_t launch_advance_set(const SeqSet *set, int n, hipStream_t st);
 hipError_t launch_dec_attn(const float *qkv, int d, int H, int n_ctx, int nth, const double *tab, float *Kc, float *Vc,

@@ -121,8 +121,10 @@ __global__ void k_embed(const int32_t *__restrict__ tokens, const uint8_t *__res
 }
 
 // batched decode step: row n = the token at *set->tok_in[n] (same dequantization as k_embed)
-__global__ void k_embed_set(const SeqSet *__restrict__ set, const uint8_t *__restrict__ emb, float *__restrict__ x, int d) {
+// (the step's first launch also gathers the rows' positions into the descriptor and opens the step's epoch: see SeqSet::pos)
+__global__ void k_embed_set(SeqSet *set, const uint8_t *__restrict__ emb, float *__restrict__ x, int d, uint32_t *epoch) {
     const int n = blockIdx.x;
+    if (blockIdx.y == 0 && threadIdx.x == 0) { set->pos[n] = set->state[n][0]; if (epoch && n == 0) epoch[0] = next_epoch(epoch[0]); }
     const int tok = *set->tok_in[n];
     const uint8_t *row = emb + (size_t) tok * (d / 32) * 20;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < d / 2; i += gridDim.y * blockDim.x) {
@@ -136,8 +138,9 @@ __global__ void k_embed_set(const SeqSet *__restrict__ set, const uint8_t *__res
     }
 }
 // ... and the residual-stream rows of a pipeline stage's set: hid_in[n] -> x row n (gather) or x row n -> hid_out[n]
-__global__ void k_rows_set(const SeqSet *__restrict__ set, float *__restrict__ x, int d, int gather) {
+__global__ void k_rows_set(SeqSet *set, float *__restrict__ x, int d, int gather, uint32_t *epoch) {
     const int n = blockIdx.x;
+    if (gather && blockIdx.y == 0 && threadIdx.x == 0) { set->pos[n] = set->state[n][0]; if (epoch && n == 0) epoch[0] = next_epoch(epoch[0]); }
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < d; i += gridDim.y * blockDim.x) {
         if (gather) x[(size_t) n * d + i] = set->hid_in[n][i];
         else set->hid_out[n][i] = x[(size_t) n * d + i];
@@ -382,13 +385,13 @@ hipError_t launch_embed(const int32_t *tokens, const uint8_t *emb, float *x, int
     return hipSuccess;
 }
 
-hipError_t launch_embed_set(const SeqSet *set, int n, const uint8_t *emb, float *x, int d, hipStream_t st) {
-    hipLaunchKernelGGL(k_embed_set, dim3(n, (d / 2 + 255) / 256), dim3(256), 0, st, set, emb, x, d);
+hipError_t launch_embed_set(SeqSet *set, int n, const uint8_t *emb, float *x, int d, hipStream_t st, uint32_t *epoch) {
+    hipLaunchKernelGGL(k_embed_set, dim3(n, (d / 2 + 255) / 256), dim3(256), 0, st, set, emb, x, d, epoch);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_rows_set(const SeqSet *set, int n, float *x, int d, bool gather, hipStream_t st) {
-    hipLaunchKernelGGL(k_rows_set, dim3(n, (d + 1023) / 1024), dim3(256), 0, st, set, x, d, gather ? 1 : 0);
+hipError_t launch_rows_set(SeqSet *set, int n, float *x, int d, bool gather, hipStream_t st, uint32_t *epoch) {
+    hipLaunchKernelGGL(k_rows_set, dim3(n, (d + 1023) / 1024), dim3(256), 0, st, set, x, d, gather ? 1 : 0, epoch);
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -76,7 +76,9 @@ def test_tiny_model_golden(L, tmp_path, nth, flags):
                                    # every (columns per wave, waves per row-group) plan of the few-row kernel (k_gemv_set): small matrices ...
                                    (264, 4096, 3), (264, 4096, 4), (264, 4096, 6), (264, 4096, 7), (264, 4096, 11), (264, 4096, 16), (200, 11008, 9), (136, 1280, 12),
                                    # ... and matrices with >= 1 024 row-groups (two columns per wave up to four rows)
-                                   (8200, 512, 2), (8200, 512, 3), (8200, 768, 4)])
+                                   (8200, 512, 2), (8200, 512, 3), (8200, 768, 4),
+                                   # ... more than four rows on those: column groups at grid level (7: 4 + 3, 9: 3 + 3 + 3, 16: 4 x 4)
+                                   (8200, 512, 7), (8200, 512, 9), (8200, 768, 16)])
 def test_mul_mat_vs_oracle(L, oracle, M, K, N):
     rng = np.random.default_rng(M + K + N)
     w = synth.quantize_q4_0_offline((0.02 * rng.standard_normal((M, K))).astype(np.float32))

@@ -19,6 +19,19 @@ def test_library_exports_every_declared_symbol(L):
     missing = [s for s in L.declared_symbols() if not hasattr(lib, s)]
     assert not missing
     assert len(L.declared_symbols()) >= 25
+
+
+def test_library_exports_nothing_but_the_declared_c_abi(L):
+    """A drop-in library linked into someone's application exports llamahip_* / llama_runner_* only (the declarations of include/*.h):
+    no lh:: internals, no kernel host stubs, no stray helpers -- `nm -D --defined-only` against the headers."""
+    import subprocess
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llama.swift_amd", "csrc", "libllamahip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    declared = set(L.declared_symbols())
+    stray = [s for s in exported if s not in declared]
+    assert not stray, f"exported but not declared in include/*.h: {stray[:20]}"
+    assert all(s.startswith(("llamahip_", "llama_runner_")) for s in exported)
     assert L.version().startswith("llamahip")
 
 

@@ -37,4 +37,47 @@ EOV
   LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_BENCH_65B=0 LLAMAHIP_PIPE_NO_INSITU=1 timeout 600 python bench.py --steps 48 --warmup 4 > $O/${tag}_nccl_world1.json 2> $O/${tag}_nccl_world1.log
   grep -v "^$" $O/${tag}_nccl_world1.log | tail -25; head -c 1500 $O/${tag}_nccl_world1.json; echo
   ;;
+b)
+  # where the few-row kernel's time goes: ablation builds (make setab: no arithmetic | no weight loads in the loop | 8-deep ring)
+  cat > /tmp/v.txt <<EOV
+sa1|LLAMAHIP_LIB=libllamahip_sa1.so
+sa2|LLAMAHIP_LIB=libllamahip_sa2.so
+sa8|LLAMAHIP_LIB=libllamahip_sa8.so
+sa1_p41|LLAMAHIP_LIB=libllamahip_sa1.so LLAMAHIP_SET_PLAN=4,1
+sa2_p41|LLAMAHIP_LIB=libllamahip_sa2.so LLAMAHIP_SET_PLAN=4,1
+sa8_p41|LLAMAHIP_LIB=libllamahip_sa8.so LLAMAHIP_SET_PLAN=4,1
+EOV
+  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=4,8 EVALS=9 timeout 900 bash tools/set_ab.sh /tmp/v.txt > $O/${tag}_ablate.txt 2>&1
+  cat $O/${tag}_ablate.txt
+  ;;
+c)
+  # operand prefetch distance 3 (default build) against 1 (libllamahip_pf1.so), and the loop without its weight loads (sa2)
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks" > $O/${tag}_quick.txt 2>&1; tail -3 $O/${tag}_quick.txt
+  cat > /tmp/v.txt <<EOV
+pf3|
+pf1|LLAMAHIP_LIB=libllamahip_pf1.so
+pf3_sa2|LLAMAHIP_LIB=libllamahip_sa2.so
+pf3_p41|LLAMAHIP_SET_PLAN=4,1
+pf3_p42|LLAMAHIP_SET_PLAN=4,2
+EOV
+  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=4,8 EVALS=9 timeout 900 bash tools/set_ab.sh /tmp/v.txt > $O/${tag}_pf.txt 2>&1
+  grep -v "k_repack\|copyBuffer\|k_argmax\|fillBuffer\|k_embed" $O/${tag}_pf.txt
+  ;;
+d)
+  # generic A/B: variants from $VARIANTS (file), quick parity first
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks" > $O/${tag}_quick.txt 2>&1; tail -3 $O/${tag}_quick.txt
+  PROF=1 PROF_SEQS="${PROF_SEQS:-4 8}" PROF_EVALS=9 SEQS=${SEQS:-4,8} EVALS=9 timeout 900 bash tools/set_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_ab.txt 2>&1
+  grep -v "k_repack\|copyBuffer\|k_argmax\|fillBuffer\|k_embed" $O/${tag}_ab.txt
+  if [ -n "$TIMELINE" ]; then bash tools/gpu_pass.sh t ${tag}; fi
+  ;;
+t)
+  # in-kernel timelines of the few-row kernel (libllamahip_setprobe.so)
+  for spec in "--seqs 4" "--seqs 8" "--evals 9"; do
+    for plan in ${PLANS:-""}; do
+      echo "== set_timeline $spec plan=[$plan]"
+      LLAMAHIP_SET_PLAN=$plan timeout 300 python tools/set_timeline.py $spec 2>&1 | tail -12
+    done
+  done > $O/${tag}_timeline.txt 2>&1
+  cat $O/${tag}_timeline.txt
+  ;;
 esac
