@@ -3,20 +3,27 @@
 // .mm:880-888).  Same arithmetic and order as k_gemv (ggml_compute_forward_mul_mat_q4_0_f32, ggml.c:5987-6285, N > 1: 6134-6152,
 // 6182-6222; vec_dot ggml.c:1415-1466), bit-exact.
 //
-// Why another kernel.  k_gemm_skinny gives a wave one row-group (8 rows x 8 chains) and <= 4 columns, and puts the other columns
-// into more workgroups that stream the SAME weight tiles again.  Round 4's tables fit one model for every matrix at 9 rows: time =
-// bytes pulled through the CUs' load paths / ~5.5 TB/s, whether the re-reads hit the L2 or not (w2: 3 x 28 MB -> 20 us; one row:
-// 7.7 us).  Reading the weights once with all columns in one wave loses more than it gains on the 4 096-row matrices: 512 waves are
-// half a wave per SIMD, and a wave alone on its SIMD issues one VALU instruction per ~8-12 cycles.  So here the waves that share a
-// row-group share its weight bytes through LDS:
-//   workgroup = RGW row-groups x CW "column waves".  Wave (rgi, ci) owns row-group blk * RGW + rgi and NC of the columns.
-//   Weights: the CW waves of a row-group take turns fetching its chunks HBM -> VGPR (chunk c by wave c % CW, non-temporal, a
-//     register ring of DR chunks each: CW * DR chunks of the row-group in flight, nothing staged twice) and publish each chunk to a
-//     two-step LDS stage; ONE workgroup barrier per step of CW chunks, then every wave runs the CW chunks of the step against its own
-//     columns.  Every weight byte crosses a CU's load path once per step of the model, whatever the number of rows.
-//   Activations: the QA operands of all NC * CW columns are staged whole in LDS (as k_gemm_skinny), zero-padded to the step grid.
-//   CW = 1 is the plain form (no stage, weights straight from the ring): k_gemm_skinny's loop with the epilogues below.
-// 22 VALU per (lane, chunk, column) as k_gemv; LDS traffic per (wave, chunk): 1.25 KiB of weights + NC x 2.6 KiB of operands.
+// Why another kernel.  k_gemm_skinny gives a wave one row-group (8 rows x 8 chains) and <= 4 columns through a 4-deep REGISTER ring, stages
+// the operand rows behind that ring and drains everything before its loop.  What the in-kernel timelines of this file's first versions
+// showed (profiles/r05_*timeline*.txt, tools/set_timeline.py) and what the kernel does about it:
+//   * a wave spends ~0.08 us per (chunk, column) item whatever shares its SIMD (21 VALU + 3 LDS reads at ~9 cycles per instruction and
+//     wave), so a launch ends when the wave with the most items does: the 4 096-row matrices (512 row-groups) want SEVERAL waves per
+//     row-group with one or two columns each.  Those waves share the row-group's weight bytes through LDS:
+//       workgroup = RGW row-groups x CW "column waves"; wave (rgi, ci) owns row-group blk * RGW + rgi and NC of the columns; the CW waves
+//       of a row-group take turns fetching its chunks (chunk c by wave c % CW) into an LDS ring of SET_DR steps by LDS-DMA
+//       (global_load_lds_dwordx4: no VGPRs, no ds_write), one workgroup barrier per step of CW chunks, then every wave runs the step's
+//       chunks against its own columns.  Every weight byte crosses a CU's load path once.  CW = 1: the same ring, private, no barrier.
+//   * with the ring in registers the compiler puts register copies in front of the loop that carries it; they wait for a wave's WHOLE
+//     prefill (with CW x DR chunks in flight that is the far end of the row), and operand rows requested behind the ring arrive behind it
+//     (vmcnt retires in order): 3 - 6.5 us between "loads issued" and step 0.  Now: epilogue operands first, operand rows next (LDS-DMA,
+//     permuted into the LDS layout by per-lane source addresses), then the ring; one counted wait, the loop starts on the first chunk.
+//   * the operand rows' LDS layout is [chunk][half][chain] -- eight chains x 16 B = all 32 banks once per read (chain-major put chains k
+//     and k + 4 on the same banks) --, operands are requested SET_PF = 3 items ahead.
+//   * matrices with >= 1 024 row-groups have waves enough without sharing: up to four columns per wave, and for more than four rows column
+//     GROUPS at grid level (the groups of a row block sit on one XCD, 8 apart in dispatch order).
+// 21 VALU per (lane, chunk, column); LDS traffic per (wave, chunk): 1.25 KiB of weights + NC x 2.6 KiB of operands.
+// Measured (7B, MI355X, profiles/r05_g_ab.txt): set step of 4 / 8 sequences 2.30 / 2.96 ms (k_gemm_skinny) -> 2.08 / 2.85 ms, the
+// reference's 9-token eval 4.00 -> 3.35 ms, bit-identical.
 //
 // Epilogues (per column):
 //   EPI_STORE / EPI_RESID   y = acc (+ resid)                                             lm head; wo, w2 (.mm:649-654, 682-687)

@@ -794,7 +794,7 @@ dump_fail:
 int check_sync_timeout(llamahip_model *m, char *err, size_t err_cap) {
     if (m->h_fault && *(volatile uint32_t *) m->h_fault) {
         *(volatile uint32_t *) m->h_fault = 0;
-        set_err(err, err_cap, "decode step: a tagged hand-off (inside the attention launch, or between the overlapped decode launches) timed out; LLAMAHIP_NO_ATTN_X=1 selects the attention launches without them (the overlapped schedule is opt-in: LLAMAHIP_OVERLAP)");
+        set_err(err, err_cap, "a tagged hand-off inside a launch (decode attention, the half-block w1|w3 workgroups of a decode step or of a short eval) timed out; LLAMAHIP_NO_ATTN_X=1 selects the launches without them");
         return LLAMAHIP_ERR_PREDICT;
     }
     return 0;
@@ -1124,7 +1124,7 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
     m->n_evals++;
     if (!sync) return LLAMAHIP_OK;          // (llamahip_eval_topk: more work follows on the stream before the one synchronisation)
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
-    if (N == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
+    if ((rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;        // (single-token steps and short evals take in-launch tagged hand-offs)
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
 }
@@ -1192,7 +1192,7 @@ int llamahip_eval_topk(llamahip_model *m, int32_t n_threads, int32_t n_past, con
     if (!mapped) HIP_TRY(hipMemcpyAsync(&h, d_sc, sizeof(h), hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
     if (mapped) { memcpy(h.sc, m->h_io->sc, sizeof(h.sc)); memcpy(h.id, m->h_io->id, sizeof(h.id)); memcpy(h.fl, m->h_io->fl, sizeof(h.fl)); }
-    if (n_tokens == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
+    if ((rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;
     m->t_eval_ms += now_ms() - t0;
     if (h.fl[0] == 1) {
         for (int i = 0; i < k; i++) { cand_scores[i] = h.sc[i]; cand_ids[i] = h.id[i]; }
@@ -1225,7 +1225,7 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
     if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t) N * d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     if (m->last_stage && logits_out) HIP_TRY(hipMemcpyAsync(logits_out, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
-    if (N == 1 && (rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;       // (single-token stage evals take the in-launch hand-offs too)
+    if ((rc = check_sync_timeout(m, err, err_cap)) != 0) return rc;       // (single-token and short stage evals take the in-launch hand-offs too)
     m->n_evals++;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;

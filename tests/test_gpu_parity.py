@@ -425,6 +425,31 @@ def test_in_launch_handoff_timeout_is_an_error_not_a_hang(model7b, which):
     assert float(r.stdout.split("SECONDS")[1].split()[0]) < 30.0, r.stdout
 
 
+def test_few_row_handoff_timeout_is_an_error_not_a_hang(model7b):
+    """The same for the few-row kernel (k_gemv_set): its half-block w1|w3 workgroups exchange a partial amax per column as tagged
+    granules.  LLAMAHIP_HANDOFF_FAULT_TEST=7 publishes them under a tag the partner does not wait for and shortens the polls: a 4-row
+    eval (the set step's kernels) returns PredictionFailed within seconds instead of hanging."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, time, numpy as np\n"
+        "import llama_swift_amd as L\n"
+        "m = L.Model(sys.argv[1], n_ctx=64)\n"
+        "m.eval(np.array([7], np.int32), 0, 8)\n"                    # single-token decode does not use the few-row kernel: works
+        "t0 = time.time()\n"
+        "try:\n"
+        "    m.eval(np.array([1, 5, 9, 13], np.int32), 1, 8)\n"
+        "    print('NO ERROR')\n"
+        "except L.LlamaHipError as e:\n"
+        "    print('ERR', e.code, str(e)); print('SECONDS', time.time() - t0)\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, LLAMAHIP_HANDOFF_FAULT_TEST="7")
+    r = subprocess.run([sys.executable, "-c", code, model7b], env=env, capture_output=True, text=True, cwd=root, timeout=300)
+    assert "ERR -1001" in r.stdout and "hand-off" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert float(r.stdout.split("SECONDS")[1].split()[0]) < 30.0, r.stdout
+
+
 def test_context_overflow_and_bad_tokens_are_errors(L, tmp_path):
     hp = synth.HParams(n_vocab=64, n_embd=256, n_mult=64, n_head=2, n_layer=1)
     path = str(tmp_path / "m.bin")
