@@ -65,7 +65,6 @@ struct GemvSetArgs {
     RopeKvArgs ra;
     uint64_t *amax_t; const uint32_t *epoch; int layer; uint32_t *fault; int lut_math;      // EPI_SILU_QAH (lut_math as GemvArgs: bit 0 SiLU evaluated, 0x1000 fault-injection test)
     unsigned long long *probe;                      // LH_SET_PROBE builds: [0] record counter, [1] capacity, records of 32 words from [32]
-    const float *in0, *in1; long in_stride; int K;  // PREP_NORM: the fp32 rows x[ncols][K] (in_stride floats apart) and the norm weights [K]
 };
 
 // LH_SET_ABLATE (measurement builds only, tools/build_set_variants.sh; results are wrong): 1 = no arithmetic (what the launch shape streams),
@@ -123,14 +122,9 @@ template <int N> __device__ __forceinline__ void set_wait_vmcnt() { asm volatile
 // threads a launch may ask for: half-block workgroups are 4 row-groups x CW waves, the others at most 8 waves
 template <int CW, int EPI> constexpr int set_max_threads() { return EPI == EPI_SILU_QAH ? (CW * 256 > 512 ? CW * 256 : 512) : 512; }
 
-//   PRE : PRE_QA the operand rows arrive quantized (qa_A / qa_d) | PREP_NORM (CW = 1 only) the rows arrive as fp32 and the workgroup runs
-//         ggml_norm + ggml_mul + quantize_row_q4_0 (ggml.c:5327-5385, :4555, :456-523; .mm:570-575, 660-665) on its <= NC columns itself:
-//         k_prep_fast's arithmetic on register-resident half-blocks (thread t owns half-block t of every row, the halves of a block in lanes
-//         t, t ^ 1), two-pass statistics, straight into the LDS operand layout -- the set step's two preparation launches per layer are gone
-template <int NC, int CW, int EPI, int PRE = PRE_QA>
-__global__ void __launch_bounds__((set_max_threads<CW, EPI>())) __attribute__((amdgpu_waves_per_eu(PRE == PREP_NORM ? 3 : 1)))
+template <int NC, int CW, int EPI>
+__global__ void __launch_bounds__((set_max_threads<CW, EPI>()))
 k_gemv_set(const GemvSetArgs a) {
-    static_assert(PRE == PRE_QA || (PRE == PREP_NORM && CW == 1), "the norm prologue is written for unshared rings (one group of <= NC columns per workgroup)");
     constexpr int DR = SET_DR, NCW = NC * CW;
     constexpr bool SHARE = CW > 1;
     extern __shared__ double smem_d[];
@@ -197,25 +191,6 @@ k_gemv_set(const GemvSetArgs a) {
             }
         }
     }
-    // (PREP_NORM) the rows' half-blocks and the norm weights: ordinary loads, requested before the ring.  The compiler counts its own loads
-    // only (the DMA instructions are opaque to it), so the waits it places in front of their uses would also wait for DMA instructions
-    // issued in between -- unless at least as many compiler-visible loads follow them: the eight pad loads below (consumed by an empty asm
-    // at the very end) keep every compiler-placed wait of the prologue above the 2 (DR - 1) ring requests.
-    f32x4 xr[NC][4], xw[4];
-    uint32_t padv[8];
-    const int nh = a.K >> 4;                                       // half-blocks per row; thread tid owns half-block tid (nt >= nh: host)
-    if (PRE == PREP_NORM) {
-        const int hc = min(tid, nh - 1);
-#pragma unroll
-        for (int n = 0; n < NC; n++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) xr[n][v] = ((const f32x4 *) (a.in0 + (size_t) (col0 + min(n, ncols - 1)) * a.in_stride))[hc * 4 + v];
-#pragma unroll
-        for (int v = 0; v < 4; v++) xw[v] = ((const f32x4 *) a.in1)[hc * 4 + v];
-#pragma unroll
-        for (int i = 0; i < 8; i++) padv[i] = ((const uint32_t *) a.in1)[min(lane + 64 * i, a.K - 1)];
-        __builtin_amdgcn_sched_barrier(0);
-    } else
     {
         // operand rows: LDS granule L of a column = (chunk L >> 4, half (L >> 3) & 1, chain L & 7)  <-  QA granule (chunk, chain, half);
         // d pairs: LDS float f of a chunk = (t = f >> 1, h = f & 1)  <-  d[4 h + t].  A wave instruction fills 64 consecutive LDS granules
@@ -251,92 +226,6 @@ k_gemv_set(const GemvSetArgs a) {
             const int n = i / (zc * 18), r = i - n * (zc * 18);
             if (r < zc * 16) sA[((size_t) n * npad + nchunks) * 16 + r] = u32x4{ 0u, 0u, 0u, 0u };
             else ((f32x4 *) sD)[((size_t) n * npad + nchunks) * 2 + (r - zc * 16)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-        }
-    }
-    if (PRE == PREP_NORM) {
-        // ggml_norm (two passes, sums in double: mean, then the squared deviations of the float-rounded... of v = x - mean in double) and
-        // ggml_mul by the weights, k_prep_fast's statements per element; the block sums cross the waves through the ring's last slot
-        // (free until step 0 refills it), behind barriers that wait for LDS only
-        double *red = (double *) (ring + (size_t) (DR - 1) * CW * TILE_BYTES);      // [2][NC][nw]
-        const bool live = tid < nh;
-        double s1[NC];
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            double s = 0.0;
-            if (live) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) { s += (double) xr[n][v].x; s += (double) xr[n][v].y; s += (double) xr[n][v].z; s += (double) xr[n][v].w; }
-            }
-            s1[n] = wave_sum_d(s);
-            if (lane == 0) red[n * nw + wave] = s1[n];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        double s2[NC];
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            double tot = 0.0;
-            for (int w2_ = 0; w2_ < nw; w2_++) tot += red[n * nw + w2_];
-            const double mean = tot / (double) a.K;
-            double s = 0.0;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const double v0 = (double) xr[n][v].x - mean, v1 = (double) xr[n][v].y - mean;
-                const double v2 = (double) xr[n][v].z - mean, v3 = (double) xr[n][v].w - mean;
-                xr[n][v].x = (float) v0; xr[n][v].y = (float) v1; xr[n][v].z = (float) v2; xr[n][v].w = (float) v3;
-                if (live) { s += v0 * v0; s += v1 * v1; s += v2 * v2; s += v3 * v3; }
-            }
-            s2[n] = wave_sum_d(s);
-            if (lane == 0) red[(NC + n) * nw + wave] = s2[n];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        uint32_t *sAw = (uint32_t *) sA;
-        float *sDw = (float *) sD;
-        const int hi = tid, half = hi & 1, b = hi >> 1, c = b >> 3, j = b & 7;
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            double tot = 0.0;
-            for (int w2_ = 0; w2_ < nw; w2_++) tot += red[(NC + n) * nw + w2_];
-            const float scale = (float) (1.0 / sqrt(tot / (double) a.K + (double) 1e-5f));
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                xr[n][v].x = xw[v].x * (xr[n][v].x * scale); xr[n][v].y = xw[v].y * (xr[n][v].y * scale);
-                xr[n][v].z = xw[v].z * (xr[n][v].z * scale); xr[n][v].w = xw[v].w * (xr[n][v].w * scale);
-            }
-            // quantize_row_q4_0, AVX2 branch (ggml.c:456-523), two lanes per block
-            float amax = 0.0f;
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-                amax = fmaxf(fmaxf(fmaxf(amax, fabsf(xr[n][v].x)), fabsf(xr[n][v].y)), fmaxf(fabsf(xr[n][v].z), fabsf(xr[n][v].w)));
-            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax));        // partner half (lane ^ 1); K / 16 is even: both live or both dead
-            const float dd = amax / 7.0f;
-            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
-            uint32_t pr[8];                                        // this half's 8 element pairs -> 16-bit fields
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const uint32_t n0 = (uint32_t) ((int) __builtin_rintf(xr[n][v].x * id)) & 0xF, n1 = (uint32_t) ((int) __builtin_rintf(xr[n][v].y * id)) & 0xF;
-                const uint32_t n2 = (uint32_t) ((int) __builtin_rintf(xr[n][v].z * id)) & 0xF, n3 = (uint32_t) ((int) __builtin_rintf(xr[n][v].w * id)) & 0xF;
-                pr[2 * v] = n0 | (n1 << 8);
-                pr[2 * v + 1] = n2 | (n3 << 8);
-            }
-            // chain k of the block = pair k of half 0 (low 16 bits) | pair k of half 1 (high 16 bits); half 0 stores chains 0..3, half 1 chains 4..7;
-            // LDS layout of a chunk: [half of the chunk's blocks (j >> 2)][chain k] granules, dword j & 3
-            const int cbase = min(n, ncols - 1) * npad;
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
-                const uint32_t other = (uint32_t) __builtin_amdgcn_mov_dpp((int) pr[kk], DPP_QUAD_XOR1, 0xF, 0xF, true);
-                const uint32_t dw = (half ? (other | (pr[kk] << 16)) : (pr[kk] | (other << 16))) << (4 * (j & 1));
-                if (live && n < ncols && (kk >> 2) == half) sAw[(((size_t) cbase + c) * 16 + (j >> 2) * 8 + kk) * 4 + (j & 3)] = dw;
-            }
-            if (live && n < ncols && half == 0) sDw[((size_t) cbase + c) * 8 + (j & 3) * 2 + (j >> 2)] = dd;
-        }
-        // blocks that pad K up to a multiple of 256
-        for (int pb = a.K / 32 + tid; pb < nchunks * 8; pb += nt) {
-            const int pc = pb >> 3, pj = pb & 7;
-            for (int n = 0; n < ncols; n++) {
-#pragma unroll
-                for (int kk = 0; kk < 8; kk++) sAw[(((size_t) n * npad + pc) * 16 + (pj >> 2) * 8 + kk) * 4 + (pj & 3)] = 0u;
-                sDw[((size_t) n * npad + pc) * 8 + (pj & 3) * 2 + (pj >> 2)] = 0.0f;
-            }
         }
     }
     set_wait_vmcnt<2 * (DR - 1)>();                                // everything older than the ring: this wave's share of the operand rows
@@ -424,10 +313,6 @@ k_gemv_set(const GemvSetArgs a) {
     for (int i = 0; i < DR - 1; i++)
         if (s0 + i < steps) LH_SSTEP(i, s0 + i)
     set_wait_vmcnt<0>();                                           // (the ring's last requests are zero tiles: nothing may still be landing in LDS below)
-    if (PRE == PREP_NORM) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) asm volatile("" :: "v"(padv[i]));     // (the pad loads of the prologue: their only use, behind the loop)
-    }
     LH_PSTAMP(24);
 #undef LH_SSTEP
 #undef LH_ITEM
@@ -610,17 +495,6 @@ static hipError_t launch_set_t(const GemvSetArgs &a, int epi, int grid, int nthr
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
-template <int NC>
-static hipError_t launch_set_norm_t(const GemvSetArgs &a, int epi, int grid, int nthreads, size_t lds, hipStream_t st) {
-    switch (epi) {
-    case EPI_STORE:    hipLaunchKernelGGL((k_gemv_set<NC, 1, EPI_STORE, PREP_NORM>), dim3(grid), dim3(nthreads), lds, st, a); break;
-    case EPI_ROPE_KV:  hipLaunchKernelGGL((k_gemv_set<NC, 1, EPI_ROPE_KV, PREP_NORM>), dim3(grid), dim3(nthreads), lds, st, a); break;
-    case EPI_SILU_QAH: hipLaunchKernelGGL((k_gemv_set<NC, 1, EPI_SILU_QAH, PREP_NORM>), dim3(grid), dim3(nthreads), lds, st, a); break;
-    default: return hipErrorInvalidValue;
-    }
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
 
 // LH_SET_PROBE builds: LLAMAHIP_SET_PROBE=<records> allocates the record buffer at the first launch; llamahip_debug_set_probe reads it
 static unsigned long long *g_set_probe = nullptr;
@@ -634,20 +508,6 @@ long set_probe_dump(unsigned long long *out, long cap_records, bool reset) {
     if (reset) { hdr[0] = 0; hdr[1] = (unsigned long long) g_set_probe_cap; (void) hipMemcpy(g_set_probe, hdr, sizeof(hdr), hipMemcpyHostToDevice); }
     return n;
 }
-
-// the norm prologue: unshared plans (cw = 1) whose workgroup has a thread per half-block of a row (LLAMAHIP_NO_SET_NORM: measurement switch)
-static bool set_norm_fits(const QMat &w, const SetPlan &p, int epi, int *rgw_out) {
-    static const bool off = getenv("LLAMAHIP_NO_SET_NORM") != nullptr;
-    if (off || p.cw != 1 || p.nc < 2 || w.K % 32 != 0 || (epi != EPI_STORE && epi != EPI_ROPE_KV && epi != EPI_SILU_QAH)) return false;
-    const int need = (w.K / 16 + 63) / 64;                           // waves
-    int rgw = p.rgw;
-    if (epi == EPI_SILU_QAH) { if (need > 4) return false; }
-    else { while (rgw < need && rgw < 8) rgw *= 2; if (rgw < need) return false; }
-    if (set_lds_bytes(w, std::min(p.nc, SET_ROWS_MAX), p.nc, p.cw, rgw) > SET_LDS_CAP) return false;
-    *rgw_out = rgw;
-    return true;
-}
-
 static hipError_t launch_set_any(const QMat &w, GemvSetArgs a, int epi, hipStream_t st) {
 #if LH_SET_PROBE
     if (!g_set_probe && getenv("LLAMAHIP_SET_PROBE")) {
@@ -657,25 +517,12 @@ static hipError_t launch_set_any(const QMat &w, GemvSetArgs a, int epi, hipStrea
     }
     a.probe = g_set_probe;
 #endif
-    SetPlan p = set_plan(w, a.ncols, epi);
-    const bool norm = a.in0 != nullptr;
-    if (norm) {
-        int rgw = 0;
-        if (!set_norm_fits(w, p, epi, &rgw)) return hipErrorInvalidValue;
-        p.rgw = rgw;
-        p.lds = set_lds_bytes(w, std::min(a.ncols, p.nc * p.cw), p.nc, p.cw, p.rgw);
-    }
+    const SetPlan p = set_plan(w, a.ncols, epi);
     if (p.lds > SET_LDS_CAP) return hipErrorInvalidValue;
     a.rgw = p.rgw; a.ncg = p.ncg;
     const int nwg = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;
     const int grid = p.ncg == 1 ? nwg : (nwg + 7) / 8 * 8 * p.ncg;
     const int nthreads = p.rgw * p.cw * 64;
-    if (norm) {
-        if (p.nc == 2) return launch_set_norm_t<2>(a, epi, grid, nthreads, p.lds, st);
-        if (p.nc == 3) return launch_set_norm_t<3>(a, epi, grid, nthreads, p.lds, st);
-        if (p.nc == 4) return launch_set_norm_t<4>(a, epi, grid, nthreads, p.lds, st);
-        return hipErrorInvalidValue;
-    }
 #define LH_SP(NCV, CWV) if (p.nc == NCV && p.cw == CWV) return launch_set_t<NCV, CWV>(a, epi, grid, nthreads, p.lds, st)
     LH_SP(1, 2); LH_SP(1, 3); LH_SP(1, 4);
     LH_SP(2, 1); LH_SP(2, 2); LH_SP(2, 3); LH_SP(2, 4);
@@ -693,34 +540,23 @@ static GemvSetArgs set_args(const QMat &w, const uint32_t *qa_A, const float *qa
     return a;
 }
 
-static void set_norm_in(GemvSetArgs &a, const QMat &w, const SetNormIn *nin) {
-    if (nin && nin->x) { a.in0 = nin->x; a.in1 = nin->norm_w; a.in_stride = nin->x_stride; a.K = w.K; }
-}
-bool gemv_set_norm_applies(const QMat &w, int N, int epi) {
-    if (!gemv_set_applies(w, N, epi)) return false;
-    int rgw = 0;
-    return set_norm_fits(w, set_plan(w, N, epi), epi, &rgw);
-}
 hipError_t launch_gemv_set(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
-                           float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, const SetNormIn *nin) {
+                           float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     GemvSetArgs a = set_args(w, qa_A, qa_d, N);
     a.y = y; a.y_stride = y_stride; a.resid = resid; a.resid_stride = resid_stride;
-    set_norm_in(a, w, nin);
     return launch_set_any(w, a, epi, st);
 }
-hipError_t launch_gemv_set_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st, const SetNormIn *nin) {
+hipError_t launch_gemv_set_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
     GemvSetArgs a = set_args(wqkv, qa_A, qa_d, N);
     a.ra = ra;
-    set_norm_in(a, wqkv, nin);
     return launch_set_any(wqkv, a, EPI_ROPE_KV, st);
 }
 hipError_t launch_gemv_set_silu(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
-                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, const SiluHalfIO &hx, hipStream_t st, const SetNormIn *nin) {
+                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, const SiluHalfIO &hx, hipStream_t st) {
     static const int fault_test = (getenv("LLAMAHIP_HANDOFF_FAULT_TEST") && atoi(getenv("LLAMAHIP_HANDOFF_FAULT_TEST")) == 7) ? 0x1000 : 0;
     GemvSetArgs a = set_args(w13, qa_A, qa_d, N);
     a.T_silu = T_silu; a.out_A = out_A; a.out_d = out_d; a.out_strideA = out_strideA; a.out_strideD = out_strideD;
     a.amax_t = hx.amax_t; a.epoch = hx.epoch; a.layer = hx.layer; a.fault = hx.fault; a.lut_math = g_lut_math | fault_test;
-    set_norm_in(a, w13, nin);
     return launch_set_any(w13, a, EPI_SILU_QAH, st);
 }
 
@@ -732,11 +568,6 @@ hipError_t init_attrs_gemv_set() {
     LH_ATTR(2, 1); LH_ATTR(2, 2); LH_ATTR(2, 3); LH_ATTR(2, 4);
     LH_ATTR(3, 1); LH_ATTR(3, 3); LH_ATTR(3, 4);
     LH_ATTR(4, 1); LH_ATTR(4, 2); LH_ATTR(4, 4);
-#define LH_ATTRN(NCV) do { hipError_t e_; if ((e_ = hipFuncSetAttribute((const void *) k_gemv_set<NCV, 1, EPI_STORE, PREP_NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) return e_; \
-        if ((e_ = hipFuncSetAttribute((const void *) k_gemv_set<NCV, 1, EPI_ROPE_KV, PREP_NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) return e_; \
-        if ((e_ = hipFuncSetAttribute((const void *) k_gemv_set<NCV, 1, EPI_SILU_QAH, PREP_NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) return e_; } while (0)
-    LH_ATTRN(2); LH_ATTRN(3); LH_ATTRN(4);
-#undef LH_ATTRN
 #undef LH_ATTR
 #undef LH_ATTR1
     return hipSuccess;

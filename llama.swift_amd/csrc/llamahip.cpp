@@ -694,16 +694,13 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
 
         // ---- general path (prompt chunks, debug dumps): prepare -> GEMM per mat-mul
         if (dmp && !sink->put(0, m->x, (int64_t) N * d)) goto dump_fail;
-        const bool rope_fused = short_chunk && !dmp && gemm_rope_kv_applies(L.qkv, N, d);
-        const bool qkv_norm_fused = rope_fused && gemv_set_norm_applies(L.qkv, N, EPI_ROPE_KV);      // (2 .. 16 rows: the norm runs in the launch's prologue)
-        if (!qkv_norm_fused)
         HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
         if (dmp && !sink->put(1, m->dbg_y, (int64_t) N * d)) goto dump_fail;
+        const bool rope_fused = short_chunk && !dmp && gemm_rope_kv_applies(L.qkv, N, d);
         if (rope_fused) {
             // short evals: q / k / v mat-mul, RoPE and the KV append in one launch (.mm:580-611)
             const RopeKvArgs ra = { m->sincos, m->qr, Kl, Vl, n_past, d, dh };
-            const SetNormIn nin = { m->x, d, L.attention_norm };
-            HIP_TRY(launch_gemm_rope_kv(L.qkv, m->qa_A, m->qa_d, N, ra, st, qkv_norm_fused ? &nin : nullptr), LLAMAHIP_ERR_PREDICT);
+            HIP_TRY(launch_gemm_rope_kv(L.qkv, m->qa_A, m->qa_d, N, ra, st), LLAMAHIP_ERR_PREDICT);
         } else
         HIP_TRY(launch_gemm(L.qkv, EPI_STORE, m->qa_A, m->qa_d, N, m->qkv, 3L * d, nullptr, 0, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);   // .mm:580-582
         if (dmp) {
@@ -735,17 +732,13 @@ int forward(llamahip_model *m, int n_threads, int n_past, int N, const float *hi
         } else {
             HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, N, m->x1, d, m->x, d, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);
         }
-        set_hx.layer = il - m->l0;
-        const bool silu_fused = short_chunk && !dmp && m->w13_interleaved && N <= 64 && gemm_silu_qa_applies(L.w13, N);
-        const bool w13_norm_fused = silu_fused && gemm_silu_qa_norm_applies(L.w13, N, &set_hx);
-        if (!w13_norm_fused)
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, N, m->qa_A, m->qa_d, dmp ? m->dbg_y : nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (dmp && !sink->put(11, m->dbg_y, (int64_t) N * d)) goto dump_fail;
-        if (silu_fused) {
+        if (short_chunk && !dmp && m->w13_interleaved && N <= 64 && gemm_silu_qa_applies(L.w13, N)) {
             // short evals: w1 | w3, SiLU * up and the quantization for w2 in one launch (.mm:668-680)
             const long KpF = ((long) F + 255) / 256 * 256;
-            const SetNormIn nin = { m->x1, d, L.ffn_norm };
-            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, N, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st, &set_hx, w13_norm_fused ? &nin : nullptr), LLAMAHIP_ERR_PREDICT);
+            set_hx.layer = il - m->l0;
+            HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, N, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st, &set_hx), LLAMAHIP_ERR_PREDICT);
             HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, N, m->x, d, m->x1, d, st, m->qb_ws, fast_prefill), LLAMAHIP_ERR_PREDICT);      // .mm:682-687
             continue;
         }
@@ -1547,24 +1540,12 @@ static int forward_set(llamahip_model *m, int nth, SeqSet *d_set, int B, char *e
         const Layer &L = m->layers[il - m->l0];
         set_hx.layer = il - m->l0;
         float *Kl = m->Kc + (size_t) (il - m->l0) * C * d, *Vl = m->Vc + (size_t) (il - m->l0) * C * d;      // slot 0's cache of this layer; rows add their slot's offset
+        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
         RopeKvArgs ra = { m->sincos, m->qr, Kl, Vl, 0, d, dh };
         ra.set = d_set;
-        // (the norm, its multiply and the Q4_0 quantization run in the prologue of the consuming launch where the few-row kernel offers it)
-        if (gemv_set_norm_applies(L.qkv, B, EPI_ROPE_KV)) {
-            const SetNormIn nin = { m->x, d, L.attention_norm };
-            HIP_TRY(launch_gemm_rope_kv(L.qkv, nullptr, nullptr, B, ra, st, &nin), LLAMAHIP_ERR_PREDICT);                          // .mm:570-611
-        } else {
-        HIP_TRY(launch_prep(PREP_NORM, m->x, L.attention_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);   // .mm:570-575
         HIP_TRY(launch_gemm_rope_kv(L.qkv, m->qa_A, m->qa_d, B, ra, st), LLAMAHIP_ERR_PREDICT);                                // .mm:580-611
-        }
         HIP_TRY(launch_attn_short(m->qr, Kl, Vl, m->set_sc, nullptr, m->qa_A, m->qa_d, 0, B, d, H, C, nth, m->T_exp, st, 0, d_set), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
         HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, B, m->x1, d, m->x, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);  // .mm:649-654
-        if (m->w13_interleaved && gemm_silu_qa_applies(L.w13, B) && gemm_silu_qa_norm_applies(L.w13, B, &set_hx)) {
-            const SetNormIn nin = { m->x1, d, L.ffn_norm };
-            HIP_TRY(launch_gemm_silu_qa(L.w13, nullptr, nullptr, B, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st, &set_hx, &nin), LLAMAHIP_ERR_PREDICT);     // .mm:660-680
-            HIP_TRY(launch_gemm(L.w2, EPI_RESID, m->qaF_A, m->qaF_d, B, m->x, d, m->x1, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);                 // .mm:682-687
-            continue;
-        }
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (m->w13_interleaved && gemm_silu_qa_applies(L.w13, B)) {
             HIP_TRY(launch_gemm_silu_qa(L.w13, m->qa_A, m->qa_d, B, m->T_silu, m->qaF_A, m->qaF_d, KpF / 4, KpF / 32, st, &set_hx), LLAMAHIP_ERR_PREDICT);       // .mm:668-680
@@ -1576,13 +1557,8 @@ static int forward_set(llamahip_model *m, int nth, SeqSet *d_set, int B, char *e
         }
     }
     if (m->last_stage) {
-        if (gemv_set_norm_applies(m->output, B, EPI_STORE)) {
-            const SetNormIn nin = { m->x, d, m->norm_w };
-            HIP_TRY(launch_gemv_set(m->output, EPI_STORE, nullptr, nullptr, B, m->logits, V, nullptr, 0, st, &nin), LLAMAHIP_ERR_PREDICT);          // .mm:695-705
-        } else {
         HIP_TRY(launch_prep(PREP_NORM, m->x, m->norm_w, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);          // .mm:695-705
         HIP_TRY(launch_gemm(m->output, EPI_STORE, m->qa_A, m->qa_d, B, m->logits, V, nullptr, 0, st), LLAMAHIP_ERR_PREDICT);
-        }
         HIP_TRY(launch_argmax_set(m->logits, V, d_set, B, st), LLAMAHIP_ERR_PREDICT);
     } else {
         HIP_TRY(launch_rows_set(d_set, B, m->x, d, false, st), LLAMAHIP_ERR_PREDICT);

@@ -160,30 +160,23 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st,
                        int chunk = 0);       // chunk > 0: the pass stands for successive evals of `chunk` rows (prompt_attn.hip split_keys)
 bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d);
-hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st,
-                               const struct SetNormIn *nin = nullptr);      // nin (gemv_set_norm_applies(wqkv, N, EPI_ROPE_KV)): the fp32 rows + norm weights instead of qa_A / qa_d
+hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st);
 bool gemm_silu_qa_applies(const QMat &w13, int N);
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st,
-                               const SiluHalfIO *hx = nullptr,       // hx: the half-block exchange of k_gemv_set may be used (2 .. 16 rows)
-                               const struct SetNormIn *nin = nullptr);      // nin (gemm_silu_qa_norm_applies): the fp32 rows + norm weights instead of qa_A / qa_d
-bool gemm_silu_qa_norm_applies(const QMat &w13, int N, const SiluHalfIO *hx);
+                               const SiluHalfIO *hx = nullptr);      // hx: the half-block exchange of k_gemv_set may be used (2 .. 16 rows)
 // k_gemv_set (gemv_set.hip): the mat-mul for 2 .. 16 activation rows -- a batched decode step's rows, the reference's 9-token evals.  The waves
 // that share a row-group share its weight bytes through LDS, so every weight byte crosses a CU's load path once per launch.
 //   gemv_set_applies(w, N, epi): EPI_STORE / EPI_RESID (launch_gemv_set), EPI_ROPE_KV (launch_gemv_set_rope_kv), EPI_SILU_QAH (launch_gemv_set_silu:
 //   interleaved w1|w3 in half-block workgroups whose halves exchange their partial amax per column as tagged granules -- needs the XCD
 //   placement xcd_selftest confirmed, the epoch word and SET_AMAX_GRANULES(F) * 16 zeroed granules)
 inline size_t set_amax_granules(int F) { return (size_t) F / 16 + 16; }      // per column
-//   SetNormIn (gemv_set_norm_applies): the launch takes the fp32 rows and the norm weights instead of quantized operands and runs the
-//   norm + multiply + Q4_0 quantization in its prologue (wq|wk|wv, w1|w3, the lm head: no preparation launch in front)
-struct SetNormIn { const float *x = nullptr; long x_stride = 0; const float *norm_w = nullptr; };
 bool gemv_set_applies(const QMat &w, int N, int epi);
-bool gemv_set_norm_applies(const QMat &w, int N, int epi);
 hipError_t launch_gemv_set(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
-                           float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, const SetNormIn *nin = nullptr);
-hipError_t launch_gemv_set_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st, const SetNormIn *nin = nullptr);
+                           float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st);
+hipError_t launch_gemv_set_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st);
 hipError_t launch_gemv_set_silu(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
-                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, const SiluHalfIO &hx, hipStream_t st, const SetNormIn *nin = nullptr);
+                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, const SiluHalfIO &hx, hipStream_t st);
 hipError_t init_attrs_gemv_set();
 long set_probe_dump(unsigned long long *out, long cap_records, bool reset);      // LH_SET_PROBE builds (tools/set_timeline.py): records of 32 words
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,

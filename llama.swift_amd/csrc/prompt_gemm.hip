@@ -1115,11 +1115,7 @@ static int skinny_pick_nc(const QMat &w, int N) {
 bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
     return N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
 }
-hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st, const SetNormIn *nin) {
-    if (nin && nin->x) {          // the caller checked gemv_set_norm_applies: norm + quantization in the launch's prologue
-        g_gemm_path_counts[GEMM_PATH_SET]++;
-        return launch_gemv_set_rope_kv(wqkv, nullptr, nullptr, N, ra, st, nin);
-    }
+hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
     if (gemv_set_applies(wqkv, N, EPI_ROPE_KV)) { g_gemm_path_counts[GEMM_PATH_SET]++; return launch_gemv_set_rope_kv(wqkv, qa_A, qa_d, N, ra, st); }
     const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
@@ -1130,21 +1126,17 @@ hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const flo
     }
 }
 
-bool gemm_silu_qa_norm_applies(const QMat &w13, int N, const SiluHalfIO *hx) {
-    return hx && hx->amax_t && hx->epoch && gemv_set_norm_applies(w13, N, EPI_SILU_QAH);
-}
 // Short evals on the interleaved w1|w3 matrix: mat-mul + SiLU * up + Q4_0 quantization of the result in one
 // launch (k_gemm_skinny<EPI_SILU_QA>).  false = not applicable (row count, layout): use the separate steps.
 bool gemm_silu_qa_applies(const QMat &w13, int N) {
     return N >= 2 && N <= skinny_max_rows() && w13.gmapF8 != 0 && w13.ngroups % 8 == 0;
 }
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
-                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st, const SiluHalfIO *hx, const SetNormIn *nin) {
+                               uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st, const SiluHalfIO *hx) {
     if (hx && hx->amax_t && hx->epoch && gemv_set_applies(w13, N, EPI_SILU_QAH)) {
         g_gemm_path_counts[GEMM_PATH_SET]++;
-        return launch_gemv_set_silu(w13, qa_A, qa_d, N, T_silu, out_A, out_d, out_strideA, out_strideD, *hx, st, (nin && nin->x) ? nin : nullptr);
+        return launch_gemv_set_silu(w13, qa_A, qa_d, N, T_silu, out_A, out_d, out_strideA, out_strideD, *hx, st);
     }
-    if (nin && nin->x) return hipErrorInvalidValue;          // (the caller checks gemm_silu_qa_norm_applies first)
     const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
     switch (nc) {
     case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
