@@ -195,12 +195,14 @@ def insitu_stage_profile(args, model_name, cfg, stage_layers, stage_set):
         return None, f"rocprofv3 rc={r.returncode}: {r.stderr[-300:]}"
     rows = list(csv.DictReader(open(stats[0])))
     shutil.rmtree(outdir, ignore_errors=True)
-    # w1|w3: the launch with the SiLU * up -> Q4_0 epilogue (EPI_SILU_QA = 2): k_gemm_skinny<NC, 1, 2> for a set, k_gemv<.., 2, ..> for single steps
+    # w1|w3: the launch with the SiLU * up -> Q4_0 epilogue: for a set k_gemv_set<NC, CW, 7> (EPI_SILU_QAH; k_gemm_skinny<NC, 1, 2> where the
+    # few-row kernel does not apply), k_gemv<.., 2 | 7, ..> for single steps
     pick = None
     for row in rows:
         n = row["Name"]
         n = (n[:n.index("(")] if "(" in n else n).replace("void ", "")
-        hit = ("k_gemm_skinny<" in n and n.rstrip(">").split(",")[-1].strip() == "2") if stage_set > 1 else ("k_gemv<" in n and n.split("<")[1].split(",")[1].strip() == "2")
+        last = n.rstrip(">").split(",")[-1].strip()
+        hit = (("k_gemv_set<" in n and last == "7") or ("k_gemm_skinny<" in n and last == "2")) if stage_set > 1 else ("k_gemv<" in n and n.split("<")[1].split(",")[1].strip() in ("2", "7"))
         if hit and int(row["Calls"]) >= steps * stage_layers // 2:
             pick = (n, float(row["AverageNs"]) / 1e3, int(row["Calls"]))
     if not pick:
@@ -539,7 +541,7 @@ def batched_sequences(args, cfg, path, n_seq):
     return {"sequences": n_seq, "tokens": n_seq * steps, "seconds": dt, "aggregate_tokens_per_s": n_seq * steps / dt, "ms_per_step": dt * 1e3 / steps,
             "per_sequence_tokens_per_s": steps / dt, "tokens_equal_single_stream": same,
             "weights_once_per_step_frac": wb / (dt / steps) / 1e9 / HBM_PEAK_GBPS,
-            "note": "one llamahip_stage_step_set per step: the short-eval kernels (k_gemm_skinny, per-row attention) with per-row position / KV cache / V*P key split; "
+            "note": "one llamahip_stage_step_set per step: the few-row kernels (k_gemv_set, per-row attention) with per-row position / KV cache / V*P key split; "
                     "not the headline metric (one sequence)"}
 
 

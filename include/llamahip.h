@@ -214,6 +214,9 @@ int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_
  * slots, each bound with plain buffers (no mailbox); one graph is captured per (set, n_threads).  n_seqs = 1 is llamahip_stage_step. */
 int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_seqs, int32_t n_threads, void *stream,
                             char *err, size_t err_cap);
+/* 1 if llamahip_stage_step_set can step n_seqs slots of this handle with this n_threads as ONE set (Q4_0 handle with layers, head size a
+ * multiple of 32, n_threads <= 32); 0: step the slots one by one with llamahip_stage_step (up to 64 threads, every handle shape). */
+int32_t llamahip_stage_set_applies(const llamahip_model *m, int32_t n_seqs, int32_t n_threads);
 
 /* Device-side mailboxes between pipeline stages: instead of the caller moving hidden_out -> hidden_in (and token_out -> token_in)
  * between stages with a collective per token, the LAST kernel of a stage step stores the residual-stream row (.mm:563-564, 687-690)

@@ -112,6 +112,8 @@ def lib() -> C.CDLL:
     L.llamahip_stage_step.argtypes = [vp, i32, i32, vp, cp, sz]
     L.llamahip_stage_trace.argtypes = [vp, i32, vp, vp, i32, cp, sz]
     L.llamahip_stage_step_set.argtypes = [vp, vp, i32, i32, vp, cp, sz]
+    L.llamahip_stage_set_applies.argtypes = [vp, i32, i32]
+    L.llamahip_stage_set_applies.restype = i32
     L.llamahip_stage_logits.argtypes = [vp, i32, vp, cp, sz]
     L.llamahip_stage_mailbox.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vp, vp, cp, sz]
     L.llamahip_stage_mailbox_connect.argtypes = [vp, i32, vp, vp, vp, vp, cp, sz]
@@ -318,6 +320,10 @@ class Model:
         """Enqueue one token step of this stage on `stream` (hipStream_t address, 0 = the null stream); asynchronous."""
         err = C.create_string_buffer(256)
         _check(lib().llamahip_stage_step(self._h, seq, n_threads, C.c_void_p(stream), err, len(err)), err)
+
+    def stage_set_applies(self, n_seqs: int, n_threads: int = 8) -> bool:
+        """Whether stage_step_set can step n_seqs slots as one set on this handle (else: stage_step per slot)."""
+        return bool(lib().llamahip_stage_set_applies(self._h, n_seqs, n_threads))
 
     def stage_step_set(self, seqs, n_threads: int = 8, stream: int = 0):
         """One decode step for all the slots in `seqs` at once (bit-identical to stepping them one by one; the weights are

@@ -1666,6 +1666,9 @@ k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) 
     const int b = blockIdx.x;
     if (b < gridA) {
         const int ncb = aa.dh / 32, wph = 3 * ncb;
+        // (round 5 measured the other dispatch order -- the q and k row-groups of every head of an XCD before any v row-group: a head's score
+        //  chain needs q and k, only its last V*P chain needs v -- and found no difference, 14.97 against 14.99 us per launch:
+        //  profiles/r05_m_qkv_order_ab.txt; the switch is gone)
         const int xcd = b & 7, slot = b >> 3, j = slot / wph, part = slot % wph, mat = part / ncb, sub = part % ncb;
         const int h = xcd + 8 * j;
         gemv_body<PRE, EPI_STORE_TAG, D, true, PG>(ga, mat * (aa.d / 32) + h * ncb + sub, 4, smem_d);    // y = tagged granules

@@ -434,7 +434,7 @@ static size_t set_lds_bytes(const QMat &w, int ncols_group, int nc, int cw, int 
 // row-group with one or two columns each (items per wave = chunks x nc); matrices with >= 1 024 row-groups (wq|wk|wv, w1|w3, the lm head)
 // have waves enough: up to four columns per wave, no sharing, and for more than four rows column GROUPS at grid level (the groups of a
 // row block run side by side on one XCD; the second read of a tile is an L2 hit hidden behind arithmetic -- at 8 rows these launches
-// are VALU bound).  LLAMAHIP_SET_PLAN[_BIG|_SMALL]="nc,cw[,ncg[,rgw]]" overrides (measurement).
+// are VALU bound).  LLAMAHIP_SET_PLAN[_BIG|_SMALL]="nc,cw[,ncg[,rgw]]" overrides (measurement; _BIG: the unshared class).
 static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int &ncg, int &rgw) {
     const char *env = getenv(name);
     if (!env) return false;
@@ -449,17 +449,20 @@ static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int
 }
 static SetPlan set_plan(const QMat &w, int N, int epi) {
     SetPlan p;
-    int nc, cw, ncg = 1, rgw = 0;
-    const bool big = w.ngroups >= 1024;
-    if (big) { ncg = (N + 3) / 4; nc = (N + ncg - 1) / ncg; cw = 1; }            // balanced groups of <= 4 columns (9 rows: 3 + 3 + 3)
-    else if (N <= 4) { nc = 1; cw = N; }
-    else if (N <= 6) { nc = 2; cw = 3; }
-    else if (N <= 8) { nc = 2; cw = 4; }
-    else if (N == 9) { nc = 3; cw = 3; }
-    else if (N <= 12) { nc = 3; cw = 4; }
-    else { nc = 4; cw = 4; }
+    // waves per row-group: enough to put about two waves on every SIMD of the chip (ngroups x cw >= ~2 000), w1|w3 always unshared (its
+    // half-block workgroups are many); then <= 4 columns per wave, column groups at grid level beyond 4 cw columns
+    const bool big = w.ngroups >= 1536 || epi == EPI_SILU_QAH;
+    int cw = big ? 1 : w.ngroups >= 768 ? 2 : 4;
+    if (cw > N) cw = N;
+    int ncg = (N + 4 * cw - 1) / (4 * cw);
+    const int ng = (N + ncg - 1) / ncg;                               // columns per group, balanced (9 rows, unshared: 3 + 3 + 3)
+    int nc = (ng + cw - 1) / cw, rgw = 0;
+    cw = (ng + nc - 1) / nc;
     if (!set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw)) set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
-    if (nc == 1 && cw == 1) { nc = 2; }                               // (no <1, 1> instantiation)
+    // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4>)
+    if (nc == 1 && cw == 1) nc = 2;
+    if (nc == 3 && cw == 2) nc = 4;
+    if (nc == 4 && cw == 3) cw = 4;
     if (!rgw) rgw = epi == EPI_SILU_QAH ? 4 : (cw >= 3 ? 2 : 4);
     if (epi == EPI_SILU_QAH) rgw = 4;
     else if (rgw * cw > 8) rgw = 8 / cw;                              // (set_max_threads)

@@ -199,8 +199,10 @@ struct llamahip_model {
     };
     std::vector<StageSlot> slots;        // one per sequence slot
     // batched decode steps over a SET of slots (llamahip_stage_step_set): one captured graph + device-resident row descriptor per set
-    struct SetGraph { SeqSet *d_set = nullptr; hipGraphExec_t exec = nullptr; };
-    std::map<std::vector<int>, SetGraph> set_graphs;      // key: {n_threads, slot ids...}
+    struct SetGraph { SeqSet *d_set = nullptr; hipGraphExec_t exec = nullptr; uint64_t last_use = 0; };
+    std::map<std::vector<int>, SetGraph> set_graphs;      // key: {n_threads, slot ids in ascending order}: at most SET_GRAPHS_MAX, least recently used evicted
+    uint64_t set_graph_clock = 0;
+    std::vector<int> last_rows;          // llamahip_stage_logits: row of the caller's i-th slot in the most recent set step (empty: identity)
     float *set_sc = nullptr;             // attention scores of a set step: [SET_MAX][H][n_ctx]
     int32_t *d_slot_state = nullptr;     // [n_seq][2]: {position, step index}, advanced on the device
     int32_t *d_slot_trace = nullptr;     // [n_seq][n_ctx]: tokens picked by the last stage
@@ -1117,6 +1119,7 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
     m->attn_sched = N == 1 ? attn_sched_at(m, n_past) : 0;
     rc = forward(m, n_threads, n_past, N, nullptr, false, want_all, sink.dump ? dump_layer : -1, sink.dump ? &sink : nullptr, err, err_cap, nullptr, chunk);
     m->tok_src = nullptr;
+    m->last_rows.clear();
     if (rc) return rc;
     const size_t V = m->hp.n_vocab;
     if (logits_last) HIP_TRY(hipMemcpyAsync(logits_last, m->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, m->stream), LLAMAHIP_ERR_PREDICT);
@@ -1519,6 +1522,7 @@ int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void 
     }
     sl.next_pos++;
     m->n_evals++;
+    m->last_rows.clear();
     return LLAMAHIP_OK;
 }
 
@@ -1568,6 +1572,17 @@ static int forward_set(llamahip_model *m, int nth, SeqSet *d_set, int B, char *e
 }
 }  // namespace
 
+// 1 if llamahip_stage_step_set can step `n_seqs` slots of this handle with this n_threads as one set, 0 if the caller has to step them one
+// by one (llamahip_stage_step takes up to 64 threads and every handle shape)
+int32_t llamahip_stage_set_applies(const llamahip_model *m, int32_t n_seqs, int32_t n_threads) {
+    if (!m || m->host_only || n_seqs < 1 || n_seqs > SET_MAX) return 0;
+    if (n_seqs == 1) return 1;
+    const int d = m->hp.n_embd, H = m->hp.n_head, dh = H > 0 ? d / H : 0;
+    const int nth = std::max(1, std::min(n_threads, 64));
+    if (m->dense || (m->flags & LLAMAHIP_FLAG_UNFUSED) || m->l1 <= m->l0 || dh <= 0 || dh % 32 != 0 || dh > 256 || nth > 32) return 0;
+    return gemm_rope_kv_applies(m->layers[0].qkv, n_seqs, d) ? 1 : 0;
+}
+
 int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_seqs, int32_t n_threads, void *stream, char *err, size_t err_cap) {
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (!seqs || n_seqs < 1 || n_seqs > SET_MAX) { set_err(err, err_cap, "llamahip_stage_step_set: 1 .. %d slots per step (got %d)", SET_MAX, n_seqs); return LLAMAHIP_ERR_PREDICT; }
@@ -1592,21 +1607,36 @@ int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_se
     if (rc) return rc;
     if (!m->set_sc) HIP_TRY(hipMalloc((void **) &m->set_sc, (size_t) SET_MAX * H * C * 4), LLAMAHIP_ERR_PREDICT);
     hipStream_t run_on = (hipStream_t) stream;
+    // The rows of a step are independent (every sequence's results are those of stepping it alone), so a set is its slots in ascending
+    // order: [0, 1] and [1, 0] share one captured graph and one device descriptor.  A server whose active set keeps changing would
+    // otherwise accumulate graphs of hundreds of kernel nodes: the map is bounded, the least recently used set goes.
+    constexpr size_t SET_GRAPHS_MAX = 32;
+    std::vector<int> order(seqs, seqs + n_seqs);
+    std::sort(order.begin(), order.end());
     std::vector<int> key;
     key.push_back(nth);
-    for (int i = 0; i < n_seqs; i++) key.push_back(seqs[i]);
+    for (int i = 0; i < n_seqs; i++) key.push_back(order[i]);
     auto it = m->set_graphs.find(key);
     if (it == m->set_graphs.end()) {
+        if (m->set_graphs.size() >= SET_GRAPHS_MAX) {
+            auto victim = m->set_graphs.begin();
+            for (auto jt = m->set_graphs.begin(); jt != m->set_graphs.end(); ++jt) if (jt->second.last_use < victim->second.last_use) victim = jt;
+            HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);          // its graph may still run on a caller's stream
+            if (victim->second.exec) (void) hipGraphExecDestroy(victim->second.exec);
+            free_dev(victim->second.d_set);
+            m->set_graphs.erase(victim);
+        }
         SeqSet hs;
         memset(&hs, 0, sizeof(hs));
         hs.n = n_seqs;
         for (int i = 0; i < n_seqs; i++) {
-            const auto &sl = m->slots[seqs[i]];
-            hs.state[i] = m->d_slot_state + 2 * seqs[i];
+            const int sq = order[i];
+            const auto &sl = m->slots[sq];
+            hs.state[i] = m->d_slot_state + 2 * sq;
             hs.tok_in[i] = sl.token_in; hs.tok_out[i] = sl.token_out;
-            hs.trace[i] = m->d_slot_trace + (size_t) seqs[i] * C;
+            hs.trace[i] = m->d_slot_trace + (size_t) sq * C;
             hs.hid_in[i] = sl.hidden_in; hs.hid_out[i] = sl.hidden_out;
-            hs.kv_off[i] = (long) ((size_t) seqs[i] * (m->l1 - m->l0) * C * d);
+            hs.kv_off[i] = (long) ((size_t) sq * (m->l1 - m->l0) * C * d);
         }
         llamahip_model::SetGraph sg;
         HIP_TRY(hipMalloc((void **) &sg.d_set, sizeof(SeqSet)), LLAMAHIP_ERR_PREDICT);
@@ -1627,6 +1657,9 @@ int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_se
         }
         it = m->set_graphs.emplace(key, sg).first;
     }
+    it->second.last_use = ++m->set_graph_clock;
+    m->last_rows.assign(n_seqs, 0);
+    for (int i = 0; i < n_seqs; i++) m->last_rows[i] = (int) (std::lower_bound(order.begin(), order.end(), seqs[i]) - order.begin());
     if (it->second.exec) HIP_TRY(hipGraphLaunch(it->second.exec, run_on), LLAMAHIP_ERR_PREDICT);
     else {
         hipStream_t own = m->stream;
@@ -1660,7 +1693,8 @@ int llamahip_stage_logits(llamahip_model *m, int32_t row, float *logits_out, cha
     if (!m->last_stage || !m->logits || row < 0 || row >= m->ws_cap) { set_err(err, err_cap, "no logits row %d on this handle", row); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipDeviceSynchronize(), LLAMAHIP_ERR_PREDICT);
-    HIP_TRY(hipMemcpy(logits_out, m->logits + (size_t) row * m->hp.n_vocab, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
+    const int r = row < (int) m->last_rows.size() ? m->last_rows[row] : row;      // (a set step orders its rows by slot id)
+    HIP_TRY(hipMemcpy(logits_out, m->logits + (size_t) r * m->hp.n_vocab, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
     return check_sync_timeout(m, err, err_cap);
 }
 

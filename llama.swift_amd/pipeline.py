@@ -250,8 +250,14 @@ class HipStage:
         self.model.stage_step(seq, self.n_threads, self._torch.cuda.current_stream().cuda_stream)
 
     def step_set(self, seqs):
-        """One decode step for all of `seqs` at once (llamahip_stage_step_set: weights streamed once for the set)."""
-        self.model.stage_step_set(list(seqs), self.n_threads, self._torch.cuda.current_stream().cuda_stream)
+        """One decode step for all of `seqs` at once (llamahip_stage_step_set: weights streamed once for the set); handles / thread
+        counts the set step does not cover (n_threads > 32, head sizes off the grid) step the slots one by one -- same results."""
+        seqs = list(seqs)
+        if not self.model.stage_set_applies(len(seqs), self.n_threads):
+            for s in seqs:
+                self.step(s)
+            return
+        self.model.stage_step_set(seqs, self.n_threads, self._torch.cuda.current_stream().cuda_stream)
 
     def trace(self, seq, cap):
         return self.model.stage_trace(seq, cap)
@@ -372,6 +378,11 @@ def pipeline_decode_sets(stage: Stage, rank: int, world: int, dist, groups: Sequ
     nxt, prv = (rank + 1) % world, (rank - 1) % world
     grp = (lambda sender: fwd_groups[fwd_group_of(sender)]) if fwd_groups else (lambda sender: None)
     sent = [None] * len(groups)
+    for seqs in groups:
+        # a group's rows travel as ONE slice [seqs[0], seqs[-1] + 1) of the per-slot buffers: a group must be a run of consecutive slots in
+        # ascending order (step_set itself takes any order; a reordered group would move the wrong rows between stages, silently)
+        if len(seqs) == 0 or list(seqs) != list(range(seqs[0], seqs[0] + len(seqs))):
+            raise ValueError(f"pipeline_decode_sets: group {list(seqs)} is not a run of consecutive slots in ascending order")
 
     def recv(t, src, group):
         dist.recv(t, src=src, group=group)

@@ -70,6 +70,26 @@ d)
   grep -v "k_repack\|copyBuffer\|k_argmax\|fillBuffer\|k_embed" $O/${tag}_ab.txt
   if [ -n "$TIMELINE" ]; then bash tools/gpu_pass.sh t ${tag}; fi
   ;;
+m)
+  # mid-round pass: the new GPU tests, single-stream decode experiments (k_qkv_attn timeline of the tree, q|k-first
+  # dispatch order A/B), kernel tables + PMC traffic of the set step, the reference's 9-token evals
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks or few_row_handoff or handoff_timeout or prompt_continuation or chunks_in_one_pass" > $O/${tag}_quick.txt 2>&1; tail -3 $O/${tag}_quick.txt
+  cat > /tmp/v.txt <<EOV
+base|
+qk_first|LLAMAHIP_QKV_QK_FIRST=1
+EOV
+  PROF=1 KEEP=1 STEPS=96 AT=8,256,440 PROF_AT=128 FILTER='k_gemv\|k_qkv\|k_embed' timeout 600 bash tools/decode_ab.sh /tmp/v.txt > $O/${tag}_qkv_order_ab.txt 2>&1
+  cat $O/${tag}_qkv_order_ab.txt
+  timeout 300 python tools/attn_timeline.py 128 3 > $O/${tag}_attn_timeline.txt 2>&1; tail -30 $O/${tag}_attn_timeline.txt
+  cat > /tmp/v2.txt <<EOV
+set|
+skinny|LLAMAHIP_NO_GEMV_SET=1
+EOV
+  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=2,4,8 EVALS=4,9,16 timeout 900 bash tools/set_ab.sh /tmp/v2.txt > $O/${tag}_set_ab.txt 2>&1
+  grep -v "k_repack\|copyBuffer\|fillBuffer" $O/${tag}_set_ab.txt
+  timeout 400 bash tools/pmc_set_pass.sh 4 > $O/${tag}_set_pmc_S4.txt 2>&1; cat $O/${tag}_set_pmc_S4.txt
+  timeout 400 bash tools/pmc_set_pass.sh 8 > $O/${tag}_set_pmc_S8.txt 2>&1; cat $O/${tag}_set_pmc_S8.txt
+  ;;
 t)
   # in-kernel timelines of the few-row kernel (libllamahip_setprobe.so)
   for spec in "--seqs 4" "--seqs 8" "--evals 9"; do
