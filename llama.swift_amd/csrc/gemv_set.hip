@@ -92,9 +92,10 @@ struct GemvSetArgs {
 #define LH_SET_DR 4
 #endif
 constexpr int SET_DR = LH_SET_DR;
-// LDS operands of an item (chunk, column) are requested SET_PF items ahead into a ring of SET_PF + 1 register buffers.
+// LDS operands of an item (chunk, column) are requested SET_PF items ahead into a ring of SET_PF + 1 register buffers.  Three items ahead
+// measured the same as one (profiles/r05_c_pf.txt: the loop is not LDS-latency bound) and costs 20 VGPRs: one.
 #ifndef LH_SET_PF
-#define LH_SET_PF 3
+#define LH_SET_PF 1
 #endif
 constexpr int SET_PF = LH_SET_PF, SET_NB = SET_PF + 1;
 static_assert((SET_DR % SET_NB) == 0 || SET_NB == 2, "the operand-buffer index is the item's position in the unrolled block of SET_DR steps");
@@ -119,6 +120,102 @@ __device__ __forceinline__ void set_dma4(uint32_t lds_dst, uint64_t base, uint32
 }
 template <int N> __device__ __forceinline__ void set_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// the epilogues of k_gemv_set / k_gemv_set_ar (file header): accs[n] = the lane's chain sums of the wave's n-th column; NCW = columns per
+// workgroup; resid_v / rope_pos / rope_kvo were requested in the prologue
+struct SetEpiCtx { int g, blk, rgi, ncol0, col0, ncols, nw, wave, lane, qah_block, qah_half; bool valid; uint32_t store_tag; };
+template <int NC, int NCW, int EPI>
+__device__ __forceinline__ void set_epilogue(const GemvSetArgs &a, double *smem_d, float (&accs)[NC], const SetEpiCtx &x,
+                                             const float (&resid_v)[NC], const int (&rope_pos)[NC], const long (&rope_kvo)[NC]) {
+    const int g = x.g, rgi = x.rgi, ncol0 = x.ncol0, col0 = x.col0, ncols = x.ncols, nw = x.nw, wave = x.wave, lane = x.lane;
+    const int qah_block = x.qah_block, qah_half = x.qah_half, k = lane & 7;
+    const bool valid = x.valid;
+    const uint32_t store_tag = x.store_tag;
+    int lg = g;
+    if (a.gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : a.gmapF8 + b8 * 4 + (w8 - 4); }
+    const int m = lg * 8 + (lane >> 3);
+    if (EPI == EPI_SILU_QAH) {
+        // the workgroup's 32 outputs per column: gu[column][gate 0 .. 15 | up 0 .. 15]; the operand area is free again
+        float *gu = (float *) smem_d;
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float acc = fold8(accs[n]);
+            if (k == 0) gu[(ncol0 + n) * 32 + rgi * 8 + (lane >> 3)] = acc;
+        }
+        __syncthreads();
+        const bool inject = (a.lut_math & 0x1000) != 0;                       // fault-injection test: a tag nobody waits for, short polls
+        for (int col = wave; col < NCW; col += nw) {
+            if (col >= ncols || qah_block * 8 >= a.ngroups) continue;
+            const int i = lane & 15;
+            const uint16_t gh = f2h_bits(gu[col * 32 + i]);
+            const float act = h2f_bits((a.lut_math & 1) ? silu_math_bits(gh) : a.T_silu[gh]) * gu[col * 32 + 16 + i];
+            float amax = wave_max_f(lane < 16 ? fabsf(act) : 0.0f);
+            // the other half's partial amax of this column: one tagged granule each way inside this XCD's L2
+            const int gcol = col0 + col;
+            uint64_t *at = a.amax_t + (size_t) gcol * ((size_t) (a.ngroups / 8) * 2 + 16);
+            const int hb = qah_block * 2 + qah_half;
+            float other = 0.0f;
+            if (lane == 0) {
+                set_store_tagged(at + hb, amax, store_tag ^ (inject ? 1u : 0u));
+                other = set_poll_tagged(at + (hb ^ 1), store_tag, a.fault, inject);
+            }
+            other = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, other)));
+            amax = fmaxf(amax, other);
+            const float dd = amax / 7.0f;                                      // ggml.c:479
+            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;              // ggml.c:482
+            const uint32_t nib = (uint32_t) ((int) __builtin_rintf(act * id)) & 0xF;      // signed nibble of (q - 8)
+            const int kk = lane & 7;
+            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+            const int b = qah_block, c = b >> 3, j = b & 7;
+            uint32_t *oA = a.out_A + (size_t) gcol * a.out_strideA;
+            if (lane < 8) ((uint16_t *) (oA + (c * 8 + kk) * 8 + j))[qah_half] = (uint16_t) ((e0 | (e1 << 8)) << (4 * (j & 1)));
+            if (lane == 0 && qah_half == 0) a.out_d[(size_t) gcol * a.out_strideD + b] = dd;
+        }
+        return;
+    }
+    if (EPI == EPI_ROPE_KV) {
+        // (ggml.c:7076-7131, .mm:586-611; k_rope_kv) rows m, m ^ 1 = lanes 8 apart; m is even iff the lane's row is.  The table entries of
+        // all columns are requested together (one round trip), then the rotations
+        const RopeKvArgs &ra = a.ra;
+        const int which = m / ra.d, c = m - which * ra.d, pe = (c % ra.dh) & ~1;
+        const bool live = valid && k == 0 && m < a.M;
+        double cs[NC], sn[NC];
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            cs[n] = 1.0; sn[n] = 0.0;
+            if (live && which != 2) { cs[n] = ra.tab[(size_t) rope_pos[n] * ra.dh + pe]; sn[n] = ra.tab[(size_t) rope_pos[n] * ra.dh + pe + 1]; }
+        }
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float acc = fold8(accs[n]);
+            const int col = ncol0 + n;
+            const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
+            if (live && col < ncols) {
+                const int pos = rope_pos[n];
+                const long kvo = rope_kvo[n];
+                if (which == 2) {
+                    ra.Vc[kvo + (size_t) pos * ra.d + c] = acc;
+                } else {
+                    const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
+                    const float val = (c & 1) ? (float) (x0 * sn[n] + x1 * cs[n]) : (float) (x0 * cs[n] - x1 * sn[n]);
+                    if (which == 0) ra.qr[(size_t) (col0 + col) * ra.d + c] = val;
+                    else ra.Kc[kvo + (size_t) pos * ra.d + c] = val;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < NC; n++) {
+        float acc = fold8(accs[n]);
+        const int col = ncol0 + n;
+        if (valid && k == 0 && m < a.M && col < ncols) {
+            if (EPI == EPI_RESID) acc = acc + resid_v[n];
+            a.y[(size_t) (col0 + col) * a.y_stride + m] = acc;
+        }
+    }
+}
+
 // threads a launch may ask for: half-block workgroups are 4 row-groups x CW waves, the others at most 8 waves
 template <int CW, int EPI> constexpr int set_max_threads() { return EPI == EPI_SILU_QAH ? (CW * 256 > 512 ? CW * 256 : 512) : 512; }
 
@@ -139,7 +236,7 @@ k_gemv_set(const GemvSetArgs a) {
     const int npad = steps * CW + SET_PF;                           // chunks per column in LDS: the step grid + the operand fetches SET_PF items ahead
     u32x4 *sA = (u32x4 *) smem_d;                                   // [ncols][npad][16]: a chunk is [half][chain] (the eight chains' 16-byte reads of one half are 128 contiguous bytes: all 32 banks once)
     f32x2 *sD = (f32x2 *) (sA + (size_t) ncols * npad * 16);        // [ncols][npad][4]: {d[t], d[t + 4]} -- lane t of a quad owns blocks t and t + 4
-    uint8_t *ring = (uint8_t *) (sD + (size_t) ncols * npad * 4);   // [rgw][DR][CW][TILE_BYTES]: slot s % DR of a row-group holds the CW chunks of step s
+    uint8_t *ring = (uint8_t *) (sD + (size_t) ncols * npad * 4);   // (CW > 1) [rgw][DR][CW][TILE_BYTES]: slot s % DR of a row-group holds the CW chunks of step s
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int) (blockDim.x >> 6), nt = (int) blockDim.x;
     const int rgi = wave / CW, ci = wave - rgi * CW;
     // (EPI_SILU_QAH: workgroup blk = half `(blk >> 3) & 1` of activation block `(blk >> 4) * 8 + (blk & 7)` -- the halves of a block are 8
@@ -155,7 +252,7 @@ k_gemv_set(const GemvSetArgs a) {
     const uint8_t *ring_rg = ring + (size_t) rgi * (DR * CW * TILE_BYTES);
 #if LH_SET_PROBE
     const bool probe_on = a.probe != nullptr && tid == 0;
-    unsigned long long *probe_t = (unsigned long long *) (ring + (size_t) rgw * DR * CW * TILE_BYTES);
+    unsigned long long *probe_t = (unsigned long long *) (ring + (SHARE ? (size_t) rgw * DR * CW * TILE_BYTES : 0));
     if (probe_on) { for (int i = 0; i < 28; i++) probe_t[i] = 0; probe_t[0] = wall_clock64(); }
 #endif
     LH_PSTAMP(1);
@@ -167,6 +264,18 @@ k_gemv_set(const GemvSetArgs a) {
         const uint32_t dst_ = ring_lds + (uint32_t) (((SLOTI) * CW + ci) * TILE_BYTES);            \
         set_dma16(dst_, tp_, (uint32_t) woff);                                                     \
         set_dma4(dst_ + 1024u, tp_ + 1024u, (uint32_t) lane * 4u, true);                           \
+    }
+    // CW = 1: nobody shares this wave's weights, so its ring stays in REGISTERS (non-temporal loads, counted waits placed by the compiler) and
+    // LDS holds the operand rows only: occupancy is then bounded by registers (5 waves per SIMD), not by 5 KiB of LDS ring per wave -- the
+    // many small workgroups of the large matrices (w1|w3 at 8 rows: 1 376) fit the chip in one round instead of two.  (The register copies in
+    // front of the loop wait for chunks 0 .. DR - 1 here, consecutive chunks that arrive together -- not for the far end of the row.)
+    u32x4 wq[DR];
+    f32x2 ws[DR];
+#define LH_LOADW(SLOT, CH)                                                                         \
+    {                                                                                              \
+        const uint8_t *tp_ = (const uint8_t *) (uintptr_t) wbase + (size_t) min((CH), nchunks) * TILE_BYTES;      \
+        wq[SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + woff));                       \
+        ws[SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + soff));                       \
     }
     // ---- prologue.  vmcnt retires in order, so the order of issue is the order of arrival: the epilogue's operands (residual values, the
     // rows' positions) first, then the operand rows of all columns (LDS-DMA, permuted into the LDS layout by per-lane source addresses),
@@ -217,8 +326,15 @@ k_gemv_set(const GemvSetArgs a) {
             while (b >= ipcD) { b -= ipcD; n++; }
         }
     }
+    if (SHARE) {
 #pragma unroll
-    for (int i = 0; i < DR - 1; i++) LH_DMAW(i, i)
+        for (int i = 0; i < DR - 1; i++) LH_DMAW(i, i)
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < DR; i++) LH_LOADW(i, i)
+        __builtin_amdgcn_sched_barrier(0);
+    }
     LH_PSTAMP(2);
     {
         const int zc = npad - nchunks;                             // zeroed chunks behind every column: A 16 granules, d 8 floats each
@@ -228,7 +344,8 @@ k_gemv_set(const GemvSetArgs a) {
             else ((f32x4 *) sD)[((size_t) n * npad + nchunks) * 2 + (r - zc * 16)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
     }
-    set_wait_vmcnt<2 * (DR - 1)>();                                // everything older than the ring: this wave's share of the operand rows
+    if (SHARE) set_wait_vmcnt<2 * (DR - 1)>();                     // everything older than the ring: this wave's share of the operand rows
+    else set_wait_vmcnt<2 * DR>();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and everybody else's (a __syncthreads() would wait for the ring as well)
     LH_PSTAMP(3);
 
@@ -274,32 +391,37 @@ k_gemv_set(const GemvSetArgs a) {
         const f32x2 q67_ = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
         if (LH_SET_ABLATE != 1) LH_FMAC8_DPP(ACC, plo_, phi_, q01_, q23_, q45_, q67_);              \
     }
-    // step S (I = S % DR, compile time).  This wave's chunk of the step is DR - 1 steps old: wait for it (counted: the DR - 2 younger steps
-    // stay in flight), then -- CW > 1 -- one workgroup barrier: every wave's chunk of step S has landed AND every wave is done reading
-    // step S - 1, whose slot the DMA for step S + DR - 1 may now overwrite.  Then the CW chunks of the step in block order against this
-    // wave's NC columns.  (CW = 1: the wave shares its ring with nobody; its own reads of step S - 1 have returned, no barrier.)
+    // step S (I = S % DR, compile time).  CW > 1: this wave's chunk of the step is DR - 1 steps old: wait for it (counted: the DR - 2 younger
+    // steps stay in flight), then one workgroup barrier: every wave's chunk of step S has landed AND every wave is done reading step S - 1,
+    // whose slot the DMA for step S + DR - 1 may now overwrite; then the CW chunks of the step in block order against this wave's NC
+    // columns.  CW = 1: chunk S from ring register I, refilled with chunk S + DR behind its last use.
 #define LH_SSTEP(I, S)                                                                             \
     {                                                                                              \
         if (s0 == 0) LH_PSTAMP(4 + 3 * (I));                                                       \
-        set_wait_vmcnt<2 * (DR - 2)>();                                                            \
-        if (s0 == 0) LH_PSTAMP(5 + 3 * (I));                                                       \
-        if (SHARE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 \
-        if (s0 == 0) LH_PSTAMP(6 + 3 * (I));                                                       \
-        if (LH_SET_ABLATE != 2) LH_DMAW(((I) + DR - 1) % DR, (S) + DR - 1)                         \
-        LH_LDSW(0, (I), 0)                                                                         \
+        if (SHARE) {                                                                               \
+            set_wait_vmcnt<2 * (DR - 2)>();                                                        \
+            if (s0 == 0) LH_PSTAMP(5 + 3 * (I));                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
+            if (s0 == 0) LH_PSTAMP(6 + 3 * (I));                                                   \
+            if (LH_SET_ABLATE != 2) LH_DMAW(((I) + DR - 1) % DR, (S) + DR - 1)                     \
+            LH_LDSW(0, (I), 0)                                                                     \
+        }                                                                                          \
         _Pragma("unroll")                                                                          \
         for (int c = 0; c < CW; c++) {                                                             \
-            if (c + 1 < CW) LH_LDSW((c + 1) & 1, (I), c + 1)                                       \
+            if (SHARE && c + 1 < CW) LH_LDSW((c + 1) & 1, (I), c + 1)                              \
             _Pragma("unroll")                                                                      \
             for (int n = 0; n < NC; n++) {                                                         \
                 const int it_ = (I) * NCW + c * NC + n;        /* item index in the unrolled block */   \
                 const int pb_ = it_ % SET_NB;                                                      \
                 LH_LDSA((it_ + SET_PF) % SET_NB, (n + SET_PF) % NC, (S) * CW + c + (n + SET_PF) / NC) \
                 __builtin_amdgcn_sched_barrier(0);      /* the reads for the items ahead go out before this item's arithmetic */ \
-                LH_ITEM(wb[c & 1], wsb[c & 1], pb_, accs[n])                                       \
+                if (SHARE) LH_ITEM(wb[c & 1], wsb[c & 1], pb_, accs[n])                            \
+                else LH_ITEM(wq[I], ws[I], pb_, accs[n])                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
             }                                                                                      \
         }                                                                                          \
+        if (!SHARE && LH_SET_ABLATE != 2) LH_LOADW(I, (S) + DR)                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
     }
 #pragma unroll
     for (int i = 0; i < SET_PF; i++) LH_LDSA(i, i % NC, i / NC)
@@ -319,6 +441,7 @@ k_gemv_set(const GemvSetArgs a) {
 #undef LH_LDSW
 #undef LH_LDSA
 #undef LH_DMAW
+#undef LH_LOADW
 
 #if LH_SET_PROBE
 #define LH_PFLUSH() do { if (probe_on) { probe_t[25] = __builtin_readcyclecounter(); probe_t[26] = wall_clock64();                       \
@@ -328,103 +451,201 @@ k_gemv_set(const GemvSetArgs a) {
 #else
 #define LH_PFLUSH() do { } while (0)
 #endif
-    int lg = g;
-    if (a.gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : a.gmapF8 + b8 * 4 + (w8 - 4); }
-    const int m = lg * 8 + (lane >> 3);
-    if (EPI == EPI_SILU_QAH) {
-        // the workgroup's 32 outputs per column: gu[column][gate 0 .. 15 | up 0 .. 15]; the operand area is free again
-        float *gu = (float *) smem_d;
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            const float acc = fold8(accs[n]);
-            if (k == 0) gu[(ncol0 + n) * 32 + rgi * 8 + (lane >> 3)] = acc;
-        }
-        __syncthreads();
-        const bool inject = (a.lut_math & 0x1000) != 0;                       // fault-injection test: a tag nobody waits for, short polls
-        for (int col = wave; col < NCW; col += nw) {
-            if (col >= ncols || qah_block * 8 >= a.ngroups) continue;
-            const int i = lane & 15;
-            const uint16_t gh = f2h_bits(gu[col * 32 + i]);
-            const float act = h2f_bits((a.lut_math & 1) ? silu_math_bits(gh) : a.T_silu[gh]) * gu[col * 32 + 16 + i];
-            float amax = wave_max_f(lane < 16 ? fabsf(act) : 0.0f);
-            // the other half's partial amax of this column: one tagged granule each way inside this XCD's L2
-            const int gcol = col0 + col;
-            uint64_t *at = a.amax_t + (size_t) gcol * ((size_t) (a.ngroups / 8) * 2 + 16);
-            const int hb = qah_block * 2 + qah_half;
-            float other = 0.0f;
-            if (lane == 0) {
-                set_store_tagged(at + hb, amax, store_tag ^ (inject ? 1u : 0u));
-                other = set_poll_tagged(at + (hb ^ 1), store_tag, a.fault, inject);
-            }
-            other = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, other)));
-            amax = fmaxf(amax, other);
-            const float dd = amax / 7.0f;                                      // ggml.c:479
-            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;              // ggml.c:482
-            const uint32_t nib = (uint32_t) ((int) __builtin_rintf(act * id)) & 0xF;      // signed nibble of (q - 8)
-            const int kk = lane & 7;
-            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
-            const int b = qah_block, c = b >> 3, j = b & 7;
-            uint32_t *oA = a.out_A + (size_t) gcol * a.out_strideA;
-            if (lane < 8) ((uint16_t *) (oA + (c * 8 + kk) * 8 + j))[qah_half] = (uint16_t) ((e0 | (e1 << 8)) << (4 * (j & 1)));
-            if (lane == 0 && qah_half == 0) a.out_d[(size_t) gcol * a.out_strideD + b] = dd;
-        }
-        LH_PFLUSH();
-        return;
-    }
-    if (EPI == EPI_ROPE_KV) {
-        // (ggml.c:7076-7131, .mm:586-611; k_rope_kv) rows m, m ^ 1 = lanes 8 apart; m is even iff the lane's row is.  The table entries of
-        // all columns are requested together (one round trip), then the rotations
-        const RopeKvArgs &ra = a.ra;
-        const int which = m / ra.d, c = m - which * ra.d, pe = (c % ra.dh) & ~1;
-        const bool live = valid && k == 0 && m < a.M;
-        double cs[NC], sn[NC];
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            cs[n] = 1.0; sn[n] = 0.0;
-            if (live && which != 2) { cs[n] = ra.tab[(size_t) rope_pos[n] * ra.dh + pe]; sn[n] = ra.tab[(size_t) rope_pos[n] * ra.dh + pe + 1]; }
-        }
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            const float acc = fold8(accs[n]);
-            const int col = ncol0 + n;
-            const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
-            if (live && col < ncols) {
-                const int pos = rope_pos[n];
-                const long kvo = rope_kvo[n];
-                if (which == 2) {
-                    ra.Vc[kvo + (size_t) pos * ra.d + c] = acc;
-                } else {
-                    const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
-                    const float val = (c & 1) ? (float) (x0 * sn[n] + x1 * cs[n]) : (float) (x0 * cs[n] - x1 * sn[n]);
-                    if (which == 0) ra.qr[(size_t) (col0 + col) * ra.d + c] = val;
-                    else ra.Kc[kvo + (size_t) pos * ra.d + c] = val;
-                }
-            }
-        }
-        LH_PFLUSH();
-        return;
-    }
-#pragma unroll
-    for (int n = 0; n < NC; n++) {
-        float acc = fold8(accs[n]);
-        const int col = ncol0 + n;
-        if (valid && k == 0 && m < a.M && col < ncols) {
-            if (EPI == EPI_RESID) acc = acc + resid_v[n];
-            a.y[(size_t) (col0 + col) * a.y_stride + m] = acc;
-        }
+    {
+        const SetEpiCtx ex = { g, blk, rgi, ncol0, col0, ncols, nw, wave, lane, qah_block, qah_half, valid, store_tag };
+        set_epilogue<NC, NCW, EPI>(a, smem_d, accs, ex, resid_v, rope_pos, rope_kvo);
     }
     LH_PFLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_gemv_set_ar: the shared-ring form for 5 .. 10 rows on the LARGE matrices (wq|wk|wv, w1|w3, the lm head).  There the unshared form needs
+// column groups, i.e. the weights pass the CUs' load paths once per group -- and what a launch can pull through them, from L2 or from HBM,
+// is ~5.3 TB/s (w1|w3 at 8 rows as 2 groups: 113 MB in 22.8 us of loop, profiles/r05_n_timeline.txt).  Sharing a row-group's ring among
+// CW = 2 waves reads the weights once, but with the operand rows staged whole (8 columns x 4 096: 44 KB) plus the ring a workgroup takes
+// 84 KB of LDS: one per CU, 688 half-block workgroups in 2.7 rounds.  So here the operand rows go through a ring as well: step S's
+// CW x ncols (chunk, column) units -- 288 B each -- are fetched by LDS-DMA one instruction per "duty" wave next to the weight chunks
+// (A: the permuted [half][chain] granules, d: the {d[t], d[t + 4]} pairs), SET_DRA = 3 steps deep: 14 + 31 KB at 8 columns, three
+// workgroups per CU, every half-block workgroup of w1|w3 resident at once.  Same items, same order, same epilogues as k_gemv_set.
+//   NC: columns per wave (3 .. 5), CW = 2; waves = rgw x 2 with rgw = 4; needs ceil(ncols x 2 x 16 / 64) + ceil(ncols x 2 x 8 / 64) <= waves.
+// ------------------------------------------------------------------------------------------------
+constexpr int SET_DRA = 3;
+template <int NC, int EPI>
+__global__ void __launch_bounds__(512)
+k_gemv_set_ar(const GemvSetArgs a) {
+    constexpr int DR = SET_DRA, CW = 2, NCW = NC * CW;
+    extern __shared__ double smem_d[];
+    const int bid = blockIdx.x, cg = (bid >> 3) % a.ncg, blk = ((bid >> 3) / a.ncg) * 8 + (bid & 7);
+    const int col0 = cg * NCW;
+    const int nchunks = a.nchunks, ncols = min(NCW, a.ncols - col0), rgw = a.rgw;
+    const uint32_t *qa_A = a.qa_A + (size_t) col0 * nchunks * 64;
+    const float *qa_d = a.qa_d + (size_t) col0 * nchunks * 8;
+    const int steps = (nchunks + CW - 1) / CW;
+    const int units = CW * ncols;                                   // (chunk, column) units of a step: unit u = c * ncols + n
+    const int GA = units * 16, GD = units * 8;                      // granules of A / floats of d per step
+    const int slot_bytes = units * 288;
+    uint8_t *aring = (uint8_t *) smem_d;                            // [DR][ A: units x 16 granules | d: units x 4 pairs ]
+    uint8_t *ring = aring + (size_t) DR * slot_bytes;               // [rgw][DR][CW][TILE_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int) (blockDim.x >> 6);
+    const int rgi = wave / CW, ci = wave - rgi * CW;
+    const int qah_block = (blk >> 4) * 8 + (blk & 7), qah_half = (blk >> 3) & 1;
+    const int g = EPI == EPI_SILU_QAH ? qah_block * 8 + (rgi >> 1) * 4 + qah_half * 2 + (rgi & 1) : blk * rgw + rgi;
+    const bool valid = g < a.ngroups;
+    const uint64_t wbase = (uint64_t) (uintptr_t) (a.wt + (size_t) (valid ? g : a.ngroups - 1) * (nchunks + 1) * TILE_BYTES);
+    const int k = lane & 7, t = lane & 3;
+    const int woff = lane * 16, soff = 1024 + ((lane >> 3) * 8 + t * 2) * 4;
+    const uint32_t store_tag = EPI == EPI_SILU_QAH ? make_tag(__builtin_nontemporal_load(a.epoch), a.layer + 1) : 0u;
+    const uint32_t aring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) aring;
+    const uint32_t ring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) ring + (uint32_t) rgi * (DR * CW * TILE_BYTES);
+    const uint8_t *ring_rg = ring + (size_t) rgi * (DR * CW * TILE_BYTES);
+    // duty of this wave in the operand ring: A instruction `wave` (64 granules), or d instruction `wave - nA` (64 floats), or none
+    const int perA = nchunks * 16, perDf = nchunks * 8;
+    const int nA = (GA + 63) >> 6, nD = (GD + 63) >> 6;
+    const int duty = wave < nA ? 1 : wave < nA + nD ? 2 : 0;        // (wave-uniform)
+    int du_c = 0;                                                   // this lane's unit -> (chunk in step, column)
+    uint32_t du_src = 0, du_dst = 0;
+    bool du_on = false;
+    if (duty == 1) {
+        const int L = wave * 64 + lane, u = min(L >> 4, units - 1), x = L & 15, n = u % ncols;
+        du_c = u / ncols; du_on = L < GA;
+        du_src = (uint32_t) (((size_t) n * perA + (size_t) ((x & 7) * 2 + (x >> 3))) * 16);      // + chunk * 256
+        du_dst = (uint32_t) (wave * 64 * 16);
+    } else if (duty == 2) {
+        const int f = (wave - nA) * 64 + lane, u = min(f >> 3, units - 1), fx = f & 7, n = u % ncols;
+        du_c = u / ncols; du_on = f < GD;
+        du_src = (uint32_t) (((size_t) n * perDf + (size_t) ((fx & 1) * 4 + (fx >> 1))) * 4);    // + chunk * 32
+        du_dst = (uint32_t) (GA * 16 + (wave - nA) * 64 * 4);
+    }
+    // step S -> slot SLOTI: this wave's weight chunk (two DMA instructions) and its duty of the step's operand units (chunks past the row
+    // end: weights from the zero tile, operands clamped to the last chunk -- any finite d_a gives fma(0 * d_a, p, acc) == acc)
+#define LH_DMAS(SLOTI, S)                                                                          \
+    {                                                                                              \
+        const uint64_t tp_ = wbase + (uint64_t) min((S) * CW + ci, nchunks) * TILE_BYTES;          \
+        const uint32_t dst_ = ring_lds + (uint32_t) (((SLOTI) * CW + ci) * TILE_BYTES);            \
+        set_dma16(dst_, tp_, (uint32_t) woff);                                                     \
+        set_dma4(dst_ + 1024u, tp_ + 1024u, (uint32_t) lane * 4u, true);                           \
+        if (duty == 1) {                                                                           \
+            const uint32_t off_ = du_src + (uint32_t) min((S) * CW + du_c, nchunks - 1) * 256u;    \
+            if (du_on) set_dma16_cached(aring_lds + (uint32_t) ((SLOTI) * slot_bytes) + du_dst, (uint64_t) (uintptr_t) qa_A, off_); \
+        } else if (duty == 2) {                                                                    \
+            const uint32_t off_ = du_src + (uint32_t) min((S) * CW + du_c, nchunks - 1) * 32u;     \
+            if (du_on) set_dma4(aring_lds + (uint32_t) ((SLOTI) * slot_bytes) + du_dst, (uint64_t) (uintptr_t) qa_d, off_, false); \
+        }                                                                                          \
+    }
+    float resid_v[NC];
+    int rope_pos[NC];
+    long rope_kvo[NC];
+#pragma unroll
+    for (int n = 0; n < NC; n++) { resid_v[n] = 0.0f; rope_pos[n] = 0; rope_kvo[n] = 0; }
+    {
+        int lg0 = g;
+        if (a.gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : a.gmapF8 + b8 * 4 + (w8 - 4); }
+        const int m0 = min(lg0 * 8 + (lane >> 3), a.M - 1);
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const int col = col0 + min(ci * NC + n, ncols - 1);
+            if (EPI == EPI_RESID) resid_v[n] = a.resid[(size_t) col * a.resid_stride + m0];
+            if (EPI == EPI_ROPE_KV) {
+                rope_pos[n] = a.ra.set ? a.ra.set->pos[col] : a.ra.n_past + col;
+                rope_kvo[n] = a.ra.set ? a.ra.set->kv_off[col] : 0L;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DR - 1; i++) LH_DMAS(i, i)
+
+    float accs[NC];
+#pragma unroll
+    for (int n = 0; n < NC; n++) accs[n] = 0.0f;
+    const int ncol0 = ci * NC;
+    int cu[NC];                                                     // the wave's columns, clamped to the real ones
+#pragma unroll
+    for (int n = 0; n < NC; n++) cu[n] = min(ncol0 + n, ncols - 1);
+    u32x4 la0[2], la1[2], wb[2];
+    f32x2 ldd[2], wsb[2];
+#define LH_LDSA(BUF, SLOTI, C, N)                                                                  \
+    {                                                                                              \
+        const uint8_t *sb_ = aring + (size_t) (SLOTI) * slot_bytes;                                \
+        const u32x4 *pa_ = (const u32x4 *) sb_ + ((C) * ncols + cu[N]) * 16 + k;                   \
+        la0[BUF] = pa_[0]; la1[BUF] = pa_[8];                                                      \
+        ldd[BUF] = ((const f32x2 *) (sb_ + (size_t) GA * 16))[((C) * ncols + cu[N]) * 4 + t];      \
+    }
+#define LH_LDSW(BUF, SLOTI, C)                                                                     \
+    {                                                                                              \
+        const uint8_t *sp_ = ring_rg + (size_t) (((SLOTI) * CW) + (C)) * TILE_BYTES;               \
+        wb[BUF] = *(const u32x4 *) (sp_ + woff); wsb[BUF] = *(const f32x2 *) (sp_ + soff);         \
+    }
+#define LH_ITEM(W, SW, PB, ACC)                                                                    \
+    {                                                                                              \
+        const u32x4 a0 = la0[PB], a1 = la1[PB];                                                    \
+        const float plo_ = (SW).x * ldd[PB].x, phi_ = (SW).y * ldd[PB].y;                          \
+        const int i0_ = __builtin_amdgcn_sdot8((int) (W).x, (int) a0.x, 0x4B400000, true);         \
+        const int i1_ = __builtin_amdgcn_sdot8((int) (W).x, (int) a0.y, 0x4B400000, true);         \
+        const int i2_ = __builtin_amdgcn_sdot8((int) (W).y, (int) a0.z, 0x4B400000, true);         \
+        const int i3_ = __builtin_amdgcn_sdot8((int) (W).y, (int) a0.w, 0x4B400000, true);         \
+        const int i4_ = __builtin_amdgcn_sdot8((int) (W).z, (int) a1.x, 0x4B400000, true);         \
+        const int i5_ = __builtin_amdgcn_sdot8((int) (W).z, (int) a1.y, 0x4B400000, true);         \
+        const int i6_ = __builtin_amdgcn_sdot8((int) (W).w, (int) a1.z, 0x4B400000, true);         \
+        const int i7_ = __builtin_amdgcn_sdot8((int) (W).w, (int) a1.w, 0x4B400000, true);         \
+        const f32x2 mg_ = { 12582912.0f, 12582912.0f };                                            \
+        const f32x2 q01_ = f32x2{ __builtin_bit_cast(float, i0_), __builtin_bit_cast(float, i1_) } - mg_; \
+        const f32x2 q23_ = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
+        const f32x2 q45_ = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
+        const f32x2 q67_ = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
+        LH_FMAC8_DPP(ACC, plo_, phi_, q01_, q23_, q45_, q67_);                                     \
+    }
+    // step S in slot I = S % DR: wait for this wave's own requests of the step (a duty wave has three per step in flight, the others two),
+    // one workgroup barrier (everybody's share of step S has landed, everybody is done with step S - 1), request step S + DR - 1 into the
+    // slot of step S - 1, then the 2 chunks x NC columns of the step.  Operands are requested one item ahead WITHIN a step only.
+#define LH_ASTEP(I, S)                                                                             \
+    {                                                                                              \
+        if (duty) set_wait_vmcnt<3 * (DR - 2)>(); else set_wait_vmcnt<2 * (DR - 2)>();             \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                            \
+        LH_DMAS(((I) + DR - 1) % DR, (S) + DR - 1)                                                 \
+        LH_LDSW(0, (I), 0)                                                                         \
+        LH_LDSA(0, (I), 0, 0)                                                                      \
+        _Pragma("unroll")                                                                          \
+        for (int c = 0; c < CW; c++) {                                                             \
+            if (c + 1 < CW) LH_LDSW((c + 1) & 1, (I), c + 1)                                       \
+            _Pragma("unroll")                                                                      \
+            for (int n = 0; n < NC; n++) {                                                         \
+                const int it_ = c * NC + n, pb_ = it_ & 1;                                         \
+                if (n + 1 < NC) LH_LDSA(pb_ ^ 1, (I), c, n + 1)                                    \
+                else if (c + 1 < CW) LH_LDSA(pb_ ^ 1, (I), c + 1, 0)                               \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                LH_ITEM(wb[c & 1], wsb[c & 1], pb_, accs[n])                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    int s0 = 0;
+    for (; s0 + DR <= steps; s0 += DR) {
+#pragma unroll
+        for (int i = 0; i < DR; i++) LH_ASTEP(i, s0 + i)
+    }
+#pragma unroll
+    for (int i = 0; i < DR - 1; i++)
+        if (s0 + i < steps) LH_ASTEP(i, s0 + i)
+    set_wait_vmcnt<0>();
+#undef LH_ASTEP
+#undef LH_ITEM
+#undef LH_LDSW
+#undef LH_LDSA
+#undef LH_DMAS
+    {
+        const SetEpiCtx ex = { g, blk, rgi, ncol0, col0, ncols, nw, wave, lane, qah_block, qah_half, valid, store_tag };
+        set_epilogue<NC, NCW, EPI>(a, smem_d, accs, ex, resid_v, rope_pos, rope_kvo);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: the (NC, CW) plan per row count, launchers
 // ------------------------------------------------------------------------------------------------
-struct SetPlan { int nc = 0, cw = 0, rgw = 0, ncg = 1; size_t lds = 0; };
+struct SetPlan { int nc = 0, cw = 0, rgw = 0, ncg = 1; size_t lds = 0; bool ar = false; };
 
 static size_t set_lds_bytes(const QMat &w, int ncols_group, int nc, int cw, int rgw) {
     const int steps = (w.nchunks + cw - 1) / cw, npad = steps * cw + SET_PF;
-    size_t lds = (size_t) ncols_group * npad * 288 + (size_t) rgw * SET_DR * cw * TILE_BYTES + (LH_SET_PROBE ? 256 : 0);
+    size_t lds = (size_t) ncols_group * npad * 288 + (cw > 1 ? (size_t) rgw * SET_DR * cw * TILE_BYTES : 0) + (LH_SET_PROBE ? 256 : 0);
     return std::max(lds, (size_t) nc * cw * 64 * 4);
 }
 
@@ -440,7 +661,7 @@ static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int
     if (!env) return false;
     int e_nc = 0, e_cw = 0, e_ncg = 0, e_rgw = 0;
     const int got = sscanf(env, "%d,%d,%d,%d", &e_nc, &e_cw, &e_ncg, &e_rgw);
-    if (got < 2 || e_nc < 1 || e_nc > 4 || e_cw < 1 || e_cw > 4) return false;
+    if (got < 2 || e_nc < 1 || e_nc > 5 || e_cw < 1 || e_cw > 4 || (e_nc == 5 && e_cw != 1)) return false;
     if (got < 3 || e_ncg < 1) e_ncg = (N + e_nc * e_cw - 1) / (e_nc * e_cw);
     if (e_nc * e_cw * e_ncg < N || (e_ncg - 1) * e_nc * e_cw >= N) return false;
     nc = e_nc; cw = e_cw; ncg = e_ncg;
@@ -454,12 +675,21 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
     const bool big = w.ngroups >= 1536 || epi == EPI_SILU_QAH;
     int cw = big ? 1 : w.ngroups >= 768 ? 2 : 4;
     if (cw > N) cw = N;
-    int ncg = (N + 4 * cw - 1) / (4 * cw);
+    const int ncmax = cw == 1 ? 5 : 4;                                // (five columns per wave are instantiated for unshared rings only: 9 rows = 5 + 4)
+    int ncg = (N + ncmax * cw - 1) / (ncmax * cw);
     const int ng = (N + ncg - 1) / ncg;                               // columns per group, balanced (9 rows, unshared: 3 + 3 + 3)
     int nc = (ng + cw - 1) / cw, rgw = 0;
     cw = (ng + nc - 1) / nc;
-    if (!set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw)) set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
-    // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4>)
+    const bool env_plan = set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw) || set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
+    // 5 .. 10 rows on matrices with >= 768 row-groups: two waves per row-group share the weight ring AND the operand rows go through a ring
+    // (k_gemv_set_ar): weights once through the load paths, 45 KB of LDS whatever K is (LLAMAHIP_NO_SET_AR: measurement switch)
+    static const bool no_ar = getenv("LLAMAHIP_NO_SET_AR") != nullptr;
+    if (!env_plan && !no_ar && (big || w.ngroups >= 768) && N >= 5 && N <= 10) {
+        p.ar = true; p.nc = (N + 1) / 2; p.cw = 2; p.rgw = 4; p.ncg = 1;
+        p.lds = (size_t) SET_DRA * 2 * N * 288 + (size_t) p.rgw * SET_DRA * 2 * TILE_BYTES;
+        return p;
+    }
+    // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4> <5,1>)
     if (nc == 1 && cw == 1) nc = 2;
     if (nc == 3 && cw == 2) nc = 4;
     if (nc == 4 && cw == 3) cw = 4;
@@ -526,11 +756,21 @@ static hipError_t launch_set_any(const QMat &w, GemvSetArgs a, int epi, hipStrea
     const int nwg = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;
     const int grid = p.ncg == 1 ? nwg : (nwg + 7) / 8 * 8 * p.ncg;
     const int nthreads = p.rgw * p.cw * 64;
+    if (p.ar) {
+#define LH_AR(NCV, E) hipLaunchKernelGGL((k_gemv_set_ar<NCV, E>), dim3(grid), dim3(nthreads), p.lds, st, a)
+#define LH_ARN(NCV) { switch (epi) { case EPI_STORE: LH_AR(NCV, EPI_STORE); break; case EPI_RESID: LH_AR(NCV, EPI_RESID); break; case EPI_ROPE_KV: LH_AR(NCV, EPI_ROPE_KV); break; \
+                                      case EPI_SILU_QAH: LH_AR(NCV, EPI_SILU_QAH); break; default: return hipErrorInvalidValue; } }
+        if (p.nc == 3) LH_ARN(3) else if (p.nc == 4) LH_ARN(4) else if (p.nc == 5) LH_ARN(5) else return hipErrorInvalidValue;
+#undef LH_ARN
+#undef LH_AR
+        LH_LAUNCH_CHECK();
+        return hipSuccess;
+    }
 #define LH_SP(NCV, CWV) if (p.nc == NCV && p.cw == CWV) return launch_set_t<NCV, CWV>(a, epi, grid, nthreads, p.lds, st)
     LH_SP(1, 2); LH_SP(1, 3); LH_SP(1, 4);
     LH_SP(2, 1); LH_SP(2, 2); LH_SP(2, 3); LH_SP(2, 4);
     LH_SP(3, 1); LH_SP(3, 3); LH_SP(3, 4);
-    LH_SP(4, 1); LH_SP(4, 2); LH_SP(4, 4);
+    LH_SP(4, 1); LH_SP(4, 2); LH_SP(4, 4); LH_SP(5, 1);
 #undef LH_SP
     return hipErrorInvalidValue;
 }
@@ -570,7 +810,7 @@ hipError_t init_attrs_gemv_set() {
     LH_ATTR(1, 2); LH_ATTR(1, 3); LH_ATTR(1, 4);
     LH_ATTR(2, 1); LH_ATTR(2, 2); LH_ATTR(2, 3); LH_ATTR(2, 4);
     LH_ATTR(3, 1); LH_ATTR(3, 3); LH_ATTR(3, 4);
-    LH_ATTR(4, 1); LH_ATTR(4, 2); LH_ATTR(4, 4);
+    LH_ATTR(4, 1); LH_ATTR(4, 2); LH_ATTR(4, 4); LH_ATTR(5, 1);
 #undef LH_ATTR
 #undef LH_ATTR1
     return hipSuccess;

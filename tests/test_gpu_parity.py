@@ -77,8 +77,10 @@ def test_tiny_model_golden(L, tmp_path, nth, flags):
                                    (264, 4096, 3), (264, 4096, 4), (264, 4096, 6), (264, 4096, 7), (264, 4096, 11), (264, 4096, 16), (200, 11008, 9), (136, 1280, 12),
                                    # ... and matrices with >= 1 024 row-groups (two columns per wave up to four rows)
                                    (8200, 512, 2), (8200, 512, 3), (8200, 768, 4),
-                                   # ... more than four rows on those: column groups at grid level (7: 4 + 3, 9: 3 + 3 + 3, 16: 4 x 4)
-                                   (8200, 512, 7), (8200, 512, 9), (8200, 768, 16)])
+                                   # ... more rows on those: up to five columns per wave, then column groups at grid level (5: one group, 7: 4 + 3, 9: 5 + 4, 16: 4 x 4)
+                                   (8200, 512, 5), (8200, 512, 7), (8200, 512, 9), (8200, 768, 16),
+                                   # ... 5 .. 10 rows on >= 768 row-groups: the operand-ring form (k_gemv_set_ar: 3 .. 5 columns per wave, two waves per row-group)
+                                   (6200, 1280, 6), (6200, 1280, 8), (6200, 1792, 10), (12296, 1024, 9)])
 def test_mul_mat_vs_oracle(L, oracle, M, K, N):
     rng = np.random.default_rng(M + K + N)
     w = synth.quantize_q4_0_offline((0.02 * rng.standard_normal((M, K))).astype(np.float32))
