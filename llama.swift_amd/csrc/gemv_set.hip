@@ -459,189 +459,9 @@ k_gemv_set(const GemvSetArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_gemv_set_ar: the shared-ring form for 5 .. 10 rows on the LARGE matrices (wq|wk|wv, w1|w3, the lm head).  There the unshared form needs
-// column groups, i.e. the weights pass the CUs' load paths once per group -- and what a launch can pull through them, from L2 or from HBM,
-// is ~5.3 TB/s (w1|w3 at 8 rows as 2 groups: 113 MB in 22.8 us of loop, profiles/r05_n_timeline.txt).  Sharing a row-group's ring among
-// CW = 2 waves reads the weights once, but with the operand rows staged whole (8 columns x 4 096: 44 KB) plus the ring a workgroup takes
-// 84 KB of LDS: one per CU, 688 half-block workgroups in 2.7 rounds.  So here the operand rows go through a ring as well: step S's
-// CW x ncols (chunk, column) units -- 288 B each -- are fetched by LDS-DMA one instruction per "duty" wave next to the weight chunks
-// (A: the permuted [half][chain] granules, d: the {d[t], d[t + 4]} pairs), SET_DRA = 3 steps deep: 14 + 31 KB at 8 columns, three
-// workgroups per CU, every half-block workgroup of w1|w3 resident at once.  Same items, same order, same epilogues as k_gemv_set.
-//   NC: columns per wave (3 .. 5), CW = 2; waves = rgw x 2 with rgw = 4; needs ceil(ncols x 2 x 16 / 64) + ceil(ncols x 2 x 8 / 64) <= waves.
-// ------------------------------------------------------------------------------------------------
-constexpr int SET_DRA = 3;
-template <int NC, int EPI>
-__global__ void __launch_bounds__(512)
-k_gemv_set_ar(const GemvSetArgs a) {
-    constexpr int DR = SET_DRA, CW = 2, NCW = NC * CW;
-    extern __shared__ double smem_d[];
-    const int bid = blockIdx.x, cg = (bid >> 3) % a.ncg, blk = ((bid >> 3) / a.ncg) * 8 + (bid & 7);
-    const int col0 = cg * NCW;
-    const int nchunks = a.nchunks, ncols = min(NCW, a.ncols - col0), rgw = a.rgw;
-    const uint32_t *qa_A = a.qa_A + (size_t) col0 * nchunks * 64;
-    const float *qa_d = a.qa_d + (size_t) col0 * nchunks * 8;
-    const int steps = (nchunks + CW - 1) / CW;
-    const int units = CW * ncols;                                   // (chunk, column) units of a step: unit u = c * ncols + n
-    const int GA = units * 16, GD = units * 8;                      // granules of A / floats of d per step
-    const int slot_bytes = units * 288;
-    uint8_t *aring = (uint8_t *) smem_d;                            // [DR][ A: units x 16 granules | d: units x 4 pairs ]
-    uint8_t *ring = aring + (size_t) DR * slot_bytes;               // [rgw][DR][CW][TILE_BYTES]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int) (blockDim.x >> 6);
-    const int rgi = wave / CW, ci = wave - rgi * CW;
-    const int qah_block = (blk >> 4) * 8 + (blk & 7), qah_half = (blk >> 3) & 1;
-    const int g = EPI == EPI_SILU_QAH ? qah_block * 8 + (rgi >> 1) * 4 + qah_half * 2 + (rgi & 1) : blk * rgw + rgi;
-    const bool valid = g < a.ngroups;
-    const uint64_t wbase = (uint64_t) (uintptr_t) (a.wt + (size_t) (valid ? g : a.ngroups - 1) * (nchunks + 1) * TILE_BYTES);
-    const int k = lane & 7, t = lane & 3;
-    const int woff = lane * 16, soff = 1024 + ((lane >> 3) * 8 + t * 2) * 4;
-    const uint32_t store_tag = EPI == EPI_SILU_QAH ? make_tag(__builtin_nontemporal_load(a.epoch), a.layer + 1) : 0u;
-    const uint32_t aring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) aring;
-    const uint32_t ring_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) ring + (uint32_t) rgi * (DR * CW * TILE_BYTES);
-    const uint8_t *ring_rg = ring + (size_t) rgi * (DR * CW * TILE_BYTES);
-    // duty of this wave in the operand ring: A instruction `wave` (64 granules), or d instruction `wave - nA` (64 floats), or none
-    const int perA = nchunks * 16, perDf = nchunks * 8;
-    const int nA = (GA + 63) >> 6, nD = (GD + 63) >> 6;
-    const int duty = wave < nA ? 1 : wave < nA + nD ? 2 : 0;        // (wave-uniform)
-    int du_c = 0;                                                   // this lane's unit -> (chunk in step, column)
-    uint32_t du_src = 0, du_dst = 0;
-    bool du_on = false;
-    if (duty == 1) {
-        const int L = wave * 64 + lane, u = min(L >> 4, units - 1), x = L & 15, n = u % ncols;
-        du_c = u / ncols; du_on = L < GA;
-        du_src = (uint32_t) (((size_t) n * perA + (size_t) ((x & 7) * 2 + (x >> 3))) * 16);      // + chunk * 256
-        du_dst = (uint32_t) (wave * 64 * 16);
-    } else if (duty == 2) {
-        const int f = (wave - nA) * 64 + lane, u = min(f >> 3, units - 1), fx = f & 7, n = u % ncols;
-        du_c = u / ncols; du_on = f < GD;
-        du_src = (uint32_t) (((size_t) n * perDf + (size_t) ((fx & 1) * 4 + (fx >> 1))) * 4);    // + chunk * 32
-        du_dst = (uint32_t) (GA * 16 + (wave - nA) * 64 * 4);
-    }
-    // step S -> slot SLOTI: this wave's weight chunk (two DMA instructions) and its duty of the step's operand units (chunks past the row
-    // end: weights from the zero tile, operands clamped to the last chunk -- any finite d_a gives fma(0 * d_a, p, acc) == acc)
-#define LH_DMAS(SLOTI, S)                                                                          \
-    {                                                                                              \
-        const uint64_t tp_ = wbase + (uint64_t) min((S) * CW + ci, nchunks) * TILE_BYTES;          \
-        const uint32_t dst_ = ring_lds + (uint32_t) (((SLOTI) * CW + ci) * TILE_BYTES);            \
-        set_dma16(dst_, tp_, (uint32_t) woff);                                                     \
-        set_dma4(dst_ + 1024u, tp_ + 1024u, (uint32_t) lane * 4u, true);                           \
-        if (duty == 1) {                                                                           \
-            const uint32_t off_ = du_src + (uint32_t) min((S) * CW + du_c, nchunks - 1) * 256u;    \
-            if (du_on) set_dma16_cached(aring_lds + (uint32_t) ((SLOTI) * slot_bytes) + du_dst, (uint64_t) (uintptr_t) qa_A, off_); \
-        } else if (duty == 2) {                                                                    \
-            const uint32_t off_ = du_src + (uint32_t) min((S) * CW + du_c, nchunks - 1) * 32u;     \
-            if (du_on) set_dma4(aring_lds + (uint32_t) ((SLOTI) * slot_bytes) + du_dst, (uint64_t) (uintptr_t) qa_d, off_, false); \
-        }                                                                                          \
-    }
-    float resid_v[NC];
-    int rope_pos[NC];
-    long rope_kvo[NC];
-#pragma unroll
-    for (int n = 0; n < NC; n++) { resid_v[n] = 0.0f; rope_pos[n] = 0; rope_kvo[n] = 0; }
-    {
-        int lg0 = g;
-        if (a.gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg0 = w8 < 4 ? b8 * 4 + w8 : a.gmapF8 + b8 * 4 + (w8 - 4); }
-        const int m0 = min(lg0 * 8 + (lane >> 3), a.M - 1);
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            const int col = col0 + min(ci * NC + n, ncols - 1);
-            if (EPI == EPI_RESID) resid_v[n] = a.resid[(size_t) col * a.resid_stride + m0];
-            if (EPI == EPI_ROPE_KV) {
-                rope_pos[n] = a.ra.set ? a.ra.set->pos[col] : a.ra.n_past + col;
-                rope_kvo[n] = a.ra.set ? a.ra.set->kv_off[col] : 0L;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < DR - 1; i++) LH_DMAS(i, i)
-
-    float accs[NC];
-#pragma unroll
-    for (int n = 0; n < NC; n++) accs[n] = 0.0f;
-    const int ncol0 = ci * NC;
-    int cu[NC];                                                     // the wave's columns, clamped to the real ones
-#pragma unroll
-    for (int n = 0; n < NC; n++) cu[n] = min(ncol0 + n, ncols - 1);
-    u32x4 la0[2], la1[2], wb[2];
-    f32x2 ldd[2], wsb[2];
-#define LH_LDSA(BUF, SLOTI, C, N)                                                                  \
-    {                                                                                              \
-        const uint8_t *sb_ = aring + (size_t) (SLOTI) * slot_bytes;                                \
-        const u32x4 *pa_ = (const u32x4 *) sb_ + ((C) * ncols + cu[N]) * 16 + k;                   \
-        la0[BUF] = pa_[0]; la1[BUF] = pa_[8];                                                      \
-        ldd[BUF] = ((const f32x2 *) (sb_ + (size_t) GA * 16))[((C) * ncols + cu[N]) * 4 + t];      \
-    }
-#define LH_LDSW(BUF, SLOTI, C)                                                                     \
-    {                                                                                              \
-        const uint8_t *sp_ = ring_rg + (size_t) (((SLOTI) * CW) + (C)) * TILE_BYTES;               \
-        wb[BUF] = *(const u32x4 *) (sp_ + woff); wsb[BUF] = *(const f32x2 *) (sp_ + soff);         \
-    }
-#define LH_ITEM(W, SW, PB, ACC)                                                                    \
-    {                                                                                              \
-        const u32x4 a0 = la0[PB], a1 = la1[PB];                                                    \
-        const float plo_ = (SW).x * ldd[PB].x, phi_ = (SW).y * ldd[PB].y;                          \
-        const int i0_ = __builtin_amdgcn_sdot8((int) (W).x, (int) a0.x, 0x4B400000, true);         \
-        const int i1_ = __builtin_amdgcn_sdot8((int) (W).x, (int) a0.y, 0x4B400000, true);         \
-        const int i2_ = __builtin_amdgcn_sdot8((int) (W).y, (int) a0.z, 0x4B400000, true);         \
-        const int i3_ = __builtin_amdgcn_sdot8((int) (W).y, (int) a0.w, 0x4B400000, true);         \
-        const int i4_ = __builtin_amdgcn_sdot8((int) (W).z, (int) a1.x, 0x4B400000, true);         \
-        const int i5_ = __builtin_amdgcn_sdot8((int) (W).z, (int) a1.y, 0x4B400000, true);         \
-        const int i6_ = __builtin_amdgcn_sdot8((int) (W).w, (int) a1.z, 0x4B400000, true);         \
-        const int i7_ = __builtin_amdgcn_sdot8((int) (W).w, (int) a1.w, 0x4B400000, true);         \
-        const f32x2 mg_ = { 12582912.0f, 12582912.0f };                                            \
-        const f32x2 q01_ = f32x2{ __builtin_bit_cast(float, i0_), __builtin_bit_cast(float, i1_) } - mg_; \
-        const f32x2 q23_ = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
-        const f32x2 q45_ = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
-        const f32x2 q67_ = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
-        LH_FMAC8_DPP(ACC, plo_, phi_, q01_, q23_, q45_, q67_);                                     \
-    }
-    // step S in slot I = S % DR: wait for this wave's own requests of the step (a duty wave has three per step in flight, the others two),
-    // one workgroup barrier (everybody's share of step S has landed, everybody is done with step S - 1), request step S + DR - 1 into the
-    // slot of step S - 1, then the 2 chunks x NC columns of the step.  Operands are requested one item ahead WITHIN a step only.
-#define LH_ASTEP(I, S)                                                                             \
-    {                                                                                              \
-        if (duty) set_wait_vmcnt<3 * (DR - 2)>(); else set_wait_vmcnt<2 * (DR - 2)>();             \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                            \
-        LH_DMAS(((I) + DR - 1) % DR, (S) + DR - 1)                                                 \
-        LH_LDSW(0, (I), 0)                                                                         \
-        LH_LDSA(0, (I), 0, 0)                                                                      \
-        _Pragma("unroll")                                                                          \
-        for (int c = 0; c < CW; c++) {                                                             \
-            if (c + 1 < CW) LH_LDSW((c + 1) & 1, (I), c + 1)                                       \
-            _Pragma("unroll")                                                                      \
-            for (int n = 0; n < NC; n++) {                                                         \
-                const int it_ = c * NC + n, pb_ = it_ & 1;                                         \
-                if (n + 1 < NC) LH_LDSA(pb_ ^ 1, (I), c, n + 1)                                    \
-                else if (c + 1 < CW) LH_LDSA(pb_ ^ 1, (I), c + 1, 0)                               \
-                __builtin_amdgcn_sched_barrier(0);                                                 \
-                LH_ITEM(wb[c & 1], wsb[c & 1], pb_, accs[n])                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                 \
-            }                                                                                      \
-        }                                                                                          \
-    }
-    int s0 = 0;
-    for (; s0 + DR <= steps; s0 += DR) {
-#pragma unroll
-        for (int i = 0; i < DR; i++) LH_ASTEP(i, s0 + i)
-    }
-#pragma unroll
-    for (int i = 0; i < DR - 1; i++)
-        if (s0 + i < steps) LH_ASTEP(i, s0 + i)
-    set_wait_vmcnt<0>();
-#undef LH_ASTEP
-#undef LH_ITEM
-#undef LH_LDSW
-#undef LH_LDSA
-#undef LH_DMAS
-    {
-        const SetEpiCtx ex = { g, blk, rgi, ncol0, col0, ncols, nw, wave, lane, qah_block, qah_half, valid, store_tag };
-        set_epilogue<NC, NCW, EPI>(a, smem_d, accs, ex, resid_v, rope_pos, rope_kvo);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // host side: the (NC, CW) plan per row count, launchers
 // ------------------------------------------------------------------------------------------------
-struct SetPlan { int nc = 0, cw = 0, rgw = 0, ncg = 1; size_t lds = 0; bool ar = false; };
+struct SetPlan { int nc = 0, cw = 0, rgw = 0, ncg = 1; size_t lds = 0; };
 
 static size_t set_lds_bytes(const QMat &w, int ncols_group, int nc, int cw, int rgw) {
     const int steps = (w.nchunks + cw - 1) / cw, npad = steps * cw + SET_PF;
@@ -655,7 +475,8 @@ static size_t set_lds_bytes(const QMat &w, int ncols_group, int nc, int cw, int 
 // row-group with one or two columns each (items per wave = chunks x nc); matrices with >= 1 024 row-groups (wq|wk|wv, w1|w3, the lm head)
 // have waves enough: up to four columns per wave, no sharing, and for more than four rows column GROUPS at grid level (the groups of a
 // row block run side by side on one XCD; the second read of a tile is an L2 hit hidden behind arithmetic -- at 8 rows these launches
-// are VALU bound).  LLAMAHIP_SET_PLAN[_BIG|_SMALL]="nc,cw[,ncg[,rgw]]" overrides (measurement; _BIG: the unshared class).
+// are VALU bound: sharing the ring there AND streaming the operand rows through a second ring, k_gemv_set_ar of round 5, read the weights once
+// and measured the same -- profiles/r05_o_operand_ring_ab.txt; removed).  LLAMAHIP_SET_PLAN[_BIG|_SMALL]="nc,cw[,ncg[,rgw]]" overrides (measurement; _BIG: the unshared class).
 static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int &ncg, int &rgw) {
     const char *env = getenv(name);
     if (!env) return false;
@@ -680,15 +501,7 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
     const int ng = (N + ncg - 1) / ncg;                               // columns per group, balanced (9 rows, unshared: 3 + 3 + 3)
     int nc = (ng + cw - 1) / cw, rgw = 0;
     cw = (ng + nc - 1) / nc;
-    const bool env_plan = set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw) || set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
-    // 5 .. 10 rows on matrices with >= 768 row-groups: two waves per row-group share the weight ring AND the operand rows go through a ring
-    // (k_gemv_set_ar): weights once through the load paths, 45 KB of LDS whatever K is (LLAMAHIP_NO_SET_AR: measurement switch)
-    static const bool no_ar = getenv("LLAMAHIP_NO_SET_AR") != nullptr;
-    if (!env_plan && !no_ar && (big || w.ngroups >= 768) && N >= 5 && N <= 10) {
-        p.ar = true; p.nc = (N + 1) / 2; p.cw = 2; p.rgw = 4; p.ncg = 1;
-        p.lds = (size_t) SET_DRA * 2 * N * 288 + (size_t) p.rgw * SET_DRA * 2 * TILE_BYTES;
-        return p;
-    }
+    if (!set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw)) set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
     // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4> <5,1>)
     if (nc == 1 && cw == 1) nc = 2;
     if (nc == 3 && cw == 2) nc = 4;
@@ -756,16 +569,6 @@ static hipError_t launch_set_any(const QMat &w, GemvSetArgs a, int epi, hipStrea
     const int nwg = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;
     const int grid = p.ncg == 1 ? nwg : (nwg + 7) / 8 * 8 * p.ncg;
     const int nthreads = p.rgw * p.cw * 64;
-    if (p.ar) {
-#define LH_AR(NCV, E) hipLaunchKernelGGL((k_gemv_set_ar<NCV, E>), dim3(grid), dim3(nthreads), p.lds, st, a)
-#define LH_ARN(NCV) { switch (epi) { case EPI_STORE: LH_AR(NCV, EPI_STORE); break; case EPI_RESID: LH_AR(NCV, EPI_RESID); break; case EPI_ROPE_KV: LH_AR(NCV, EPI_ROPE_KV); break; \
-                                      case EPI_SILU_QAH: LH_AR(NCV, EPI_SILU_QAH); break; default: return hipErrorInvalidValue; } }
-        if (p.nc == 3) LH_ARN(3) else if (p.nc == 4) LH_ARN(4) else if (p.nc == 5) LH_ARN(5) else return hipErrorInvalidValue;
-#undef LH_ARN
-#undef LH_AR
-        LH_LAUNCH_CHECK();
-        return hipSuccess;
-    }
 #define LH_SP(NCV, CWV) if (p.nc == NCV && p.cw == CWV) return launch_set_t<NCV, CWV>(a, epi, grid, nthreads, p.lds, st)
     LH_SP(1, 2); LH_SP(1, 3); LH_SP(1, 4);
     LH_SP(2, 1); LH_SP(2, 2); LH_SP(2, 3); LH_SP(2, 4);

@@ -79,7 +79,7 @@ def test_tiny_model_golden(L, tmp_path, nth, flags):
                                    (8200, 512, 2), (8200, 512, 3), (8200, 768, 4),
                                    # ... more rows on those: up to five columns per wave, then column groups at grid level (5: one group, 7: 4 + 3, 9: 5 + 4, 16: 4 x 4)
                                    (8200, 512, 5), (8200, 512, 7), (8200, 512, 9), (8200, 768, 16),
-                                   # ... 5 .. 10 rows on >= 768 row-groups: the operand-ring form (k_gemv_set_ar: 3 .. 5 columns per wave, two waves per row-group)
+                                   # ... the row-group classes in between (768 .. 1 535 row-groups: two waves per row-group) and wider K
                                    (6200, 1280, 6), (6200, 1280, 8), (6200, 1792, 10), (12296, 1024, 9)])
 def test_mul_mat_vs_oracle(L, oracle, M, K, N):
     rng = np.random.default_rng(M + K + N)
