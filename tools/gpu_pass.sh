@@ -1,97 +1,36 @@
 #!/bin/bash
-# Round-5 GPU passes (one parameterised script; the per-round r0N_pass_*.sh scripts of rounds 3-4 are gone).
-# usage (on the GPU box, repo root):  bash tools/gpu_pass.sh <pass> [tag]
-#   a      first pass of the few-row kernel (k_gemv_set): quick parity, A/B against k_gemm_skinny with per-kernel tables, plan sweep,
-#          the nccl world-1 dry run of the pipeline bench
-#   final  everything profiles/<tag>_* is made from (see the case below)
-pass=${1:-a}; tag=${2:-r05_$pass}
+# The GPU passes of a round in ONE parameterised script (rounds 3-4 kept thirty one-shot r0N_pass_*.sh files; they are gone).
+# usage (on the GPU box, repo root):  bash tools/gpu_pass.sh <pass> [tag]      -- outputs under gpurun_out/<tag>_*
+#   quick  parity subset of the few-row paths (mat-mul shapes, set steps, short evals, fault injection)
+#   ab     A/B of library / switch variants: VARIANTS=<file of "label|ENV=VAL ..." lines> (tools/set_ab.sh: per-kernel tables with PROF=1,
+#          tools/fresh_ab.sh: every measurement in a fresh process), TIMELINE=1 adds the in-kernel timelines
+#   t      in-kernel timelines of k_gemv_set (libllamahip_setprobe.so: tools/build_set_variants.sh setprobe:"-DLH_SET_PROBE=1")
+#   mid    single-stream decode experiments (k_qkv_attn timeline, decode A/B over VARIANTS), set-step kernel tables + PMC traffic
+#   nccl   the RCCL branch of the pipeline bench at world 1 (communicators, self-check, forced one-rank schedule) with its log
+#   65b    BASELINE configs[4]'s model on one GPU: the forced one-rank pipeline in set mode (in-situ roofline of the stage step, parity gate)
+#   final  everything profiles/<tag>_* is made from: full GPU test suite, bench.py (7B, 13B), config[3] mixed run with HBM counters,
+#          prefill kernel table, prompt / chunk / runner probes, set-step tables + PMC, fresh-process set / eval rates
+pass=${1:-quick}; tag=${2:-r05_$pass}
 O=gpurun_out; mkdir -p $O; R=$PWD
 bash tools/ensure_7b.sh
+quick() { timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks or few_row or handoff_timeout or prompt_continuation or chunks_in_one_pass" --durations=5 > $O/${tag}_quick.txt 2>&1; tail -4 $O/${tag}_quick.txt; }
+set_tables() {      # kernel tables of the set step (4 and 8 sequences, then 9-token evals) + PMC traffic, product build against k_gemm_skinny
+  printf 'set|\nskinny|LLAMAHIP_NO_GEMV_SET=1\n' > /tmp/v_set.txt
+  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS= EVALS= timeout 900 bash tools/set_ab.sh /tmp/v_set.txt > $O/${tag}_set_step_kernel_stats.txt 2>&1
+  grep -v "k_repack\|copyBuffer\|fillBuffer" $O/${tag}_set_step_kernel_stats.txt | head -80
+  SEQS="2 4 8" EVALS="4 9 16" timeout 600 bash tools/fresh_ab.sh /tmp/v_set.txt > $O/${tag}_set_fresh_process_ab.txt 2>&1; cat $O/${tag}_set_fresh_process_ab.txt
+  for S in 4 8; do timeout 400 bash tools/pmc_set_pass.sh $S > $O/${tag}_set_pmc_S$S.txt 2>&1; head -12 $O/${tag}_set_pmc_S$S.txt; done
+}
 case $pass in
-a)
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or tiny_model_golden or multipart or prompt_continuation or short_chunks or other_head or batched_set" --durations=5 > $O/${tag}_quick.txt 2>&1
-  tail -25 $O/${tag}_quick.txt
-  cat > /tmp/v.txt <<EOV
-set|
-skinny|LLAMAHIP_NO_GEMV_SET=1
-EOV
-  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=2,4,8 EVALS=4,9,16 timeout 900 bash tools/set_ab.sh /tmp/v.txt > $O/${tag}_ab.txt 2>&1
-  cat $O/${tag}_ab.txt
-  cat > /tmp/v2.txt <<EOV
-p41|LLAMAHIP_SET_PLAN=4,1
-p22|LLAMAHIP_SET_PLAN=2,2
-p14|LLAMAHIP_SET_PLAN=1,4
-EOV
-  PROF=1 PROF_SEQS="4" SEQS=4 EVALS= timeout 600 bash tools/set_ab.sh /tmp/v2.txt > $O/${tag}_plans4.txt 2>&1
-  cat $O/${tag}_plans4.txt
-  cat > /tmp/v3.txt <<EOV
-p24|LLAMAHIP_SET_PLAN=2,4
-p42|LLAMAHIP_SET_PLAN=4,2
-p33|LLAMAHIP_SET_PLAN=3,3
-p34|LLAMAHIP_SET_PLAN=3,4
-EOV
-  PROF=1 PROF_SEQS="8" SEQS=8 EVALS=9 timeout 700 bash tools/set_ab.sh /tmp/v3.txt > $O/${tag}_plans8.txt 2>&1
-  cat $O/${tag}_plans8.txt
-  # the RCCL branch of the pipeline bench at world 1: init_process_group("nccl", device_id), the three communicators, barrier, object
-  # all-gather, the forced one-rank schedule in set mode
-  LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_BENCH_65B=0 LLAMAHIP_PIPE_NO_INSITU=1 timeout 600 python bench.py --steps 48 --warmup 4 > $O/${tag}_nccl_world1.json 2> $O/${tag}_nccl_world1.log
-  grep -v "^$" $O/${tag}_nccl_world1.log | tail -25; head -c 1500 $O/${tag}_nccl_world1.json; echo
-  ;;
-b)
-  # where the few-row kernel's time goes: ablation builds (make setab: no arithmetic | no weight loads in the loop | 8-deep ring)
-  cat > /tmp/v.txt <<EOV
-sa1|LLAMAHIP_LIB=libllamahip_sa1.so
-sa2|LLAMAHIP_LIB=libllamahip_sa2.so
-sa8|LLAMAHIP_LIB=libllamahip_sa8.so
-sa1_p41|LLAMAHIP_LIB=libllamahip_sa1.so LLAMAHIP_SET_PLAN=4,1
-sa2_p41|LLAMAHIP_LIB=libllamahip_sa2.so LLAMAHIP_SET_PLAN=4,1
-sa8_p41|LLAMAHIP_LIB=libllamahip_sa8.so LLAMAHIP_SET_PLAN=4,1
-EOV
-  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=4,8 EVALS=9 timeout 900 bash tools/set_ab.sh /tmp/v.txt > $O/${tag}_ablate.txt 2>&1
-  cat $O/${tag}_ablate.txt
-  ;;
-c)
-  # operand prefetch distance 3 (default build) against 1 (libllamahip_pf1.so), and the loop without its weight loads (sa2)
-  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks" > $O/${tag}_quick.txt 2>&1; tail -3 $O/${tag}_quick.txt
-  cat > /tmp/v.txt <<EOV
-pf3|
-pf1|LLAMAHIP_LIB=libllamahip_pf1.so
-pf3_sa2|LLAMAHIP_LIB=libllamahip_sa2.so
-pf3_p41|LLAMAHIP_SET_PLAN=4,1
-pf3_p42|LLAMAHIP_SET_PLAN=4,2
-EOV
-  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=4,8 EVALS=9 timeout 900 bash tools/set_ab.sh /tmp/v.txt > $O/${tag}_pf.txt 2>&1
-  grep -v "k_repack\|copyBuffer\|k_argmax\|fillBuffer\|k_embed" $O/${tag}_pf.txt
-  ;;
-d)
-  # generic A/B: variants from $VARIANTS (file), quick parity first
-  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks" > $O/${tag}_quick.txt 2>&1; tail -3 $O/${tag}_quick.txt
-  PROF=1 PROF_SEQS="${PROF_SEQS:-4 8}" PROF_EVALS=9 SEQS=${SEQS:-4,8} EVALS=9 timeout 900 bash tools/set_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_ab.txt 2>&1
+quick) quick ;;
+ab)
+  quick
+  PROF=${PROF-1} PROF_SEQS="${PROF_SEQS:-4 8}" PROF_EVALS=9 SEQS=${SEQS:-4,8} EVALS=9 timeout 900 bash tools/set_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_ab.txt 2>&1
   grep -v "k_repack\|copyBuffer\|k_argmax\|fillBuffer\|k_embed" $O/${tag}_ab.txt
+  timeout 600 bash tools/fresh_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_fresh_ab.txt 2>&1; cat $O/${tag}_fresh_ab.txt
   if [ -n "$TIMELINE" ]; then bash tools/gpu_pass.sh t ${tag}; fi
   ;;
-m)
-  # mid-round pass: the new GPU tests, single-stream decode experiments (k_qkv_attn timeline of the tree, q|k-first
-  # dispatch order A/B), kernel tables + PMC traffic of the set step, the reference's 9-token evals
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks or few_row_handoff or handoff_timeout or prompt_continuation or chunks_in_one_pass" > $O/${tag}_quick.txt 2>&1; tail -3 $O/${tag}_quick.txt
-  cat > /tmp/v.txt <<EOV
-base|
-qk_first|LLAMAHIP_QKV_QK_FIRST=1
-EOV
-  PROF=1 KEEP=1 STEPS=96 AT=8,256,440 PROF_AT=128 FILTER='k_gemv\|k_qkv\|k_embed' timeout 600 bash tools/decode_ab.sh /tmp/v.txt > $O/${tag}_qkv_order_ab.txt 2>&1
-  cat $O/${tag}_qkv_order_ab.txt
-  timeout 300 python tools/attn_timeline.py 128 3 > $O/${tag}_attn_timeline.txt 2>&1; tail -30 $O/${tag}_attn_timeline.txt
-  cat > /tmp/v2.txt <<EOV
-set|
-skinny|LLAMAHIP_NO_GEMV_SET=1
-EOV
-  PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS=2,4,8 EVALS=4,9,16 timeout 900 bash tools/set_ab.sh /tmp/v2.txt > $O/${tag}_set_ab.txt 2>&1
-  grep -v "k_repack\|copyBuffer\|fillBuffer" $O/${tag}_set_ab.txt
-  timeout 400 bash tools/pmc_set_pass.sh 4 > $O/${tag}_set_pmc_S4.txt 2>&1; cat $O/${tag}_set_pmc_S4.txt
-  timeout 400 bash tools/pmc_set_pass.sh 8 > $O/${tag}_set_pmc_S8.txt 2>&1; cat $O/${tag}_set_pmc_S8.txt
-  ;;
 t)
-  # in-kernel timelines of the few-row kernel (libllamahip_setprobe.so)
   for spec in "--seqs 4" "--seqs 8" "--evals 9"; do
     for plan in ${PLANS:-""}; do
       echo "== set_timeline $spec plan=[$plan]"
@@ -99,5 +38,51 @@ t)
     done
   done > $O/${tag}_timeline.txt 2>&1
   cat $O/${tag}_timeline.txt
+  ;;
+mid)
+  quick
+  PROF=1 KEEP=1 STEPS=96 AT=8,256,440 PROF_AT=128 FILTER='k_gemv\|k_qkv\|k_embed' timeout 600 bash tools/decode_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_decode_ab.txt 2>&1
+  cat $O/${tag}_decode_ab.txt
+  timeout 300 python tools/attn_timeline.py 128 3 > $O/${tag}_attn_timeline.txt 2>&1; tail -8 $O/${tag}_attn_timeline.txt
+  set_tables
+  ;;
+nccl)
+  LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_BENCH_65B=0 timeout 900 python bench.py --steps 64 --warmup 8 > $O/${tag}_nccl_world1.json 2> $O/${tag}_nccl_world1.log
+  grep -v "^$" $O/${tag}_nccl_world1.log | tail -25; head -c 2500 $O/${tag}_nccl_world1.json; echo
+  ;;
+65b)
+  LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_PIPE_PARITY_S=${PARITY_S:-60} timeout 2400 python bench.py --model 65B --steps 32 --warmup 4 > $O/${tag}_bench_65B_1gpu.json 2> $O/${tag}_bench_65B_1gpu.log
+  tail -12 $O/${tag}_bench_65B_1gpu.log; head -c 3000 $O/${tag}_bench_65B_1gpu.json; echo
+  ;;
+final)
+  python -m pytest tests -x -q -m gpu --durations=8 > $O/${tag}_pytest.txt 2>&1; tail -12 $O/${tag}_pytest.txt
+  timeout 1200 python bench.py --save-profile $O/${tag}_decode_kernel_stats.txt > $O/${tag}_bench.json 2> $O/${tag}_bench.log; tail -3 $O/${tag}_bench.log; python - <<PY
+import json
+d = json.load(open("$O/${tag}_bench.json"))
+print({k: d[k] for k in ("metric", "value", "unit", "ms_per_step")}, d["roofline"].get("frac"), d["roofline"].get("end_to_end_frac"), d["roofline"].get("traffic"))
+print("config", d["config"])
+print("roofline scalars", {k: v for k, v in d["roofline"].items() if k.startswith("dominant_by_time_") or k.startswith("full_context")})
+print("full_context", d.get("full_context", {}).get("tokens_per_s"), "prefill2048", d["prefill"].get("configs2_2048_tokens_one_eval", {}).get("tokens_per_s"),
+      "decode after", d["prefill"].get("configs2_2048_tokens_one_eval", {}).get("decode_after_prompt"))
+print("concurrent", [c.get("aggregate_tokens_per_s") for c in d.get("concurrent_sequences", [])] if isinstance(d.get("concurrent_sequences"), list) else d.get("concurrent_sequences"))
+print("batched", [(c.get("sequences"), c.get("aggregate_tokens_per_s"), c.get("tokens_equal_single_stream")) for c in d.get("batched_sequences", [])] if isinstance(d.get("batched_sequences"), list) else d.get("batched_sequences"))
+print("parity", d.get("parity"), "cpu", d.get("cpu_baseline", {}).get("value"))
+PY
+  # configs[3]: 13B bench line (parity gate + cpu_baseline) and the mixed prefill + decode run under rocprofv3 (decode crosses position 544)
+  timeout 1200 python bench.py --model 13B --no-prefill-2048 --no-concurrent > $O/${tag}_bench_13B.json 2> $O/${tag}_bench_13B.log; python - <<PY
+import json
+d = json.load(open("$O/${tag}_bench_13B.json"))
+print("13B", {k: d[k] for k in ("value", "ms_per_step")}, d["roofline"].get("frac"), d["roofline"].get("end_to_end_frac"), d.get("parity"), d.get("cpu_baseline", {}).get("value"), d["config"])
+PY
+  timeout 1200 bash tools/run_config4.sh 13B > $O/${tag}_cfg4.log 2>&1; { grep -h "prefill\|decode" $O/cfg4/run_plain.txt | sed 's/^/# /'; cat $O/cfg4/hbm_summary.txt; } > $O/${tag}_13B_mixed_hbm.txt; head -24 $O/${tag}_13B_mixed_hbm.txt
+  # prompt paths
+  cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pf1
+  LLAMAHIP_WITH_TORCH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf1 -o p -- python $R/tools/prefill_one.py 2048 2 > /tmp/pf1.log 2>&1
+  cd $R
+  python tools/prof_summary.py $(find /tmp/pf1 -name "*kernel_stats.csv") "rocprofv3 --kernel-trace --stats -- python tools/prefill_one.py 2048 2   (MI355X, synthetic LLaMA-7B Q4_0: model load, building the prompt copies, three 2048-token evals at n_ctx 2560; exact path, k_gemm_mfma4)" > $O/${tag}_prefill_2048_kernel_stats.txt
+  timeout 300 python tools/prefill_probe.py > $O/${tag}_prefill_probe.txt 2>&1; tail -6 $O/${tag}_prefill_probe.txt
+  timeout 300 python tools/chunk_probe.py > $O/${tag}_chunk_probe.txt 2>&1; tail -7 $O/${tag}_chunk_probe.txt
+  timeout 300 python tools/runner_probe.py > $O/${tag}_runner_probe.txt 2>&1; tail -3 $O/${tag}_runner_probe.txt
+  set_tables
   ;;
 esac
