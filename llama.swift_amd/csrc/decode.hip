@@ -1152,6 +1152,9 @@ k_dec_pv_stream(const float *__restrict__ sc, const float *__restrict__ Vc, int 
 // Workgroup barriers: one raw s_barrier before the loaders start (a __syncthreads would make them wait for their DMA), then an LDS
 // counter among the six worker waves.  grid H x split, 512 threads; LDS = red + p[n_ctx] + part[nth][128] + flags + ring.  dh = 128.
 // ------------------------------------------------------------------------------------------------
+#ifndef LH_PVD_ABLATE
+#define LH_PVD_ABLATE 0
+#endif
 constexpr int PVD_SR = 8;            // rows per chain and stage: four DMA instructions of two rows
 template <int N> __device__ __forceinline__ void pvd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void pvd_barrier() {      // LDS writes of this wave done, then the hardware barrier; nothing waits for VMEM
@@ -1258,6 +1261,9 @@ k_dec_pv_dma(const float *__restrict__ sc, const float *__restrict__ Vc, int d, 
         double sum = 0.0;
 #pragma unroll
         for (int i = 0; i < PV_ROW; i++) {
+#if LH_PVD_ABLATE == 1     /* measurement only (wrong sums): exponentiate this workgroup's OWN keys only -- the upper bound of what splitting the soft_max over a head's workgroups could save, before its exchange costs (profiles/r05_q_pv_softmax_ablation.txt: 15.23 -> 15.74 us, i.e. nothing) */
+            if (i * NWT + wt < T && (i * NWT + wt < dc * th_lo || i * NWT + wt >= dc * (th_lo + nloc))) rv[i] = 0.0f; else
+#endif
             if (i * NWT + wt < T) {
                 const uint16_t xh = f2h_bits(rv[i] - m2);
                 rv[i] = h2f_bits((lut_math & 2) ? exp_math_bits(xh) : T_exp[xh]);
@@ -2029,6 +2035,10 @@ hipError_t launch_gemv_pick(const QMat &w, const float *in0, const float *in1, f
     return hipSuccess;
 }
 // w1|w3 in half-block workgroups (EPI_SILU_QAH, llamahip_internal.h)
+// (QUARTER-block workgroups of two waves -- VERDICT r04 item 4c: 13B's 432 blocks would go from max / mean 1.19 to 1.04 workgroups per CU --
+//  were built in round 5, parity green, and measured: w1|w3 at 13B 16.60 us in block workgroups, 21.48 in halves, 25.01 in quarters; decode
+//  466 / 427 / 405 tokens/s (profiles/r05_q_w13_quarter_ab.txt).  Every workgroup repeats the norm -> Q4_0 prologue of the whole row, so
+//  halving the workgroup doubles that work per CU, and at K = 5120 a 128-thread workgroup needs three prologue passes.  Removed.)
 bool gemv_silu_half_applies(const QMat &w) {
     static const bool off = getenv("LLAMAHIP_NO_W13_HALF") != nullptr;
     static const bool force = getenv("LLAMAHIP_W13_HALF") && atoi(getenv("LLAMAHIP_W13_HALF")) == 1;      // tests: shapes the balance rule leaves with block workgroups

@@ -6,6 +6,7 @@
 #          tools/fresh_ab.sh: every measurement in a fresh process), TIMELINE=1 adds the in-kernel timelines
 #   t      in-kernel timelines of k_gemv_set (libllamahip_setprobe.so: tools/build_set_variants.sh setprobe:"-DLH_SET_PROBE=1")
 #   mid    single-stream decode experiments (k_qkv_attn timeline, decode A/B over VARIANTS), set-step kernel tables + PMC traffic
+#   x      soft_max ablation of k_dec_pv_dma at 2 048 keys (libllamahip_pvabl.so)
 #   nccl   the RCCL branch of the pipeline bench at world 1 (communicators, self-check, forced one-rank schedule) with its log
 #   65b    BASELINE configs[4]'s model on one GPU: the forced one-rank pipeline in set mode (in-situ roofline of the stage step, parity gate)
 #   final  everything profiles/<tag>_* is made from: full GPU test suite, bench.py (7B, 13B), config[3] mixed run with HBM counters,
@@ -49,6 +50,11 @@ mid)
 nccl)
   LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_BENCH_65B=0 timeout 900 python bench.py --steps 64 --warmup 8 > $O/${tag}_nccl_world1.json 2> $O/${tag}_nccl_world1.log
   grep -v "^$" $O/${tag}_nccl_world1.log | tail -25; head -c 2500 $O/${tag}_nccl_world1.json; echo
+  ;;
+x)    # round 5's last bounded experiment still in the tree: the soft_max of k_dec_pv_dma reduced to a workgroup's own keys (upper bound of a split;
+      # SRC=decode tools/build_set_variants.sh pvabl:"-DLH_PVD_ABLATE=1").  (The quarter-block w1|w3 A/B of the same pass: profiles/r05_q_w13_quarter.diff.)
+  printf 'product|\nsoft_max_own_keys_only|LLAMAHIP_LIB=libllamahip_pvabl.so\n' > /tmp/v_p.txt
+  PROF=1 STEPS=48 AT=2048 PROF_AT=2048 N_CTX=2560 FILTER='k_dec_pv\|k_dec_scores' timeout 600 bash tools/decode_ab.sh /tmp/v_p.txt > $O/${tag}_pv_softmax_ablation.txt 2>&1; cat $O/${tag}_pv_softmax_ablation.txt
   ;;
 65b)
   LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_PIPE_PARITY_S=${PARITY_S:-60} timeout 2400 python bench.py --model 65B --steps 32 --warmup 4 > $O/${tag}_bench_65B_1gpu.json 2> $O/${tag}_bench_65B_1gpu.log
