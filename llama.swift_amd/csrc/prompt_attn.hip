@@ -137,6 +137,8 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 //   k_attnq_softmax      grid (NB/64, H) x (64 queries x 16 key phases): exp LUT, double sum -> S = e, inv
 //   k_attnq_pv_mfma      grid (NB/64, H, nth): p = e * inv; the FMA chains of ONE chunk of the reference's nth-way key split -> part
 //   k_attnq_merge        the ordered add of the nth partials                              -> merged
+// (Round 5 kept e as the 16 bits of its table entry in a second workspace -- half the bytes V*P reads back; bit-identical; 2 048-token eval
+// 165.6 -> 166.4 ms, i.e. nothing: the workspace round trips are not what these launches wait for.  profiles/r05_r_prefill_e16_ab.txt; reverted.)
 // Arithmetic is identical to k_attn.  (Rounds 1-2 had three more score kernels / one more V*P kernel with lane = query row and the key /
 // value row as SGPR operands, through LDS broadcasts, or on the VALU: 201 / 152 us per score launch at 2 048 tokens against 100 here;
 // removed in round 3, DESIGN_HISTORY.md.)

@@ -35,7 +35,11 @@ n = lib.llamahip_debug_decode_phases(m._h, n_past, int(np.argmax(lg)), steps, re
 assert n > 0, err.value
 rec = rec[:n].astype(np.int64)
 kind = rec[:, 5] >> 48
-tpu = float((rec[:, 4] - rec[:, 0]).sum()) / (float((rec[:, 6] - rec[:, 7]).sum()) / 100.0)
+# s_memtime ticks per microsecond, from the mat-vec records only: their last stamp is taken right before the exit wall clock (a score /
+# soft_max.V workgroup's stamp 4 can lie well before its exit, which made the all-records ratio of rounds 3-4 read 1 443 instead of ~2 320)
+_mv = (kind == 0x44) | (kind == 0x24)
+_cal = rec[_mv] if _mv.any() else rec
+tpu = float((_cal[:, 4] - _cal[:, 0]).sum()) / (float((_cal[:, 6] - _cal[:, 7]).sum()) / 100.0)
 order = np.argsort(rec[:, 7], kind="stable")
 rec = rec[order]; kind = kind[order]
 # launches are serialised: a launch = a maximal run of records (by entry time) whose kinds all belong to the attention

@@ -7,6 +7,7 @@
 #   t      in-kernel timelines of k_gemv_set (libllamahip_setprobe.so: tools/build_set_variants.sh setprobe:"-DLH_SET_PROBE=1")
 #   mid    single-stream decode experiments (k_qkv_attn timeline, decode A/B over VARIANTS), set-step kernel tables + PMC traffic
 #   x      soft_max ablation of k_dec_pv_dma at 2 048 keys (libllamahip_pvabl.so)
+#   pf     long-prompt A/B of library / switch variants (VARIANTS) + the prompt parity tests
 #   nccl   the RCCL branch of the pipeline bench at world 1 (communicators, self-check, forced one-rank schedule) with its log
 #   65b    BASELINE configs[4]'s model on one GPU: the forced one-rank pipeline in set mode (in-situ roofline of the stage step, parity gate)
 #   final  everything profiles/<tag>_* is made from: full GPU test suite, bench.py (7B, 13B), config[3] mixed run with HBM counters,
@@ -55,6 +56,10 @@ x)    # round 5's last bounded experiment still in the tree: the soft_max of k_d
       # SRC=decode tools/build_set_variants.sh pvabl:"-DLH_PVD_ABLATE=1").  (The quarter-block w1|w3 A/B of the same pass: profiles/r05_q_w13_quarter.diff.)
   printf 'product|\nsoft_max_own_keys_only|LLAMAHIP_LIB=libllamahip_pvabl.so\n' > /tmp/v_p.txt
   PROF=1 STEPS=48 AT=2048 PROF_AT=2048 N_CTX=2560 FILTER='k_dec_pv\|k_dec_scores' timeout 600 bash tools/decode_ab.sh /tmp/v_p.txt > $O/${tag}_pv_softmax_ablation.txt 2>&1; cat $O/${tag}_pv_softmax_ablation.txt
+  ;;
+pf)   # long-prompt A/B over VARIANTS (tools/prefill_ab.sh) + the prompt parity tests on the product build
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "prompt_continuation or chunks_in_one_pass or 2048_token_prefill or reference_flow" --durations=5 > $O/${tag}_prompt_parity.txt 2>&1; tail -4 $O/${tag}_prompt_parity.txt
+  PROF=1 N=2048 timeout 900 bash tools/prefill_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_prefill_ab.txt 2>&1; cat $O/${tag}_prefill_ab.txt
   ;;
 65b)
   LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_PIPE_PARITY_S=${PARITY_S:-60} timeout 2400 python bench.py --model 65B --steps 32 --warmup 4 > $O/${tag}_bench_65B_1gpu.json 2> $O/${tag}_bench_65B_1gpu.log
