@@ -95,5 +95,7 @@ PY
   timeout 300 python tools/chunk_probe.py > $O/${tag}_chunk_probe.txt 2>&1; tail -7 $O/${tag}_chunk_probe.txt
   timeout 300 python tools/runner_probe.py > $O/${tag}_runner_probe.txt 2>&1; tail -3 $O/${tag}_runner_probe.txt
   set_tables
+  timeout 300 python tools/attn_timeline.py 128 3 > $O/${tag}_attn_timeline.txt 2>&1; tail -6 $O/${tag}_attn_timeline.txt
+  bash tools/gpu_pass.sh t ${tag}_set
   ;;
 esac
