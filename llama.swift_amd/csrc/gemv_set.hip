@@ -34,6 +34,11 @@
 //                           halves of a block exchange their partial amax per column as tagged granules inside one XCD's L2 (k_gemv's
 //                           EPI_SILU_QAH: fmaxf is exact in any order).  Half blocks because whole blocks are F / 32 = 344 workgroups
 //                           on 256 CUs at 7B.
+//   EPI_SILU_QA             the same in WHOLE-block workgroups (RGW = 8: the block's four gate row-groups + its four up row-groups, as
+//                           k_gemv's 8-wave w1|w3 launch): no exchange.  Taken from two column groups on (6+ rows): the groups double
+//                           the workgroups, so the CU balance that asked for halves is there anyway, and with more columns per step a
+//                           half-block workgroup waited 4 - 11 us for its partner (profiles/r05_final_set_timeline.txt: epilogue 1.6 /
+//                           3.8 / 10.7 us at 4 / 8 / 9 rows).
 #include <cstring>
 
 #include "kcommon.hip.h"
@@ -133,6 +138,34 @@ __device__ __forceinline__ void set_epilogue(const GemvSetArgs &a, double *smem_
     int lg = g;
     if (a.gmapF8) { const int b8 = g >> 3, w8 = g & 7; lg = w8 < 4 ? b8 * 4 + w8 : a.gmapF8 + b8 * 4 + (w8 - 4); }
     const int m = lg * 8 + (lane >> 3);
+    if (EPI == EPI_SILU_QA) {
+        // whole block: gu[column][gate 0 .. 31 | up 0 .. 31] (row-groups 0 - 3 gate, 4 - 7 up); k_gemv's EPI_SILU_QA per column
+        float *gu = (float *) smem_d;
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float acc = fold8(accs[n]);
+            if (k == 0) gu[(ncol0 + n) * 64 + rgi * 8 + (lane >> 3)] = acc;
+        }
+        __syncthreads();
+        for (int col = wave; col < NCW; col += nw) {
+            if (col >= ncols || x.blk * 8 >= a.ngroups) continue;
+            const int i = lane & 31;
+            const uint16_t gh = f2h_bits(gu[col * 64 + i]);
+            const float act = h2f_bits((a.lut_math & 1) ? silu_math_bits(gh) : a.T_silu[gh]) * gu[col * 64 + 32 + i];
+            const float amax = wave_max_f(fabsf(act));                         // (lanes 32 .. 63 repeat lanes 0 .. 31)
+            const float dd = amax / 7.0f;                                      // ggml.c:479
+            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;              // ggml.c:482
+            const uint32_t nib = (uint32_t) ((int) __builtin_rintf(act * id)) & 0xF;      // signed nibble of (q - 8)
+            const int kk = lane & 7;
+            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
+            const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
+            const int gcol = col0 + col, b = x.blk, c = b >> 3, j = b & 7;
+            if (lane < 8) a.out_A[(size_t) gcol * a.out_strideA + (c * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
+            if (lane == 0) a.out_d[(size_t) gcol * a.out_strideD + b] = dd;
+        }
+        return;
+    }
     if (EPI == EPI_SILU_QAH) {
         // the workgroup's 32 outputs per column: gu[column][gate 0 .. 15 | up 0 .. 15]; the operand area is free again
         float *gu = (float *) smem_d;
@@ -486,14 +519,14 @@ static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int
     if (got < 3 || e_ncg < 1) e_ncg = (N + e_nc * e_cw - 1) / (e_nc * e_cw);
     if (e_nc * e_cw * e_ncg < N || (e_ncg - 1) * e_nc * e_cw >= N) return false;
     nc = e_nc; cw = e_cw; ncg = e_ncg;
-    if (got >= 4 && e_rgw >= 1 && e_rgw <= 8 && epi != EPI_SILU_QAH) rgw = e_rgw;
+    if (got >= 4 && e_rgw >= 1 && e_rgw <= 8 && epi != EPI_SILU_QAH && epi != EPI_SILU_QA) rgw = e_rgw;
     return true;
 }
 static SetPlan set_plan(const QMat &w, int N, int epi) {
     SetPlan p;
     // waves per row-group: enough to put about two waves on every SIMD of the chip (ngroups x cw >= ~2 000), w1|w3 always unshared (its
     // half-block workgroups are many); then <= 4 columns per wave, column groups at grid level beyond 4 cw columns
-    const bool big = w.ngroups >= 1536 || epi == EPI_SILU_QAH;
+    const bool big = w.ngroups >= 1536 || epi == EPI_SILU_QAH || epi == EPI_SILU_QA;
     int cw = big ? 1 : w.ngroups >= 768 ? 2 : 4;
     if (cw > N) cw = N;
     const int ncmax = cw == 1 ? 5 : 4;                                // (five columns per wave are instantiated for unshared rings only: 9 rows = 5 + 4)
@@ -501,6 +534,14 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
     const int ng = (N + ncg - 1) / ncg;                               // columns per group, balanced (9 rows, unshared: 3 + 3 + 3)
     int nc = (ng + cw - 1) / cw, rgw = 0;
     cw = (ng + nc - 1) / nc;
+    // the small class by row count, measured (7B wo / w2, fresh processes, profiles/r05_u_fresh_ab.txt, r05_v_small_plans.txt): three
+    // column-waves leave 16 chunks a ragged last step (5 - 6 rows: <2,4> -1.5 %); from 9 rows on the launches are VALU bound and a step's
+    // barrier is pure loss: unshared rings in column groups of 3 (9 - 12 rows: -4 ... -6 % per eval) or 4 (13 - 16: -2 %)
+    if (!big && w.ngroups < 768 && N >= 5) {
+        if (N <= 8) { nc = 2; cw = 4; ncg = 1; }
+        else if (N <= 12) { nc = 3; cw = 1; ncg = (N + 2) / 3; }
+        else { nc = 4; cw = 1; ncg = (N + 3) / 4; }
+    }
     if (!set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw)) set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
     // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4> <5,1>)
     if (nc == 1 && cw == 1) nc = 2;
@@ -508,6 +549,7 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
     if (nc == 4 && cw == 3) cw = 4;
     if (!rgw) rgw = epi == EPI_SILU_QAH ? 4 : (cw >= 3 ? 2 : 4);
     if (epi == EPI_SILU_QAH) rgw = 4;
+    else if (epi == EPI_SILU_QA) rgw = 8;
     else if (rgw * cw > 8) rgw = 8 / cw;                              // (set_max_threads)
     p.nc = nc; p.cw = cw; p.rgw = rgw; p.ncg = ncg;
     p.lds = set_lds_bytes(w, std::min(N, nc * cw), nc, cw, rgw);
@@ -524,9 +566,11 @@ constexpr size_t SET_LDS_CAP = 160 * 1024;
 bool gemv_set_applies(const QMat &w, int N, int epi) {
     if (set_disabled() || N < 2 || N > SET_ROWS_MAX || !w.tiles) return false;
     if (epi == EPI_ROPE_KV && w.gmapF8 != 0) return false;
-    if (epi == EPI_SILU_QAH && (w.gmapF8 == 0 || w.ngroups % 8 != 0)) return false;
-    if (epi != EPI_STORE && epi != EPI_RESID && epi != EPI_ROPE_KV && epi != EPI_SILU_QAH) return false;
-    return set_plan(w, N, epi).lds <= SET_LDS_CAP;
+    if ((epi == EPI_SILU_QAH || epi == EPI_SILU_QA) && (w.gmapF8 == 0 || w.ngroups % 8 != 0)) return false;
+    if (epi != EPI_STORE && epi != EPI_RESID && epi != EPI_ROPE_KV && epi != EPI_SILU_QAH && epi != EPI_SILU_QA) return false;
+    const SetPlan p = set_plan(w, N, epi);
+    if (epi == EPI_SILU_QA && p.cw != 1) return false;                // (whole-block workgroups are instantiated for unshared rings)
+    return p.lds <= SET_LDS_CAP;
 }
 
 template <int NC, int CW>
@@ -536,6 +580,9 @@ static hipError_t launch_set_t(const GemvSetArgs &a, int epi, int grid, int nthr
     case EPI_RESID:    hipLaunchKernelGGL((k_gemv_set<NC, CW, EPI_RESID>), dim3(grid), dim3(nthreads), lds, st, a); break;
     case EPI_ROPE_KV:  hipLaunchKernelGGL((k_gemv_set<NC, CW, EPI_ROPE_KV>), dim3(grid), dim3(nthreads), lds, st, a); break;
     case EPI_SILU_QAH: hipLaunchKernelGGL((k_gemv_set<NC, CW, EPI_SILU_QAH>), dim3(grid), dim3(nthreads), lds, st, a); break;
+    case EPI_SILU_QA:
+        if constexpr (CW == 1) { hipLaunchKernelGGL((k_gemv_set<NC, 1, EPI_SILU_QA>), dim3(grid), dim3(nthreads), lds, st, a); break; }
+        else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
     LH_LAUNCH_CHECK();
@@ -566,7 +613,7 @@ static hipError_t launch_set_any(const QMat &w, GemvSetArgs a, int epi, hipStrea
     const SetPlan p = set_plan(w, a.ncols, epi);
     if (p.lds > SET_LDS_CAP) return hipErrorInvalidValue;
     a.rgw = p.rgw; a.ncg = p.ncg;
-    const int nwg = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;
+    const int nwg = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;      // (EPI_SILU_QA: rgw = 8, a workgroup per block)
     const int grid = p.ncg == 1 ? nwg : (nwg + 7) / 8 * 8 * p.ncg;
     const int nthreads = p.rgw * p.cw * 64;
 #define LH_SP(NCV, CWV) if (p.nc == NCV && p.cw == CWV) return launch_set_t<NCV, CWV>(a, epi, grid, nthreads, p.lds, st)
@@ -586,6 +633,15 @@ static GemvSetArgs set_args(const QMat &w, const uint32_t *qa_A, const float *qa
     return a;
 }
 
+// w1|w3: whole-block workgroups (no exchange) from two column groups on, or where the half-block exchange has no buffers;
+// LLAMAHIP_SET_W13_BLOCKS=0|1 forces halves / whole blocks (parity tests: both epilogues at every row count)
+bool gemv_set_silu_whole_blocks(const QMat &w13, int N, bool have_exchange) {
+    static const int force = getenv("LLAMAHIP_SET_W13_BLOCKS") ? atoi(getenv("LLAMAHIP_SET_W13_BLOCKS")) : -1;
+    if (!gemv_set_applies(w13, N, EPI_SILU_QA)) return false;
+    if (!have_exchange || !gemv_set_applies(w13, N, EPI_SILU_QAH)) return true;
+    if (force == 0 || force == 1) return force == 1;
+    return set_plan(w13, N, EPI_SILU_QA).ncg >= 2;
+}
 hipError_t launch_gemv_set(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                            float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
     GemvSetArgs a = set_args(w, qa_A, qa_d, N);
@@ -603,13 +659,13 @@ hipError_t launch_gemv_set_silu(const QMat &w13, const uint32_t *qa_A, const flo
     GemvSetArgs a = set_args(w13, qa_A, qa_d, N);
     a.T_silu = T_silu; a.out_A = out_A; a.out_d = out_d; a.out_strideA = out_strideA; a.out_strideD = out_strideD;
     a.amax_t = hx.amax_t; a.epoch = hx.epoch; a.layer = hx.layer; a.fault = hx.fault; a.lut_math = g_lut_math | fault_test;
-    return launch_set_any(w13, a, EPI_SILU_QAH, st);
+    return launch_set_any(w13, a, gemv_set_silu_whole_blocks(w13, N, hx.amax_t && hx.epoch) ? EPI_SILU_QA : EPI_SILU_QAH, st);
 }
 
 hipError_t init_attrs_gemv_set() {
     const int cap = (int) SET_LDS_CAP;
 #define LH_ATTR1(NCV, CWV, E) do { hipError_t e_ = hipFuncSetAttribute((const void *) k_gemv_set<NCV, CWV, E>, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
-#define LH_ATTR(NCV, CWV) do { LH_ATTR1(NCV, CWV, EPI_STORE); LH_ATTR1(NCV, CWV, EPI_RESID); LH_ATTR1(NCV, CWV, EPI_ROPE_KV); LH_ATTR1(NCV, CWV, EPI_SILU_QAH); } while (0)
+#define LH_ATTR(NCV, CWV) do { LH_ATTR1(NCV, CWV, EPI_STORE); LH_ATTR1(NCV, CWV, EPI_RESID); LH_ATTR1(NCV, CWV, EPI_ROPE_KV); LH_ATTR1(NCV, CWV, EPI_SILU_QAH); if (CWV == 1) LH_ATTR1(NCV, 1, EPI_SILU_QA); } while (0)
     LH_ATTR(1, 2); LH_ATTR(1, 3); LH_ATTR(1, 4);
     LH_ATTR(2, 1); LH_ATTR(2, 2); LH_ATTR(2, 3); LH_ATTR(2, 4);
     LH_ATTR(3, 1); LH_ATTR(3, 3); LH_ATTR(3, 4);

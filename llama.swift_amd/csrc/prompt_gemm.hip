@@ -1133,9 +1133,10 @@ bool gemm_silu_qa_applies(const QMat &w13, int N) {
 }
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st, const SiluHalfIO *hx) {
-    if (hx && hx->amax_t && hx->epoch && gemv_set_applies(w13, N, EPI_SILU_QAH)) {
+    const bool have_hx = hx && hx->amax_t && hx->epoch;
+    if ((have_hx && gemv_set_applies(w13, N, EPI_SILU_QAH)) || gemv_set_silu_whole_blocks(w13, N, have_hx)) {
         g_gemm_path_counts[GEMM_PATH_SET]++;
-        return launch_gemv_set_silu(w13, qa_A, qa_d, N, T_silu, out_A, out_d, out_strideA, out_strideD, *hx, st);
+        return launch_gemv_set_silu(w13, qa_A, qa_d, N, T_silu, out_A, out_d, out_strideA, out_strideD, have_hx ? *hx : SiluHalfIO(), st);
     }
     const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
     switch (nc) {

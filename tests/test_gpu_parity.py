@@ -379,6 +379,22 @@ def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape
     om.close()
 
 
+@pytest.mark.parametrize("env", [{"LLAMAHIP_SET_W13_BLOCKS": "0"}, {"LLAMAHIP_SET_W13_BLOCKS": "1"}, {"LLAMAHIP_NO_GEMV_SET": "1"}],
+                         ids=["w13_half_blocks_at_every_row_count", "w13_whole_blocks_at_every_row_count", "k_gemm_skinny"])
+def test_few_row_kernel_selectable_epilogues_and_fallback(env):
+    """The few-row mat-mul (k_gemv_set) runs w1|w3 in half-block workgroups with a tagged amax exchange for one column group and in
+    whole-block workgroups (no exchange) from two column groups on; LLAMAHIP_SET_W13_BLOCKS=0 / 1 forces either epilogue onto every row
+    count, LLAMAHIP_NO_GEMV_SET restores round 4's k_gemm_skinny -- the short-eval and set-step parity tests re-run under each (switches
+    are read once per process, hence the subprocess; same tests, same oracle)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), os.path.join(here, "test_pipeline.py"), "-k",
+                        "short_chunks or batched_set_steps_equal or prompt_continuation"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("env", [{"LLAMAHIP_NO_LUT_MATH": "1"}, {"LLAMAHIP_NORM_MODE": "0"}, {"LLAMAHIP_NORM_MODE": "1"},
                                  {"LLAMAHIP_NO_HOST_IO": "1", "LLAMAHIP_HOST_SAMPLER": "1"},
                                  {"LLAMAHIP_MFMA_I8": "1", "LLAMAHIP_MFMA_MIN": "32"}, {"LLAMAHIP_EAGER_PREFILL_COPY": "1"}])

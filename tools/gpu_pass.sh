@@ -8,6 +8,7 @@
 #   mid    single-stream decode experiments (k_qkv_attn timeline, decode A/B over VARIANTS), set-step kernel tables + PMC traffic
 #   x      soft_max ablation of k_dec_pv_dma at 2 048 keys (libllamahip_pvabl.so)
 #   pf     long-prompt A/B of library / switch variants (VARIANTS) + the prompt parity tests
+#   w13    whole- vs half-block w1|w3 workgroups of the few-row kernel + 9-row plans (fresh processes), the variant parity test
 #   nccl   the RCCL branch of the pipeline bench at world 1 (communicators, self-check, forced one-rank schedule) with its log
 #   65b    BASELINE configs[4]'s model on one GPU: the forced one-rank pipeline in set mode (in-situ roofline of the stage step, parity gate)
 #   final  everything profiles/<tag>_* is made from: full GPU test suite, bench.py (7B, 13B), config[3] mixed run with HBM counters,
@@ -60,6 +61,10 @@ x)    # round 5's last bounded experiment still in the tree: the soft_max of k_d
 pf)   # long-prompt A/B over VARIANTS (tools/prefill_ab.sh) + the prompt parity tests on the product build
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "prompt_continuation or chunks_in_one_pass or 2048_token_prefill or reference_flow" --durations=5 > $O/${tag}_prompt_parity.txt 2>&1; tail -4 $O/${tag}_prompt_parity.txt
   PROF=1 N=2048 timeout 900 bash tools/prefill_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_prefill_ab.txt 2>&1; cat $O/${tag}_prefill_ab.txt
+  ;;
+w13)  # whole-block vs half-block w1|w3 workgroups and the 9-row plans, fresh processes; the variant parity test
+  timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "few_row_kernel_selectable or few_row_handoff or mul_mat" > $O/${tag}_parity.txt 2>&1; tail -3 $O/${tag}_parity.txt
+  SEQS="${SEQS:-4 8}" EVALS="${EVALS:-9 16}" timeout 900 bash tools/fresh_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_fresh_ab.txt 2>&1; cat $O/${tag}_fresh_ab.txt
   ;;
 65b)
   LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_PIPE_PARITY_S=${PARITY_S:-60} timeout 2400 python bench.py --model 65B --steps 32 --warmup 4 > $O/${tag}_bench_65B_1gpu.json 2> $O/${tag}_bench_65B_1gpu.log
