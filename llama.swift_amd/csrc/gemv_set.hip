@@ -18,12 +18,15 @@
 //     (vmcnt retires in order): 3 - 6.5 us between "loads issued" and step 0.  Now: epilogue operands first, operand rows next (LDS-DMA,
 //     permuted into the LDS layout by per-lane source addresses), then the ring; one counted wait, the loop starts on the first chunk.
 //   * the operand rows' LDS layout is [chunk][half][chain] -- eight chains x 16 B = all 32 banks once per read (chain-major put chains k
-//     and k + 4 on the same banks) --, operands are requested SET_PF = 3 items ahead.
-//   * matrices with >= 1 024 row-groups have waves enough without sharing: up to four columns per wave, and for more than four rows column
-//     GROUPS at grid level (the groups of a row block sit on one XCD, 8 apart in dispatch order).
-// 21 VALU per (lane, chunk, column); LDS traffic per (wave, chunk): 1.25 KiB of weights + NC x 2.6 KiB of operands.
-// Measured (7B, MI355X, profiles/r05_g_ab.txt): set step of 4 / 8 sequences 2.30 / 2.96 ms (k_gemm_skinny) -> 2.08 / 2.85 ms, the
-// reference's 9-token eval 4.00 -> 3.35 ms, bit-identical.
+//     and k + 4 on the same banks) --, operands are requested SET_PF items ahead (1: three measured the same).
+//   * matrices with >= 1 536 row-groups have waves enough without sharing: up to five columns per wave through k_gemv's REGISTER ring (CW = 1),
+//     and for more rows column GROUPS at grid level (the groups of a row block sit on one XCD, 8 apart in dispatch order).
+//   * from ~8 columns on a launch is VALU bound (22 instructions per (lane, chunk, column), 12 of them half rate: 57 ns of a SIMD per item),
+//     and a shared ring's barrier per step is then pure loss: the small matrices take unshared column groups from 9 rows on (set_plan).
+// LDS traffic per (wave, chunk): 1.25 KiB of weights (CW > 1) + NC x 288 B of operands.
+// Measured (7B, MI355X, every figure from a fresh process, profiles/r05_w_fresh_ab_final_plan.txt): set step of 2 / 4 / 8 sequences 1.94 / 2.30 /
+// 2.99 ms (k_gemm_skinny) -> 1.79 / 2.03 / 2.74 ms; evals of 4 / 9 / 10 / 16 tokens 2.39 / 3.31 / 3.86 / 4.34 -> 2.16 / 3.16 / 3.18 / 4.14 ms;
+// bit-identical.  HBM traffic 1.05 - 1.10 x algorithmic per launch (profiles/r05_final_set_pmc_S4.txt, _S8.txt).
 //
 // Epilogues (per column):
 //   EPI_STORE / EPI_RESID   y = acc (+ resid)                                             lm head; wo, w2 (.mm:649-654, 682-687)
