@@ -195,14 +195,14 @@ def insitu_stage_profile(args, model_name, cfg, stage_layers, stage_set):
         return None, f"rocprofv3 rc={r.returncode}: {r.stderr[-300:]}"
     rows = list(csv.DictReader(open(stats[0])))
     shutil.rmtree(outdir, ignore_errors=True)
-    # w1|w3: the launch with the SiLU * up -> Q4_0 epilogue: for a set k_gemv_set<NC, CW, 7 | 2> (EPI_SILU_QAH, or EPI_SILU_QA from two column groups on; k_gemm_skinny<NC, 1, 2> where the
-    # few-row kernel does not apply), k_gemv<.., 2 | 7, ..> for single steps
+    # w1|w3: the launch with the SiLU * up -> Q4_0 epilogue: for a set k_gemv_set<NC, CW, 7 | 2> (EPI_SILU_QAH, or EPI_SILU_QA from two column groups on),
+    # k_gemv<.., 2 | 7, ..> for single steps
     pick = None
     for row in rows:
         n = row["Name"]
         n = (n[:n.index("(")] if "(" in n else n).replace("void ", "")
         last = n.rstrip(">").split(",")[-1].strip()
-        hit = (("k_gemv_set<" in n and last in ("7", "2")) or ("k_gemm_skinny<" in n and last == "2")) if stage_set > 1 else ("k_gemv<" in n and n.split("<")[1].split(",")[1].strip() in ("2", "7"))
+        hit = ("k_gemv_set<" in n and last in ("7", "2")) if stage_set > 1 else ("k_gemv<" in n and n.split("<")[1].split(",")[1].strip() in ("2", "7"))
         if hit and int(row["Calls"]) >= steps * stage_layers // 2:
             pick = (n, float(row["AverageNs"]) / 1e3, int(row["Calls"]))
     if not pick:

@@ -138,7 +138,7 @@ def gemm_paths() -> dict:
     """Launch counts of the multi-row mat-mul kernel families since process start (llamahip_debug_gemm_paths)."""
     a = np.zeros(8, np.int64)
     n = lib().llamahip_debug_gemm_paths(a.ctypes.data_as(C.c_void_p), 8)
-    return dict(zip(("mfma", "skinny", "rows", "lds", "gemv", "set"), a[:n].tolist()))
+    return dict(zip(("mfma", "rows", "lds", "gemv", "set"), a[:n].tolist()))
 
 
 def version() -> str:

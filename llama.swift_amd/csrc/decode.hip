@@ -60,7 +60,7 @@ namespace lh {
 // per-lane address arithmetic) made the decode kernels 0.1-0.4 us SLOWER per launch, the zero-padded LDS
 // operand tail (clamp-free `base + immediate` reads) helps the ring kernels (wq|wk|wv 9.05 -> 8.58 us) and
 // costs the whole-row-in-flight one 0.3 us -- so: no SGPR base here, padding for RING kernels only.
-// (k_gemm_skinny keeps both: +2 % there.)
+// (the few-row kernels keep both: +2 % there.)
 #ifndef LH_GEMV_SADDR
 #define LH_GEMV_SADDR 0
 #endif
@@ -2444,14 +2444,12 @@ hipError_t launch_advance(int32_t *state, hipStream_t st) {
 
 
 hipError_t init_attrs_prep();
-hipError_t init_attrs_prompt_gemm();
 hipError_t init_attrs_prompt_attn();
 hipError_t init_attrs_decode();
 hipError_t init_kernel_attrs() {
     hipError_t e;
     if ((e = init_attrs_prep()) != hipSuccess) return e;
     if ((e = init_attrs_decode()) != hipSuccess) return e;
-    if ((e = init_attrs_prompt_gemm()) != hipSuccess) return e;
     if ((e = init_attrs_gemv_set()) != hipSuccess) return e;
     return init_attrs_prompt_attn();
 }

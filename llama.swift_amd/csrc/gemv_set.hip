@@ -3,8 +3,8 @@
 // .mm:880-888).  Same arithmetic and order as k_gemv (ggml_compute_forward_mul_mat_q4_0_f32, ggml.c:5987-6285, N > 1: 6134-6152,
 // 6182-6222; vec_dot ggml.c:1415-1466), bit-exact.
 //
-// Why another kernel.  k_gemm_skinny gives a wave one row-group (8 rows x 8 chains) and <= 4 columns through a 4-deep REGISTER ring, stages
-// the operand rows behind that ring and drains everything before its loop.  What the in-kernel timelines of this file's first versions
+// Why another kernel.  k_gemm_skinny (rounds 1-4, removed in round 5) gave a wave one row-group (8 rows x 8 chains) and <= 4 columns through a 4-deep REGISTER ring, staged
+// the operand rows behind that ring and drained everything before its loop.  What the in-kernel timelines of this file's first versions
 // showed (profiles/r05_*timeline*.txt, tools/set_timeline.py) and what the kernel does about it:
 //   * a wave spends ~0.08 us per (chunk, column) item whatever shares its SIMD (21 VALU + 3 LDS reads at ~9 cycles per instruction and
 //     wave), so a launch ends when the wave with the most items does: the 4 096-row matrices (512 row-groups) want SEVERAL waves per
@@ -30,7 +30,7 @@
 //
 // Epilogues (per column):
 //   EPI_STORE / EPI_RESID   y = acc (+ resid)                                             lm head; wo, w2 (.mm:649-654, 682-687)
-//   EPI_ROPE_KV             wq|wk|wv: RoPE of q and k, append of k and v at the row's own position (k_gemm_skinny's epilogue;
+//   EPI_ROPE_KV             wq|wk|wv: RoPE of q and k, append of k and v at the row's own position (k_rope_kv's arithmetic;
 //                           ggml.c:7076-7131, .mm:586-611)
 //   EPI_SILU_QAH            interleaved w1|w3 in HALF-block workgroups (RGW = 4: 16 gate rows + the same 16 up rows): SiLU * up
 //                           (ggml.c:1956-1963, .mm:678-680) and the Q4_0 quantization of the block for w2 (ggml.c:456-523); the two
@@ -262,7 +262,7 @@ k_gemv_set(const GemvSetArgs a) {
     constexpr bool SHARE = CW > 1;
     extern __shared__ double smem_d[];
     // grid: blockIdx -> (row block `blk`, column group `cg`); the column groups of a row block sit on one XCD, 8 apart in dispatch order
-    // (their weight tiles meet in that XCD's L2), as in k_gemm_skinny.  One group (ncg = 1): blk = blockIdx.
+    // (their weight tiles meet in that XCD's L2).  One group (ncg = 1): blk = blockIdx.
     const int bid = blockIdx.x, cg = (bid >> 3) % a.ncg, blk = ((bid >> 3) / a.ncg) * 8 + (bid & 7);
     const int col0 = cg * NCW;
     const int nchunks = a.nchunks, ncols = min(NCW, a.ncols - col0), rgw = a.rgw;      // this group's columns: col0 .. col0 + ncols - 1
@@ -559,15 +559,13 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
     return p;
 }
 
-static bool set_disabled() {
-    static const bool off = getenv("LLAMAHIP_NO_GEMV_SET") != nullptr;
-    return off;
-}
-constexpr int SET_ROWS_MAX = 16;
+// the short evals: up to 60 rows (measured crossover against the row-per-lane kernel at 7B shapes, round 1: +25 % at 33 rows, +7 % at 56, -1 % at
+// 63; k_gemv_set against k_gemm_skinny at 20 / 24 / 32 / 48 / 60 rows: -5.5 / -5.5 / -0.7 / -5.2 / -6.3 % per eval, profiles/r05_y_rows_max.txt)
+constexpr int SET_ROWS_MAX = 60;
 constexpr size_t SET_LDS_CAP = 160 * 1024;
 
 bool gemv_set_applies(const QMat &w, int N, int epi) {
-    if (set_disabled() || N < 2 || N > SET_ROWS_MAX || !w.tiles) return false;
+    if (N < 2 || N > SET_ROWS_MAX || !w.tiles) return false;
     if (epi == EPI_ROPE_KV && w.gmapF8 != 0) return false;
     if ((epi == EPI_SILU_QAH || epi == EPI_SILU_QA) && (w.gmapF8 == 0 || w.ngroups % 8 != 0)) return false;
     if (epi != EPI_STORE && epi != EPI_RESID && epi != EPI_ROPE_KV && epi != EPI_SILU_QAH && epi != EPI_SILU_QA) return false;

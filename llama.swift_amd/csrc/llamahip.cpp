@@ -366,7 +366,7 @@ int make_rows(QMat &q, llamahip_model *m) {
     } else if (!build(&q.mt4, q.mt4_bytes(), [&]() { return launch_tiles_to_mt4(q, m->stream); })) return 1;
     return 0;
 }
-constexpr int PROMPT_COPY_MIN_ROWS = 61;       // evals up to 60 rows take k_gemm_skinny on the decode tiles
+constexpr int PROMPT_COPY_MIN_ROWS = 61;       // evals up to 60 rows take k_gemv_set on the decode tiles
 int ensure_prompt_copies(llamahip_model *m, int N, char *err, size_t err_cap) {
     if (N < PROMPT_COPY_MIN_ROWS || m->dense || m->prompt_copies || (m->flags & LLAMAHIP_FLAG_NO_PREFILL_COPY)) return 0;
     (void) err; (void) err_cap;

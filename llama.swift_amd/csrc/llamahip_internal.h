@@ -140,7 +140,7 @@ hipError_t launch_gemv(const QMat &w, int pre, int epi, const uint32_t *qa_A, co
 // embedding row of ONE token (decode) + its {sum x, sum x^2} pair for the first norm (part_out[0])
 hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x, int d, double *part_out, hipStream_t st, uint32_t *epoch = nullptr, uint64_t *xt = nullptr,
                              const uint64_t *token_mb = nullptr, const int32_t *state = nullptr, uint32_t *fault = nullptr, int n_vocab = 0);      // token_mb: the token arrives as a mailbox granule
-enum { GEMM_PATH_MFMA = 0, GEMM_PATH_SKINNY = 1, GEMM_PATH_ROWS = 2, GEMM_PATH_LDS = 3, GEMM_PATH_GEMV = 4, GEMM_PATH_SET = 5, GEMM_PATH_COUNT = 6 };
+enum { GEMM_PATH_MFMA = 0, GEMM_PATH_ROWS = 1, GEMM_PATH_LDS = 2, GEMM_PATH_GEMV = 3, GEMM_PATH_SET = 4, GEMM_PATH_COUNT = 5 };
 extern long g_gemm_path_counts[GEMM_PATH_COUNT];     // launches per kernel family of launch_gemm (process-wide; tests)
 // qb_ws: scratch for the int8 operand of the matrix-core path (N * nchunks * 256 B), or nullptr
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,

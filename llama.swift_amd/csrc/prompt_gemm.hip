@@ -1,6 +1,5 @@
 // prompt_gemm.hip -- the Q4_0 x Q4_0 mat-mul for MULTI-ROW evals (prompt chunks), bit-exact with ggml_compute_forward_mul_mat_q4_0_f32
-// (ggml.c:5987-6285, vec_dot :1415-1466): k_gemm_lds (decode tiles, QA in LDS), k_gemm_skinny (2..60 rows, epilogues with RoPE + KV append /
-// SiLU*up -> Q4_0), k_gemm_rows (row-lane tiles), k_gemm_mfma / k_gemm_mfma4 (integer sums on the matrix cores), the tile converters,
+// (ggml.c:5987-6285, vec_dot :1415-1466): k_gemm_lds (decode tiles, QA in LDS), k_gemm_rows (row-lane tiles), k_gemm_mfma / k_gemm_mfma4 (integer sums on the matrix cores), the tile converters,
 // and launch_gemm with its kernel selection rules.  Conventions and layouts: decode.hip / DESIGN.md.
 #include "kcommon.hip.h"
 
@@ -106,280 +105,9 @@ k_gemm_lds(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int 
     }
 }
 
-// Short prompt chunks (2 <= N <= ~32 columns; the reference feeds prompts n_batch = 8 tokens at a time): the
-// decode kernel's work distribution -- lane = (row, chain), weights streamed once per wave through a
-// register ring -- with NC activation columns per wave.  The row-per-lane kernel below needs 64 rows per
-// wave, which leaves a 4096-row matrix with 64 waves per column and makes every column re-read the
-// weights from L2; here a 4096-row matrix is 512 / RG waves per column GROUP and the weights are read once
-// per group.  The QA operands of the workgroup's NC columns are staged whole in LDS before the main loop
-// (no barriers inside it); the weight ring is put in flight before the staging so the two latencies
-// overlap.  Same arithmetic and order as k_gemv.  What bounds this kernel is VALU issue and LDS read
-// bandwidth together (a 16-byte broadcast read still delivers 1 KiB per wave), so:
-//   * a wave owns RG row-groups (lane = row r of each, chain k): every activation read serves RG rows;
-//   * the d_w * d_a products are computed once per quad lane (lane t of a quad holds the weight scales of
-//     blocks t and t + 4 -- the tile's scale layout -- and reads the two matching activation scales with
-//     one 4-byte LDS read each), and the FMA takes them through the DPP quad broadcast of v_fmac_f32_dpp:
-//     8 dots + 4 packed subtractions + 2 products + 8 FMAs = 22 VALU per (lane, chunk, column), not 28.
-//     The DPP form is written as inline assembly (the compiler keeps v_mov_dpp + v_fmac); its one hazard
-//     -- a VALU write of the DPP source needs two wait states before the read -- is padded inside.
-//   grid: XCD-aware, blockIdx -> (row-block of 4 * RG row-groups, column group), column groups of a row-block on one XCD
-//   dynamic LDS: [NC][(nchunks + 4) * 64] dwords A, then [NC][(nchunks + 4) * 8] floats d (4 zeroed padding chunks per column)
-// two independent chains interleaved (a dependent v_fmac issues ~1.7x slower than an independent one)
-#define LH_FMAC8_DPP2(ACC0, PLO0, PHI0, A01, A23, A45, A67, ACC1, PLO1, PHI1, B01, B23, B45, B67)  \
-    asm("s_nop 1\n\t"                                                                              \
-        "v_fmac_f32_dpp %0, %2, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %1, %12, %14 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"           \
-        "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %1, %12, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"           \
-        "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %1, %12, %16 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"           \
-        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %1, %12, %17 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"           \
-        "v_fmac_f32_dpp %0, %3, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %1, %13, %18 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"           \
-        "v_fmac_f32_dpp %0, %3, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"             \
-        "v_fmac_f32_dpp %1, %13, %19 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"           \
-        "v_fmac_f32_dpp %0, %3, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"            \
-        "v_fmac_f32_dpp %1, %13, %20 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"           \
-        "v_fmac_f32_dpp %0, %3, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"            \
-        "v_fmac_f32_dpp %1, %13, %21 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"                \
-        : "+v"(ACC0), "+v"(ACC1)                                                                   \
-        : "v"(PLO0), "v"(PHI0), "v"((A01).x), "v"((A01).y), "v"((A23).x), "v"((A23).y),            \
-          "v"((A45).x), "v"((A45).y), "v"((A67).x), "v"((A67).y),                                  \
-          "v"(PLO1), "v"(PHI1), "v"((B01).x), "v"((B01).y), "v"((B23).x), "v"((B23).y),            \
-          "v"((B45).x), "v"((B45).y), "v"((B67).x), "v"((B67).y))
-
-//   EPI_ROPE_KV (the wq|wk|wv matrix): the epilogue is k_rope_kv -- outputs 2i, 2i+1 of a row sit in lanes 8
-//         apart of one DPP row, so the pair is rotated in place (double arithmetic, host-built cos/sin table)
-//         and q goes to qr, k and v straight into the cache rows n_past + column: no fp32 qkv round trip,
-//         no RoPE launch
-//   EPI_SILU_QA (the interleaved w1|w3 matrix only, RG = 1): 8 waves per workgroup = 32 gate rows + the same 32
-//         up rows; wave n of the workgroup then turns column n's 64 outputs into silu_lut(gate) * up
-//         (ggml.c:1956-1963, .mm:678-680) and quantizes them as one Q4_0 activation block (ggml.c:456-523)
-//         of the w2 mat-mul's operand: out_A / out_d, row strides out_strideA dwords / out_strideD floats
-//         (no fp32 round trip, no preparation launch in between)
-template <int NC, int RG, int EPI>
-__global__ void __launch_bounds__(EPI == EPI_SILU_QA ? 512 : 256)
-k_gemm_skinny(const uint8_t *__restrict__ wt, int ngroups, int nchunks, int M, int gmapF8,
-              const uint32_t *__restrict__ qa_A, const float *__restrict__ qa_d, int ncols, int ncg,
-              float *__restrict__ y, long y_stride, const float *__restrict__ resid, long resid_stride,
-              const uint16_t *__restrict__ T_silu, uint32_t *__restrict__ out_A, float *__restrict__ out_d,
-              long out_strideA, long out_strideD, RopeKvArgs ra) {
-    constexpr int D = 4;
-    constexpr int NW = EPI == EPI_SILU_QA ? 8 : 4, NT = NW * 64;
-    static_assert(EPI != EPI_SILU_QA || RG == 1, "the fused FFN epilogue pairs one gate wave with one up wave");
-    extern __shared__ double smem_d[];
-    // every column's operand is padded with D zeroed chunks: the ring tail and the one-step-ahead operand
-    // fetch run past the row end (against the zero tile) without an index clamp (see k_gemv)
-    const int npad = nchunks + D;
-    u32x4 *sA = (u32x4 *) smem_d;                            // [NC][npad * 16]
-    f32x4 *sD = (f32x4 *) (sA + (size_t) NC * npad * 16);    // [NC][npad * 2]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x, xcd = b & 7, q = b >> 3, cg = q % ncg, wgi = (q / ncg) * 8 + xcd;
-    const int g0 = (wgi * NW + wave) * RG;                    // first of this wave's RG consecutive row-groups
-    const int n0 = cg * NC;
-    const int k = lane & 7, t = lane & 3;
-    const uint32_t voff_w = (uint32_t) lane * 16u, voff_s = 1024u + (uint32_t) ((lane >> 3) * 8 + t * 2) * 4u;
-    uint32_t vw_ = voff_w, vs_ = voff_s;                     // (see k_gemv: SGPR base + per-lane offset addressing)
-#define LH_OPAQUE_OFFSETS() { vw_ = voff_w; vs_ = voff_s; asm volatile("" : "+v"(vw_), "+v"(vs_)); }
-    const uint8_t *wbase[RG];
-#pragma unroll
-    for (int rg = 0; rg < RG; rg++) wbase[rg] = wt + (size_t) min(g0 + rg, ngroups - 1) * (nchunks + 1) * TILE_BYTES;
-
-    u32x4 wq[RG][D];
-    f32x2 ws[RG][D];
-#define LH_LOADW(SLOT, CH)                                                                         \
-    _Pragma("unroll")                                                                              \
-    for (int rg = 0; rg < RG; rg++) {                                                              \
-        const uint8_t *tp_ = wbase[rg] + (size_t) min((CH), nchunks) * TILE_BYTES;                 \
-        wq[rg][SLOT] = __builtin_nontemporal_load((const u32x4 *) (tp_ + (size_t) vw_));           \
-        ws[rg][SLOT] = __builtin_nontemporal_load((const f32x2 *) (tp_ + (size_t) vs_));           \
-    }
-#pragma unroll
-    for (int i = 0; i < D; i++) { LH_LOADW(i, i) }
-    __builtin_amdgcn_sched_barrier(0);
-    // stage the NC columns' operands (columns past ncols are clamped duplicates, never stored);
-    // 8 loads per thread in flight per pass: a pass is one L2 round trip
-    {
-        constexpr int LB = 8;
-        const int perA = nchunks * 16, perD = nchunks * 2;     // QA row strides in 16-byte granules
-        const int totA = NC * perA, totD = NC * perD;
-        for (int base = tid; base < totA; base += NT * LB) {
-            u32x4 v[LB];
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = min(base + u * NT, totA - 1), n = i / perA, r = i - n * perA;
-                v[u] = ((const u32x4 *) qa_A)[(long) min(n0 + n, ncols - 1) * perA + r];
-            }
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = base + u * NT, n = i / perA, r = i - n * perA;
-                if (i < totA) sA[n * npad * 16 + r] = v[u];
-            }
-        }
-        for (int base = tid; base < totD; base += NT * LB) {
-            f32x4 v[LB];
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = min(base + u * NT, totD - 1), n = i / perD, r = i - n * perD;
-                v[u] = ((const f32x4 *) qa_d)[(long) min(n0 + n, ncols - 1) * perD + r];
-            }
-#pragma unroll
-            for (int u = 0; u < LB; u++) {
-                const int i = base + u * NT, n = i / perD, r = i - n * perD;
-                if (i < totD) sD[n * npad * 2 + r] = v[u];
-            }
-        }
-        for (int i = tid; i < NC * D * 18; i += NT) {         // zero the padding chunks
-            const int n = i / (D * 18), r = i - n * (D * 18);
-            if (r < D * 16) sA[(n * npad + nchunks) * 16 + r] = u32x4{ 0u, 0u, 0u, 0u };
-            else sD[(n * npad + nchunks) * 2 + (r - D * 16)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-        }
-    }
-    // The staging loops have run-time trip counts, after which the compiler's waitcnt pass no longer knows
-    // how old the ring loads are and would put a vmcnt(0) at the top of the single-block main loop, i.e. in
-    // EVERY iteration (no prefetch left).  Draining explicitly here makes the loop's entry state exact, and
-    // the waits inside become the counted vmcnt(2 * RG * (D - 1)) of the back edge.
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), nothing else
-    __syncthreads();
-
-    const float *sDf = (const float *) sD;
-    float accs[RG][NC];
-#pragma unroll
-    for (int rg = 0; rg < RG; rg++)
-#pragma unroll
-        for (int n = 0; n < NC; n++) accs[rg][n] = 0.0f;
-    // LDS operands of step (slot, column) are fetched one step ahead into the other half of a two-entry
-    // register buffer (D * NC steps per loop trip is even, so the parity is a compile-time constant)
-    u32x4 la0[2], la1[2];
-    float ldl[2], ldh[2];
-#define LH_LDSLOAD(BUF, N, CH)                                                                     \
-    {                                                                                              \
-        const u32x4 *pa_ = sA + ((N) * npad + (CH)) * 16 + k * 2;                                  \
-        la0[BUF] = pa_[0]; la1[BUF] = pa_[1];                                                      \
-        const float *pd_ = sDf + ((N) * npad + (CH)) * 8 + t;                                      \
-        ldl[BUF] = pd_[0]; ldh[BUF] = pd_[4];                                                      \
-    }
-#define LH_CONSUME(SLOT, CH)                                                                       \
-    {                                                                                              \
-        _Pragma("unroll")                                                                          \
-        for (int n = 0; n < NC; n++) {                                                             \
-            const int pb_ = ((SLOT) * NC + n) & 1;                                                 \
-            const u32x4 a0 = la0[pb_], a1 = la1[pb_];                                              \
-            const float dlo_ = ldl[pb_], dhi_ = ldh[pb_];                                          \
-            if (n + 1 < NC) LH_LDSLOAD(pb_ ^ 1, n + 1, (CH))                                       \
-            else LH_LDSLOAD(pb_ ^ 1, 0, (CH) + 1)                                                  \
-            __builtin_amdgcn_sched_barrier(0);     /* reads for the next step go out before this step's arithmetic */ \
-            float plo_[RG], phi_[RG];                                                              \
-            f32x2 q01_[RG], q23_[RG], q45_[RG], q67_[RG];                                          \
-            _Pragma("unroll")                                                                      \
-            for (int rg = 0; rg < RG; rg++) {                                                      \
-                const u32x4 w = wq[rg][SLOT];                                                      \
-                plo_[rg] = ws[rg][SLOT].x * dlo_; phi_[rg] = ws[rg][SLOT].y * dhi_;                \
-                const int i0_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.x, 0x4B400000, true);   \
-                const int i1_ = __builtin_amdgcn_sdot8((int) w.x, (int) a0.y, 0x4B400000, true);   \
-                const int i2_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.z, 0x4B400000, true);   \
-                const int i3_ = __builtin_amdgcn_sdot8((int) w.y, (int) a0.w, 0x4B400000, true);   \
-                const int i4_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.x, 0x4B400000, true);   \
-                const int i5_ = __builtin_amdgcn_sdot8((int) w.z, (int) a1.y, 0x4B400000, true);   \
-                const int i6_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.z, 0x4B400000, true);   \
-                const int i7_ = __builtin_amdgcn_sdot8((int) w.w, (int) a1.w, 0x4B400000, true);   \
-                const f32x2 mg_ = { 12582912.0f, 12582912.0f };                                    \
-                q01_[rg] = f32x2{ __builtin_bit_cast(float, i0_), __builtin_bit_cast(float, i1_) } - mg_; \
-                q23_[rg] = f32x2{ __builtin_bit_cast(float, i2_), __builtin_bit_cast(float, i3_) } - mg_; \
-                q45_[rg] = f32x2{ __builtin_bit_cast(float, i4_), __builtin_bit_cast(float, i5_) } - mg_; \
-                q67_[rg] = f32x2{ __builtin_bit_cast(float, i6_), __builtin_bit_cast(float, i7_) } - mg_; \
-            }                                                                                      \
-            if (RG == 2) {                                                                         \
-                LH_FMAC8_DPP2(accs[0][n], plo_[0], phi_[0], q01_[0], q23_[0], q45_[0], q67_[0],    \
-                              accs[RG - 1][n], plo_[RG - 1], phi_[RG - 1], q01_[RG - 1], q23_[RG - 1], q45_[RG - 1], q67_[RG - 1]); \
-            } else {                                                                               \
-                LH_FMAC8_DPP(accs[0][n], plo_[0], phi_[0], q01_[0], q23_[0], q45_[0], q67_[0]);    \
-            }                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-        }                                                                                          \
-    }
-    LH_LDSLOAD(0, 0, 0)
-    // straight-line ring body (see k_gemv): chunks past the row end read the zero tile (scale 0)
-    for (int c0 = 0; c0 < nchunks; c0 += D) {
-        LH_OPAQUE_OFFSETS()
-#pragma unroll
-        for (int i = 0; i < D; i++) {
-            LH_CONSUME(i, c0 + i)
-            LH_LOADW(i, c0 + D + i)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef LH_CONSUME
-#undef LH_LDSLOAD
-#undef LH_LOADW
-#undef LH_OPAQUE_OFFSETS
-
-    if (EPI == EPI_SILU_QA) {
-        // waves 0-3 hold gate rows wgi*32 .. +31, waves 4-7 the matching up rows
-        float *gu = (float *) smem_d;                          // [NC][64]; the operand staging area is free again
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            const float acc = fold8(accs[0][n]);
-            if (k == 0) gu[n * 64 + wave * 8 + (lane >> 3)] = acc;
-        }
-        __syncthreads();
-        if (wave < NC && n0 + wave < ncols && wgi * 8 < ngroups) {
-            const int i = lane & 31;
-            const float act = h2f_bits(T_silu[f2h_bits(gu[wave * 64 + i])]) * gu[wave * 64 + 32 + i];
-            const float amax = max_lanes_0_31(fabsf(act));
-            const float dd = amax / 7.0f;
-            const float id = (amax != 0.0f) ? 7.0f / amax : 0.0f;
-            const uint32_t nib = (uint32_t) ((int) __builtin_rintf(act * id)) & 0xF;       // signed nibble of (q - 8)
-            const int kk = lane & 7;
-            const uint32_t e0 = __shfl(nib, 2 * kk), e1 = __shfl(nib, 2 * kk + 1);
-            const uint32_t e2 = __shfl(nib, 16 + 2 * kk), e3 = __shfl(nib, 17 + 2 * kk);
-            const int bb = wgi, c = bb >> 3, j = bb & 7;
-            uint32_t *oA = out_A + (size_t) (n0 + wave) * out_strideA;
-            float *oD = out_d + (size_t) (n0 + wave) * out_strideD;
-            if (lane < 8) oA[(c * 8 + kk) * 8 + j] = (e0 | (e1 << 8) | (e2 << 16) | (e3 << 24)) << (4 * (j & 1));
-            if (lane == 0) oD[bb] = dd;
-        }
-        return;
-    }
-#pragma unroll
-    for (int rg = 0; rg < RG; rg++) {
-        const int g = g0 + rg;
-        int lg = g;
-        if (gmapF8) { const int blk = g >> 3, w8 = g & 7; lg = w8 < 4 ? blk * 4 + w8 : gmapF8 + blk * 4 + (w8 - 4); }
-        const int m = lg * 8 + (lane >> 3);
-#pragma unroll
-        for (int n = 0; n < NC; n++) {
-            float acc = fold8(accs[rg][n]);
-            if (EPI == EPI_ROPE_KV) {
-                // (ggml.c:7076-7131, .mm:586-611; see k_rope_kv) rows m, m^1 = lanes 8 apart; m is even iff the lane's row is
-                const float up = dpp_f<0x108>(acc), dn = dpp_f<0x118>(acc);        // row_shl:8 / row_shr:8
-                if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
-                    const int which = m / ra.d, c = m - which * ra.d;
-                    // (batched decode step: the row's own position and cache)
-                    const int pos = ra.set ? ra.set->state[n0 + n][0] : ra.n_past + n0 + n;
-                    const long kvo = ra.set ? ra.set->kv_off[n0 + n] : 0L;
-                    if (which == 2) {
-                        ra.Vc[kvo + (size_t) pos * ra.d + c] = acc;
-                    } else {
-                        const int pe = (c % ra.dh) & ~1;
-                        const double cs = ra.tab[(size_t) pos * ra.dh + pe], sn = ra.tab[(size_t) pos * ra.dh + pe + 1];
-                        const double x0 = (double) ((c & 1) ? dn : acc), x1 = (double) ((c & 1) ? acc : up);
-                        const float val = (c & 1) ? (float) (x0 * sn + x1 * cs) : (float) (x0 * cs - x1 * sn);
-                        if (which == 0) ra.qr[(size_t) (n0 + n) * ra.d + c] = val;
-                        else ra.Kc[kvo + (size_t) pos * ra.d + c] = val;
-                    }
-                }
-                continue;
-            }
-            if (g < ngroups && k == 0 && m < M && n0 + n < ncols) {
-                if (EPI == EPI_RESID) acc = acc + resid[(size_t) (n0 + n) * resid_stride + m];
-                y[(size_t) (n0 + n) * y_stride + m] = acc;
-            }
-        }
-    }
-}
+// (k_gemm_skinny, the 2 .. 60-row kernel of rounds 1-4 -- a wave = one row-group x <= 4 columns through a register ring, the epilogues with
+//  RoPE + KV append / SiLU * up -> Q4_0 -- was replaced by k_gemv_set (gemv_set.hip) in round 5: faster at every row count from 2 to 60,
+//  profiles/r05_w_fresh_ab_final_plan.txt, r05_y_rows_max.txt; removed.)
 
 // ------------------------------------------------------------------------------------------------
 // Prompt path, row-per-lane: second resident copy of a matrix in ROW-LANE tiles.
@@ -1058,93 +786,28 @@ static hipError_t launch_gemm_lds_t(const QMat &w, int epi, const uint32_t *qa_A
     return hipSuccess;
 }
 
-template <int NC, int RG>
-static hipError_t launch_gemm_skinny_t(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg,
-                                       float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st) {
-    const int nwg = (w.ngroups + 4 * RG - 1) / (4 * RG);
-    const int grid = ((nwg + 7) / 8) * ncg * 8;
-    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
-    if (epi == EPI_RESID)
-        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_RESID>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
-                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, RopeKvArgs{});
-    else
-        hipLaunchKernelGGL((k_gemm_skinny<NC, RG, EPI_STORE>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg, y, y_stride, resid, resid_stride,
-                           (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, RopeKvArgs{});
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-template <int NC>
-static hipError_t launch_gemm_skinny_silu_t(const QMat &w, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg,
-                                            const uint16_t *T_silu, uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st) {
-    const int nwg = (w.ngroups + 7) / 8;
-    const int grid = ((nwg + 7) / 8) * ncg * 8;
-    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
-    hipLaunchKernelGGL((k_gemm_skinny<NC, 1, EPI_SILU_QA>), dim3(grid), dim3(512), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg,
-                       (float *) nullptr, 0L, (const float *) nullptr, 0L, T_silu, out_A, out_d, out_strideA, out_strideD, RopeKvArgs{});
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-template <int NC>
-static hipError_t launch_gemm_skinny_rope_t(const QMat &w, const uint32_t *qa_A, const float *qa_d, int ncols, int ncg, const RopeKvArgs &ra, hipStream_t st) {
-    const int nwg = (w.ngroups + 3) / 4;
-    const int grid = ((nwg + 7) / 8) * ncg * 8;
-    const size_t lds = (size_t) NC * (w.nchunks + 4) * 288;
-    hipLaunchKernelGGL((k_gemm_skinny<NC, 1, EPI_ROPE_KV>), dim3(grid), dim3(256), lds, st, w.tiles, w.ngroups, w.nchunks, w.M, w.gmapF8, qa_A, qa_d, ncols, ncg,
-                       (float *) nullptr, 0L, (const float *) nullptr, 0L, (const uint16_t *) nullptr, (uint32_t *) nullptr, (float *) nullptr, 0L, 0L, ra);
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-static int skinny_max_rows() {
-    // measured crossover against the row-per-lane kernel at 7B shapes: +25 % at 33 rows, +7 % at 56, -1 % at 63
-    return 60;
-}
-// column-group width of k_gemm_skinny for N rows: the widest (<= 4) that still leaves ~1500 waves, balanced
-static int skinny_pick_nc(const QMat &w, int N) {
-    int nc = 4;                                              // (3 072 / 6 144 waves: 5-8 % slower at 9 columns, profiles/r04_r_skinny_waves_ab.txt)
-    while (nc > 1 && (long) w.ngroups * ((N + nc - 1) / nc) < 1536) nc--;
-    if (nc > N) nc = N;
-    while (nc > 1 && (size_t) nc * (w.nchunks + 4) * 288 > 150 * 1024) nc--;
-    const int ncg = (N + nc - 1) / nc;
-    return (N + ncg - 1) / ncg;                            // balance the groups (9 columns: 3 + 3 + 3, not 4 + 4 + 1)
-}
-
-// Short evals, wq|wk|wv: mat-mul + RoPE + KV append in one launch (k_gemm_skinny<EPI_ROPE_KV>)
+// Short evals (2 .. 60 rows), wq|wk|wv: mat-mul + RoPE + KV append in one launch (k_gemv_set<EPI_ROPE_KV>)
 bool gemm_rope_kv_applies(const QMat &wqkv, int N, int d) {
-    return N >= 2 && N <= skinny_max_rows() && wqkv.gmapF8 == 0 && wqkv.M == 3 * d && d % 8 == 0;
+    return wqkv.M == 3 * d && d % 8 == 0 && gemv_set_applies(wqkv, N, EPI_ROPE_KV);
 }
 hipError_t launch_gemm_rope_kv(const QMat &wqkv, const uint32_t *qa_A, const float *qa_d, int N, const RopeKvArgs &ra, hipStream_t st) {
-    if (gemv_set_applies(wqkv, N, EPI_ROPE_KV)) { g_gemm_path_counts[GEMM_PATH_SET]++; return launch_gemv_set_rope_kv(wqkv, qa_A, qa_d, N, ra, st); }
-    const int nc = skinny_pick_nc(wqkv, N), ncg = (N + nc - 1) / nc;
-    switch (nc) {
-    case 4:  return launch_gemm_skinny_rope_t<4>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    case 3:  return launch_gemm_skinny_rope_t<3>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    case 2:  return launch_gemm_skinny_rope_t<2>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    default: return launch_gemm_skinny_rope_t<1>(wqkv, qa_A, qa_d, N, ncg, ra, st);
-    }
+    if (!gemv_set_applies(wqkv, N, EPI_ROPE_KV)) return hipErrorInvalidValue;
+    g_gemm_path_counts[GEMM_PATH_SET]++;
+    return launch_gemv_set_rope_kv(wqkv, qa_A, qa_d, N, ra, st);
 }
 
-// Short evals on the interleaved w1|w3 matrix: mat-mul + SiLU * up + Q4_0 quantization of the result in one
-// launch (k_gemm_skinny<EPI_SILU_QA>).  false = not applicable (row count, layout): use the separate steps.
+// Short evals, the interleaved w1|w3: mat-mul + SiLU * up + Q4_0 quantization of the w2 operand in one launch (k_gemv_set<EPI_SILU_QAH> in
+// half-block workgroups where the exchange buffers exist and one column group covers the rows, else <EPI_SILU_QA> in whole-block
+// workgroups).  false = not applicable (row count, layout): use the separate steps.
 bool gemm_silu_qa_applies(const QMat &w13, int N) {
-    return N >= 2 && N <= skinny_max_rows() && w13.gmapF8 != 0 && w13.ngroups % 8 == 0;
+    return gemv_set_applies(w13, N, EPI_SILU_QA);
 }
 hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const float *qa_d, int N, const uint16_t *T_silu,
                                uint32_t *out_A, float *out_d, long out_strideA, long out_strideD, hipStream_t st, const SiluHalfIO *hx) {
     const bool have_hx = hx && hx->amax_t && hx->epoch;
-    if ((have_hx && gemv_set_applies(w13, N, EPI_SILU_QAH)) || gemv_set_silu_whole_blocks(w13, N, have_hx)) {
-        g_gemm_path_counts[GEMM_PATH_SET]++;
-        return launch_gemv_set_silu(w13, qa_A, qa_d, N, T_silu, out_A, out_d, out_strideA, out_strideD, have_hx ? *hx : SiluHalfIO(), st);
-    }
-    const int nc = skinny_pick_nc(w13, N), ncg = (N + nc - 1) / nc;
-    switch (nc) {
-    case 4:  return launch_gemm_skinny_silu_t<4>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    case 3:  return launch_gemm_skinny_silu_t<3>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    case 2:  return launch_gemm_skinny_silu_t<2>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    default: return launch_gemm_skinny_silu_t<1>(w13, qa_A, qa_d, N, ncg, T_silu, out_A, out_d, out_strideA, out_strideD, st);
-    }
+    if (!((have_hx && gemv_set_applies(w13, N, EPI_SILU_QAH)) || gemv_set_silu_whole_blocks(w13, N, have_hx))) return hipErrorInvalidValue;
+    g_gemm_path_counts[GEMM_PATH_SET]++;
+    return launch_gemv_set_silu(w13, qa_A, qa_d, N, T_silu, out_A, out_d, out_strideA, out_strideD, have_hx ? *hx : SiluHalfIO(), st);
 }
 
 template <int NC, bool DB, int WPE>
@@ -1221,7 +884,7 @@ hipError_t launch_tiles_to_rows(const QMat &w, hipStream_t st) {
 //   else: LDS-staged column tiles of 16 (the last one clamped), small remainders as 8 / 4 columns
 //   a single row always goes through the decode GEMV
 // which kernel family served a mat-mul (tests assert that the full-size shapes take the path they are meant to)
-long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0, 0 };
+long g_gemm_path_counts[GEMM_PATH_COUNT] = { 0, 0, 0, 0, 0 };
 
 hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                        float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st, uint8_t *qb_ws, bool fast) {
@@ -1246,27 +909,10 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
         return launch_gemm_mfma(w, epi, qb_ws, qa_d, N, y, y_stride, resid, resid_stride, st, fast);
     }
     const long strideA = (long) w.nchunks * 64, strideD = (long) w.nchunks * 8;
-    // a few rows (a batched decode step, the reference's 9-token evals): the waves of a row-group share its weights through LDS
+    // 2 .. 60 rows (a batched decode step, the reference's 9-token evals, short prompt chunks): k_gemv_set
     if ((epi == EPI_STORE || epi == EPI_RESID) && gemv_set_applies(w, N, epi)) {
         g_gemm_path_counts[GEMM_PATH_SET]++;
         return launch_gemv_set(w, epi, qa_A, qa_d, N, y, y_stride, resid, resid_stride, st);
-    }
-    // short chunks: decode-shaped kernel, NC columns per wave; as many column groups as it takes to put
-    // ~1500 waves on the chip
-    if (N >= 2 && N <= skinny_max_rows()) {
-        // (two row-groups per wave -- half the LDS operand reads per row -- measured 3-7 % slower at 9 columns; removed in round 3)
-        const int nc = skinny_pick_nc(w, N), ncg = (N + nc - 1) / nc;
-        g_gemm_path_counts[GEMM_PATH_SKINNY]++;
-#define LH_SK_ARGS w, epi, qa_A, qa_d, N, ncg, y, y_stride, resid, resid_stride, st
-#define LH_SK_CASE(NCV) case NCV: return launch_gemm_skinny_t<NCV, 1>(LH_SK_ARGS)
-        switch (nc) {
-        LH_SK_CASE(4);
-        LH_SK_CASE(3);
-        LH_SK_CASE(2);
-        default: return launch_gemm_skinny_t<1, 1>(LH_SK_ARGS);
-        }
-#undef LH_SK_CASE
-#undef LH_SK_ARGS
     }
     if (w.rows && N >= 2) {
         // widest column group that still gives the chip >= 2 waves per SIMD.  Wider groups (8, 16
@@ -1305,14 +951,5 @@ hipError_t launch_gemm(const QMat &w, int epi, const uint32_t *qa_A, const float
     return hipSuccess;
 }
 
-
-hipError_t init_attrs_prompt_gemm() {
-    const int cap = 160 * 1024;          // fused prologues / wide rows need more than the default 64 KB of dynamic LDS
-#define LH_ATTR(KERNEL) do { hipError_t e_ = hipFuncSetAttribute((const void *) KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e_ != hipSuccess) return e_; } while (0)
-    LH_ATTR((k_gemm_skinny<1, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_ROPE_KV>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_ROPE_KV>));
-    LH_ATTR((k_gemm_skinny<1, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<2, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<3, 1, EPI_SILU_QA>)); LH_ATTR((k_gemm_skinny<4, 1, EPI_SILU_QA>));
-#undef LH_ATTR
-    return hipSuccess;
-}
 
 }  // namespace lh

@@ -227,7 +227,7 @@ def test_prompt_chunks_in_one_pass_vs_chunk_by_chunk_oracle(L, oracle, tmp_path,
 @pytest.mark.parametrize("nth", [1, 4, 8])
 def test_short_chunks_vs_oracle(L, oracle, tmp_path, nth):
     """The reference feeds a prompt n_batch = 8 tokens at a time, so short evals are THE prompt path of the
-    drop-in: 2..60 rows take the column-grouped decode-shaped GEMM (k_gemm_skinny, with RoPE + KV append and
+    drop-in: 2..60 rows take the few-row kernel (k_gemv_set, with RoPE + KV append and
     SiLU * up -> QA in its epilogues) and the per-row attention that quantizes its output for wo
     (k_decn_scores / k_dec_pv_blk<true>); 61 is the first size past both.  n_embd 320 / n_ff 896 leave padded QA blocks (K not a multiple of 256) that these
     kernels must zero themselves."""
@@ -379,13 +379,13 @@ def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape
     om.close()
 
 
-@pytest.mark.parametrize("env", [{"LLAMAHIP_SET_W13_BLOCKS": "0"}, {"LLAMAHIP_SET_W13_BLOCKS": "1"}, {"LLAMAHIP_NO_GEMV_SET": "1"}],
-                         ids=["w13_half_blocks_at_every_row_count", "w13_whole_blocks_at_every_row_count", "k_gemm_skinny"])
-def test_few_row_kernel_selectable_epilogues_and_fallback(env):
+@pytest.mark.parametrize("env", [{"LLAMAHIP_SET_W13_BLOCKS": "0"}, {"LLAMAHIP_SET_W13_BLOCKS": "1"}, {"LLAMAHIP_SET_PLAN": "3,1"}, {"LLAMAHIP_SET_PLAN_SMALL": "2,4"}],
+                         ids=["w13_half_blocks_where_they_apply", "w13_whole_blocks_at_every_row_count", "unshared_groups_of_3_everywhere", "shared_rings_on_the_small_matrices"])
+def test_few_row_kernel_selectable_epilogues_and_plans(env):
     """The few-row mat-mul (k_gemv_set) runs w1|w3 in half-block workgroups with a tagged amax exchange for one column group and in
     whole-block workgroups (no exchange) from two column groups on; LLAMAHIP_SET_W13_BLOCKS=0 / 1 forces either epilogue onto every row
-    count, LLAMAHIP_NO_GEMV_SET restores round 4's k_gemm_skinny -- the short-eval and set-step parity tests re-run under each (switches
-    are read once per process, hence the subprocess; same tests, same oracle)."""
+    count it can serve, LLAMAHIP_SET_PLAN[_SMALL] another (columns per wave, column-waves) plan than the measured default -- the short-eval
+    and set-step parity tests re-run under each (switches are read once per process, hence the subprocess; same tests, same oracle)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -790,7 +790,7 @@ def test_7b_width_2048_token_prefill_vs_oracle(L, oracle, tmp_path):
         after = L.gemm_paths()
         assert after["mfma"] - before["mfma"] >= 4 * kw["n_layer"], (before, after)      # wq|wk|wv, wo, w1|w3, w2 of every layer
         # (only the lm head over all 2048 rows -- a debug-eval extra, it has no prompt copies -- takes another kernel)
-        assert after["rows"] == before["rows"] and after["lds"] - before["lds"] <= 1 and after["skinny"] == before["skinny"], (before, after)
+        assert after["rows"] == before["rows"] and after["lds"] - before["lds"] <= 1, (before, after)
         assert same(got["logits"], want["logits"]), "last row: " + describe(got["logits"], want["logits"])
         for r in (0, 1, 63, 64, 777, 1500, 2046):
             assert same(got["logits_all"][r], want["logits_all"][r]), f"row {r}: " + describe(got["logits_all"][r], want["logits_all"][r])

@@ -900,9 +900,8 @@ def test_batched_set_steps_equal_one_eval_per_sequence_on_the_oracle(L, oracle, 
             om.close()
         with pytest.raises(L.LlamaHipError, match="twice"):
             gm.stage_step_set([0, 1, 0], nth, st)
-    if not os.environ.get("LLAMAHIP_NO_GEMV_SET"):
-        # the set steps ran on the few-row kernel (k_gemv_set), not on a fall-back
-        assert L.gemm_paths()["set"] > paths_before["set"], (paths_before, L.gemm_paths())
+    # the set steps ran on the few-row kernel (k_gemv_set), not on a fall-back
+    assert L.gemm_paths()["set"] > paths_before["set"], (paths_before, L.gemm_paths())
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 #!/bin/bash
 # set steps and short evals, every measurement in a FRESH process (a handle loaded after another one was closed in the same process decodes
-# ~20 % slower here -- device memory comes back fragmented), for each "label|ENV=VAL ..." line of $1 (default: the product against k_gemm_skinny)
+# ~20 % slower here -- device memory comes back fragmented), for each "label|ENV=VAL ..." line of $1 (e.g. "product|" and library / plan variants)
 cd "$(dirname "$0")/.."
 V=${1:-/dev/stdin}
 [ -f "$V" ] || V=/dev/stdin

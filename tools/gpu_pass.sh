@@ -17,8 +17,8 @@ pass=${1:-quick}; tag=${2:-r05_$pass}
 O=gpurun_out; mkdir -p $O; R=$PWD
 bash tools/ensure_7b.sh
 quick() { timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks or few_row or handoff_timeout or prompt_continuation or chunks_in_one_pass" --durations=5 > $O/${tag}_quick.txt 2>&1; tail -4 $O/${tag}_quick.txt; }
-set_tables() {      # kernel tables of the set step (4 and 8 sequences, then 9-token evals) + PMC traffic, product build against k_gemm_skinny
-  printf 'set|\nskinny|LLAMAHIP_NO_GEMV_SET=1\n' > /tmp/v_set.txt
+set_tables() {      # kernel tables of the set step (4 and 8 sequences, then 9-token evals) + PMC traffic (k_gemm_skinny, the baseline of round 5's A/Bs, is gone)
+  printf 'set|\n' > /tmp/v_set.txt
   PROF=1 PROF_SEQS="4 8" PROF_EVALS=9 SEQS= EVALS= timeout 900 bash tools/set_ab.sh /tmp/v_set.txt > $O/${tag}_set_step_kernel_stats.txt 2>&1
   grep -v "k_repack\|copyBuffer\|fillBuffer" $O/${tag}_set_step_kernel_stats.txt | head -80
   SEQS="2 4 8" EVALS="4 9 16" timeout 600 bash tools/fresh_ab.sh /tmp/v_set.txt > $O/${tag}_set_fresh_process_ab.txt 2>&1; cat $O/${tag}_set_fresh_process_ab.txt
