@@ -9,6 +9,7 @@
 #   x      soft_max ablation of k_dec_pv_dma at 2 048 keys (libllamahip_pvabl.so)
 #   pf     long-prompt A/B of library / switch variants (VARIANTS) + the prompt parity tests
 #   w13    whole- vs half-block w1|w3 workgroups of the few-row kernel + 9-row plans (fresh processes), the variant parity test
+#   verify the last check of a tree: full GPU suite, smoke(), bench.py with defaults, chunk / prefill probes
 #   nccl   the RCCL branch of the pipeline bench at world 1 (communicators, self-check, forced one-rank schedule) with its log
 #   65b    BASELINE configs[4]'s model on one GPU: the forced one-rank pipeline in set mode (in-situ roofline of the stage step, parity gate)
 #   final  everything profiles/<tag>_* is made from: full GPU test suite, bench.py (7B, 13B), config[3] mixed run with HBM counters,
@@ -65,6 +66,19 @@ pf)   # long-prompt A/B over VARIANTS (tools/prefill_ab.sh) + the prompt parity 
 w13)  # whole-block vs half-block w1|w3 workgroups and the 9-row plans, fresh processes; the variant parity test
   timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "few_row_kernel_selectable or few_row_handoff or mul_mat" > $O/${tag}_parity.txt 2>&1; tail -3 $O/${tag}_parity.txt
   SEQS="${SEQS:-4 8}" EVALS="${EVALS:-9 16}" timeout 900 bash tools/fresh_ab.sh ${VARIANTS:-tools/variants.txt} > $O/${tag}_fresh_ab.txt 2>&1; cat $O/${tag}_fresh_ab.txt
+  ;;
+verify)   # the last check of a tree: full GPU suite, smoke(), bench.py with defaults, the chunk / prefill probes
+  python -m pytest tests -x -q -m gpu --durations=8 > $O/${tag}_pytest.txt 2>&1; tail -12 $O/${tag}_pytest.txt
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+  timeout 1200 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.log; tail -2 $O/${tag}_bench.log; python - <<PY
+import json
+d = json.load(open("$O/${tag}_bench.json"))
+print({k: d[k] for k in ("metric", "value", "unit", "ms_per_step")}, d["roofline"].get("frac"), d["roofline"].get("end_to_end_frac"), d["roofline"].get("traffic"))
+print("config", {k: v for k, v in d["config"].items() if not isinstance(v, (dict, list))})
+print("parity", d.get("parity", {}).get("identical"), d.get("parity", {}).get("tokens_compared"), "cpu", d.get("cpu_baseline", {}).get("value"))
+PY
+  timeout 300 python tools/chunk_probe.py > $O/${tag}_chunk_probe.txt 2>&1; tail -7 $O/${tag}_chunk_probe.txt
+  timeout 300 python tools/prefill_probe.py > $O/${tag}_prefill_probe.txt 2>&1; tail -6 $O/${tag}_prefill_probe.txt
   ;;
 65b)
   LLAMAHIP_FORCE_PIPELINE=1 LLAMAHIP_PIPE_PARITY_S=${PARITY_S:-60} timeout 2400 python bench.py --model 65B --steps 32 --warmup 4 > $O/${tag}_bench_65B_1gpu.json 2> $O/${tag}_bench_65B_1gpu.log
