@@ -211,7 +211,13 @@ int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_
  * (every operator of llama_eval's graph works row by row, .mm:563-705; each row keeps its own position, KV cache and V*P key split of
  * its own single-token eval, ggml.c:5459-5480) -- but every weight matrix is streamed ONCE per step for all the sequences, which is
  * what a decode step costs ("throughput scales only with independent sequences in flight").  2 .. 16 distinct
- * slots, each bound with plain buffers (no mailbox); one graph is captured per (set, n_threads).  n_seqs = 1 is llamahip_stage_step. */
+ * slots, each bound with plain buffers (no mailbox); one graph is captured per (set of slots, n_threads), at most 32 are kept (least
+ * recently used first out).  n_seqs = 1 is llamahip_stage_step.
+ * (Norm statistics: a set step runs the reference's two-pass form (ggml.c:5327-5385), a single step takes them one-pass from its
+ * producer's partial sums -- both narrow to the same fp32 bits except with probability ~2^-29 per value; the equality
+ * of set steps and single steps is therefore tested (tests/test_pipeline.py), not structural.)
+ * The score launch of a set covers every key slice of n_ctx whatever the rows' positions (slices beyond a row's position return at
+ * once): per-step launch overhead that grows with n_ctx, not with the context. */
 int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_seqs, int32_t n_threads, void *stream,
                             char *err, size_t err_cap);
 /* 1 if llamahip_stage_step_set can step n_seqs slots of this handle with this n_threads as ONE set (Q4_0 handle with layers, head size a
