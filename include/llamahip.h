@@ -297,9 +297,14 @@ int64_t llamahip_debug_decode_phases(llamahip_model *m, int32_t n_past, int32_t 
                                      uint64_t *records, int64_t cap, char *err, size_t err_cap);
 
 /* Launch counts of the multi-row mat-mul kernel families since process start, in the order
- * {matrix-core (k_gemm_mfma), short-eval (k_gemm_skinny), row-per-lane (k_gemm_rows), LDS-staged, mat-vec}:
+ * {matrix-core (k_gemm_mfma4), row-per-lane (k_gemm_rows), LDS-staged (k_gemm_lds), mat-vec (k_gemv), few rows (k_gemv_set)}:
  * lets a test assert that a shape took the path it is meant to.  Returns the number of families. */
 int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap);
+/* Host-only (no device needed): how the few-row mat-mul would take n_rows activation rows against an m x k Q4_0 matrix (interleaved:
+ * the w1|w3 layout; epi: 0 store, 1 +residual, 2 / 7 SiLU*up -> Q4_0 in whole- / half-block workgroups, 3 RoPE + KV append) --
+ * out = {columns per wave, column-waves per row-group, column groups, row-groups per workgroup, LDS bytes}; 0 = the kernel does not
+ * take that shape (the caller's generic path runs).  Lets a CPU test walk every LLaMA shape and row count. */
+int32_t llamahip_debug_set_plan(int32_t m, int32_t k, int32_t interleaved, int32_t n_rows, int32_t epi, int64_t out[5]);
 /* in-kernel phase records of the few-row mat-mul (measurement builds only; 0 records in the product build) */
 int64_t llamahip_debug_set_probe(uint64_t *records, int64_t cap, int32_t reset);
 

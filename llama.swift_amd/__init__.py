@@ -27,6 +27,7 @@ from .binding import (  # noqa: F401
     op_quantize_row_q4_0,
     op_topk,
     quantize_file,
+    set_plan,
     version,
 )
 from .runner import Config, LlamaRunner, RunState  # noqa: F401

@@ -134,6 +134,15 @@ def lib() -> C.CDLL:
     return L
 
 
+def set_plan(m: int, k: int, n_rows: int, epi: int, interleaved: bool = False):
+    """Host-only: the few-row kernel's plan (nc, cw, ncg, rgw, lds_bytes) for n_rows against an m x k matrix, or None (llamahip_debug_set_plan)."""
+    a = np.zeros(5, np.int64)
+    f = lib().llamahip_debug_set_plan
+    f.restype = C.c_int32
+    f.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    return tuple(int(x) for x in a) if f(m, k, int(interleaved), n_rows, epi, a.ctypes.data_as(C.c_void_p)) else None
+
+
 def gemm_paths() -> dict:
     """Launch counts of the multi-row mat-mul kernel families since process start (llamahip_debug_gemm_paths)."""
     a = np.zeros(8, np.int64)

@@ -513,6 +513,17 @@ static size_t set_lds_bytes(const QMat &w, int ncols_group, int nc, int cw, int 
 // row block run side by side on one XCD; the second read of a tile is an L2 hit hidden behind arithmetic -- at 8 rows these launches
 // are VALU bound: sharing the ring there AND streaming the operand rows through a second ring, k_gemv_set_ar of round 5, read the weights once
 // and measured the same -- profiles/r05_o_operand_ring_ab.txt; removed).  LLAMAHIP_SET_PLAN[_BIG|_SMALL]="nc,cw[,ncg[,rgw]]" overrides (measurement; _BIG: the unshared class).
+// the short evals: up to 60 rows (measured crossover against the row-per-lane kernel at 7B shapes, round 1: +25 % at 33 rows, +7 % at 56, -1 % at
+// 63; k_gemv_set against k_gemm_skinny at 20 / 24 / 32 / 48 / 60 rows: -5.5 / -5.5 / -0.7 / -5.2 / -6.3 % per eval, profiles/r05_y_rows_max.txt)
+constexpr int SET_ROWS_MAX = 60;
+constexpr size_t SET_LDS_CAP = 160 * 1024;
+// the (NC, CW) pairs k_gemv_set is instantiated for (launch_set_any's dispatch list)
+static bool set_plan_instantiated(int nc, int cw) {
+    static const int pairs[][2] = { {1, 2}, {1, 3}, {1, 4}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {3, 1}, {3, 3}, {3, 4}, {4, 1}, {4, 2}, {4, 4}, {5, 1} };
+    for (const auto &pr : pairs) if (pr[0] == nc && pr[1] == cw) return true;
+    return false;
+}
+
 static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int &ncg, int &rgw) {
     const char *env = getenv(name);
     if (!env) return false;
@@ -540,29 +551,41 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
     // the small class by row count, measured (7B wo / w2, fresh processes, profiles/r05_u_fresh_ab.txt, r05_v_small_plans.txt): three
     // column-waves leave 16 chunks a ragged last step (5 - 6 rows: <2,4> -1.5 %); from 9 rows on the launches are VALU bound and a step's
     // barrier is pure loss: unshared rings in column groups of 3 (9 - 12 rows: -4 ... -6 % per eval) or 4 (13 - 16: -2 %)
-    if (!big && w.ngroups < 768 && N >= 5) {
-        if (N <= 8) { nc = 2; cw = 4; ncg = 1; }
+    // (the 768 .. 1 535 row-group class -- wo of the 30B / 65B -- takes the same rule from 9 rows on: the argument does not depend on the size)
+    if (!big && N >= 5) {
+        if (N <= 8) { if (w.ngroups < 768) { nc = 2; cw = 4; ncg = 1; } }
         else if (N <= 12) { nc = 3; cw = 1; ncg = (N + 2) / 3; }
         else { nc = 4; cw = 1; ncg = (N + 3) / 4; }
     }
-    if (!set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw)) set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
-    // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4> <5,1>)
-    if (nc == 1 && cw == 1) nc = 2;
-    if (nc == 3 && cw == 2) nc = 4;
-    if (nc == 4 && cw == 3) cw = 4;
-    if (!rgw) rgw = epi == EPI_SILU_QAH ? 4 : (cw >= 3 ? 2 : 4);
-    if (epi == EPI_SILU_QAH) rgw = 4;
-    else if (epi == EPI_SILU_QA) rgw = 8;
-    else if (rgw * cw > 8) rgw = 8 / cw;                              // (set_max_threads)
-    p.nc = nc; p.cw = cw; p.rgw = rgw; p.ncg = ncg;
-    p.lds = set_lds_bytes(w, std::min(N, nc * cw), nc, cw, rgw);
+    const bool forced = set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw) || set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
+    auto finish = [&]() {
+        // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4> <5,1>)
+        if (nc == 1 && cw == 1) nc = 2;
+        if (nc == 3 && cw == 2) nc = 4;
+        if (nc == 4 && cw == 3) cw = 4;
+        if (!rgw) rgw = epi == EPI_SILU_QAH ? 4 : (cw >= 3 ? 2 : 4);
+        if (epi == EPI_SILU_QAH) rgw = 4;
+        else if (epi == EPI_SILU_QA) rgw = 8;
+        else if (rgw * cw > 8) rgw = 8 / cw;                          // (set_max_threads)
+        p.nc = nc; p.cw = cw; p.rgw = rgw; p.ncg = ncg;
+        p.lds = set_lds_bytes(w, std::min(N, nc * cw), nc, cw, rgw);
+    };
+    finish();
+    if (!forced && p.lds > SET_LDS_CAP) {
+        // wide rows (w2 of the 13B / 65B: 54 / 86 chunks): the operand rows of a whole group do not fit next to a shared ring.  Unshared
+        // column groups of as many columns (<= 4) as leave two workgroups' worth of LDS per CU where possible
+        const size_t per_col = set_lds_bytes(w, 1, 1, 1, 4);
+        int fit = (int) std::min<size_t>(4, (SET_LDS_CAP / 2) / per_col);
+        if (fit < 2) fit = (int) std::min<size_t>(4, SET_LDS_CAP / per_col);
+        if (fit >= 1) {
+            cw = 1; rgw = 0;
+            ncg = (N + fit - 1) / fit;
+            nc = (N + ncg - 1) / ncg;
+            finish();
+        }
+    }
     return p;
 }
-
-// the short evals: up to 60 rows (measured crossover against the row-per-lane kernel at 7B shapes, round 1: +25 % at 33 rows, +7 % at 56, -1 % at
-// 63; k_gemv_set against k_gemm_skinny at 20 / 24 / 32 / 48 / 60 rows: -5.5 / -5.5 / -0.7 / -5.2 / -6.3 % per eval, profiles/r05_y_rows_max.txt)
-constexpr int SET_ROWS_MAX = 60;
-constexpr size_t SET_LDS_CAP = 160 * 1024;
 
 bool gemv_set_applies(const QMat &w, int N, int epi) {
     if (N < 2 || N > SET_ROWS_MAX || !w.tiles) return false;
@@ -571,7 +594,16 @@ bool gemv_set_applies(const QMat &w, int N, int epi) {
     if (epi != EPI_STORE && epi != EPI_RESID && epi != EPI_ROPE_KV && epi != EPI_SILU_QAH && epi != EPI_SILU_QA) return false;
     const SetPlan p = set_plan(w, N, epi);
     if (epi == EPI_SILU_QA && p.cw != 1) return false;                // (whole-block workgroups are instantiated for unshared rings)
-    return p.lds <= SET_LDS_CAP;
+    return p.lds <= SET_LDS_CAP && set_plan_instantiated(p.nc, p.cw);
+}
+// host-only query (tests, no device needed): the plan for N rows against an M x K matrix -- out = { nc, cw, ncg, rgw, LDS bytes }
+bool gemv_set_plan_query(int M, int K, bool interleaved, int N, int epi, long out[5]) {
+    QMat w;
+    w.tiles = (uint8_t *) (uintptr_t) 16; w.M = M; w.K = K; w.ngroups = (M + 7) / 8; w.nchunks = (K + 255) / 256; w.gmapF8 = interleaved ? w.ngroups / 2 : 0;
+    if (!gemv_set_applies(w, N, epi)) return false;
+    const SetPlan p = set_plan(w, N, epi);
+    out[0] = p.nc; out[1] = p.cw; out[2] = p.ncg; out[3] = p.rgw; out[4] = (long) p.lds;
+    return true;
 }
 
 template <int NC, int CW>
@@ -612,7 +644,7 @@ static hipError_t launch_set_any(const QMat &w, GemvSetArgs a, int epi, hipStrea
     a.probe = g_set_probe;
 #endif
     const SetPlan p = set_plan(w, a.ncols, epi);
-    if (p.lds > SET_LDS_CAP) return hipErrorInvalidValue;
+    if (p.lds > SET_LDS_CAP || !set_plan_instantiated(p.nc, p.cw)) return hipErrorInvalidValue;
     a.rgw = p.rgw; a.ncg = p.ncg;
     const int nwg = epi == EPI_SILU_QAH ? (w.ngroups / 8 + 7) / 8 * 16 : (w.ngroups + p.rgw - 1) / p.rgw;      // (EPI_SILU_QA: rgw = 8, a workgroup per block)
     const int grid = p.ncg == 1 ? nwg : (nwg + 7) / 8 * 8 * p.ncg;

@@ -1767,6 +1767,13 @@ int64_t llamahip_debug_set_probe(uint64_t *records, int64_t cap, int32_t reset) 
     return (int64_t) set_probe_dump((unsigned long long *) records, (long) cap, reset != 0);
 }
 
+int32_t llamahip_debug_set_plan(int32_t m, int32_t k, int32_t interleaved, int32_t n_rows, int32_t epi, int64_t out[5]) {
+    long o[5] = { 0, 0, 0, 0, 0 };
+    if (m < 1 || k < 1 || !out || !gemv_set_plan_query(m, k, interleaved != 0, n_rows, epi, o)) return 0;
+    for (int i = 0; i < 5; i++) out[i] = o[i];
+    return 1;
+}
+
 int32_t llamahip_debug_gemm_paths(int64_t *out, int32_t cap) {
     for (int i = 0; out && i < cap && i < GEMM_PATH_COUNT; i++) out[i] = g_gemm_path_counts[i];
     return GEMM_PATH_COUNT;

@@ -172,6 +172,7 @@ hipError_t launch_gemm_silu_qa(const QMat &w13, const uint32_t *qa_A, const floa
 //   placement xcd_selftest confirmed, the epoch word and SET_AMAX_GRANULES(F) * 16 zeroed granules)
 inline size_t set_amax_granules(int F) { return (size_t) F / 16 + 16; }      // per column
 bool gemv_set_applies(const QMat &w, int N, int epi);
+bool gemv_set_plan_query(int M, int K, bool interleaved, int N, int epi, long out[5]);      // host-only: the (nc, cw, ncg, rgw, LDS) plan, false = the kernel does not take the shape
 bool gemv_set_silu_whole_blocks(const QMat &w13, int N, bool have_exchange);      // EPI_SILU_QA (whole-block workgroups, no exchange) instead of EPI_SILU_QAH
 hipError_t launch_gemv_set(const QMat &w, int epi, const uint32_t *qa_A, const float *qa_d, int N,
                            float *y, long y_stride, const float *resid, long resid_stride, hipStream_t st);

@@ -365,3 +365,28 @@ def test_dense_model_files_parse_on_the_host(L, tmp_path):
     open(str(tmp_path / "q41.bin"), "wb").write(raw)
     with pytest.raises(L.LlamaHipError, match="wrong size"):
         L.Model(str(tmp_path / "q41.bin"), n_ctx=16, n_parts=1, flags=4)
+
+
+def test_few_row_kernel_plans_every_llama_shape_and_row_count(L):
+    """Host-only walk of the few-row mat-mul's plan (csrc/gemv_set.hip set_plan; no device needed): for every matrix of the four LLaMA
+    sizes and every row count a short eval or a batched decode step can have (2 .. 60), the kernel takes the shape -- so no eval silently
+    falls to the slow generic path -- with an instantiated (columns per wave, column-waves) pair, column groups that cover the rows
+    exactly, and operand rows + weight ring inside the CU's 160 KB of LDS (13B / 65B w2 rows are 54 / 86 chunks long: they take
+    unshared column groups)."""
+    EPI_STORE, EPI_RESID, EPI_SILU_QA, EPI_ROPE_KV, EPI_SILU_QAH = 0, 1, 2, 3, 7
+    pairs = {(1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4), (3, 1), (3, 3), (3, 4), (4, 1), (4, 2), (4, 4), (5, 1)}
+    for d, mult in ((4096, 256), (5120, 256), (6656, 256), (8192, 256)):
+        F = ((2 * (4 * d) // 3 + mult - 1) // mult) * mult                  # .mm:118-120
+        mats = [("wq|wk|wv", 3 * d, d, EPI_ROPE_KV, False), ("wo", d, d, EPI_RESID, False), ("w1|w3 halves", 2 * F, d, EPI_SILU_QAH, True),
+                ("w1|w3 blocks", 2 * F, d, EPI_SILU_QA, True), ("w2", d, F, EPI_RESID, False), ("output", 32000, d, EPI_STORE, False)]
+        for name, M, K, epi, inter in mats:
+            for N in range(2, 61):
+                p = L.set_plan(M, K, N, epi, inter)
+                assert p is not None, (d, name, N)
+                nc, cw, ncg, rgw, lds = p
+                assert (nc, cw) in pairs and lds <= 160 * 1024 and 1 <= rgw * cw <= 16, (d, name, N, p)
+                assert nc * cw * ncg >= N > nc * cw * (ncg - 1), (d, name, N, p)
+                if epi in (EPI_SILU_QA, EPI_SILU_QAH):
+                    assert cw == 1 and rgw == (8 if epi == EPI_SILU_QA else 4), (d, name, N, p)
+    assert L.set_plan(4096, 4096, 1, EPI_RESID) is None and L.set_plan(4096, 4096, 61, EPI_RESID) is None       # one row: k_gemv; 61+: the prompt kernels
+    assert L.set_plan(2 * 11008, 4096, 4, EPI_SILU_QAH, False) is None                                           # not the interleaved layout
