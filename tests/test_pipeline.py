@@ -900,8 +900,9 @@ def test_batched_set_steps_equal_one_eval_per_sequence_on_the_oracle(L, oracle, 
             om.close()
         with pytest.raises(L.LlamaHipError, match="twice"):
             gm.stage_step_set([0, 1, 0], nth, st)
-    # the set steps ran on the few-row kernel (k_gemv_set), not on a fall-back
-    assert L.gemm_paths()["set"] > paths_before["set"], (paths_before, L.gemm_paths())
+    # the set steps (and the prompts' short evals) ran on the few-row kernel (k_gemv_set), none of their mat-muls on a generic fall-back
+    after = L.gemm_paths()
+    assert after["set"] > paths_before["set"] and after["lds"] == paths_before["lds"] and after["rows"] == paths_before["rows"], (paths_before, after)
 
 
 @pytest.mark.gpu
