@@ -93,7 +93,7 @@ struct GemvSetArgs {
 #endif
 // The weight ring lives in LDS and is filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB of LDS, no VGPRs, no ds_write):
 // SET_DR slots of CW chunks per row-group, SET_DR - 1 steps in flight.  (The first version kept the ring in registers and published
-// every chunk with a ds_write.  Its in-kernel timeline, profiles/r05_t_timeline.txt: 3.0 - 6.5 us between "ring issued" and the first
+// every chunk with a ds_write.  Its in-kernel timeline, profiles/r05_t_timeline_register_ring.txt: 3.0 - 6.5 us between "ring issued" and the first
 // step -- the operand rows were requested BEHIND the ring and vmcnt retires in order, and the register copies the compiler places in
 // front of a loop that carries a ring made every wave wait for ALL of its prefill, i.e. for the far end of its rows, before step 0.)
 #ifndef LH_SET_DR
