@@ -207,7 +207,6 @@ hipError_t launch_qkv_attn(const QMat &w, const float *x, const float *norm_w, c
                            const MailboxIO *mb = nullptr);      // mb->in_t: the row arrives as tagged granules (pipeline mailbox)
 hipError_t launch_bump_epoch(uint32_t *epoch, hipStream_t st);
 // a residual-stream row re-published as tagged granules, slot 0 of the current epoch (pipeline mailbox tests, single-GPU stage chains)
-hipError_t launch_tag_row(const float *x, int d, const uint32_t *epoch, uint64_t *xt, hipStream_t st);
 hipError_t launch_quantize_offline(const void *src, int f16, uint8_t *dst, long nblocks, hipStream_t st);
 hipError_t launch_advance(int32_t *state, hipStream_t st);
 // sampler front end (utils.cpp:345-395): the k best candidate scores of the last row of logits, on the device

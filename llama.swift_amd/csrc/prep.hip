@@ -197,14 +197,6 @@ k_embed_part(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ emb
     if (epoch && !xt && threadIdx.x == 0) epoch[0] = next_epoch(epoch[0]);       // one forward pass = one epoch of the tagged hand-offs (k_qkv_attn)
 }
 
-// a residual-stream row that arrived behind a kernel boundary (pipeline stage input) re-published as tagged granules, slot 0
-__global__ void __launch_bounds__(256)
-k_tag_row(const float *__restrict__ x, int d, const uint32_t *__restrict__ epoch, uint64_t *__restrict__ xt) {
-    const uint32_t tag = make_tag(epoch[0], 0);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d; i += gridDim.x * blockDim.x) store_tagged_agent(xt + i, __builtin_bit_cast(uint32_t, x[i]), tag);
-}
-
-
 // grid.x = rows; dynamic LDS = (K + K/32 + 64) floats + 32 doubles
 template <int MODE>
 __global__ void k_prep_qa(const float *__restrict__ in0, const float *__restrict__ in1, long in_stride, long in1_stride,
@@ -404,12 +396,6 @@ hipError_t launch_embed_part(const int32_t *token, const uint8_t *emb, float *x,
     LH_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_tag_row(const float *x, int d, const uint32_t *epoch, uint64_t *xt, hipStream_t st) {
-    hipLaunchKernelGGL(k_tag_row, dim3((d + 1023) / 1024), dim3(256), 0, st, x, d, epoch, xt);
-    LH_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
 hipError_t launch_prep(int mode, const float *in0, const float *in1, long in_stride, long in1_stride, int K, int N,
                        uint32_t *qa_A, float *qa_d, float *y_out, uint8_t *raw_out, const uint16_t *T_silu,
                        hipStream_t st) {
