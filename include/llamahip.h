@@ -244,7 +244,9 @@ int llamahip_stage_mailbox_connect(llamahip_model *m, int32_t seq, const void *n
                                    const void *token_handle64, void *token_ptr, char *err, size_t err_cap);
 
 /* Row `row` of the logits the most recent step / eval left on the device (last stage; waits for the device): row 0 after
- * llamahip_stage_step, row i = the i-th slot of the set after llamahip_stage_step_set.  Parity tooling. */
+ * llamahip_stage_step, row i = the i-th slot of the set (in the caller's order) after llamahip_stage_step_set, row i = the i-th row of the
+ * eval after llamahip_eval / llamahip_eval_stage.  Every entry point that rewrites the logits resets the row map; a caller that steps
+ * a set's slots one by one instead (llamahip_stage_set_applies() == 0) finds the LAST stepped slot's logits in row 0.  Parity tooling. */
 int llamahip_stage_logits(llamahip_model *m, int32_t row, float *logits_out, char *err, size_t err_cap);
 
 /* Select which of the handle's n_seq KV caches subsequent evals read and write (default 0). */

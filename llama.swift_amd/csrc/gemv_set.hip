@@ -266,6 +266,7 @@ k_gemv_set(const GemvSetArgs a) {
     const int bid = blockIdx.x, cg = (bid >> 3) % a.ncg, blk = ((bid >> 3) / a.ncg) * 8 + (bid & 7);
     const int col0 = cg * NCW;
     const int nchunks = a.nchunks, ncols = min(NCW, a.ncols - col0), rgw = a.rgw;      // this group's columns: col0 .. col0 + ncols - 1
+    if (ncols <= 0) return;                                         // (a plan never has an empty group -- set_plan; uniform per workgroup, before any barrier)
     const uint32_t *qa_A = a.qa_A + (size_t) col0 * nchunks * 64;
     const float *qa_d = a.qa_d + (size_t) col0 * nchunks * 8;
     const int steps = (nchunks + CW - 1) / CW;
@@ -524,16 +525,25 @@ static bool set_plan_instantiated(int nc, int cw) {
     return false;
 }
 
-static bool set_plan_env(const char *name, int N, int epi, int &nc, int &cw, int &ncg, int &rgw) {
+// LLAMAHIP_SET_PLAN[_BIG|_SMALL] are parsed once per process (the switches of this library are read once; set_plan runs several times per launch)
+struct SetPlanEnv { int got = 0, nc = 0, cw = 0, ncg = 0, rgw = 0; };
+static SetPlanEnv set_plan_env_parse(const char *name) {
+    SetPlanEnv e;
     const char *env = getenv(name);
-    if (!env) return false;
-    int e_nc = 0, e_cw = 0, e_ncg = 0, e_rgw = 0;
-    const int got = sscanf(env, "%d,%d,%d,%d", &e_nc, &e_cw, &e_ncg, &e_rgw);
-    if (got < 2 || e_nc < 1 || e_nc > 5 || e_cw < 1 || e_cw > 4 || (e_nc == 5 && e_cw != 1)) return false;
-    if (got < 3 || e_ncg < 1) e_ncg = (N + e_nc * e_cw - 1) / (e_nc * e_cw);
-    if (e_nc * e_cw * e_ncg < N || (e_ncg - 1) * e_nc * e_cw >= N) return false;
-    nc = e_nc; cw = e_cw; ncg = e_ncg;
-    if (got >= 4 && e_rgw >= 1 && e_rgw <= 8 && epi != EPI_SILU_QAH && epi != EPI_SILU_QA) rgw = e_rgw;
+    if (!env) return e;
+    e.got = sscanf(env, "%d,%d,%d,%d", &e.nc, &e.cw, &e.ncg, &e.rgw);
+    if (e.got < 2 || e.nc < 1 || e.nc > 5 || e.cw < 1 || e.cw > 4 || (e.nc == 5 && e.cw != 1)) e.got = 0;
+    return e;
+}
+static bool set_plan_env(int which, int N, int epi, int &nc, int &cw, int &ncg, int &rgw) {
+    static const SetPlanEnv envs[3] = { set_plan_env_parse("LLAMAHIP_SET_PLAN_BIG"), set_plan_env_parse("LLAMAHIP_SET_PLAN_SMALL"), set_plan_env_parse("LLAMAHIP_SET_PLAN") };
+    const SetPlanEnv &e = envs[which];
+    if (e.got < 2) return false;
+    int e_ncg = e.ncg;
+    if (e.got < 3 || e_ncg < 1) e_ncg = (N + e.nc * e.cw - 1) / (e.nc * e.cw);
+    if (e.nc * e.cw * e_ncg < N || (e_ncg - 1) * e.nc * e.cw >= N) return false;
+    nc = e.nc; cw = e.cw; ncg = e_ncg;
+    if (e.got >= 4 && e.rgw >= 1 && e.rgw <= 8 && epi != EPI_SILU_QAH && epi != EPI_SILU_QA) rgw = e.rgw;
     return true;
 }
 static SetPlan set_plan(const QMat &w, int N, int epi) {
@@ -557,12 +567,13 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
         else if (N <= 12) { nc = 3; cw = 1; ncg = (N + 2) / 3; }
         else { nc = 4; cw = 1; ncg = (N + 3) / 4; }
     }
-    const bool forced = set_plan_env(big ? "LLAMAHIP_SET_PLAN_BIG" : "LLAMAHIP_SET_PLAN_SMALL", N, epi, nc, cw, ncg, rgw) || set_plan_env("LLAMAHIP_SET_PLAN", N, epi, nc, cw, ncg, rgw);
+    (void) (set_plan_env(big ? 0 : 1, N, epi, nc, cw, ncg, rgw) || set_plan_env(2, N, epi, nc, cw, ncg, rgw));
     auto finish = [&]() {
         // (instantiated: <1,2> <1,3> <1,4> <2,1> <2,2> <2,3> <2,4> <3,1> <3,3> <3,4> <4,1> <4,2> <4,4> <5,1>)
         if (nc == 1 && cw == 1) nc = 2;
         if (nc == 3 && cw == 2) nc = 4;
         if (nc == 4 && cw == 3) cw = 4;
+        ncg = (N + nc * cw - 1) / (nc * cw);                          // (the promotions above widen a group: no column group may start past row N)
         if (!rgw) rgw = epi == EPI_SILU_QAH ? 4 : (cw >= 3 ? 2 : 4);
         if (epi == EPI_SILU_QAH) rgw = 4;
         else if (epi == EPI_SILU_QA) rgw = 8;
@@ -571,7 +582,8 @@ static SetPlan set_plan(const QMat &w, int N, int epi) {
         p.lds = set_lds_bytes(w, std::min(N, nc * cw), nc, cw, rgw);
     };
     finish();
-    if (!forced && p.lds > SET_LDS_CAP) {
+    if (p.lds > SET_LDS_CAP) {
+        // (a forced plan that cannot fit degrades to this rule for that shape too: a measurement variant never sends a shape to the generic kernel)
         // wide rows (w2 of the 13B / 65B: 54 / 86 chunks): the operand rows of a whole group do not fit next to a shared ring.  Unshared
         // column groups of as many columns (<= 4) as leave two workgroups' worth of LDS per CU where possible
         const size_t per_col = set_lds_bytes(w, 1, 1, 1, 4);

@@ -1223,6 +1223,7 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
     if (m->first_stage) HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     m->attn_sched = N == 1 ? attn_sched_at(m, n_past) : 0;
     rc = forward(m, n_threads, n_past, N, (const float *) hidden_in, false, false, -1, nullptr, err, err_cap);
+    m->last_rows.clear();                                                 // (m->logits rewritten: llamahip_stage_logits rows are this eval's rows again)
     if (rc) return rc;
     const size_t d = m->hp.n_embd, V = m->hp.n_vocab;
     if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t) N * d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
@@ -1243,6 +1244,7 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
         return LLAMAHIP_ERR_PREDICT;
     }
     if (!m->first_stage || !m->last_stage) { set_err(err, err_cap, "greedy decode needs a whole-model handle"); return LLAMAHIP_ERR_PREDICT; }
+    m->last_rows.clear();
     const double t0 = now_ms();
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     rc = ensure_workspace(m, 1, err, err_cap);

@@ -251,7 +251,8 @@ class HipStage:
 
     def step_set(self, seqs):
         """One decode step for all of `seqs` at once (llamahip_stage_step_set: weights streamed once for the set); handles / thread
-        counts the set step does not cover (n_threads > 32, head sizes off the grid) step the slots one by one -- same results."""
+        counts the set step does not cover (n_threads > 32, head sizes off the grid) step the slots one by one -- same tokens and KV rows;
+        stage_logits then holds only the LAST slot's logits, in row 0 (include/llamahip.h)."""
         seqs = list(seqs)
         if not self.model.stage_set_applies(len(seqs), self.n_threads):
             for s in seqs:

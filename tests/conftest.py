@@ -18,6 +18,48 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the GPU suite (`-x` stops at the first failure, so what matters most runs first -- VERDICT r05: a measurement
+# variant's test bug hid the headline's parity tests behind it):
+#   0  BASELINE.json configs[0] / [1] / [2] on the full 7B file (test_7b_*)
+#   1  the wider models and every pipeline / stage / set-step test (configs[4]'s path)
+#   2  full depth 13B / 65B and the 2048-token prompts against the CPU path (their expectations have been computing since collection)
+#   3  goldens and per-op parity
+#   4  variants re-run in nested pytest processes, fault injection, timeouts
+def _group(item):
+    name, mod = item.name, item.module.__name__ if item.module else ""
+    if item.get_closest_marker("gpu") is None:
+        return 3
+    if any(k in name for k in ("_selectable_", "_fallback", "_forced_on_", "_timeout_", "_lost_row_", "_silent_peer_")):
+        return 4
+    if mod.endswith("test_gpu_fullsize"):
+        return 2
+    for i, k in enumerate(("test_7b_logits", "test_7b_greedy_trace_128", "test_7b_greedy_trace_512", "test_7b_full_context", "test_7b_")):
+        if name.startswith(k):
+            return 0.1 * i
+    if mod.endswith("test_pipeline") or name.startswith("test_wider_models"):
+        return 1
+    return 3
+
+
+def pytest_collection_modifyitems(config, items):
+    if any(it.get_closest_marker("gpu") is not None for it in items):
+        items.sort(key=_group)              # (stable: file order inside a group)
+
+
+def pytest_collection_finish(session):
+    """a full GPU session: start every long CPU expectation now (tests/bg_expect.py), the tests wait only for what is left"""
+    n_gpu = sum(1 for it in session.items if it.get_closest_marker("gpu") is not None)
+    if n_gpu >= 40 and not os.environ.get("LLAMAHIP_NESTED") and not session.config.option.collectonly:
+        _ensure_built()
+        import bg_expect
+        bg_expect.start_all()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if "bg_expect" in sys.modules:
+        sys.modules["bg_expect"].stop_all()
+
+
 def _ensure_built():
     import reflib
     lib = os.path.join(ROOT, "llama.swift_amd", "csrc", "libllamahip.so")
@@ -66,3 +108,10 @@ def synth_tool(out, **kw):
         args += [f"--{k}", str(v)]
     subprocess.run(args, check=True, capture_output=True)
     return str(out)
+
+
+def nested(env, select, files, tag):
+    """one variant = one nested pytest run; ONE summary line on stdout, the inner tail only in the assertion message"""
+    import variants
+    ok, summary, tail = variants.run_nested(env, select, files, tag)
+    assert ok, summary + "\n" + tail

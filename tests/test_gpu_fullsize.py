@@ -6,7 +6,8 @@ oracle/_ref, when it travelled with the snapshot; else the standalone restatemen
   configs[4]  LLaMA-65B, 80 layers, 8-part file -- the model the 8-GPU pipeline shards
 
 Model files are synthetic (random Q4_0 weights of the exact shapes, written in the reference's file format by
-csrc/tools/make_synth_model) and shared with bench.py through LLAMAHIP_MODEL_DIR.  The 65B file is 40 GB: that test
+csrc/tools/make_synth_model) and shared with bench.py through LLAMAHIP_MODEL_DIR.  The CPU expectations are child processes
+started when the session is collected (tests/bg_expect.py): they compute side by side while earlier GPU tests run.  The 65B file is 40 GB: that test
 needs ~45 GB of /tmp and of host RAM and takes a few minutes; LLAMAHIP_SKIP_65B=1 skips it.
 """
 import os
@@ -15,7 +16,6 @@ import numpy as np
 import pytest
 
 import synth
-from conftest import synth_tool
 
 pytestmark = pytest.mark.gpu
 
@@ -33,79 +33,19 @@ def describe(a, b):
     return f"{bad.size}/{a.size} differ, first at {bad[:4]}, got {a.ravel()[bad[:3]]} want {b.ravel()[bad[:3]]}"
 
 
-def _model(preset: str) -> str:
-    d = os.environ.get("LLAMAHIP_MODEL_DIR", "/tmp/llamahip_models")
-    path = os.path.join(d, f"{preset}-seed20230312", "ggml-model-q4_0.bin")
-    if not os.path.exists(path + ".done"):
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        synth_tool(path, preset=preset, seed=20230312)
-        open(path + ".done", "w").close()
-    return path
+import bg_expect                                  # model files + background CPU expectations (started at collection, conftest.py)
 
-
-# 2-layer models of the 13B / 65B WIDTHS (n_embd, heads, n_ff; 2 / 8-part files as the reference derives from n_embd, .mm:33-38): the
-# decode step's attention schedule switches by POSITION at thresholds that depend on the width (llamahip.cpp attn_sched_at: 13B 544 and
-# 1600, 65B 448), far beyond what a full-depth CPU expectation can reach -- prompts in the bridge's nine-token evals up to just below a
-# threshold, then greedy tokens across it with NO environment override.  name -> (shape, n_ctx, prompt tokens, generated tokens)
-_WIDE = {
-    "13Bw_544": (dict(n_vocab=512, n_embd=5120, n_mult=256, n_head=40, n_layer=2), 640, 531, 24),       # positions 531 .. 554: fused launch -> three launches at 544
-    "13Bw_1600": (dict(n_vocab=512, n_embd=5120, n_mult=256, n_head=40, n_layer=2), 1664, 1593, 16),    # 1593 .. 1608: three launches -> streaming soft_max . V at 1600
-    "65Bw_448": (dict(n_vocab=512, n_embd=8192, n_mult=256, n_head=64, n_layer=2), 512, 441, 14),       # 441 .. 454: fused launch -> three launches at 448
-}
-
-
-def _wide_model(tag: str, kw: dict) -> str:
-    d = os.environ.get("LLAMAHIP_MODEL_DIR", "/tmp/llamahip_models")
-    path = os.path.join(d, f"{tag}-2layer-seed31", "ggml-model-q4_0.bin")
-    if not os.path.exists(path + ".done"):
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        synth_tool(path, seed=31, **kw)
-        open(path + ".done", "w").close()
-    return path
+_model = bg_expect.model
+_WIDE = bg_expect.WIDE
 
 
 class _Expect:
-    """The CPU expectations of this module, each computed by its own child process (tests/cpu_expect.py), all of them side by side
-    from the first test on: the host time of the four full-size tests overlaps instead of adding up."""
-
-    def __init__(self, tmp):
-        self.tmp, self.jobs = tmp, {}
-
-    def start(self, name, kind, path, n_ctx, n_prompt, n_gen, nth=8, seed=3, n_vocab=32000):
-        import subprocess
-        import sys
-        if name in self.jobs:
-            return
-        out = os.path.join(self.tmp, name + ".npz")
-        here = os.path.dirname(os.path.abspath(__file__))
-        p = subprocess.Popen([sys.executable, os.path.join(here, "cpu_expect.py"), kind, path, str(n_ctx), str(n_prompt), str(n_gen), str(nth), str(seed), out, str(n_vocab)],
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        self.jobs[name] = (p, out)
-
-    def get(self, name):
-        p, out = self.jobs[name]
-        log, _ = p.communicate(timeout=1500)
-        assert p.returncode == 0 and os.path.exists(out), f"cpu_expect {name} failed:\n{log[-3000:]}"
-        return np.load(out)
+    get = staticmethod(bg_expect.get)
 
 
 @pytest.fixture(scope="module")
-def expect(tmp_path_factory):
-    e = _Expect(str(tmp_path_factory.mktemp("cpu_expect")))
-    # the 7B and 13B files take seconds to write and their children start at once; the 65B file is written next, its child last
-    p7 = _model("7B")
-    e.start("flow2048", "flow", p7, 2560, 2048, 3, seed=6)
-    e.start("single2048", "single", p7, 2560, 2048, 3, seed=5)
-    e.start("13B", "decode", _model("13B"), 64, 9, 5)
-    e.start("13B_128", "flow", _model("13B"), 256, 128, 32, seed=9)
-    for name, (kw, n_ctx, n_prompt, n_gen) in _WIDE.items():
-        e.start(name, "flow", _wide_model(name.split("_")[0], kw), n_ctx, n_prompt, n_gen, seed=12, n_vocab=kw["n_vocab"])
-    if not os.environ.get("LLAMAHIP_SKIP_65B"):
-        e.start("65B", "decode", _model("65B"), 64, 9, 4)                 # (writing the 40 GB file takes a minute or three: the 7B / 13B children run meanwhile)
-    yield e
-    for p, _ in e.jobs.values():
-        if p.poll() is None:
-            p.kill()
+def expect():
+    return _Expect()
 
 
 def _decode_vs_cpu(L, expect, name, preset, n_ctx, n_prompt, n_gen, nth=8):
@@ -186,4 +126,4 @@ def test_wide_models_decode_across_their_default_attention_schedule_thresholds(L
     """13B-width and 65B-width rows decoded ACROSS the positions where attn_sched_at switches the decode step's attention schedule
     (no environment override: the thresholds the production build uses), against the reference build."""
     kw, n_ctx, n_prompt, n_gen = _WIDE[name]
-    _flow_vs_cpu(L, expect, name, _wide_model(name.split("_")[0], kw), n_ctx, n_gen)
+    _flow_vs_cpu(L, expect, name, _model(name.split("_")[0]), n_ctx, n_gen)

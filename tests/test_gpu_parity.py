@@ -282,13 +282,8 @@ def test_matrix_core_prompt_gemm_forced_on_small_models():
     DMA-staged operands) is only selected when its workgroups fill the chip, which the small test models never do: re-run the
     prompt tests with LLAMAHIP_MFMA_MIN=32 (read once per process, hence the subprocess) so that every eval of >= 32 rows
     goes through the matrix cores -- ragged row and column counts, odd numbers of 32-row blocks, the wider models' shapes."""
-    import subprocess
-    import sys
-    env = dict(os.environ, LLAMAHIP_MFMA_MIN="32")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "prompt_continuation or long_prompt or multipart or wider_models"],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    from conftest import nested
+    nested({"LLAMAHIP_MFMA_MIN": "32"}, "prompt_continuation or long_prompt or multipart or wider_models", [os.path.abspath(__file__)], "matrix_core_prompt_gemm_forced")
 
 
 _FULL = "wider_models or greedy_trace_128 or tiny_model_golden or prompt_continuation or thread_splits"
@@ -317,12 +312,8 @@ def test_decode_attention_fallback_paths(switch, select):
     exchange their partial amax inside one XCD) -- LLAMAHIP_NO_W13_HALF keeps the 8-wave block workgroups everywhere, LLAMAHIP_W13_HALF=1
     forces the halves onto the 13B / 65B widths (their two-granule prologue variant).
     The switches are read once per process, hence the subprocess; same parity tests, same oracle."""
-    import subprocess
-    import sys
-    env = dict(os.environ, **switch)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", select],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    from conftest import nested
+    nested(switch, select, [os.path.abspath(__file__)], "decode_attention_fallback")
 
 
 
@@ -379,20 +370,20 @@ def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape
     om.close()
 
 
-@pytest.mark.parametrize("env", [{"LLAMAHIP_SET_W13_BLOCKS": "0"}, {"LLAMAHIP_SET_W13_BLOCKS": "1"}, {"LLAMAHIP_SET_PLAN": "3,1"}, {"LLAMAHIP_SET_PLAN_SMALL": "2,4"}],
-                         ids=["w13_half_blocks_where_they_apply", "w13_whole_blocks_at_every_row_count", "unshared_groups_of_3_everywhere", "shared_rings_on_the_small_matrices"])
+def _set_plan_variants():
+    import variants           # (ONE list: tests/test_host.py walks the same environments host-only)
+    return [pytest.param(env, id=tag) for env, tag in variants.SET_PLAN_VARIANTS]
+
+
+@pytest.mark.parametrize("env", _set_plan_variants())
 def test_few_row_kernel_selectable_epilogues_and_plans(env):
     """The few-row mat-mul (k_gemv_set) runs w1|w3 in half-block workgroups with a tagged amax exchange for one column group and in
     whole-block workgroups (no exchange) from two column groups on; LLAMAHIP_SET_W13_BLOCKS=0 / 1 forces either epilogue onto every row
     count it can serve, LLAMAHIP_SET_PLAN[_SMALL] another (columns per wave, column-waves) plan than the measured default -- the short-eval
     and set-step parity tests re-run under each (switches are read once per process, hence the subprocess; same tests, same oracle)."""
-    import subprocess
-    import sys
+    from conftest import nested
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), os.path.join(here, "test_pipeline.py"), "-k",
-                        "short_chunks or batched_set_steps_equal or prompt_continuation"],
-                       env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(here))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    nested(env, "short_chunks or batched_set_steps_equal or prompt_continuation", [os.path.abspath(__file__), os.path.join(here, "test_pipeline.py")], "few_row_kernel_plan")
 
 
 @pytest.mark.parametrize("env", [{"LLAMAHIP_NO_LUT_MATH": "1"}, {"LLAMAHIP_NORM_MODE": "0"}, {"LLAMAHIP_NORM_MODE": "1"},
@@ -406,12 +397,9 @@ def test_production_fallbacks_and_selectable_variants(env):
     copies and the host-side candidate selection; MFMA_I8 -- the int8 matrix-core prompt GEMM of round 1; EAGER_PREFILL_COPY -- the
     prompt-only weight copies built at load.  Switches are read once
     per process, hence the subprocess; same parity tests, same oracle."""
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "dc_offset or thread_splits or tiny_model_golden or wider_models or prompt_continuation or runner_event or topk_candidates"],
-                       env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    from conftest import nested
+    nested(env, "dc_offset or thread_splits or tiny_model_golden or wider_models or prompt_continuation or runner_event or topk_candidates", [os.path.abspath(__file__)],
+           "production_fallback")
 
 
 @pytest.mark.parametrize("which", [{"LLAMAHIP_HANDOFF_FAULT_TEST": "1"}, {"LLAMAHIP_HANDOFF_FAULT_TEST": "4", "LLAMAHIP_ATTN_LONG_FROM": "0"},
@@ -690,14 +678,9 @@ def test_fused_decode_launch_thread_splits_and_slice_boundaries(L, oracle, tmp_p
 
 # ------------------------------------------------------------------------------------------------ full LLaMA-7B size
 @pytest.fixture(scope="module")
-def model7b(tmp_path_factory):
-    d = os.environ.get("LLAMAHIP_MODEL_DIR", "/tmp/llamahip_models")
-    path = os.path.join(d, "7B-seed20230312", "ggml-model-q4_0.bin")
-    if not os.path.exists(path + ".done"):
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        synth_tool(path, preset="7B", seed=20230312)
-        open(path + ".done", "w").close()
-    return path
+def model7b():
+    import bg_expect
+    return bg_expect.model("7B")
 
 
 def test_7b_logits_and_greedy_tokens_vs_oracle(L, oracle, model7b):
@@ -723,20 +706,9 @@ def trace7b(model7b):
     the reference's own ggml.c (oracle/_ref) when it travelled with the snapshot, else the standalone
     restatement.  One token per llama_eval, as the bridge does (.mm:834-896): 504 tokens after an 8-token prompt
     fill the context; the first 128 of them are configs[0].  Keeps the top-2 logit margin of every step."""
-    import reflib
-    lib = reflib.RefLib() if reflib.have_ref() else reflib.OracleLib()
-    m = lib.load(model7b, 512)
-    prompt = synth.synth_prompt(8, 32000, seed=2)
-    lg = m.eval(prompt, 0, 8)["logits"]
-    first = int(np.argmax(lg))
-    toks, margins, t = [], [], first
-    for i in range(504):
-        lg = m.eval(np.array([t], np.int32), 8 + i, 8)["logits"]
-        t = int(np.argmax(lg))
-        top2 = np.partition(lg, -2)[-2:]
-        toks.append(t); margins.append(float(top2[1] - top2[0]))
-    m.close()
-    return dict(prompt=prompt, first=first, toks=np.array(toks, np.int32), margins=np.array(margins), last=lg)
+    import bg_expect
+    x = bg_expect.get("trace7b")           # (a child process started at collection, tests/bg_expect.py; nested variant runs read its .npz)
+    return dict(prompt=x["prompt"], first=int(x["first"]), toks=x["want"], margins=x["margins"], last=x["lo"])
 
 
 def _trace_report(got, want, margins):

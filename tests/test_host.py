@@ -19,20 +19,23 @@ def test_library_exports_every_declared_symbol(L):
     missing = [s for s in L.declared_symbols() if not hasattr(lib, s)]
     assert not missing
     assert len(L.declared_symbols()) >= 25
+    assert L.version().startswith("llamahip")
 
 
 def test_library_exports_nothing_but_the_declared_c_abi(L):
     """A drop-in library linked into someone's application exports llamahip_* / llama_runner_* only (the declarations of include/*.h):
     no lh:: internals, no kernel host stubs, no stray helpers -- `nm -D --defined-only` against the headers."""
+    import shutil
     import subprocess
     so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llama.swift_amd", "csrc", "libllamahip.so")
+    if not (shutil.which("nm") and os.path.exists(so)):
+        pytest.skip("needs binutils' nm and the built libllamahip.so")
     out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
     exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
     declared = set(L.declared_symbols())
     stray = [s for s in exported if s not in declared]
     assert not stray, f"exported but not declared in include/*.h: {stray[:20]}"
     assert all(s.startswith(("llamahip_", "llama_runner_")) for s in exported)
-    assert L.version().startswith("llamahip")
 
 
 def test_load_errors_follow_the_reference_messages(L, tmp_path):
@@ -372,21 +375,27 @@ def test_few_row_kernel_plans_every_llama_shape_and_row_count(L):
     sizes and every row count a short eval or a batched decode step can have (2 .. 60), the kernel takes the shape -- so no eval silently
     falls to the slow generic path -- with an instantiated (columns per wave, column-waves) pair, column groups that cover the rows
     exactly, and operand rows + weight ring inside the CU's 160 KB of LDS (13B / 65B w2 rows are 54 / 86 chunks long: they take
-    unshared column groups)."""
-    EPI_STORE, EPI_RESID, EPI_SILU_QA, EPI_ROPE_KV, EPI_SILU_QAH = 0, 1, 2, 3, 7
-    pairs = {(1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4), (3, 1), (3, 3), (3, 4), (4, 1), (4, 2), (4, 4), (5, 1)}
-    for d, mult in ((4096, 256), (5120, 256), (6656, 256), (8192, 256)):
-        F = ((2 * (4 * d) // 3 + mult - 1) // mult) * mult                  # .mm:118-120
-        mats = [("wq|wk|wv", 3 * d, d, EPI_ROPE_KV, False), ("wo", d, d, EPI_RESID, False), ("w1|w3 halves", 2 * F, d, EPI_SILU_QAH, True),
-                ("w1|w3 blocks", 2 * F, d, EPI_SILU_QA, True), ("w2", d, F, EPI_RESID, False), ("output", 32000, d, EPI_STORE, False)]
-        for name, M, K, epi, inter in mats:
-            for N in range(2, 61):
-                p = L.set_plan(M, K, N, epi, inter)
-                assert p is not None, (d, name, N)
-                nc, cw, ncg, rgw, lds = p
-                assert (nc, cw) in pairs and lds <= 160 * 1024 and 1 <= rgw * cw <= 16, (d, name, N, p)
-                assert nc * cw * ncg >= N > nc * cw * (ncg - 1), (d, name, N, p)
-                if epi in (EPI_SILU_QA, EPI_SILU_QAH):
-                    assert cw == 1 and rgw == (8 if epi == EPI_SILU_QA else 4), (d, name, N, p)
+    unshared column groups).  The walk itself lives in tests/variants.py."""
+    import variants
+    assert variants.walk_set_plans(L) == 4 * 6 * 59
+    EPI_RESID, EPI_SILU_QAH = variants.EPI_RESID, variants.EPI_SILU_QAH
     assert L.set_plan(4096, 4096, 1, EPI_RESID) is None and L.set_plan(4096, 4096, 61, EPI_RESID) is None       # one row: k_gemv; 61+: the prompt kernels
     assert L.set_plan(2 * 11008, 4096, 4, EPI_SILU_QAH, False) is None                                           # not the interleaved layout
+
+
+def _variant_params():
+    import variants
+    return [pytest.param(env, id=tag) for env, tag in variants.SET_PLAN_VARIANTS]
+
+
+@pytest.mark.parametrize("env", _variant_params())
+def test_few_row_kernel_forced_plans_take_every_shape_too(built, env):
+    """The same walk under every environment tests/test_gpu_parity.py::test_few_row_kernel_selectable_epilogues_and_plans forces (one
+    list, tests/variants.py): a forced plan that does not fit a shape's LDS budget degrades to the default rule for that shape, it never
+    sends the shape to a generic kernel -- the GPU tests assert exactly that through the path counters (switches are read once per
+    process, hence the subprocess)."""
+    import subprocess
+    import sys
+    import variants
+    r = subprocess.run([sys.executable, os.path.join(variants.HERE, "variants.py"), "walk"], env=dict(os.environ, **env), capture_output=True, text=True, cwd=variants.ROOT)
+    assert r.returncode == 0 and "plans walked: 1416" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
