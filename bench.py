@@ -391,7 +391,7 @@ def run_single(args, cfg, path):
     out = m.decode_greedy(tok, n_past, steps, args.threads)       # synchronises before returning
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    gpu_trace = [int(x) for x in warm] + [int(x) for x in out]     # every token generated after the prompt's pick `first`
+    gpu_trace = [int(x) for x in warm] + [int(x) for x in out]     # every token generated after the prompt's pick `first` (extended by the full-context run below)
     # PCIe-inclusive variant: the reference boundary (llama_eval returning host logits every token); its tokens must
     # be those of the device-resident loop
     n_pcie = min(64, steps)
@@ -411,6 +411,8 @@ def run_single(args, cfg, path):
         out_full = m.decode_greedy(tok, len(prompt) + args.warmup, n_full, args.threads)
         dt_full = time.perf_counter() - t3
         full = {"steps": n_full, "seconds": dt_full, "tokens": out_full, "same_prefix": [int(x) for x in out_full[:steps]] == [int(x) for x in out]}
+        if full["same_prefix"]:
+            gpu_trace = [int(x) for x in warm] + [int(x) for x in out_full]      # the parity gate can follow the CPU path past a short --steps (configs[0]: 128 tokens)
     # stand-alone probe of the mat-vec kernel (PRE_QA / STORE variant, back-to-back launches cycling over the layers):
     # kept as a secondary figure -- this variant never runs in the decode step
     shapes = []
@@ -455,6 +457,25 @@ def run_single(args, cfg, path):
                gemv_bytes_per_token=tot_bytes, gemv_us_per_token=tot_us, prefill=prefill, first=first, gpu_trace=gpu_trace,
                n_past0=n_past, gpu_logits_at=gpu_logits_at, model=m, full=full)
     return res
+
+
+def inprocess_pipeline(args, cfg, path, n_stages, single_trace):
+    """single-stream greedy decode through ONE handle loaded with a device list (llamahip_opts.n_devices): n_stages stage handles in this
+    process, all on device 0.  Tokens must be the single-device run's."""
+    import llama_swift_amd as L
+    with L.Model(path, n_ctx=args.n_ctx, devices=[0] * n_stages) as m:
+        prompt = PROMPT % cfg["n_vocab"]
+        prompt[0] = 1
+        first = int(np.argmax(m.eval(prompt, 0, args.threads)))
+        n = min(128, args.n_ctx - len(prompt) - 8)
+        warm = m.decode_greedy(first, len(prompt), 8, args.threads)
+        t0 = time.perf_counter()
+        out = m.decode_greedy(int(warm[-1]), len(prompt) + 8, n, args.threads)
+        dt = time.perf_counter() - t0
+        got = [int(x) for x in warm] + [int(x) for x in out]
+    return {"stages": n_stages, "devices": [0] * n_stages, "tokens": n, "tokens_per_s": n / dt, "ms_per_step": dt * 1e3 / n,
+            "tokens_equal_single_device": got == [int(x) for x in single_trace[:len(got)]],
+            "note": "one process, one llamahip_model_load; stage steps as captured graphs on one stream per stage, residual row and picked token handed on by stream-ordered copies"}
 
 
 def concurrent_sequences(args, cfg, path, n_seq):
@@ -1004,7 +1025,11 @@ def main():
     cpu_base = None
     if not args.no_cpu_baseline and args.cpu_seconds > 0:
         try:
+            # the timed run's tokens, and configs[0]'s 128 greedy tokens whenever the budget allows (~7 s of the reference's 8-thread path;
+            # the driver's --steps 20 would otherwise stop the CPU side at 25 tokens)
             want = args.warmup + r["steps"]
+            if args.cpu_seconds >= 10:
+                want = min(max(want, 128), len(r["gpu_trace"]))
             c = cpu_decode(path, 8, args.cpu_seconds, args.n_ctx, want)
             n = min(len(c["toks"]), len(r["gpu_trace"]))
             bad = [i for i in range(n) if c["toks"][i] != r["gpu_trace"][i]]
@@ -1012,10 +1037,11 @@ def main():
             if n > 0 and not bad and c["first"] == r["first"]:
                 dl = float(np.abs(r["gpu_logits_at"](n) - c["last_logits"]).max())
             parity = {"checked": True, "against": c["kind"] + " CPU path, 8 threads", "tokens_compared": n, "tokens_in_timed_run_covered": max(0, n - args.warmup),
-                      "timed_run_fully_covered": n >= want, "identical": not bad and c["first"] == r["first"], "first_divergence": bad[0] if bad else None,
+                      "timed_run_fully_covered": n >= args.warmup + r["steps"], "configs0_128_tokens_covered": n >= 128, "identical": not bad and c["first"] == r["first"], "first_divergence": bad[0] if bad else None,
                       "max_abs_dlogit_at_last_compared_step": dl, "tolerance": 1e-3,
                       "pcie_loop_tokens_equal_device_loop": r["pcie_same"]}
-            cpu_base = {"value": len(c["toks"]) / c["dt"], "unit": "tokens/s", "cores": 8, "kind": c["kind"],
+            cpu_base = {"value": len(c["toks"]) / c["dt"], "unit": "tokens/s", "cores": 8, "kind": c["kind"], "tokens": len(c["toks"]),
+                        "covers_configs0_128_tokens": len(c["toks"]) >= 128,
                         "sample": f"{len(c['toks'])} greedy decode tokens after an 8-token prompt, same synthetic model file, {c['dt']:.1f}s wall, "
                                   f"8 threads (reference default numThreads=8, Sources/llama/LlamaRunner.swift:17)",
                         "host_cpus": os.cpu_count()}
@@ -1121,8 +1147,9 @@ def main():
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "q4_0 x q4_0 -> int32 block sums, fp32 scales/accumulate",
         "data": "synthetic (random-init 7B-architecture weights in the reference file format, synthetic token ids)",
-        "config": {"workload": f"LLaMA-{args.model} Q4_0 single-token decode, greedy, n_ctx {args.n_ctx}, "
-                               f"{r['steps']} timed tokens after 8 prompt + {args.warmup} warm-up tokens",
+        "config": {"workload": f"LLaMA-{args.model} Q4_0 single-token decode, greedy, n_ctx {args.n_ctx}: `value` = {r['steps']} timed tokens at context positions "
+                               f"{r['n_past0']} .. {r['n_past0'] + r['steps'] - 1} (after 8 prompt + {args.warmup} warm-up tokens); BASELINE.json configs[1] proper -- the generation "
+                               f"to the end of the {args.n_ctx}-token context -- is config.full_context_tokens_per_s / roofline.full_context_*",
                    "n_threads_semantics": args.threads, "parallelism": "1 GPU"},
         "value_pcie": r["value_pcie"],
         "load_s": r["t_load"],
@@ -1157,12 +1184,23 @@ def main():
             result["batched_sequences"] = [batched_sequences(args, cfg, path, n) for n in (2, 4, 8)]
         except Exception as e:
             result["batched_sequences"] = {"error": repr(e)}
+    # the layer pipeline behind the C ABI (one llamahip_model_load with a device list, include/llamahip.h): every stage on THIS GPU -- the
+    # stage launches, streams, events and hand-off copies of the multi-GPU handle, none of its parallel hardware (secondary figure)
+    if args.model == "7B" and not args.no_concurrent:
+        try:
+            result["inprocess_pipeline"] = [inprocess_pipeline(args, cfg, path, n, r["gpu_trace"]) for n in (2, 8)]
+        except Exception as e:
+            result["inprocess_pipeline"] = {"error": repr(e)}
     # figures that must survive a reader that keeps only metric / value / config / roofline of this line
     if "full_context" in result:
         result["roofline"]["full_context_tokens_per_s"] = result["full_context"]["tokens_per_s"]
         result["roofline"]["full_context_end_to_end_frac"] = result["full_context"]["end_to_end_frac"]
         result["config"]["full_context_tokens_per_s"] = result["full_context"]["tokens_per_s"]
     # (scalars only: nested objects of config / roofline do not survive such a reader)
+    if isinstance(result.get("inprocess_pipeline"), list):
+        for b in result["inprocess_pipeline"]:
+            result["config"][f"inprocess_pipeline_{b['stages']}_stages_one_gpu_tokens_per_s"] = round(b["tokens_per_s"], 1)
+        result["config"]["inprocess_pipeline_tokens_equal_single_device"] = all(b["tokens_equal_single_device"] for b in result["inprocess_pipeline"])
     if isinstance(result.get("batched_sequences"), list):
         for b in result["batched_sequences"]:
             result["config"][f"batched_sequences_aggregate_tokens_per_s_{b['sequences']}_seq"] = round(b["aggregate_tokens_per_s"], 1)
@@ -1177,6 +1215,7 @@ def main():
         result["roofline"]["dominant_by_time_kernel"] = dbt_.get("kernel")
         result["roofline"]["dominant_by_time_us"] = dbt_.get("us")
         result["roofline"]["dominant_by_time_frac"] = dbt_.get("frac")
+        result["roofline"]["frac_dominant_by_time"] = dbt_.get("frac")          # (next to `frac`: the launch with the most GPU time, K / V rows counted)
         result["roofline"]["dominant_by_time_share"] = dbt_.get("share_of_gpu_time")
     p9 = result["prefill"].get("reference_9_token_chunks") if isinstance(result.get("prefill"), dict) else None
     if isinstance(p9, dict):

@@ -62,7 +62,18 @@ typedef struct llamahip_opts {
     int32_t n_parts;       /* 0 = by n_embd as the reference (.mm:33-38; unknown widths -> 1) */
     int32_t flags;         /* LLAMAHIP_FLAG_* */
     int32_t n_seq;         /* independent KV caches held by this handle (pipeline micro-batching); 0 = 1 */
+    int32_t n_devices;     /* > 1: an in-process layer pipeline, stage s = an even share of the layers on devices[s] (below); 0 / 1 = `device` */
+    int32_t devices[8];    /* HIP device ordinals of the stages, in layer order (an ordinal may repeat: several stages on one GPU) */
 } llamahip_opts;
+#define LLAMAHIP_MAX_DEVICES 8
+/* In-process layer pipeline (SURVEY.md section 8e behind the reference's own surface): the bridge makes ONE llama_model_load call from ONE
+ * process (.mm:790; LlamaRunnerBridge.mm:18-26).  A handle loaded with n_devices > 1 -- or, for a caller that passes no options such as the
+ * replacement bridge, with the environment variable LLAMAHIP_DEVICES="0,1,...,7" (or a count: "8" = devices 0 .. 7) -- holds one stage per
+ * device; llamahip_eval / llamahip_eval_chunks / llamahip_eval_topk / llamahip_decode_greedy / llamahip_kv_read / llamahip_get_stats and the
+ * llama_runner_* driver work on it unchanged, the residual stream (.mm:563-564, 687-690) crosses devices as stream-ordered peer copies.
+ * Results are bit for bit the single-device handle's.  The stage-level entry points (llamahip_eval_stage, llamahip_stage_*) and
+ * llamahip_eval_debug's dumps refuse such a handle.  LLAMAHIP_DEVICES never applies to a handle loaded with an explicit device, layer range
+ * or LLAMAHIP_FLAG_HOST_ONLY. */
 
 #define LLAMAHIP_FLAG_NO_GRAPH   1   /* launch decode kernels eagerly instead of via hipGraph */
 #define LLAMAHIP_FLAG_UNFUSED    2   /* use the separate prepare+GEMV kernels for decode */

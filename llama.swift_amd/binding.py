@@ -46,7 +46,8 @@ _lib = None
 
 class _Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("layer_begin", C.c_int32),
-                ("layer_end", C.c_int32), ("n_parts", C.c_int32), ("flags", C.c_int32), ("n_seq", C.c_int32)]
+                ("layer_end", C.c_int32), ("n_parts", C.c_int32), ("flags", C.c_int32), ("n_seq", C.c_int32),
+                ("n_devices", C.c_int32), ("devices", C.c_int32 * 8)]
 
 
 class _GemvBench(C.Structure):
@@ -190,11 +191,16 @@ class Model:
     """Opaque model handle (llama_model + gpt_vocab of the reference, .mm:71-88, utils.h:49-55)."""
 
     def __init__(self, path: str, n_ctx: int = 512, device: int = -1, layer_begin: int = 0,
-                 layer_end: int = -1, n_parts: int = 0, flags: int = 0, n_seq: int = 1):
+                 layer_end: int = -1, n_parts: int = 0, flags: int = 0, n_seq: int = 1, devices=None):
+        """devices: a list of HIP device ordinals = an in-process layer pipeline, one stage per entry (include/llamahip.h);
+        the same entry points work on it (eval, eval_chunks, eval_topk, decode_greedy, kv, stats)."""
         L = lib()
         err = C.create_string_buffer(1024)
         h = C.c_void_p()
-        opts = _Opts(C.sizeof(_Opts), device, layer_begin, layer_end, n_parts, flags, n_seq)
+        devices = list(devices or [])
+        if len(devices) > 8:
+            raise ValueError("at most 8 pipeline stages")
+        opts = _Opts(C.sizeof(_Opts), device, layer_begin, layer_end, n_parts, flags, n_seq, len(devices), (C.c_int32 * 8)(*devices))
         self.layer_begin, self.n_seq = layer_begin, n_seq
         rc = L.llamahip_model_load(path.encode(), n_ctx, C.byref(opts), C.byref(h), err, len(err))
         _check(rc, err)

@@ -17,6 +17,7 @@
 #include <memory>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "llamahip_internal.h"
@@ -211,6 +212,17 @@ struct llamahip_model {
     int64_t weight_bytes = 0, kv_bytes = 0, n_evals = 0;
     double t_load_ms = 0, t_eval_ms = 0;
 
+    // in-process layer pipeline (llamahip_opts.n_devices > 1 or LLAMAHIP_DEVICES; SURVEY.md 8e behind the reference's ONE llama_model_load /
+    // llama_eval call, .mm:790, 840): a handle with `stages` is the FRONT -- file, vocab and hparams, no device state of its own -- and every
+    // compute entry point walks its stage handles (layers [l0, l1) of stage s on devices[s]), handing the residual stream from one device to
+    // the next with hipMemcpyPeerAsync + an event on the producer's stream.  The pipe_* members below live on the STAGE handles.
+    std::vector<llamahip_model *> stages;
+    float *pipe_in = nullptr;            // rows of the residual stream arriving from the previous stage: [pipe_in_cap][n_embd]
+    int pipe_in_cap = 0;
+    float *pipe_hout = nullptr;          // decode steps: the row this stage hands on, [n_embd]
+    int32_t *pipe_tok = nullptr;         // decode steps: first stage token_in / last stage token_out
+    hipEvent_t pipe_ev = nullptr;        // recorded on this stage's stream behind its hand-off copy
+
     ~llamahip_model();
 };
 
@@ -230,6 +242,7 @@ static hipError_t malloc_mailbox(void **p, size_t bytes) {
 }
 
 llamahip_model::~llamahip_model() {
+    for (llamahip_model *st : stages) delete st;
     if (host_only) return;
     (void) hipSetDevice(device);
     (void) hipDeviceSynchronize();      // captured steps may still run on a caller's stream: nothing is freed or destroyed under them
@@ -264,6 +277,8 @@ llamahip_model::~llamahip_model() {
     free_dev(set_sc);
     free_dev(d_slot_state); free_dev(d_slot_trace);
     free_dev(attn_ws.S); free_dev(attn_ws.pmax); free_dev(attn_ws.inv); free_dev(attn_ws.part);
+    free_dev(pipe_in); free_dev(pipe_hout); free_dev(pipe_tok);
+    if (pipe_ev) (void) hipEventDestroy(pipe_ev);
     if (stream) (void) hipStreamDestroy(stream);
 }
 
@@ -843,7 +858,7 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
     if (opts && opts->struct_size >= 24) {             // fields up to `flags`
         force_parts = opts->n_parts; layer_begin = opts->layer_begin; layer_end = opts->layer_end;
         device = opts->device; m->flags = opts->flags;
-        if (opts->struct_size >= (int32_t) sizeof(llamahip_opts) && opts->n_seq > 0) m->n_seq = opts->n_seq;
+        if (opts->struct_size >= 28 && opts->n_seq > 0) m->n_seq = opts->n_seq;      // (28: the struct up to n_seq, as older callers pass it)
     }
     std::string e;
     if (!m->file.open(path, n_ctx, force_parts, e)) { set_err(err, err_cap, "%s", e.c_str()); return LLAMAHIP_ERR_LOAD; }
@@ -1059,10 +1074,28 @@ static int model_load_impl(const char *path, int32_t n_ctx, const llamahip_opts 
     return LLAMAHIP_OK;
 }
 
+// ---- in-process layer pipeline: defined behind the stage entry points below
+static int pipe_devices(const llamahip_opts *opts, std::vector<int> &devices, char *err, size_t err_cap);
+static int pipe_load(const char *path, int32_t n_ctx, const llamahip_opts *opts, const std::vector<int> &devices, llamahip_model **out, char *err, size_t err_cap);
+static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t N, int32_t chunk, float *logits_out, char *err, size_t err_cap);
+static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token, int32_t n_steps, int32_t *out_tokens, float *logits_last,
+                              char *err, size_t err_cap);
+#define PIPE_REFUSE(m, what) do { if ((m) && !(m)->stages.empty()) { set_err(err, err_cap, what " is not available on a multi-device pipeline handle (llamahip_opts.n_devices / LLAMAHIP_DEVICES): load a stage handle with layer_begin / layer_end"); return LLAMAHIP_ERR_PREDICT; } } while (0)
+
 // No C++ exception may cross the C ABI (std::bad_alloc on a corrupt header would abort the host process).
 int llamahip_model_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
                         llamahip_model **out, char *err, size_t err_cap) {
     try {
+        std::vector<int> devices;
+        const int rc = pipe_devices(opts, devices, err, err_cap);
+        if (rc) { if (out) *out = nullptr; return rc; }
+        if (devices.size() > 1) return pipe_load(path, n_ctx, opts, devices, out, err, err_cap);
+        if (devices.size() == 1 && opts && opts->struct_size >= 24) {      // (a one-entry list is the plain handle on that device)
+            llamahip_opts o = {}; memcpy(&o, opts, std::min((size_t) opts->struct_size, sizeof(o)));
+            o.struct_size = (int32_t) std::min((size_t) opts->struct_size, sizeof(o)); o.device = devices[0];
+            return model_load_impl(path, n_ctx, &o, out, err, err_cap);
+        }
+        if (devices.size() == 1) { llamahip_opts o = {}; o.struct_size = 28; o.device = devices[0]; o.layer_end = -1; return model_load_impl(path, n_ctx, &o, out, err, err_cap); }
         return model_load_impl(path, n_ctx, opts, out, err, err_cap);
     } catch (const std::exception &ex) {
         if (out) *out = nullptr;
@@ -1095,6 +1128,10 @@ static int eval_impl(llamahip_model *m, int32_t n_threads, int32_t n_past,
                      const int32_t *tokens, int32_t N, float *logits_last, float *logits_all,
                      int32_t dump_layer, float *dump, int64_t dump_cap, int64_t *dump_sizes,
                      bool sync, char *err, size_t err_cap, int chunk = 0) {
+    if (m && !m->stages.empty()) {
+        if (logits_all || (dump_layer >= 0 && dump)) PIPE_REFUSE(m, "llamahip_eval_debug (all rows of logits / per-layer dumps)");
+        return pipe_eval(m, n_threads, n_past, tokens, N, chunk, logits_last, err, err_cap);      // (synchronous: `sync` = false is eval_topk's, which never gets here)
+    }
     int rc = check_eval_args(m, n_past, tokens, N, true, err, err_cap);
     if (rc) return rc;
     if (!m->first_stage || !m->last_stage) { set_err(err, err_cap, "llamahip_eval on a pipeline-stage handle: use llamahip_eval_stage"); return LLAMAHIP_ERR_PREDICT; }
@@ -1151,7 +1188,7 @@ int llamahip_eval_chunks(llamahip_model *m, int32_t n_threads, int32_t n_past, c
                          int32_t chunk_tokens, float *logits_out, char *err, size_t err_cap) {
     if (chunk_tokens < 1) { set_err(err, err_cap, "llamahip_eval_chunks: chunk_tokens must be >= 1"); return LLAMAHIP_ERR_PREDICT; }
     if (!m || n_tokens <= chunk_tokens) return llamahip_eval(m, n_threads, n_past, tokens, n_tokens, logits_out, err, err_cap);
-    if (m->host_only || m->dense) {          // f16 / f32 model files: the evals themselves, one after the other
+    if ((m->host_only && m->stages.empty()) || m->dense) {          // f16 / f32 model files: the evals themselves, one after the other
         for (int32_t c0 = 0; c0 < n_tokens; c0 += chunk_tokens) {
             const int32_t n = std::min(chunk_tokens, n_tokens - c0);
             const int rc = llamahip_eval(m, n_threads, n_past + c0, tokens + c0, n, c0 + n == n_tokens ? logits_out : nullptr, err, err_cap);
@@ -1172,7 +1209,8 @@ int llamahip_eval_topk(llamahip_model *m, int32_t n_threads, int32_t n_past, con
     *exact = 0;
     const int V = m ? m->hp.n_vocab : 0;
     const int k = std::min(std::max(top_k, 1), V);
-    const bool device_ok = m && !m->host_only && V <= 32768 && k <= 64 && n_last >= 0 && n_last <= 1024 && (n_last == 0 || last_n_tokens);
+    // (a multi-device pipeline handle returns the logits row: *exact = 0, the caller samples on the host -- the documented fall-back)
+    const bool device_ok = m && m->stages.empty() && !m->host_only && V <= 32768 && k <= 64 && n_last >= 0 && n_last <= 1024 && (n_last == 0 || last_n_tokens);
     if (!device_ok) return llamahip_eval(m, n_threads, n_past, tokens, n_tokens, logits_out, err, err_cap);
     const double t0 = now_ms();
     int rc = eval_impl(m, n_threads, n_past, tokens, n_tokens, nullptr, nullptr, -1, nullptr, 0, nullptr, false, err, err_cap);   // logits stay on the device, no wait
@@ -1206,13 +1244,12 @@ int llamahip_eval_topk(llamahip_model *m, int32_t n_threads, int32_t n_past, con
     return LLAMAHIP_OK;
 }
 
-int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
-                        const int32_t *tokens, int32_t N, const void *hidden_in, void *hidden_out,
-                        float *logits_out, char *err, size_t err_cap) {
+// the launches of a stage eval, enqueued on m->stream without waiting (llamahip_eval_stage; the in-process pipeline walks its stages with it)
+static int eval_stage_enqueue(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t N, const void *hidden_in,
+                              int chunk, char *err, size_t err_cap) {
     int rc = check_eval_args(m, n_past, tokens, N, m && m->first_stage, err, err_cap);
     if (rc) return rc;
     if (!m->first_stage && !hidden_in) { set_err(err, err_cap, "stage [%d,%d) needs hidden_in", m->l0, m->l1); return LLAMAHIP_ERR_PREDICT; }
-    const double t0 = now_ms();
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     rc = ensure_workspace(m, N, err, err_cap);
     if (rc) return rc;
@@ -1222,8 +1259,17 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
     if (rc) return rc;
     if (m->first_stage) HIP_TRY(hipMemcpyAsync(m->d_tokens, tokens, (size_t) N * 4, hipMemcpyHostToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
     m->attn_sched = N == 1 ? attn_sched_at(m, n_past) : 0;
-    rc = forward(m, n_threads, n_past, N, (const float *) hidden_in, false, false, -1, nullptr, err, err_cap);
+    rc = forward(m, n_threads, n_past, N, (const float *) hidden_in, false, false, -1, nullptr, err, err_cap, nullptr, chunk);
     m->last_rows.clear();                                                 // (m->logits rewritten: llamahip_stage_logits rows are this eval's rows again)
+    return rc;
+}
+
+int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
+                        const int32_t *tokens, int32_t N, const void *hidden_in, void *hidden_out,
+                        float *logits_out, char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_eval_stage");
+    const double t0 = now_ms();
+    int rc = eval_stage_enqueue(m, n_threads, n_past, tokens, N, hidden_in, 0, err, err_cap);
     if (rc) return rc;
     const size_t d = m->hp.n_embd, V = m->hp.n_vocab;
     if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t) N * d * 4, hipMemcpyDeviceToDevice, m->stream), LLAMAHIP_ERR_PREDICT);
@@ -1237,6 +1283,7 @@ int llamahip_eval_stage(llamahip_model *m, int32_t n_threads, int32_t n_past,
 
 int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token,
                            int32_t n_steps, int32_t *out_tokens, float *logits_last, char *err, size_t err_cap) {
+    if (m && !m->stages.empty()) return pipe_decode_greedy(m, n_threads, n_past, first_token, n_steps, out_tokens, logits_last, err, err_cap);
     int rc = check_eval_args(m, n_past, &first_token, 1, true, err, err_cap);
     if (rc) return rc;
     if (n_steps < 1 || n_past + n_steps > m->hp.n_ctx) {
@@ -1320,6 +1367,7 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
 int llamahip_stage_bind(llamahip_model *m, int32_t seq, int32_t n_past,
                         void *token_in, const void *hidden_in, void *hidden_out, void *token_out,
                         char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_stage_bind");
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (m->host_only) { set_err(err, err_cap, "model was loaded with LLAMAHIP_FLAG_HOST_ONLY: no device state, cannot evaluate"); return LLAMAHIP_ERR_PREDICT; }
     if (seq < 0 || seq >= m->n_seq) { set_err(err, err_cap, "sequence slot %d out of range [0, %d)", seq, m->n_seq); return LLAMAHIP_ERR_PREDICT; }
@@ -1387,6 +1435,7 @@ static int drop_slot_graphs(llamahip_model *m, int seq, char *err, size_t err_ca
 // ---- device-side mailboxes between pipeline stages (include/llamahip.h) -------------------------
 int llamahip_stage_mailbox(llamahip_model *m, int32_t seq, void **hidden_inbox, void **token_inbox,
                            void *hidden_handle64, void *token_handle64, char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_stage_mailbox");
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (m->host_only || m->dense || (m->flags & LLAMAHIP_FLAG_UNFUSED) || !m->w13_interleaved || m->l1 <= m->l0) {
         set_err(err, err_cap, "pipeline mailboxes need a Q4_0 stage handle with layers and the fused decode schedule"); return LLAMAHIP_ERR_PREDICT; }
@@ -1423,6 +1472,7 @@ int llamahip_stage_mailbox(llamahip_model *m, int32_t seq, void **hidden_inbox, 
 
 int llamahip_stage_mailbox_connect(llamahip_model *m, int32_t seq, const void *next_hidden_handle64, void *next_hidden_ptr,
                                    const void *token_handle64, void *token_ptr, char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_stage_mailbox_connect");
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (m->host_only || m->dense || (m->flags & LLAMAHIP_FLAG_UNFUSED) || !m->w13_interleaved || m->l1 <= m->l0) {
         set_err(err, err_cap, "pipeline mailboxes need a Q4_0 stage handle with layers and the fused decode schedule"); return LLAMAHIP_ERR_PREDICT; }
@@ -1700,13 +1750,221 @@ int llamahip_stage_logits(llamahip_model *m, int32_t row, float *logits_out, cha
     return check_sync_timeout(m, err, err_cap);
 }
 
+// ------------------------------------------------------------------------------------------------
+// In-process layer pipeline behind the reference's own surface (north_star: "the 65B model is layer-sharded across the
+// 8 GPUs of one node ... called through a thin C-ABI shim from the existing Objective-C++ bridge").  The bridge makes ONE
+// llama_model_load call from ONE process (.mm:790, LlamaRunnerBridge.mm:18-26) and one llama_eval per step (.mm:840, 865): a handle
+// loaded with a device list holds one stage handle per device (layers split as evenly as possible, earlier stages take the remainder --
+// pipeline.py layer_range) and llamahip_eval / llamahip_eval_chunks / llamahip_decode_greedy / llamahip_eval_topk walk them.  The only
+// tensor that crosses a stage boundary is the residual stream inpL f32[n_embd][N] (.mm:563-564, 687-690): hipMemcpyPeerAsync on the
+// producer's stream (an xGMI peer copy between two GPUs, a device copy when both stages sit on one), an event behind it, and the
+// consumer's stream waits for that event -- no host round trip between stages, no collective.  Every stage runs the launches it would run
+// as a stage of the multi-process RCCL pipeline (bench.py --gpus N), so results are bit for bit the whole-model handle's.
+// ------------------------------------------------------------------------------------------------
+static int pipe_devices(const llamahip_opts *opts, std::vector<int> &devices, char *err, size_t err_cap) {
+    devices.clear();
+    if (opts && opts->struct_size >= (int32_t) (offsetof(llamahip_opts, devices) + sizeof(opts->devices)) && opts->n_devices > 0) {
+        if (opts->n_devices > LLAMAHIP_MAX_DEVICES) { set_err(err, err_cap, "llamahip_opts.n_devices %d: at most %d pipeline stages", opts->n_devices, LLAMAHIP_MAX_DEVICES); return LLAMAHIP_ERR_LOAD; }
+        devices.assign(opts->devices, opts->devices + opts->n_devices);
+    } else if (const char *env = getenv("LLAMAHIP_DEVICES")) {
+        // the replacement bridge passes no options (integration/LlamaPredictOperation_llamahip.mm): "0,1,2,3,4,5,6,7", or a count "8" = devices 0 .. 7.
+        // An explicit stage handle (layer range / device in opts) or a host-only handle is never turned into a pipeline.
+        if (opts && opts->struct_size >= 24 && (opts->layer_begin != 0 || opts->layer_end >= 0 || opts->device >= 0 || (opts->flags & LLAMAHIP_FLAG_HOST_ONLY))) return 0;
+        std::vector<int> v;
+        const char *q = env;
+        while (*q) {
+            char *end = nullptr;
+            const long x = strtol(q, &end, 10);
+            if (end == q || x < 0 || x > 1023) { set_err(err, err_cap, "LLAMAHIP_DEVICES='%s': expected a device count or a comma-separated list of device ordinals", env); return LLAMAHIP_ERR_LOAD; }
+            v.push_back((int) x);
+            q = end;
+            if (*q == ',') q++;
+            else if (*q) { set_err(err, err_cap, "LLAMAHIP_DEVICES='%s': expected a device count or a comma-separated list of device ordinals", env); return LLAMAHIP_ERR_LOAD; }
+        }
+        if (v.size() == 1 && !strchr(env, ',') && v[0] >= 1) { const int n = v[0]; v.clear(); for (int i = 0; i < n; i++) v.push_back(i); }
+        if ((int) v.size() > LLAMAHIP_MAX_DEVICES) { set_err(err, err_cap, "LLAMAHIP_DEVICES='%s': at most %d pipeline stages", env, LLAMAHIP_MAX_DEVICES); return LLAMAHIP_ERR_LOAD; }
+        devices = v;
+    }
+    for (int dv : devices) if (dv < 0) { set_err(err, err_cap, "pipeline device ordinal %d is negative", dv); return LLAMAHIP_ERR_LOAD; }
+    return 0;
+}
+
+static int pipe_load(const char *path, int32_t n_ctx, const llamahip_opts *opts, const std::vector<int> &devices, llamahip_model **out, char *err, size_t err_cap) {
+    const double t0 = now_ms();
+    if (!out || !path) { set_err(err, err_cap, "null argument"); return LLAMAHIP_ERR_LOAD; }
+    *out = nullptr;
+    llamahip_opts base = {};
+    if (opts) memcpy(&base, opts, std::min((size_t) std::max(opts->struct_size, 0), sizeof(base)));
+    if (!opts || opts->struct_size < 24) { base.n_parts = 0; base.flags = 0; }
+    if (!opts || opts->struct_size < 28) base.n_seq = 0;
+    if (opts && opts->struct_size >= 24 && (opts->layer_begin != 0 || opts->layer_end >= 0)) { set_err(err, err_cap, "a device list and a layer range exclude each other: the pipeline splits the layers itself"); return LLAMAHIP_ERR_LOAD; }
+    if (base.flags & LLAMAHIP_FLAG_HOST_ONLY) { set_err(err, err_cap, "a device list and LLAMAHIP_FLAG_HOST_ONLY exclude each other"); return LLAMAHIP_ERR_LOAD; }
+    // the front: file, vocab, hparams (the reader's validation and error messages, .mm:98-498), no device state
+    llamahip_opts fo = base;
+    fo.struct_size = 28; fo.device = -1; fo.layer_begin = 0; fo.layer_end = -1; fo.flags = base.flags | LLAMAHIP_FLAG_HOST_ONLY;
+    llamahip_model *front = nullptr;
+    int rc = model_load_impl(path, n_ctx, &fo, &front, err, err_cap);
+    if (rc) return rc;
+    std::unique_ptr<llamahip_model> guard(front);
+    front->flags = base.flags;
+    const int S = (int) devices.size(), L = front->hp.n_layer;
+    if (S > L) { set_err(err, err_cap, "%d pipeline stages for a model of %d layers", S, L); return LLAMAHIP_ERR_LOAD; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err(err, err_cap, "no HIP device available: libllamahip has no CPU fallback"); return LLAMAHIP_ERR_LOAD; }
+    for (int dv : devices) if (dv >= ndev) { set_err(err, err_cap, "pipeline device %d: this process sees %d HIP device(s)", dv, ndev); return LLAMAHIP_ERR_LOAD; }
+    // the stages load side by side (one thread each: the file reads and repack launches of different devices overlap)
+    std::vector<llamahip_model *> stages(S, nullptr);
+    std::vector<int> rcs(S, 0);
+    std::vector<std::string> errs(S);
+    std::vector<std::thread> th;
+    for (int s = 0; s < S; s++) {
+        th.emplace_back([&, s]() {
+            char e[512] = "";
+            llamahip_opts so = base;
+            so.struct_size = 28; so.device = devices[s];
+            const int bq = L / S, rem = L % S;
+            so.layer_begin = s * bq + std::min(s, rem);
+            so.layer_end = so.layer_begin + bq + (s < rem ? 1 : 0);
+            try { rcs[s] = model_load_impl(path, n_ctx, &so, &stages[s], e, sizeof(e)); }
+            catch (const std::exception &ex) { rcs[s] = LLAMAHIP_ERR_LOAD; snprintf(e, sizeof(e), "%s", ex.what()); }
+            errs[s] = e;
+        });
+    }
+    for (auto &t : th) t.join();
+    front->stages = stages;                                  // (owned from here on: the front's destructor frees whatever loaded)
+    front->stages.erase(std::remove(front->stages.begin(), front->stages.end(), nullptr), front->stages.end());
+    for (int s = 0; s < S; s++) if (rcs[s]) { set_err(err, err_cap, "pipeline stage %d of %d (device %d): %s", s, S, devices[s], errs[s].c_str()); return LLAMAHIP_ERR_LOAD; }
+    for (int s = 0; s < S; s++) {
+        llamahip_model *st = stages[s];
+        HIP_TRY(hipSetDevice(st->device), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipEventCreateWithFlags(&st->pipe_ev, hipEventDisableTiming), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &st->pipe_tok, 64), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMemset(st->pipe_tok, 0, 64), LLAMAHIP_ERR_LOAD);
+        HIP_TRY(hipMalloc((void **) &st->pipe_hout, (size_t) front->hp.n_embd * 4), LLAMAHIP_ERR_LOAD);
+        // direct peer copies to the next stage's device and (last stage) back to the first; without peer access the copy is staged by the runtime
+        const int peers[2] = { stages[(s + 1) % S]->device, stages[0]->device };
+        for (int pd : peers) {
+            int can = 0;
+            if (pd != st->device && hipDeviceCanAccessPeer(&can, st->device, pd) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(pd, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e, LLAMAHIP_ERR_LOAD);
+                (void) hipGetLastError();
+            }
+        }
+        front->weight_bytes += 0;
+    }
+    front->t_load_ms = now_ms() - t0;
+    *out = guard.release();
+    return LLAMAHIP_OK;
+}
+
+// consumer side of a hand-off: room for N rows on stage `st` (grown outside any enqueued work: the stage is idle between entry points)
+static int pipe_ensure_in(llamahip_model *st, int N, char *err, size_t err_cap) {
+    if (N <= st->pipe_in_cap) return 0;
+    HIP_TRY(hipSetDevice(st->device), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamSynchronize(st->stream), LLAMAHIP_ERR_PREDICT);
+    free_dev(st->pipe_in); st->pipe_in = nullptr; st->pipe_in_cap = 0;
+    const int cap = std::max(N, 16);
+    HIP_TRY(hipMalloc((void **) &st->pipe_in, (size_t) cap * st->hp.n_embd * 4), LLAMAHIP_ERR_PREDICT);
+    st->pipe_in_cap = cap;
+    return 0;
+}
+// producer side: `bytes` from `src` on stage a's device to `dst` on stage b's, ordered behind a's stream; b's stream waits for the copy
+static int pipe_hand_off(llamahip_model *a, llamahip_model *b, void *dst, const void *src, size_t bytes, char *err, size_t err_cap) {
+    HIP_TRY(hipSetDevice(a->device), LLAMAHIP_ERR_PREDICT);
+    if (a->device == b->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, a->stream), LLAMAHIP_ERR_PREDICT);
+    else HIP_TRY(hipMemcpyPeerAsync(dst, b->device, src, a->device, bytes, a->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipEventRecord(a->pipe_ev, a->stream), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipSetDevice(b->device), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipStreamWaitEvent(b->stream, a->pipe_ev, 0), LLAMAHIP_ERR_PREDICT);
+    return 0;
+}
+// wait for every stage and collect their fault words (a hand-off that timed out inside a launch of ANY stage invalidates the result)
+static int pipe_sync(llamahip_model *m, char *err, size_t err_cap) {
+    int rc = 0;
+    for (int s = (int) m->stages.size() - 1; s >= 0; s--) {
+        llamahip_model *st = m->stages[s];
+        HIP_TRY(hipSetDevice(st->device), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipStreamSynchronize(st->stream), LLAMAHIP_ERR_PREDICT);
+        const int r = check_sync_timeout(st, err, err_cap);
+        if (r) rc = r;
+    }
+    return rc;
+}
+
+static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t N, int32_t chunk, float *logits_out, char *err, size_t err_cap) {
+    const int S = (int) m->stages.size();
+    int rc = check_eval_args(m->stages[0], n_past, tokens, N, true, err, err_cap);
+    if (rc) return rc;
+    const double t0 = now_ms();
+    const size_t d = m->hp.n_embd, V = m->hp.n_vocab;
+    for (int s = 1; s < S; s++) if ((rc = pipe_ensure_in(m->stages[s], N, err, err_cap)) != 0) return rc;
+    for (int s = 0; s < S; s++) {
+        llamahip_model *st = m->stages[s];
+        st->cur_seq = m->cur_seq;
+        if ((rc = eval_stage_enqueue(st, n_threads, n_past, tokens, N, s ? st->pipe_in : nullptr, st->dense ? 0 : chunk, err, err_cap)) != 0) { (void) pipe_sync(m, nullptr, 0); return rc; }
+        if (s + 1 < S && (rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->x, (size_t) N * d * 4, err, err_cap)) != 0) { (void) pipe_sync(m, nullptr, 0); return rc; }
+    }
+    llamahip_model *last = m->stages[S - 1];
+    HIP_TRY(hipSetDevice(last->device), LLAMAHIP_ERR_PREDICT);
+    if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, last->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, last->stream), LLAMAHIP_ERR_PREDICT);
+    if ((rc = pipe_sync(m, err, err_cap)) != 0) return rc;
+    m->n_evals++;
+    m->t_eval_ms += now_ms() - t0;
+    return LLAMAHIP_OK;
+}
+
+// The greedy loop on the pipeline: every stage's single-token step is its captured graph (llamahip_stage_step), the row travels stage to
+// stage and the picked token travels from the last stage back to the first as stream-ordered peer copies; the host enqueues all n_steps
+// without waiting and reads the trace at the end.
+static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token, int32_t n_steps, int32_t *out_tokens, float *logits_last,
+                              char *err, size_t err_cap) {
+    const int S = (int) m->stages.size();
+    llamahip_model *first = m->stages[0], *last = m->stages[S - 1];
+    int rc = check_eval_args(first, n_past, &first_token, 1, true, err, err_cap);
+    if (rc) return rc;
+    if (n_steps < 1 || n_past + n_steps > m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_steps (%d) > n_ctx (%d)", n_past, n_steps, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
+    if (!out_tokens) { set_err(err, err_cap, "null out_tokens"); return LLAMAHIP_ERR_PREDICT; }
+    const double t0 = now_ms();
+    const size_t d = m->hp.n_embd;
+    const int seq = m->cur_seq;
+    for (int s = 1; s < S; s++) if ((rc = pipe_ensure_in(m->stages[s], 1, err, err_cap)) != 0) return rc;
+    HIP_TRY(hipSetDevice(first->device), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMemcpy(first->pipe_tok, &first_token, 4, hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
+    for (int s = 0; s < S; s++) {
+        llamahip_model *st = m->stages[s];
+        if ((rc = llamahip_stage_bind(st, seq, n_past, s == 0 ? first->pipe_tok : nullptr, s ? st->pipe_in : nullptr, s + 1 < S ? st->pipe_hout : nullptr,
+                                      s + 1 == S ? last->pipe_tok : nullptr, err, err_cap)) != 0) return rc;
+    }
+    for (int i = 0; i < n_steps && rc == 0; i++) {
+        for (int s = 0; s < S && rc == 0; s++) {
+            llamahip_model *st = m->stages[s];
+            if ((rc = llamahip_stage_step(st, seq, n_threads, st->stream, err, err_cap)) != 0) break;
+            if (s + 1 < S) rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->pipe_hout, d * 4, err, err_cap);
+            else if (S > 1 && i + 1 < n_steps) rc = pipe_hand_off(last, first, first->pipe_tok, last->pipe_tok, 4, err, err_cap);      // (S == 1: never a pipe)
+        }
+    }
+    if (rc) { (void) pipe_sync(m, nullptr, 0); return rc; }
+    if ((rc = pipe_sync(m, err, err_cap)) != 0) return rc;
+    int32_t pos = 0;
+    const int n = llamahip_stage_trace(last, seq, &pos, out_tokens, n_steps, err, err_cap);
+    if (n < 0) return n;
+    if (n != n_steps || pos != n_past + n_steps) { set_err(err, err_cap, "pipeline decode: %d of %d steps recorded, position %d", n, n_steps, pos); return LLAMAHIP_ERR_PREDICT; }
+    if (logits_last && (rc = llamahip_stage_logits(last, 0, logits_last, err, err_cap)) != 0) return rc;
+    m->n_evals += n_steps;
+    m->t_eval_ms += now_ms() - t0;
+    return LLAMAHIP_OK;
+}
+
 int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap) {
     if (!m || seq < 0 || seq >= m->n_seq) { set_err(err, err_cap, "sequence slot %d out of range [0, %d)", seq, m ? m->n_seq : 0); return LLAMAHIP_ERR_PREDICT; }
     m->cur_seq = seq;
+    for (llamahip_model *st : m->stages) st->cur_seq = seq;
     return LLAMAHIP_OK;
 }
 
 int llamahip_kv_read(llamahip_model *m, int32_t il, int32_t n_pos, float *out_k, float *out_v, char *err, size_t err_cap) {
+    if (m) for (llamahip_model *st : m->stages) if (il >= st->l0 && il < st->l1) return llamahip_kv_read(st, il, n_pos, out_k, out_v, err, err_cap);
     if (!m || m->host_only || il < m->l0 || il >= m->l1 || n_pos < 0 || n_pos > m->hp.n_ctx) { set_err(err, err_cap, "bad kv_read arguments"); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
     const size_t d = m->hp.n_embd, off = ((size_t) m->cur_seq * (m->l1 - m->l0) + (il - m->l0)) * m->hp.n_ctx * d;
@@ -1789,6 +2047,7 @@ int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out) {
     out->n_evals = m->n_evals;
     out->t_load_ms = m->t_load_ms;
     out->t_eval_ms_total = m->t_eval_ms;
+    for (const llamahip_model *st : m->stages) { out->weight_bytes_device += st->weight_bytes; out->kv_bytes_device += st->kv_bytes; }
     return LLAMAHIP_OK;
 }
 

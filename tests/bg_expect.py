@@ -10,6 +10,8 @@ import fcntl
 import os
 import subprocess
 import sys
+import threading
+import time
 
 import numpy as np
 
@@ -68,40 +70,72 @@ JOBS = {
     **{name: ("flow", name.split("_")[0], n_ctx, n_prompt, n_gen, 8, 12, kw["n_vocab"]) for name, (kw, n_ctx, n_prompt, n_gen) in WIDE.items()},
     "65B": ("decode", "65B", 64, 9, 4, 8, 3, 32000),                    # configs[4]'s model
 }
+# Host DRAM bandwidth is what these jobs share (r06_a: all nine at once stretched the 30 s trace to 195 s): at most MAX_JOBS run side by
+# side, in the order the tests need them -- the 7B trace first, the 65B job (mostly its 40 GB file write) early because it is the longest.
+ORDER = ["trace7b", "65B", "13B", "13B_128", "13Bw_544", "13Bw_1600", "65Bw_448", "flow2048", "single2048"]
+MAX_JOBS = int(os.environ.get("LLAMAHIP_EXPECT_JOBS", "3"))
 _running = {}
+_queue = []
+_lock = threading.Lock()
+_pump_thread = None
 
 
-def start(name):
-    out = os.path.join(EXPECT_DIR, name + ".npz")
-    if name in _running or os.path.exists(out):
-        return
-    if name == "65B" and os.environ.get("LLAMAHIP_SKIP_65B"):
-        return
+def _out(name):
+    return os.path.join(EXPECT_DIR, name + ".npz")
+
+
+def _launch(name):
     os.makedirs(EXPECT_DIR, exist_ok=True)
     kind, spec, n_ctx, n_prompt, n_gen, nth, seed, n_vocab = JOBS[name]
     log = open(os.path.join(EXPECT_DIR, name + ".log"), "w")
     _running[name] = subprocess.Popen([sys.executable, os.path.join(HERE, "cpu_expect.py"), kind, "spec:" + spec, str(n_ctx), str(n_prompt), str(n_gen), str(nth), str(seed),
-                                       out, str(n_vocab)], stdout=log, stderr=subprocess.STDOUT)
+                                       _out(name), str(n_vocab)], stdout=log, stderr=subprocess.STDOUT)
+
+
+def _pump():
+    while True:
+        with _lock:
+            busy = sum(1 for p in _running.values() if p.poll() is None)
+            while _queue and busy < MAX_JOBS:
+                name = _queue.pop(0)
+                if name not in _running and not os.path.exists(_out(name)):
+                    _launch(name)
+                    busy += 1
+            if not _queue:
+                return
+        time.sleep(0.5)
 
 
 def start_all():
-    # cheapest first: the 7B / 13B files take seconds to write; the 65B child writes its 40 GB file itself (a minute or three) meanwhile
-    for name in JOBS:
-        start(name)
+    global _pump_thread
+    with _lock:
+        for name in ORDER:
+            if name == "65B" and os.environ.get("LLAMAHIP_SKIP_65B"):
+                continue
+            if name not in _running and name not in _queue and not os.path.exists(_out(name)):
+                _queue.append(name)
+    if _pump_thread is None or not _pump_thread.is_alive():
+        _pump_thread = threading.Thread(target=_pump, daemon=True)
+        _pump_thread.start()
 
 
 def get(name, timeout=1500):
-    out = os.path.join(EXPECT_DIR, name + ".npz")
-    if not os.path.exists(out):
-        start(name)
+    if not os.path.exists(_out(name)):
+        with _lock:                                     # asked for before its turn (or never queued: a single-test run): start it now
+            if name in _queue:
+                _queue.remove(name)
+            if name not in _running:
+                _launch(name)
         p = _running[name]
         p.wait(timeout=timeout)
         log = open(os.path.join(EXPECT_DIR, name + ".log")).read()
-        assert p.returncode == 0 and os.path.exists(out), f"cpu_expect {name} failed:\n{log[-3000:]}"
-    return np.load(out)
+        assert p.returncode == 0 and os.path.exists(_out(name)), f"cpu_expect {name} failed:\n{log[-3000:]}"
+    return np.load(_out(name))
 
 
 def stop_all():
-    for p in _running.values():
-        if p.poll() is None:
-            p.kill()
+    with _lock:
+        _queue.clear()
+        for p in _running.values():
+            if p.poll() is None:
+                p.kill()

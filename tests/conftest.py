@@ -36,7 +36,7 @@ def _group(item):
     for i, k in enumerate(("test_7b_logits", "test_7b_greedy_trace_128", "test_7b_greedy_trace_512", "test_7b_full_context", "test_7b_")):
         if name.startswith(k):
             return 0.1 * i
-    if mod.endswith("test_pipeline") or name.startswith("test_wider_models"):
+    if "pipeline" in mod or name.startswith("test_wider_models"):
         return 1
     return 3
 
@@ -49,6 +49,8 @@ def pytest_collection_modifyitems(config, items):
 def pytest_collection_finish(session):
     """a full GPU session: start every long CPU expectation now (tests/bg_expect.py), the tests wait only for what is left"""
     n_gpu = sum(1 for it in session.items if it.get_closest_marker("gpu") is not None)
+    import variants
+    variants.SELECTED = [it.callspec.params["nested_tag"] for it in session.items if hasattr(it, "callspec") and "nested_tag" in it.callspec.params]
     if n_gpu >= 40 and not os.environ.get("LLAMAHIP_NESTED") and not session.config.option.collectonly:
         _ensure_built()
         import bg_expect
@@ -110,8 +112,10 @@ def synth_tool(out, **kw):
     return str(out)
 
 
-def nested(env, select, files, tag):
-    """one variant = one nested pytest run; ONE summary line on stdout, the inner tail only in the assertion message"""
+def nested(tag):
+    """one variant = one nested pytest run (tests/variants.py NESTED; the session's variants run a few at a time from the first one asked
+    for); ONE summary line on stdout, the inner tail only in the assertion message"""
     import variants
-    ok, summary, tail = variants.run_nested(env, select, files, tag)
+    ok, summary, tail = variants.nested_result(tag)
+    print(summary)
     assert ok, summary + "\n" + tail

@@ -277,29 +277,23 @@ def test_other_head_sizes_vs_oracle(L, oracle, tmp_path, n_embd, n_head):
                 assert same(gk, ok) and same(gv, ov)
 
 
-def test_matrix_core_prompt_gemm_forced_on_small_models():
+@pytest.mark.parametrize("nested_tag", ["matrix_core_prompt_gemm_forced"], ids=["mfma_min_32"])
+def test_matrix_core_prompt_gemm_forced_on_small_models(nested_tag):
     """k_gemm_mfma4 (the exact long-prompt kernel: fp16 K = 4 matrix instructions, four chains per issue, four waves per SIMD,
     DMA-staged operands) is only selected when its workgroups fill the chip, which the small test models never do: re-run the
     prompt tests with LLAMAHIP_MFMA_MIN=32 (read once per process, hence the subprocess) so that every eval of >= 32 rows
     goes through the matrix cores -- ragged row and column counts, odd numbers of 32-row blocks, the wider models' shapes."""
     from conftest import nested
-    nested({"LLAMAHIP_MFMA_MIN": "32"}, "prompt_continuation or long_prompt or multipart or wider_models", [os.path.abspath(__file__)], "matrix_core_prompt_gemm_forced")
+    nested(nested_tag)
 
 
-_FULL = "wider_models or greedy_trace_128 or tiny_model_golden or prompt_continuation or thread_splits"
-_SMALL = "wider_models or tiny_model_golden or prompt_continuation or thread_splits"
+def _nested_params(prefix):
+    import variants           # (ONE registry of variants: tests/variants.py; tests/test_host.py walks the forced few-row plans host-only)
+    return [pytest.param(t, id=t.split(":", 1)[1]) for t in variants.NESTED if t.startswith(prefix)]
 
 
-@pytest.mark.parametrize("switch,select", [
-    ({"LLAMAHIP_NO_QKV_ATTN": "1"}, _FULL), ({"LLAMAHIP_NO_ATTN_X": "1"}, _FULL), ({"LLAMAHIP_NO_W13_HALF": "1"}, "wider_models or greedy_trace_128 or ragged_contexts"),
-    ({"LLAMAHIP_W13_HALF": "1"}, "wider_models"),
-    ({"LLAMAHIP_ATTN_TWO_FROM": "0", "LLAMAHIP_ATTN_LONG_FROM": "-1"}, _SMALL),
-    ({"LLAMAHIP_ATTN_LONG_FROM": "0"}, _SMALL + " or ragged_contexts"),          # (on the real 7B: tests/test_gpu_fullsize.py decodes behind 2048-token prompts)
-    ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_DMA": "0"}, "ragged_contexts or thread_splits"),
-    ({"LLAMAHIP_ATTN_TWO_FROM": "33", "LLAMAHIP_ATTN_LONG_FROM": "50", "LLAMAHIP_PV_STAGE_ROWS": "3"}, _SMALL),
-    ({"LLAMAHIP_ATTN_LONG_FROM": "0", "LLAMAHIP_PV_STAGE_ROWS": "2", "LLAMAHIP_PV_SPLIT": "1"}, _SMALL)],
-    ids=["no_qkv_attn", "no_attn_x", "w13_block_workgroups", "w13_half_workgroups_13b_65b_widths", "two_launch_everywhere", "stream_everywhere", "stream_everywhere_without_dma", "three_schedules_in_one_call", "stream_unsplit_short_stages"])
-def test_decode_attention_fallback_paths(switch, select):
+@pytest.mark.parametrize("nested_tag", _nested_params("attn:"))
+def test_decode_attention_fallback_paths(nested_tag):
     """The decode step runs wq|wk|wv + attention as one launch with in-launch hand-offs (k_qkv_attn) where the shapes allow;
     the paths it replaces stay in the library for every other shape: the single-launch attention with per-head counters
     (k_dec_attn_x: LLAMAHIP_NO_QKV_ATTN=1) and the two-launch attention (LLAMAHIP_NO_ATTN_X=1).  The schedule also changes with
@@ -313,7 +307,7 @@ def test_decode_attention_fallback_paths(switch, select):
     forces the halves onto the 13B / 65B widths (their two-granule prologue variant).
     The switches are read once per process, hence the subprocess; same parity tests, same oracle."""
     from conftest import nested
-    nested(switch, select, [os.path.abspath(__file__)], "decode_attention_fallback")
+    nested(nested_tag)
 
 
 
@@ -370,26 +364,18 @@ def test_norm_statistics_branches_with_dc_offset_rows(L, oracle, tmp_path, shape
     om.close()
 
 
-def _set_plan_variants():
-    import variants           # (ONE list: tests/test_host.py walks the same environments host-only)
-    return [pytest.param(env, id=tag) for env, tag in variants.SET_PLAN_VARIANTS]
-
-
-@pytest.mark.parametrize("env", _set_plan_variants())
-def test_few_row_kernel_selectable_epilogues_and_plans(env):
+@pytest.mark.parametrize("nested_tag", _nested_params("plan:"))
+def test_few_row_kernel_selectable_epilogues_and_plans(nested_tag):
     """The few-row mat-mul (k_gemv_set) runs w1|w3 in half-block workgroups with a tagged amax exchange for one column group and in
     whole-block workgroups (no exchange) from two column groups on; LLAMAHIP_SET_W13_BLOCKS=0 / 1 forces either epilogue onto every row
     count it can serve, LLAMAHIP_SET_PLAN[_SMALL] another (columns per wave, column-waves) plan than the measured default -- the short-eval
     and set-step parity tests re-run under each (switches are read once per process, hence the subprocess; same tests, same oracle)."""
     from conftest import nested
-    here = os.path.dirname(os.path.abspath(__file__))
-    nested(env, "short_chunks or batched_set_steps_equal or prompt_continuation", [os.path.abspath(__file__), os.path.join(here, "test_pipeline.py")], "few_row_kernel_plan")
+    nested(nested_tag)
 
 
-@pytest.mark.parametrize("env", [{"LLAMAHIP_NO_LUT_MATH": "1"}, {"LLAMAHIP_NORM_MODE": "0"}, {"LLAMAHIP_NORM_MODE": "1"},
-                                 {"LLAMAHIP_NO_HOST_IO": "1", "LLAMAHIP_HOST_SAMPLER": "1"},
-                                 {"LLAMAHIP_MFMA_I8": "1", "LLAMAHIP_MFMA_MIN": "32"}, {"LLAMAHIP_EAGER_PREFILL_COPY": "1"}])
-def test_production_fallbacks_and_selectable_variants(env):
+@pytest.mark.parametrize("nested_tag", _nested_params("prod:"))
+def test_production_fallbacks_and_selectable_variants(nested_tag):
     """Arithmetic that ships in libllamahip.so but that the default configuration of this box never selects:
     NO_LUT_MATH -- the SiLU / exp fp16 tables GATHERED (ggml.c:1956-1963, 7024-7036) instead of evaluated, what a device whose
     double-precision exp failed the exhaustive load-time check would run; NORM_MODE 0 / 1 -- the reference's two-pass statistics /
@@ -398,8 +384,7 @@ def test_production_fallbacks_and_selectable_variants(env):
     prompt-only weight copies built at load.  Switches are read once
     per process, hence the subprocess; same parity tests, same oracle."""
     from conftest import nested
-    nested(env, "dc_offset or thread_splits or tiny_model_golden or wider_models or prompt_continuation or runner_event or topk_candidates", [os.path.abspath(__file__)],
-           "production_fallback")
+    nested(nested_tag)
 
 
 @pytest.mark.parametrize("which", [{"LLAMAHIP_HANDOFF_FAULT_TEST": "1"}, {"LLAMAHIP_HANDOFF_FAULT_TEST": "4", "LLAMAHIP_ATTN_LONG_FROM": "0"},
