@@ -33,7 +33,7 @@ def _group(item):
         return 4
     if mod.endswith("test_gpu_fullsize"):
         return 2
-    for i, k in enumerate(("test_7b_logits", "test_7b_greedy_trace_128", "test_7b_greedy_trace_512", "test_7b_full_context", "test_7b_")):
+    for i, k in enumerate(("test_7b_logits", "test_7b_greedy_trace_128", "test_7b_greedy_trace_512", "test_7b_full_context")):      # (the full 7B file; test_7b_width_*: group 3)
         if name.startswith(k):
             return 0.1 * i
     if "pipeline" in mod or name.startswith("test_wider_models"):

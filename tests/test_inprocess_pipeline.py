@@ -165,7 +165,8 @@ def test_runner_event_stream_through_the_pipeline_with_no_change_to_the_caller(t
             "for greedy in (True, False):\n"
             "    states, toks = [], []\n"
             "    r = L.LlamaRunner(sys.argv[1]).run('hello world abc tok00050 zz', L.Config(numThreads=8, numTokens=14, greedy=greedy, n_ctx=64), toks.append, lambda s, e: states.append(s.name))\n"
-            "    out[str(greedy)] = dict(states=states, toks=toks, ret=r)\n"
+            "    tx = lambda v: [x.decode('latin-1') if isinstance(x, bytes) else x for x in v]\n"
+            "    out[str(greedy)] = dict(states=states, toks=tx(toks), ret=tx(r))\n"
             "print('JSON' + json.dumps(out))\n")
     res = {}
     for tag, env in (("plain", {}), ("pipe", {"LLAMAHIP_DEVICES": "0,0"}), ("pipe_count", {"LLAMAHIP_DEVICES": "1"})):
