@@ -1372,6 +1372,9 @@ __device__ __forceinline__ float load_f32_sc1(const float *p) {
     return __builtin_bit_cast(float, __hip_atomic_load((const uint32_t *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+#ifndef LH_ATTN_ABLATE
+#define LH_ATTN_ABLATE 0
+#endif
 struct AttnXArgs {
     const float *qkv; int d, dh; const double *sincos_tab; float *Kc, *Vc, *sc; int n_ctx, nth; float kq_scale;
     float *merged; uint32_t *qa_A; float *qa_d; const uint16_t *T_exp; const int32_t *st; uint32_t *sync, *fault; int lut_math;
@@ -1556,7 +1559,12 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
         const uint32_t tag = make_tag(aa.epoch[0], aa.layer + 1);
         const bool nowait = (lut_math & 0x1000) != 0;
         // (a thread's granules, up to four at a time, are polled together: one round trip per look instead of one per granule)
+#if LH_ATTN_ABLATE == 2        /* measurement build, results wrong: the soft_max . V workgroups do not wait for the scores (bound of the hop + soft_max) */
+        for (int t0 = tid; t0 < T; t0 += nt) p[t0] = 0.0f;
+        for (int t0 = T; t0 < T; t0 += 4 * nt) {
+#else
         for (int t0 = tid; t0 < T; t0 += 4 * nt) {
+#endif
             uint64_t g_[4] = { 0, 0, 0, 0 };
             int spins = 0;
             for (;;) {
@@ -1578,6 +1586,9 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
         }
     } else
     for (int t = tid; t < T; t += nt) { const float v = load_f32_sc1(row + t); p[t] = v; mx = fmaxf(mx, v); }
+#if LH_ATTN_ABLATE == 1 || LH_ATTN_ABLATE == 2      /* measurement build, results wrong: no soft_max arithmetic between the scores and the V*P chains (bound of every soft_max restructuring) */
+    if (!QKV_WAIT) {
+#endif
     mx = block_max_f(mx, red, 0);
     double sum = 0.0;
     for (int t = tid; t < T; t += nt) {
@@ -1589,6 +1600,9 @@ __device__ __forceinline__ void attn_x_body(const AttnXArgs &aa, const int h, co
     sum = block_sum_d(sum, red, 1);
     const float inv = (float) (1.0 / sum);
     for (int t = tid; t < T; t += nt) p[t] *= inv;
+#if LH_ATTN_ABLATE == 1 || LH_ATTN_ABLATE == 2
+    }
+#endif
     __syncthreads();
     LH_ASTAMP(2);
     for (int th = sub; th < nth; th += nsub) {

@@ -239,6 +239,118 @@ k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, 
         if (m == 0) pmax[((size_t) h * KS + ks) * NB + nl0 + 4 * kk + r] = v;
     }
 }
+
+// The same scores with the key tile SHARED by QW query tiles through LDS (round 6, VERDICT r05 item 5 / DESIGN 11.8 "the step that pays first").
+// k_attnq_scores_mfma gives every wave its own copy of each 16-key tile straight from L2: 8 KB per 256 (query, key) pairs, 2.1 GB per
+// layer at 2 048 tokens.  Here a workgroup is QW waves = QW x 16 consecutive queries walking ONE key slice together: the tile (16 rows x 512 B)
+// is fetched once per workgroup by LDS-DMA (global_load_lds_dwordx4: no staging registers -- with them the kernel spilled at three waves
+// per SIMD), double buffered, one barrier per step; a wave whose queries cannot see the step's keys (causal mask: its Tb is lower than the
+// workgroup's) skips the arithmetic, not the barrier.  LDS layout: rows 33 units of 16 bytes apart (32 + one unit of padding: the 16 rows of
+// a quarter-wave's ds_read_b128 -- same column unit, m = 0 .. 15 -- fall on 16 distinct bank groups; unpadded rows would all hit one; a lane reads
+// its 8 units through ONE address and immediates).  A DMA instruction writes lane l's 16 bytes at LDS unit 64 i + l, so the lane FETCHES
+// column unit (64 i + l) % 33 of row (64 i + l) / 33 (the pad unit and the overshoot of the ninth instruction fetch something harmless).  The arithmetic per
+// (query, key) pair is the macro above, unchanged: bit-identical scores, same S / pmax layout; k_attnq_softmax / _pv_mfma / _merge follow as they are.
+__device__ __forceinline__ void sc_dma16(uint32_t lds_dst, uint64_t base, uint32_t voff) {      // (gemv_set.hip set_dma16_cached: K rows are read by every query tile)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+}
+template <int QW>
+__global__ void __launch_bounds__(64 * QW) __attribute__((amdgpu_waves_per_eu(3)))
+k_attnq_scores_lds(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
+                   int n_past, int N, int nb0, int NB, int nb, int d, int T, float kq_scale, int KS) {
+    constexpr int TILE_B = 9 * 1024;                                    // 16 rows x 528 B = 8 448 B, fetched as nine instructions of 1 KiB
+    __shared__ __attribute__((aligned(1024))) uint8_t ktile[2][TILE_B];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, m = lane & 15, kk = lane >> 4, h = blockIdx.y, ks = blockIdx.z;
+    const int nl0 = (blockIdx.x * QW + w) * 16;
+    const bool active = nl0 < nb;                                       // (the last workgroup of a batch may hold tiles past its end)
+    const int Tb = n_past + min(nb0 + nl0 + 16, N);                    // keys any query of this wave's tile can see
+    const int Tg = n_past + min(nb0 + min((int) (blockIdx.x * QW + QW) * 16, nb), N);      // ... of the workgroup's last tile: the slice is the workgroup's
+    const int per = (Tg + KS - 1) / KS, t0 = ks * per, t1 = min(Tg, t0 + per);
+    float mx[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    if (t0 < t1) {                                                      // (uniform per workgroup)
+        float aq[32];
+        {
+            const int nq = min(nb0 + nl0 + m, N - 1);
+            const f32x4 *qp = (const f32x4 *) (qr + (size_t) nq * d + h * 128 + 32 * kk);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const f32x4 v = qp[j]; aq[4 * j] = v.x; aq[4 * j + 1] = v.y; aq[4 * j + 2] = v.z; aq[4 * j + 3] = v.w; }
+        }
+        const int tq0 = n_past + nb0 + nl0 + 4 * kk, tqmax = n_past + N - 1;                 // last key query 4 kk + r sees: min(tq0 + r, tqmax)
+        const float *kbase = Kc + h * 128;
+        float *sbase = S + (size_t) h * T * NB + nl0;
+        const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) (uint8_t *) &ktile[0][0];
+        // nine DMA instructions of 64 units per tile, instruction i by wave i % QW
+        auto fetch = [&](int tb, int buf) {
+#pragma unroll
+            for (int f = 0; f < (9 + QW - 1) / QW; f++) {
+                const int i = w + f * QW;
+                if (i < 9) {
+                    const int U = 64 * i + lane, row = min((U * 993) >> 15, 15), cu = min(U - 33 * ((U * 993) >> 15), 31);      // (U / 33 for U < 640)
+                    const uint32_t voff = (uint32_t) (min(tb + row, t1 - 1) * d + 4 * cu) * 4u;
+                    sc_dma16(lds0 + (uint32_t) buf * (uint32_t) TILE_B + (uint32_t) i * 1024u, (uint64_t) (uintptr_t) kbase, voff);
+                }
+            }
+        };
+        fetch(t0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int tb = t0; tb < t1; tb += 16, buf ^= 1) {
+            if (tb + 16 < t1) fetch(tb + 16, buf ^ 1);                  // in flight behind this step's arithmetic (the other buffer's readers passed the previous barrier)
+            if (active && tb < Tb) {
+                float bk[32];
+                {
+                    const f32x4 *kp = (const f32x4 *) (&ktile[buf][(m * 33 + 8 * kk) * 16]);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { const f32x4 v = kp[j]; bk[4 * j] = v.x; bk[4 * j + 1] = v.y; bk[4 * j + 2] = v.z; bk[4 * j + 3] = v.w; }
+                }
+                f32x4v D[8];
+                float ra[4][4], u[4][4], vsum[4][4];
+#pragma unroll
+                for (int half = 0; half < 2; half++) {                       // j 0-3, then j 4-7
+                    LH_SC_GROUP(D, 0, 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) ra[j][r] = D[j][r] + D[j + 4][r];
+                    LH_SC_GROUP(D, 1, 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float uj = ra[j][r] + (D[j][r] + D[j + 4][r]);
+                            if (half == 0) u[j][r] = uj; else vsum[j][r] = u[j][r] + uj;
+                        }
+                }
+                float scv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) scv[r] = ((vsum[0][r] + vsum[1][r]) + (vsum[2][r] + vsum[3][r])) * kq_scale;
+                const int t = tb + m;                                       // this lane's key
+                const int te = min(t1, Tb);
+#pragma unroll
+                for (int r = 0; r < 4; r++) mx[r] = fmaxf(mx[r], (t < te && t <= min(tq0 + r, tqmax)) ? scv[r] : -INFINITY);
+                if (t < te) {
+                    f32x4 out;
+                    out.x = scv[0]; out.y = scv[1]; out.z = scv[2]; out.w = scv[3];
+                    *(f32x4 *) (sbase + (uint32_t) (t * NB + 4 * kk)) = out;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's share of the next tile has landed (and its S stores are out)
+            __syncthreads();
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float v = mx[r];
+        v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
+        v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+        v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+        v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+        if (m == 0) pmax[((size_t) h * KS + ks) * NB + nl0 + 4 * kk + r] = v;
+    }
+}
 #undef LH_SC_GROUP
 
 
@@ -393,6 +505,7 @@ hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, cons
     return hipSuccess;
 }
 
+constexpr int SCORES_QW_DEFAULT = 0;      // (A/B pending: profiles/r06_*scores*)
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st, int chunk) {
     const int dh = d / H, T = n_past + N;
@@ -404,6 +517,16 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             const int qt = (nb + 15) / 16;
             int KS = (4096 + qt * H - 1) / (qt * H);         // (8 192 / 16 384 waves per launch measured the same: profiles/r04_u_attn_ab.txt)
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
+            // LLAMAHIP_SCORES_QW = 4 | 8: the key tile shared through LDS by that many query tiles (k_attnq_scores_lds); 0: every wave its own copy
+            static const int scores_qw = getenv("LLAMAHIP_SCORES_QW") ? atoi(getenv("LLAMAHIP_SCORES_QW")) : SCORES_QW_DEFAULT;
+            if (scores_qw == 4 || scores_qw == 8) {
+                const int qg = (qt + scores_qw - 1) / scores_qw;
+                int KSl = (4096 + qt * H - 1) / (qt * H);     // (the same number of waves per launch)
+                KSl = KSl < 1 ? 1 : KSl > ws->KS_cap ? ws->KS_cap : KSl;
+                KS = KSl;
+                if (scores_qw == 4) hipLaunchKernelGGL((k_attnq_scores_lds<4>), dim3(qg, H, KS), dim3(256), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, nb, d, T, kq_scale, KS);
+                else hipLaunchKernelGGL((k_attnq_scores_lds<8>), dim3(qg, H, KS), dim3(512), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, nb, d, T, kq_scale, KS);
+            } else
             hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 16 * 64 * sizeof(double) + 65536, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
