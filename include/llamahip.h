@@ -227,8 +227,8 @@ int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_
  * (Norm statistics: a set step runs the reference's two-pass form (ggml.c:5327-5385), a single step takes them one-pass from its
  * producer's partial sums -- both narrow to the same fp32 bits except with probability ~2^-29 per value; the equality
  * of set steps and single steps is therefore tested (tests/test_pipeline.py), not structural.)
- * The score launch of a set covers every key slice of n_ctx whatever the rows' positions (slices beyond a row's position return at
- * once): per-step launch overhead that grows with n_ctx, not with the context. */
+ * The score launch of a set covers the key slices up to the set's highest position rounded up to 128 (the host tracks every slot's position;
+ * a captured step is keyed by that bucket too and re-captured when a row crosses into the next one). */
 int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_seqs, int32_t n_threads, void *stream,
                             char *err, size_t err_cap);
 /* 1 if llamahip_stage_step_set can step n_seqs slots of this handle with this n_threads as ONE set (Q4_0 handle with layers, head size a

@@ -2103,8 +2103,10 @@ bool gemv_pick_applies(const QMat &w) {
 //   sc : scratch of N * H * n_ctx floats
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
-                             const uint16_t *T_exp, hipStream_t st, int chunk, const SeqSet *set) {
-    const int dh = d / H, T = set ? n_ctx : n_past + N;      // (set: positions live on the device -- every key slice is launched, those beyond a row's position return at once)
+                             const uint16_t *T_exp, hipStream_t st, int chunk, const SeqSet *set, int set_keys) {
+    // (set: positions live on the device -- the key slices up to `set_keys`, the host's bound on every row's position + 1 over the life of the
+    //  captured step (0: n_ctx), are launched; those beyond a row's position return at once)
+    const int dh = d / H, T = set ? (set_keys > 0 && set_keys < n_ctx ? set_keys : n_ctx) : n_past + N;
     const float kq_scale = 1.0f / sqrtf((float) d / (float) H);          // .mm:620
     const int Kp = (d + 255) / 256 * 256;
     hipLaunchKernelGGL(k_decn_scores, dim3(H, (T + DEC_TS - 1) / DEC_TS, N), dim3(256), 0, st, qr, d, dh, Kc, sc, n_ctx, kq_scale, n_past, set);

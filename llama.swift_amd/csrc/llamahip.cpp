@@ -1583,7 +1583,7 @@ namespace {
 // llama_eval's graph works row by row (.mm:563-705), so row b is bit for bit a single-token llama_eval of its sequence: its own
 // position in RoPE / the KV append / the causal range, its own cache, and the V*P key split of ITS eval, n_past_b + 1 keys over
 // n_threads (ggml.c:5459-5480).  The weights are streamed once per step for all rows.
-static int forward_set(llamahip_model *m, int nth, SeqSet *d_set, int B, char *err, size_t err_cap) {
+static int forward_set(llamahip_model *m, int nth, SeqSet *d_set, int B, char *err, size_t err_cap, int set_keys = 0) {
     const HParams &hp = m->hp;
     const int d = hp.n_embd, F = hp.n_ff, H = hp.n_head, dh = d / H, C = hp.n_ctx, V = hp.n_vocab;
     hipStream_t st = m->stream;
@@ -1600,7 +1600,7 @@ static int forward_set(llamahip_model *m, int nth, SeqSet *d_set, int B, char *e
         RopeKvArgs ra = { m->sincos, m->qr, Kl, Vl, 0, d, dh };
         ra.set = d_set;
         HIP_TRY(launch_gemm_rope_kv(L.qkv, m->qa_A, m->qa_d, B, ra, st), LLAMAHIP_ERR_PREDICT);                                // .mm:580-611
-        HIP_TRY(launch_attn_short(m->qr, Kl, Vl, m->set_sc, nullptr, m->qa_A, m->qa_d, 0, B, d, H, C, nth, m->T_exp, st, 0, d_set), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
+        HIP_TRY(launch_attn_short(m->qr, Kl, Vl, m->set_sc, nullptr, m->qa_A, m->qa_d, 0, B, d, H, C, nth, m->T_exp, st, 0, d_set, set_keys), LLAMAHIP_ERR_PREDICT);   // .mm:614-646
         HIP_TRY(launch_gemm(L.wo, EPI_RESID, m->qa_A, m->qa_d, B, m->x1, d, m->x, d, st, m->qb_ws, false), LLAMAHIP_ERR_PREDICT);  // .mm:649-654
         HIP_TRY(launch_prep(PREP_NORM, m->x1, L.ffn_norm, d, 0, d, B, m->qa_A, m->qa_d, nullptr, nullptr, m->T_silu, st), LLAMAHIP_ERR_PREDICT);        // .mm:660-665
         if (m->w13_interleaved && gemm_silu_qa_applies(L.w13, B)) {
@@ -1665,8 +1665,16 @@ int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_se
     constexpr size_t SET_GRAPHS_MAX = 32;
     std::vector<int> order(seqs, seqs + n_seqs);
     std::sort(order.begin(), order.end());
+    // The score launch of a step covers the key slices up to the set's highest position, in buckets of SET_KEY_BUCKET positions: the host
+    // tracks every slot's position (next_pos), a captured step is keyed by its bucket and replayed until a row crosses into the next one
+    // (n_ctx / 128 captures per set at most; the launch used to cover every slice of n_ctx whatever the positions -- ADVICE r04).
+    constexpr int SET_KEY_BUCKET = 128;
+    int max_pos = 0;
+    for (int i = 0; i < n_seqs; i++) max_pos = std::max(max_pos, m->slots[seqs[i]].next_pos);
+    const int set_keys = std::min(C, (max_pos / SET_KEY_BUCKET + 1) * SET_KEY_BUCKET);
     std::vector<int> key;
     key.push_back(nth);
+    key.push_back(set_keys);
     for (int i = 0; i < n_seqs; i++) key.push_back(order[i]);
     auto it = m->set_graphs.find(key);
     if (it == m->set_graphs.end()) {
@@ -1697,7 +1705,7 @@ int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_se
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamSynchronize(m->stream), LLAMAHIP_ERR_PREDICT);
             if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { free_dev(sg.d_set); set_err(err, err_cap, "HIP error: stream capture"); return LLAMAHIP_ERR_PREDICT; }
-            rc = forward_set(m, nth, sg.d_set, n_seqs, err, err_cap);
+            rc = forward_set(m, nth, sg.d_set, n_seqs, err, err_cap, set_keys);
             hipError_t e2 = hipStreamEndCapture(m->stream, &graph);
             if (rc || e2 != hipSuccess || hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
                 if (graph) (void) hipGraphDestroy(graph);
@@ -1716,7 +1724,7 @@ int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_se
     else {
         hipStream_t own = m->stream;
         m->stream = run_on;
-        rc = forward_set(m, nth, it->second.d_set, n_seqs, err, err_cap);
+        rc = forward_set(m, nth, it->second.d_set, n_seqs, err, err_cap, set_keys);
         m->stream = own;
         if (rc) return rc;
     }

@@ -183,7 +183,8 @@ hipError_t init_attrs_gemv_set();
 long set_probe_dump(unsigned long long *out, long cap_records, bool reset);      // LH_SET_PROBE builds (tools/set_timeline.py): records of 32 words
 hipError_t launch_attn_short(const float *qr, const float *Kc, const float *Vc, float *sc, float *merged,
                              uint32_t *qa_A, float *qa_d, int n_past, int N, int d, int H, int n_ctx, int nth,
-                             const uint16_t *T_exp, hipStream_t st, int chunk = 0, const SeqSet *set = nullptr);      // set: N independent single-row evals (batched decode step)
+                             const uint16_t *T_exp, hipStream_t st, int chunk = 0, const SeqSet *set = nullptr,      // set: N independent single-row evals (batched decode step)
+                             int set_keys = 0);                                                                   // ... whose positions are all < set_keys (0: n_ctx): bounds the score grid
 // batched decode step: embedding rows / residual rows in and out / greedy picks of the set's rows
 // (the step's FIRST launch -- embed, or rows with gather -- also writes set->pos and, given the epoch word, opens the step's epoch)
 hipError_t launch_embed_set(SeqSet *set, int n, const uint8_t *emb, float *x, int d, hipStream_t st, uint32_t *epoch = nullptr);
