@@ -712,7 +712,7 @@ def pipeline_bench_main(args, cfg, model_path_fn, log, models=None, env=None, em
     # sequences per stage: a stage steps them as ONE set (llamahip_stage_step_set: its weights are streamed once per step for all of
     # them) and the set's rows cross to the next stage in one message.  LLAMAHIP_PIPE_SET=0: one sequence per step, device-side
     # mailboxes between the stages (round 3's schedule; the single-stream latency leg always runs one sequence per step).
-    per_stage = max(1, int(os.environ.get("LLAMAHIP_PIPE_SEQS_PER_STAGE", "4")))
+    per_stage = max(1, int(os.environ.get("LLAMAHIP_PIPE_SEQS_PER_STAGE", "8")))      # (8: 2 930 against 1 965 tokens/s for sets of 4 on one GPU, profiles/r05_*)
     set_mode = os.environ.get("LLAMAHIP_PIPE_SET", "1") != "0" and per_stage >= 2 and not sync_schedule
     want_mailbox = os.environ.get("LLAMAHIP_PIPE_MAILBOX", "1") != "0" and not sync_schedule and world > 1 and not set_mode
 
