@@ -57,7 +57,7 @@ class _GemvBench(C.Structure):
 
 class _Stats(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("weight_bytes_device", C.c_int64), ("kv_bytes_device", C.c_int64),
-                ("n_evals", C.c_int64), ("t_load_ms", C.c_double), ("t_eval_ms_total", C.c_double)]
+                ("n_evals", C.c_int64), ("t_load_ms", C.c_double), ("t_eval_ms_total", C.c_double), ("n_stages", C.c_int32), ("hand_off", C.c_int32)]
 
 
 def lib() -> C.CDLL:

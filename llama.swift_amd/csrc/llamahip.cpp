@@ -221,7 +221,10 @@ struct llamahip_model {
     int pipe_in_cap = 0;
     float *pipe_hout = nullptr;          // decode steps: the row this stage hands on, [n_embd]
     int32_t *pipe_tok = nullptr;         // decode steps: first stage token_in / last stage token_out
-    hipEvent_t pipe_ev = nullptr;        // recorded on this stage's stream behind its hand-off copy
+    hipEvent_t pipe_ev = nullptr;        // recorded on this stage's stream behind its hand-off
+    bool pipe_direct = false;            // the next stage's (last stage: the first stage's) memory is peer-mapped here: this stage's kernels store into it, no copy
+    int pipe_hand_off = 0;               // (front) llamahip_stats.hand_off
+    int pipe_mailbox_seq = -1;           // (front) the slot whose device-side mailboxes are wired between the stages (LLAMAHIP_PIPE_MAILBOX=1), -1: none
 
     ~llamahip_model();
 };
@@ -1851,15 +1854,16 @@ static int pipe_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
         HIP_TRY(hipMalloc((void **) &st->pipe_hout, (size_t) front->hp.n_embd * 4), LLAMAHIP_ERR_LOAD);
         // direct peer copies to the next stage's device and (last stage) back to the first; without peer access the copy is staged by the runtime
         const int peers[2] = { stages[(s + 1) % S]->device, stages[0]->device };
+        st->pipe_direct = true;
         for (int pd : peers) {
+            if (pd == st->device) continue;
             int can = 0;
-            if (pd != st->device && hipDeviceCanAccessPeer(&can, st->device, pd) == hipSuccess && can) {
+            if (hipDeviceCanAccessPeer(&can, st->device, pd) == hipSuccess && can) {
                 const hipError_t e = hipDeviceEnablePeerAccess(pd, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e, LLAMAHIP_ERR_LOAD);
                 (void) hipGetLastError();
-            }
+            } else st->pipe_direct = false;                  // (no peer mapping: the hand-off stays a runtime-staged copy)
         }
-        front->weight_bytes += 0;
     }
     front->t_load_ms = now_ms() - t0;
     *out = guard.release();
@@ -1877,11 +1881,14 @@ static int pipe_ensure_in(llamahip_model *st, int N, char *err, size_t err_cap) 
     st->pipe_in_cap = cap;
     return 0;
 }
-// producer side: `bytes` from `src` on stage a's device to `dst` on stage b's, ordered behind a's stream; b's stream waits for the copy
+// producer side: what a's stream has enqueued so far happens before anything b's stream is given from here on; `bytes` > 0: a copy of `src` on
+// a's device to `dst` on b's first (stages without a peer mapping, and the rows of a multi-token eval)
 static int pipe_hand_off(llamahip_model *a, llamahip_model *b, void *dst, const void *src, size_t bytes, char *err, size_t err_cap) {
     HIP_TRY(hipSetDevice(a->device), LLAMAHIP_ERR_PREDICT);
-    if (a->device == b->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, a->stream), LLAMAHIP_ERR_PREDICT);
-    else HIP_TRY(hipMemcpyPeerAsync(dst, b->device, src, a->device, bytes, a->stream), LLAMAHIP_ERR_PREDICT);
+    if (bytes) {
+        if (a->device == b->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, a->stream), LLAMAHIP_ERR_PREDICT);
+        else HIP_TRY(hipMemcpyPeerAsync(dst, b->device, src, a->device, bytes, a->stream), LLAMAHIP_ERR_PREDICT);
+    }
     HIP_TRY(hipEventRecord(a->pipe_ev, a->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipSetDevice(b->device), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamWaitEvent(b->stream, a->pipe_ev, 0), LLAMAHIP_ERR_PREDICT);
@@ -1922,9 +1929,14 @@ static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const
     return LLAMAHIP_OK;
 }
 
-// The greedy loop on the pipeline: every stage's single-token step is its captured graph (llamahip_stage_step), the row travels stage to
-// stage and the picked token travels from the last stage back to the first as stream-ordered peer copies; the host enqueues all n_steps
-// without waiting and reads the trace at the end.
+// The greedy loop on the pipeline: every stage's single-token step is its captured graph (llamahip_stage_step).  Default hand-off: the last
+// kernel of a stage step stores the residual row straight into the NEXT stage's buffer (peer-mapped memory: an xGMI store; a copy where
+// there is no peer mapping) and the last stage's pick kernel stores the token into the first stage's token word; an event on the producer's
+// stream orders the consumer's step behind it.  The host enqueues all n_steps without waiting and reads the trace at the end.
+// LLAMAHIP_PIPE_MAILBOX=1: the device-side mailboxes of include/llamahip.h instead -- the row and the token travel as position-tagged
+// granules the consumer's first kernel polls, no event and no host-visible dependency between the stages' streams.  Lowest hop latency
+// between GPUs; NOT the default because every stage's step must then be able to run concurrently with its predecessor's (stages that share one
+// GPU compete for its hardware queues: fine for the two- and three-stage tests, not guaranteed for eight).
 static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token, int32_t n_steps, int32_t *out_tokens, float *logits_last,
                               char *err, size_t err_cap) {
     const int S = (int) m->stages.size();
@@ -1936,20 +1948,50 @@ static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_pa
     const double t0 = now_ms();
     const size_t d = m->hp.n_embd;
     const int seq = m->cur_seq;
+    static const bool want_mailbox = getenv("LLAMAHIP_PIPE_MAILBOX") && atoi(getenv("LLAMAHIP_PIPE_MAILBOX")) == 1;
     for (int s = 1; s < S; s++) if ((rc = pipe_ensure_in(m->stages[s], 1, err, err_cap)) != 0) return rc;
     HIP_TRY(hipSetDevice(first->device), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMemcpy(first->pipe_tok, &first_token, 4, hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
+    bool mailbox = false;
+    if (want_mailbox && !first->dense && first->w13_interleaved) {
+        bool direct = true;
+        for (llamahip_model *st : m->stages) direct = direct && st->pipe_direct;
+        if (direct) {
+            // wire slot `seq` once: every stage opens its successor's hidden inbox, the last stage the first stage's token inbox (raw pointers: one process)
+            if (m->pipe_mailbox_seq != seq) {
+                std::vector<void *> hin(S, nullptr);
+                void *tin = nullptr;
+                for (int s = 0; s < S && rc == 0; s++) rc = llamahip_stage_mailbox(m->stages[s], seq, &hin[s], s == 0 ? &tin : nullptr, nullptr, nullptr, err, err_cap);
+                for (int s = 0; s < S && rc == 0; s++)
+                    rc = llamahip_stage_mailbox_connect(m->stages[s], seq, nullptr, s + 1 < S ? hin[s + 1] : nullptr, nullptr, s + 1 == S ? tin : nullptr, err, err_cap);
+                if (rc) return rc;
+                m->pipe_mailbox_seq = seq;
+            }
+            mailbox = true;
+        }
+    }
+    {
+        bool direct = true;
+        for (llamahip_model *st : m->stages) direct = direct && st->pipe_direct;
+        m->pipe_hand_off = mailbox ? 3 : direct ? 2 : 1;
+    }
     for (int s = 0; s < S; s++) {
         llamahip_model *st = m->stages[s];
-        if ((rc = llamahip_stage_bind(st, seq, n_past, s == 0 ? first->pipe_tok : nullptr, s ? st->pipe_in : nullptr, s + 1 < S ? st->pipe_hout : nullptr,
-                                      s + 1 == S ? last->pipe_tok : nullptr, err, err_cap)) != 0) return rc;
+        void *h_in = nullptr, *h_out = nullptr, *t_out = nullptr;
+        if (!mailbox) {
+            h_in = s ? st->pipe_in : nullptr;
+            h_out = s + 1 < S ? (st->pipe_direct ? (void *) m->stages[s + 1]->pipe_in : (void *) st->pipe_hout) : nullptr;
+            t_out = s + 1 == S ? (last->pipe_direct ? (void *) first->pipe_tok : (void *) last->pipe_tok) : nullptr;
+        }
+        if ((rc = llamahip_stage_bind(st, seq, n_past, s == 0 ? first->pipe_tok : nullptr, h_in, h_out, t_out, err, err_cap)) != 0) return rc;
     }
     for (int i = 0; i < n_steps && rc == 0; i++) {
         for (int s = 0; s < S && rc == 0; s++) {
             llamahip_model *st = m->stages[s];
             if ((rc = llamahip_stage_step(st, seq, n_threads, st->stream, err, err_cap)) != 0) break;
-            if (s + 1 < S) rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->pipe_hout, d * 4, err, err_cap);
-            else if (S > 1 && i + 1 < n_steps) rc = pipe_hand_off(last, first, first->pipe_tok, last->pipe_tok, 4, err, err_cap);      // (S == 1: never a pipe)
+            if (mailbox) continue;
+            if (s + 1 < S) rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->pipe_hout, st->pipe_direct ? 0 : d * 4, err, err_cap);
+            else if (i + 1 < n_steps) rc = pipe_hand_off(last, first, first->pipe_tok, last->pipe_tok, last->pipe_direct ? 0 : 4, err, err_cap);
         }
     }
     if (rc) { (void) pipe_sync(m, nullptr, 0); return rc; }
@@ -2056,6 +2098,8 @@ int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out) {
     out->t_load_ms = m->t_load_ms;
     out->t_eval_ms_total = m->t_eval_ms;
     for (const llamahip_model *st : m->stages) { out->weight_bytes_device += st->weight_bytes; out->kv_bytes_device += st->kv_bytes; }
+    out->n_stages = m->stages.empty() ? 1 : (int32_t) m->stages.size();
+    out->hand_off = m->pipe_hand_off;
     return LLAMAHIP_OK;
 }
 

@@ -505,7 +505,7 @@ hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, cons
     return hipSuccess;
 }
 
-constexpr int SCORES_QW_DEFAULT = 0;      // (A/B pending: profiles/r06_*scores*)
+constexpr int SCORES_QW_DEFAULT = 4;      // (95.5 -> 76.3 us per launch at 2 048 tokens, 8 tiles: 83.9; profiles/r06_d_prefill_scores_ab.txt)
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st, int chunk) {
     const int dh = d / H, T = n_past + N;

@@ -29,8 +29,10 @@ def _group(item):
     name, mod = item.name, item.module.__name__ if item.module else ""
     if item.get_closest_marker("gpu") is None:
         return 3
-    if any(k in name for k in ("_selectable_", "_fallback", "_forced_on_", "_timeout_", "_lost_row_", "_silent_peer_")):
-        return 4
+    if hasattr(item, "callspec") and "nested_tag" in item.callspec.params:
+        return 4                            # nested variant runs (a pool of them, tests/variants.py) ...
+    if any(k in name for k in ("_timeout_", "_lost_row_", "_silent_peer_")):
+        return 4.5                          # ... drained before the tests that time bounded polls
     if mod.endswith("test_gpu_fullsize"):
         return 2
     for i, k in enumerate(("test_7b_logits", "test_7b_greedy_trace_128", "test_7b_greedy_trace_512", "test_7b_full_context")):      # (the full 7B file; test_7b_width_*: group 3)
