@@ -1679,11 +1679,12 @@ k_dec_attn_x(const AttnXArgs aa) {
 // of k_dec_attn_x in the same order (soft_max . V, then scores; gridA is a multiple of 8, so head h's stay on XCD h % 8); they
 // request their V / K rows first, then wait.  The mat-vec workgroups never wait and are dispatched first; the 4 H
 // soft_max . V workgroups are the only ones that wait for HIGHER block indices, and they cannot fill the chip.
-// (register budget: 4 / 3 waves per SIMD for the prologue that takes the producer's partial sums -- every layer of a whole-model handle; the
-//  self-contained norm prologues -- the FIRST layer of a later pipeline stage, one launch per stage step -- need ~20 registers more and get one
-//  wave less instead of spilling them: tools/kernel_scratch_report.py)
+// (register budget: 4 / 3 waves per SIMD.  The self-contained norm prologue PREP_NORM -- the FIRST layer of a later pipeline stage that takes its row
+//  from a plain buffer, one launch per stage step -- needs ~20 registers more and gets one wave less instead of spilling them
+//  (tools/kernel_scratch_report.py).  The mailbox prologue PREP_NORM_TAG keeps 4 / 3 and its few spilled registers: its workgroups WAIT for
+//  another stage's row, and when stages share one GPU (tests, one-GPU smoke runs) the fewer slots they hold while waiting the better.)
 template <int PRE, int D, int PG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRE == PREP_NORMP ? (PG == 1 ? 4 : 3) : (PG == 1 ? 3 : 2))))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRE == PREP_NORM ? (PG == 1 ? 3 : 2) : (PG == 1 ? 4 : 3))))
 k_qkv_attn(const GemvArgs ga, const AttnXArgs aa, const int gridA, const int H) {
     extern __shared__ double smem_d[];
     const int b = blockIdx.x;

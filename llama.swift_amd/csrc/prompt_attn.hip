@@ -133,7 +133,7 @@ k_attn(const float *__restrict__ qr, const float *__restrict__ Kc, const float *
 // k_attn above gives every (head, query) its own workgroup and re-reads the head's whole K and V for each query: 2 048 rows stream
 // 69 GB per layer through L2.  Here scores are materialised like the reference's KQ tensor (.mm:614), in a [head][key][query]
 // workspace so that lanes read and write it coalesced; queries are processed in batches of NB rows to bound it.
-//   k_attnq_scores_mfma  grid (NB/16, H, KS): KQ * scale for its key slice, running max   -> S, pmax
+//   k_attnq_scores_lds   grid (NB/64, H, KS) x 4 waves: KQ * scale for its key slice, running max -> S, pmax
 //   k_attnq_softmax      grid (NB/64, H) x (64 queries x 16 key phases): exp LUT, double sum -> S = e, inv
 //   k_attnq_pv_mfma      grid (NB/64, H, nth): p = e * inv; the FMA chains of ONE chunk of the reference's nth-way key split -> part
 //   k_attnq_merge        the ordered add of the nth partials                              -> merged
@@ -171,78 +171,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
                    "v"(aq[16 * (HF) + (J0) + 8]), "v"(aq[16 * (HF) + (J0) + 9]), "v"(aq[16 * (HF) + (J0) + 10]), "v"(aq[16 * (HF) + (J0) + 11]), \
                    "v"(bk[16 * (HF) + (J0)]), "v"(bk[16 * (HF) + (J0) + 1]), "v"(bk[16 * (HF) + (J0) + 2]), "v"(bk[16 * (HF) + (J0) + 3]),   \
                    "v"(bk[16 * (HF) + (J0) + 8]), "v"(bk[16 * (HF) + (J0) + 9]), "v"(bk[16 * (HF) + (J0) + 10]), "v"(bk[16 * (HF) + (J0) + 11]))
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
-k_attnq_scores_mfma(const float *__restrict__ qr, const float *__restrict__ Kc, float *__restrict__ S, float *__restrict__ pmax,
-                     int n_past, int N, int nb0, int NB, int d, int T, float kq_scale, int KS) {
-    const int lane = threadIdx.x, m = lane & 15, kk = lane >> 4, h = blockIdx.y, ks = blockIdx.z;
-    const int nl0 = blockIdx.x * 16;
-    const int Tb = n_past + min(nb0 + nl0 + 16, N);                    // keys any query of this tile can see
-    const int per = (Tb + KS - 1) / KS, t0 = ks * per, t1 = min(Tb, t0 + per);
-    float mx[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
-    if (t0 < t1) {
-        float aq[32];
-        {
-            const int nq = min(nb0 + nl0 + m, N - 1);
-            const f32x4 *qp = (const f32x4 *) (qr + (size_t) nq * d + h * 128 + 32 * kk);
-#pragma unroll
-            for (int j = 0; j < 8; j++) { const f32x4 v = qp[j]; aq[4 * j] = v.x; aq[4 * j + 1] = v.y; aq[4 * j + 2] = v.z; aq[4 * j + 3] = v.w; }
-        }
-        const int tq0 = n_past + nb0 + nl0 + 4 * kk, tqmax = n_past + N - 1;                 // last key query 4 kk + r sees: min(tq0 + r, tqmax)
-        const float *kbase = Kc + h * 128;
-        float *sbase = S + (size_t) h * T * NB + nl0;
-        for (int tb = t0; tb < t1; tb += 16) {
-            float bk[32];
-            {
-                const f32x4 *kp = (const f32x4 *) (kbase + (uint32_t) (min(tb + m, t1 - 1) * d + 32 * kk));
-#pragma unroll
-                for (int j = 0; j < 8; j++) { const f32x4 v = kp[j]; bk[4 * j] = v.x; bk[4 * j + 1] = v.y; bk[4 * j + 2] = v.z; bk[4 * j + 3] = v.w; }
-            }
-            f32x4v D[8];
-            float ra[4][4], u[4][4], vsum[4][4];
-#pragma unroll
-            for (int half = 0; half < 2; half++) {                       // j 0-3, then j 4-7
-                LH_SC_GROUP(D, 0, 4 * half);
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) ra[j][r] = D[j][r] + D[j + 4][r];              // r1[0][4 half + j]
-                LH_SC_GROUP(D, 1, 4 * half);
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float uj = ra[j][r] + (D[j][r] + D[j + 4][r]);                   // u[4 half + j] = r1[0][.] + r1[1][.]
-                        if (half == 0) u[j][r] = uj; else vsum[j][r] = u[j][r] + uj;            // v_j = u_j + u_{j+4}
-                    }
-            }
-            float scv[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) scv[r] = ((vsum[0][r] + vsum[1][r]) + (vsum[2][r] + vsum[3][r])) * kq_scale;
-            const int t = tb + m;                                       // this lane's key
-            // (the running maximum is taken unconditionally so that the additions cannot sink into the store's branch and keep results live)
-#pragma unroll
-            for (int r = 0; r < 4; r++) mx[r] = fmaxf(mx[r], (t < t1 && t <= min(tq0 + r, tqmax)) ? scv[r] : -INFINITY);
-            if (t < t1) {
-                f32x4 out;
-                out.x = scv[0]; out.y = scv[1]; out.z = scv[2]; out.w = scv[3];
-                *(f32x4 *) (sbase + (uint32_t) (t * NB + 4 * kk)) = out;
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float v = mx[r];
-        v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
-        v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
-        v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
-        v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
-        if (m == 0) pmax[((size_t) h * KS + ks) * NB + nl0 + 4 * kk + r] = v;
-    }
-}
-
-// The same scores with the key tile SHARED by QW query tiles through LDS (round 6, VERDICT r05 item 5 / DESIGN 11.8 "the step that pays first").
-// k_attnq_scores_mfma gives every wave its own copy of each 16-key tile straight from L2: 8 KB per 256 (query, key) pairs, 2.1 GB per
-// layer at 2 048 tokens.  Here a workgroup is QW waves = QW x 16 consecutive queries walking ONE key slice together: the tile (16 rows x 512 B)
+// The score kernel: the key tile SHARED by QW query tiles through LDS (round 6, VERDICT r05 item 5 / DESIGN 11.8 "the step that pays first").
+// Rounds 2-5 (k_attnq_scores_mfma, removed) gave every wave its own copy of each 16-key tile straight from L2: 8 KB per 256 (query, key) pairs,
+// 2.1 GB per layer at 2 048 tokens -- 95.5 us per launch; four tiles sharing: 76.3 us, eight: 83.9 (profiles/r06_d_prefill_scores_ab.txt; logits CRC
+// equal).  A workgroup is QW waves = QW x 16 consecutive queries walking ONE key slice together: the tile (16 rows x 512 B)
 // is fetched once per workgroup by LDS-DMA (global_load_lds_dwordx4: no staging registers -- with them the kernel spilled at three waves
 // per SIMD), double buffered, one barrier per step; a wave whose queries cannot see the step's keys (causal mask: its Tb is lower than the
 // workgroup's) skips the arithmetic, not the barrier.  LDS layout: rows 33 units of 16 bytes apart (32 + one unit of padding: the 16 rows of
@@ -505,7 +437,6 @@ hipError_t launch_rope_kv(const float *qkv, long qkv_stride, int d, int dh, cons
     return hipSuccess;
 }
 
-constexpr int SCORES_QW_DEFAULT = 4;      // (95.5 -> 76.3 us per launch at 2 048 tokens, 8 tiles: 83.9; profiles/r06_d_prefill_scores_ab.txt)
 hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float *merged, float *dbg_p, float *dbg_kqv,
                        int n_past, int N, int d, int H, int nth, const uint16_t *T_exp, const AttnWs *ws, hipStream_t st, int chunk) {
     const int dh = d / H, T = n_past + N;
@@ -517,17 +448,10 @@ hipError_t launch_attn(const float *qr, const float *Kc, const float *Vc, float 
             const int qt = (nb + 15) / 16;
             int KS = (4096 + qt * H - 1) / (qt * H);         // (8 192 / 16 384 waves per launch measured the same: profiles/r04_u_attn_ab.txt)
             KS = KS < 1 ? 1 : KS > ws->KS_cap ? ws->KS_cap : KS;
-            // LLAMAHIP_SCORES_QW = 4 | 8: the key tile shared through LDS by that many query tiles (k_attnq_scores_lds); 0: every wave its own copy
-            static const int scores_qw = getenv("LLAMAHIP_SCORES_QW") ? atoi(getenv("LLAMAHIP_SCORES_QW")) : SCORES_QW_DEFAULT;
-            if (scores_qw == 4 || scores_qw == 8) {
-                const int qg = (qt + scores_qw - 1) / scores_qw;
-                int KSl = (4096 + qt * H - 1) / (qt * H);     // (the same number of waves per launch)
-                KSl = KSl < 1 ? 1 : KSl > ws->KS_cap ? ws->KS_cap : KSl;
-                KS = KSl;
-                if (scores_qw == 4) hipLaunchKernelGGL((k_attnq_scores_lds<4>), dim3(qg, H, KS), dim3(256), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, nb, d, T, kq_scale, KS);
-                else hipLaunchKernelGGL((k_attnq_scores_lds<8>), dim3(qg, H, KS), dim3(512), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, nb, d, T, kq_scale, KS);
-            } else
-            hipLaunchKernelGGL(k_attnq_scores_mfma, dim3(qt, H, KS), dim3(64), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, d, T, kq_scale, KS);
+            {
+                constexpr int QW = 4;                         // query tiles sharing a key tile (8 measured slower: fewer, larger workgroups)
+                hipLaunchKernelGGL((k_attnq_scores_lds<QW>), dim3((qt + QW - 1) / QW, H, KS), dim3(64 * QW), 0, st, qr, Kc, ws->S, ws->pmax, n_past, N, nb0, ws->NB, nb, d, T, kq_scale, KS);
+            }
             LH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_attnq_softmax, dim3(qb, H), dim3(1024), 16 * 64 * sizeof(double) + 65536, st, ws->S, ws->pmax, ws->inv, n_past, N, nb0, ws->NB, T, KS, T_exp);
             LH_LAUNCH_CHECK();

@@ -71,6 +71,7 @@ _SHAPES = {
     "65b_width_2_stages": (dict(n_vocab=512, n_embd=8192, n_mult=256, n_head=64, n_layer=2, parts=8), [0, 0], 8),
     "65b_width_4_stages": (dict(n_vocab=512, n_embd=8192, n_mult=256, n_head=64, n_layer=4, parts=8), [0, 0, 0, 0], 5),
     "13b_width_2_stages": (dict(n_vocab=512, n_embd=5120, n_mult=256, n_head=40, n_layer=3, parts=2), [0, 0], 3),
+    "7b_width_2_stages": (dict(n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=3), [0, 0], 8),
 }
 
 
