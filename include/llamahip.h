@@ -334,7 +334,7 @@ typedef struct llamahip_stats {
     double  t_eval_ms_total;
     int32_t n_stages;              /* in-process layer pipeline: stages of this handle (1: a plain handle) */
     int32_t hand_off;              /* ... how the most recent llamahip_decode_greedy moved the row between its stages: 0 not yet / one stage,
-                                      1 stream-ordered copies, 2 stores into the next stage's peer-mapped buffer, 3 device-side mailboxes */
+                                      1 stream-ordered copies (no peer mapping between two of the devices), 2 stores into the next stage's peer-mapped buffer */
 } llamahip_stats;
 int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out);
 

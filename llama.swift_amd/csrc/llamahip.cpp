@@ -224,7 +224,6 @@ struct llamahip_model {
     hipEvent_t pipe_ev = nullptr;        // recorded on this stage's stream behind its hand-off
     bool pipe_direct = false;            // the next stage's (last stage: the first stage's) memory is peer-mapped here: this stage's kernels store into it, no copy
     int pipe_hand_off = 0;               // (front) llamahip_stats.hand_off
-    int pipe_mailbox_seq = -1;           // (front) the slot whose device-side mailboxes are wired between the stages (LLAMAHIP_PIPE_MAILBOX=1), -1: none
 
     ~llamahip_model();
 };
@@ -1933,10 +1932,11 @@ static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const
 // kernel of a stage step stores the residual row straight into the NEXT stage's buffer (peer-mapped memory: an xGMI store; a copy where
 // there is no peer mapping) and the last stage's pick kernel stores the token into the first stage's token word; an event on the producer's
 // stream orders the consumer's step behind it.  The host enqueues all n_steps without waiting and reads the trace at the end.
-// LLAMAHIP_PIPE_MAILBOX=1: the device-side mailboxes of include/llamahip.h instead -- the row and the token travel as position-tagged
-// granules the consumer's first kernel polls, no event and no host-visible dependency between the stages' streams.  Lowest hop latency
-// between GPUs; NOT the default because every stage's step must then be able to run concurrently with its predecessor's (stages that share one
-// GPU compete for its hardware queues: fine for the two- and three-stage tests, not guaranteed for eight).
+// (Round 6 also wired the device-side mailboxes of include/llamahip.h between the stages of such a handle -- no event, the consumer's first
+//  kernel polls.  With every stage on ONE GPU it passed the two- and three-stage oracle tests on narrow models and then timed out
+//  intermittently on the full 7B (a polling stage holds CU slots and queue positions its producer needs; profiles/r06_g_inprocess_mailbox_diag.txt);
+//  it cannot be validated without a second GPU, so it was removed again.  The multi-process pipeline keeps its mailbox schedule behind a
+//  one-token handshake with a common fall-back to RCCL: bench.py --gpus N.)
 static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token, int32_t n_steps, int32_t *out_tokens, float *logits_last,
                               char *err, size_t err_cap) {
     const int S = (int) m->stages.size();
@@ -1948,48 +1948,25 @@ static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_pa
     const double t0 = now_ms();
     const size_t d = m->hp.n_embd;
     const int seq = m->cur_seq;
-    static const bool want_mailbox = getenv("LLAMAHIP_PIPE_MAILBOX") && atoi(getenv("LLAMAHIP_PIPE_MAILBOX")) == 1;
     for (int s = 1; s < S; s++) if ((rc = pipe_ensure_in(m->stages[s], 1, err, err_cap)) != 0) return rc;
     HIP_TRY(hipSetDevice(first->device), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMemcpy(first->pipe_tok, &first_token, 4, hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
-    bool mailbox = false;
-    if (want_mailbox && !first->dense && first->w13_interleaved) {
-        bool direct = true;
-        for (llamahip_model *st : m->stages) direct = direct && st->pipe_direct;
-        if (direct) {
-            // wire slot `seq` once: every stage opens its successor's hidden inbox, the last stage the first stage's token inbox (raw pointers: one process)
-            if (m->pipe_mailbox_seq != seq) {
-                std::vector<void *> hin(S, nullptr);
-                void *tin = nullptr;
-                for (int s = 0; s < S && rc == 0; s++) rc = llamahip_stage_mailbox(m->stages[s], seq, &hin[s], s == 0 ? &tin : nullptr, nullptr, nullptr, err, err_cap);
-                for (int s = 0; s < S && rc == 0; s++)
-                    rc = llamahip_stage_mailbox_connect(m->stages[s], seq, nullptr, s + 1 < S ? hin[s + 1] : nullptr, nullptr, s + 1 == S ? tin : nullptr, err, err_cap);
-                if (rc) return rc;
-                m->pipe_mailbox_seq = seq;
-            }
-            mailbox = true;
-        }
-    }
     {
         bool direct = true;
         for (llamahip_model *st : m->stages) direct = direct && st->pipe_direct;
-        m->pipe_hand_off = mailbox ? 3 : direct ? 2 : 1;
+        m->pipe_hand_off = direct ? 2 : 1;
     }
     for (int s = 0; s < S; s++) {
         llamahip_model *st = m->stages[s];
-        void *h_in = nullptr, *h_out = nullptr, *t_out = nullptr;
-        if (!mailbox) {
-            h_in = s ? st->pipe_in : nullptr;
-            h_out = s + 1 < S ? (st->pipe_direct ? (void *) m->stages[s + 1]->pipe_in : (void *) st->pipe_hout) : nullptr;
-            t_out = s + 1 == S ? (last->pipe_direct ? (void *) first->pipe_tok : (void *) last->pipe_tok) : nullptr;
-        }
+        void *h_in = s ? st->pipe_in : nullptr;
+        void *h_out = s + 1 < S ? (st->pipe_direct ? (void *) m->stages[s + 1]->pipe_in : (void *) st->pipe_hout) : nullptr;
+        void *t_out = s + 1 == S ? (last->pipe_direct ? (void *) first->pipe_tok : (void *) last->pipe_tok) : nullptr;
         if ((rc = llamahip_stage_bind(st, seq, n_past, s == 0 ? first->pipe_tok : nullptr, h_in, h_out, t_out, err, err_cap)) != 0) return rc;
     }
     for (int i = 0; i < n_steps && rc == 0; i++) {
         for (int s = 0; s < S && rc == 0; s++) {
             llamahip_model *st = m->stages[s];
             if ((rc = llamahip_stage_step(st, seq, n_threads, st->stream, err, err_cap)) != 0) break;
-            if (mailbox) continue;
             if (s + 1 < S) rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->pipe_hout, st->pipe_direct ? 0 : d * 4, err, err_cap);
             else if (i + 1 < n_steps) rc = pipe_hand_off(last, first, first->pipe_tok, last->pipe_tok, last->pipe_direct ? 0 : 4, err, err_cap);
         }

@@ -122,8 +122,8 @@ def test_pipeline_handle_equals_the_oracle(L, oracle, tmp_path, shape):
             assert same(gk, ok) and same(gv, ov), f"KV cache layer {il}"
         st = pm.stats()
         assert st["weight_bytes_device"] > 0 and st["kv_bytes_device"] == 2 * 4 * hp.n_layer * n_ctx * hp.n_embd and st["n_evals"] >= 10
-        # the greedy loop's hand-off: stores into the next stage's buffer (one GPU: every stage's memory is local); mailboxes when asked for
-        assert st["n_stages"] == len(devices) and st["hand_off"] == (3 if os.environ.get("LLAMAHIP_PIPE_MAILBOX") == "1" else 2), st
+        # the greedy loop's hand-off: stores into the next stage's buffer (one GPU: every stage's memory is local)
+        assert st["n_stages"] == len(devices) and st["hand_off"] == 2, st
         # what a pipeline handle refuses, and the errors it shares with a plain handle
         with pytest.raises(L.LlamaHipError, match="pipeline handle"):
             pm.eval_stage(0, tokens=warm)
@@ -135,17 +135,6 @@ def test_pipeline_handle_equals_the_oracle(L, oracle, tmp_path, shape):
         with pytest.raises(L.LlamaHipError, match="out of range"):
             pm.eval(np.array([hp.n_vocab], np.int32), 0, nth)
     om.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("nested_tag", ["pipe:mailbox"], ids=["device_side_mailboxes"])
-def test_pipeline_handle_selectable_hand_off(nested_tag):
-    """LLAMAHIP_PIPE_MAILBOX=1: the greedy loop of a pipeline handle moves the row and the token between its stages through the
-    device-side mailboxes (position-tagged granules polled inside the kernels, include/llamahip.h) instead of event-ordered stores --
-    the two- and three-stage oracle tests above re-run under it (read once per process: a nested run, tests/variants.py), and
-    llamahip_stats.hand_off must say 3."""
-    from conftest import nested
-    nested(nested_tag)
 
 
 @pytest.mark.gpu

@@ -51,10 +51,6 @@ NESTED = {"matrix_core_prompt_gemm_forced": ({"LLAMAHIP_MFMA_MIN": "32"}, "promp
 NESTED.update({"attn:" + tag: (env, sel, [PARITY]) for env, sel, tag in ATTN_FALLBACKS})
 NESTED.update({"plan:" + tag: (env, "short_chunks or batched_set_steps_equal or prompt_continuation", [PARITY, PIPELINE]) for env, tag in SET_PLAN_VARIANTS})
 NESTED.update({"prod:" + tag: (env, _PROD_SELECT, [PARITY]) for env, tag in PRODUCTION_FALLBACKS})
-# (one GPU: a stage's polling workgroups hold CU slots the producing stage needs -- the narrow shapes leave room, tests/test_pipeline.py's mailbox tests likewise)
-NESTED["pipe:mailbox"] = ({"LLAMAHIP_PIPE_MAILBOX": "1", "GPU_MAX_HW_QUEUES": "8"}, "pipeline_handle_equals_the_oracle and (small_3_stages or 7b_width_2_stages)",
-                          [os.path.join(HERE, "test_inprocess_pipeline.py")])
-
 EPI_STORE, EPI_RESID, EPI_SILU_QA, EPI_ROPE_KV, EPI_SILU_QAH = 0, 1, 2, 3, 7
 SET_PAIRS = {(1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4), (3, 1), (3, 3), (3, 4), (4, 1), (4, 2), (4, 4), (5, 1)}
 

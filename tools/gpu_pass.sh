@@ -14,7 +14,7 @@
 #   65b    BASELINE configs[4]'s model on one GPU: the forced one-rank pipeline in set mode (in-situ roofline of the stage step, parity gate)
 #   final  everything profiles/<tag>_* is made from: full GPU test suite, bench.py (7B, 13B), config[3] mixed run with HBM counters,
 #          prefill kernel table, prompt / chunk / runner probes, set-step tables + PMC, fresh-process set / eval rates
-pass=${1:-quick}; tag=${2:-r05_$pass}
+pass=${1:-quick}; tag=${2:-r06_$pass}
 O=gpurun_out; mkdir -p $O; R=$PWD
 bash tools/ensure_7b.sh
 quick() { timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pipeline.py -x -q -m gpu -k "mul_mat or batched_set or short_chunks or few_row or handoff_timeout or prompt_continuation or chunks_in_one_pass" --durations=5 > $O/${tag}_quick.txt 2>&1; tail -4 $O/${tag}_quick.txt; }
@@ -85,7 +85,9 @@ PY
   tail -12 $O/${tag}_bench_65B_1gpu.log; head -c 3000 $O/${tag}_bench_65B_1gpu.json; echo
   ;;
 final)
-  python -m pytest tests -x -q -m gpu --durations=8 > $O/${tag}_pytest.txt 2>&1; tail -12 $O/${tag}_pytest.txt
+  # (LLAMAHIP_HEAD: the commit the snapshot was taken from -- there is no .git on the GPU box; the caller passes `git rev-parse HEAD`)
+  { echo "# tree: ${LLAMAHIP_HEAD:-unknown} -- python -m pytest tests -x -q -m gpu --durations=12 on $(date -u +%Y-%m-%dT%H:%MZ)"; python -m pytest tests -x -q -m gpu --durations=12; } > $O/${tag}_pytest.txt 2>&1; tail -16 $O/${tag}_pytest.txt
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
   timeout 1200 python bench.py --save-profile $O/${tag}_decode_kernel_stats.txt > $O/${tag}_bench.json 2> $O/${tag}_bench.log; tail -3 $O/${tag}_bench.log; python - <<PY
 import json
 d = json.load(open("$O/${tag}_bench.json"))
@@ -115,6 +117,10 @@ PY
   timeout 300 python tools/runner_probe.py > $O/${tag}_runner_probe.txt 2>&1; tail -3 $O/${tag}_runner_probe.txt
   set_tables
   timeout 300 python tools/attn_timeline.py 128 3 > $O/${tag}_attn_timeline.txt 2>&1; tail -6 $O/${tag}_attn_timeline.txt
-  bash tools/gpu_pass.sh t ${tag}_set
+  # the in-process layer pipeline (one llamahip_model_load with a device list) on this one GPU, and every launch of the default schedules with its scratch
+  timeout 600 python tools/inprocess_probe.py 7B 1,2,4,8 128 > $O/${tag}_inprocess_pipeline_7B.txt 2>&1; cat $O/${tag}_inprocess_pipeline_7B.txt
+  cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/sw
+  LLAMAHIP_WITH_TORCH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sw -o w -- python $R/tools/schedule_walk.py > /tmp/sw.log 2>&1; cd $R
+  cp $(find /tmp/sw -name "*kernel_stats.csv" | head -1) $O/${tag}_schedule_walk_kernel_stats.csv 2>/dev/null; tail -2 /tmp/sw.log | cut -c1-160
   ;;
 esac
