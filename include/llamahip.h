@@ -333,8 +333,7 @@ typedef struct llamahip_stats {
     double  t_load_ms;             /* the reference measures t_load_us/t_predict_us and drops them (.mm:778,845) */
     double  t_eval_ms_total;
     int32_t n_stages;              /* in-process layer pipeline: stages of this handle (1: a plain handle) */
-    int32_t hand_off;              /* ... how the most recent llamahip_decode_greedy moved the row between its stages: 0 not yet / one stage,
-                                      1 stream-ordered copies (no peer mapping between two of the devices), 2 stores into the next stage's peer-mapped buffer */
+    int32_t hand_off;              /* ... 1 once llamahip_decode_greedy has run on it: the row and the token move between its stages as stream-ordered copies */
 } llamahip_stats;
 int llamahip_get_stats(const llamahip_model *m, llamahip_stats *out);
 

@@ -222,7 +222,6 @@ struct llamahip_model {
     float *pipe_hout = nullptr;          // decode steps: the row this stage hands on, [n_embd]
     int32_t *pipe_tok = nullptr;         // decode steps: first stage token_in / last stage token_out
     hipEvent_t pipe_ev = nullptr;        // recorded on this stage's stream behind its hand-off
-    bool pipe_direct = false;            // the next stage's (last stage: the first stage's) memory is peer-mapped here: this stage's kernels store into it, no copy
     int pipe_hand_off = 0;               // (front) llamahip_stats.hand_off
 
     ~llamahip_model();
@@ -1538,6 +1537,7 @@ static int stage_step_launches(llamahip_model *m, int seq, int nth, char *err, s
 }  // namespace
 
 int llamahip_stage_step(llamahip_model *m, int32_t seq, int32_t n_threads, void *stream, char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_stage_step");
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (seq < 0 || seq >= (int32_t) m->slots.size() || !m->slots[seq].bound) { set_err(err, err_cap, "sequence slot %d is not bound (llamahip_stage_bind)", seq); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
@@ -1638,6 +1638,7 @@ int32_t llamahip_stage_set_applies(const llamahip_model *m, int32_t n_seqs, int3
 }
 
 int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_seqs, int32_t n_threads, void *stream, char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_stage_step_set");
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (!seqs || n_seqs < 1 || n_seqs > SET_MAX) { set_err(err, err_cap, "llamahip_stage_step_set: 1 .. %d slots per step (got %d)", SET_MAX, n_seqs); return LLAMAHIP_ERR_PREDICT; }
     if (n_seqs == 1) return llamahip_stage_step(m, seqs[0], n_threads, stream, err, err_cap);
@@ -1736,6 +1737,7 @@ int llamahip_stage_step_set(llamahip_model *m, const int32_t *seqs, int32_t n_se
 }
 
 int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_t *tokens, int32_t cap, char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_stage_trace");
     if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
     if (seq < 0 || seq >= (int32_t) m->slots.size() || !m->slots[seq].bound) { set_err(err, err_cap, "sequence slot %d is not bound (llamahip_stage_bind)", seq); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
@@ -1751,6 +1753,7 @@ int llamahip_stage_trace(llamahip_model *m, int32_t seq, int32_t *n_past, int32_
 }
 
 int llamahip_stage_logits(llamahip_model *m, int32_t row, float *logits_out, char *err, size_t err_cap) {
+    PIPE_REFUSE(m, "llamahip_stage_logits");
     if (!m || m->host_only || !logits_out) { set_err(err, err_cap, "bad arguments"); return LLAMAHIP_ERR_PREDICT; }
     if (!m->last_stage || !m->logits || row < 0 || row >= m->ws_cap) { set_err(err, err_cap, "no logits row %d on this handle", row); return LLAMAHIP_ERR_PREDICT; }
     HIP_TRY(hipSetDevice(m->device), LLAMAHIP_ERR_PREDICT);
@@ -1852,8 +1855,8 @@ static int pipe_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
         HIP_TRY(hipMemset(st->pipe_tok, 0, 64), LLAMAHIP_ERR_LOAD);
         HIP_TRY(hipMalloc((void **) &st->pipe_hout, (size_t) front->hp.n_embd * 4), LLAMAHIP_ERR_LOAD);
         // direct peer copies to the next stage's device and (last stage) back to the first; without peer access the copy is staged by the runtime
+        // peer access lets the runtime copy device to device over xGMI (without it hipMemcpyPeerAsync stages through host memory)
         const int peers[2] = { stages[(s + 1) % S]->device, stages[0]->device };
-        st->pipe_direct = true;
         for (int pd : peers) {
             if (pd == st->device) continue;
             int can = 0;
@@ -1861,7 +1864,7 @@ static int pipe_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
                 const hipError_t e = hipDeviceEnablePeerAccess(pd, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e, LLAMAHIP_ERR_LOAD);
                 (void) hipGetLastError();
-            } else st->pipe_direct = false;                  // (no peer mapping: the hand-off stays a runtime-staged copy)
+            }
         }
     }
     front->t_load_ms = now_ms() - t0;
@@ -1880,14 +1883,14 @@ static int pipe_ensure_in(llamahip_model *st, int N, char *err, size_t err_cap) 
     st->pipe_in_cap = cap;
     return 0;
 }
-// producer side: what a's stream has enqueued so far happens before anything b's stream is given from here on; `bytes` > 0: a copy of `src` on
-// a's device to `dst` on b's first (stages without a peer mapping, and the rows of a multi-token eval)
+// producer side: `bytes` from `src` on stage a's device to `dst` on stage b's, ordered behind a's stream; b's stream waits for the copy.  (A copy,
+// not a store by a's kernels into b's memory: hipMemcpyPeerAsync + an event is the hand-off whose visibility on the consumer's device the HIP
+// runtime guarantees, and it is the path the one-GPU tests exercise; a round-6 build that let the stage kernels store into peer-mapped memory
+// measured 679 against 675 tokens/s at two stages on one GPU and could not be validated across two.)
 static int pipe_hand_off(llamahip_model *a, llamahip_model *b, void *dst, const void *src, size_t bytes, char *err, size_t err_cap) {
     HIP_TRY(hipSetDevice(a->device), LLAMAHIP_ERR_PREDICT);
-    if (bytes) {
-        if (a->device == b->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, a->stream), LLAMAHIP_ERR_PREDICT);
-        else HIP_TRY(hipMemcpyPeerAsync(dst, b->device, src, a->device, bytes, a->stream), LLAMAHIP_ERR_PREDICT);
-    }
+    if (a->device == b->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, a->stream), LLAMAHIP_ERR_PREDICT);
+    else HIP_TRY(hipMemcpyPeerAsync(dst, b->device, src, a->device, bytes, a->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipEventRecord(a->pipe_ev, a->stream), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipSetDevice(b->device), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipStreamWaitEvent(b->stream, a->pipe_ev, 0), LLAMAHIP_ERR_PREDICT);
@@ -1928,10 +1931,9 @@ static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const
     return LLAMAHIP_OK;
 }
 
-// The greedy loop on the pipeline: every stage's single-token step is its captured graph (llamahip_stage_step).  Default hand-off: the last
-// kernel of a stage step stores the residual row straight into the NEXT stage's buffer (peer-mapped memory: an xGMI store; a copy where
-// there is no peer mapping) and the last stage's pick kernel stores the token into the first stage's token word; an event on the producer's
-// stream orders the consumer's step behind it.  The host enqueues all n_steps without waiting and reads the trace at the end.
+// The greedy loop on the pipeline: every stage's single-token step is its captured graph (llamahip_stage_step), the row travels stage to
+// stage and the picked token travels from the last stage back to the first as stream-ordered copies (pipe_hand_off); the host enqueues all
+// n_steps without waiting and reads the trace at the end.
 // (Round 6 also wired the device-side mailboxes of include/llamahip.h between the stages of such a handle -- no event, the consumer's first
 //  kernel polls.  With every stage on ONE GPU it passed the two- and three-stage oracle tests on narrow models and then timed out
 //  intermittently on the full 7B (a polling stage holds CU slots and queue positions its producer needs; profiles/r06_g_inprocess_mailbox_diag.txt);
@@ -1951,24 +1953,18 @@ static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_pa
     for (int s = 1; s < S; s++) if ((rc = pipe_ensure_in(m->stages[s], 1, err, err_cap)) != 0) return rc;
     HIP_TRY(hipSetDevice(first->device), LLAMAHIP_ERR_PREDICT);
     HIP_TRY(hipMemcpy(first->pipe_tok, &first_token, 4, hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
-    {
-        bool direct = true;
-        for (llamahip_model *st : m->stages) direct = direct && st->pipe_direct;
-        m->pipe_hand_off = direct ? 2 : 1;
-    }
+    m->pipe_hand_off = 1;
     for (int s = 0; s < S; s++) {
         llamahip_model *st = m->stages[s];
-        void *h_in = s ? st->pipe_in : nullptr;
-        void *h_out = s + 1 < S ? (st->pipe_direct ? (void *) m->stages[s + 1]->pipe_in : (void *) st->pipe_hout) : nullptr;
-        void *t_out = s + 1 == S ? (last->pipe_direct ? (void *) first->pipe_tok : (void *) last->pipe_tok) : nullptr;
-        if ((rc = llamahip_stage_bind(st, seq, n_past, s == 0 ? first->pipe_tok : nullptr, h_in, h_out, t_out, err, err_cap)) != 0) return rc;
+        if ((rc = llamahip_stage_bind(st, seq, n_past, s == 0 ? first->pipe_tok : nullptr, s ? st->pipe_in : nullptr, s + 1 < S ? st->pipe_hout : nullptr,
+                                      s + 1 == S ? last->pipe_tok : nullptr, err, err_cap)) != 0) return rc;
     }
     for (int i = 0; i < n_steps && rc == 0; i++) {
         for (int s = 0; s < S && rc == 0; s++) {
             llamahip_model *st = m->stages[s];
             if ((rc = llamahip_stage_step(st, seq, n_threads, st->stream, err, err_cap)) != 0) break;
-            if (s + 1 < S) rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->pipe_hout, st->pipe_direct ? 0 : d * 4, err, err_cap);
-            else if (i + 1 < n_steps) rc = pipe_hand_off(last, first, first->pipe_tok, last->pipe_tok, last->pipe_direct ? 0 : 4, err, err_cap);
+            if (s + 1 < S) rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->pipe_hout, d * 4, err, err_cap);
+            else if (i + 1 < n_steps) rc = pipe_hand_off(last, first, first->pipe_tok, last->pipe_tok, 4, err, err_cap);
         }
     }
     if (rc) { (void) pipe_sync(m, nullptr, 0); return rc; }
