@@ -478,6 +478,29 @@ def inprocess_pipeline(args, cfg, path, n_stages, single_trace):
             "note": "one process, one llamahip_model_load; stage steps as captured graphs on one stream per stage, residual row and picked token handed on by stream-ordered copies"}
 
 
+def inprocess_pipeline_multi(args, cfg, path, n_stages, n_seq, single_trace):
+    """llamahip_decode_greedy_multi on a pipeline handle with every stage on device 0: n_seq sequences in groups (sets), the groups pipelined over
+    the stages -- the native form of the multi-process schedule; sequence 0 decodes the bench prompt and must reproduce the single-stream tokens."""
+    import llama_swift_amd as L
+    with L.Model(path, n_ctx=args.n_ctx, devices=[0] * n_stages if n_stages > 1 else None, n_seq=n_seq) as m:
+        rng = np.random.default_rng(99)
+        prompts = [PROMPT % cfg["n_vocab"]] + [np.concatenate([[1], rng.integers(3, cfg["n_vocab"], 7 + s % 3)]).astype(np.int32) for s in range(1, n_seq)]
+        prompts[0][0] = 1
+        firsts = []
+        for i, p in enumerate(prompts):
+            m.set_seq(i)
+            firsts.append(int(np.argmax(m.eval(p, 0, args.threads))))
+        n_past = [len(p) for p in prompts]
+        n = min(128, args.n_ctx - max(n_past) - 8)
+        warm = m.decode_greedy_multi(firsts, n_past, 8, args.threads)
+        t0 = time.perf_counter()
+        out = m.decode_greedy_multi(warm[:, -1], [x + 8 for x in n_past], n, args.threads)
+        dt = time.perf_counter() - t0
+        got0 = [int(x) for x in warm[0]] + [int(x) for x in out[0]]
+    return {"stages": n_stages, "sequences": n_seq, "steps": n, "aggregate_tokens_per_s": n_seq * n / dt, "ms_per_step": dt * 1e3 / n,
+            "sequence0_tokens_equal_single_stream": got0 == [int(x) for x in single_trace[:len(got0)]]}
+
+
 def concurrent_sequences(args, cfg, path, n_seq):
     """NOT the headline workload: `n_seq` independent greedy sequences decoded at the same time on ONE GPU -- one handle (its own weight
     copy, KV cache, stream and captured graph) and one host thread per sequence, no batching across sequences.  Every sequence is the
@@ -1191,6 +1214,10 @@ def main():
             result["inprocess_pipeline"] = [inprocess_pipeline(args, cfg, path, n, r["gpu_trace"]) for n in (2, 8)]
         except Exception as e:
             result["inprocess_pipeline"] = {"error": repr(e)}
+        try:        # ... and several sequences through it (llamahip_decode_greedy_multi): one stage x 16, two stages x 32, four stages x 32 sequences
+            result["inprocess_pipeline_multi"] = [inprocess_pipeline_multi(args, cfg, path, st, sq, r["gpu_trace"]) for st, sq in ((1, 16), (2, 32), (4, 32))]
+        except Exception as e:
+            result["inprocess_pipeline_multi"] = {"error": repr(e)}
     # figures that must survive a reader that keeps only metric / value / config / roofline of this line
     if "full_context" in result:
         result["roofline"]["full_context_tokens_per_s"] = result["full_context"]["tokens_per_s"]
@@ -1201,6 +1228,10 @@ def main():
         for b in result["inprocess_pipeline"]:
             result["config"][f"inprocess_pipeline_{b['stages']}_stages_one_gpu_tokens_per_s"] = round(b["tokens_per_s"], 1)
         result["config"]["inprocess_pipeline_tokens_equal_single_device"] = all(b["tokens_equal_single_device"] for b in result["inprocess_pipeline"])
+    if isinstance(result.get("inprocess_pipeline_multi"), list):
+        for b in result["inprocess_pipeline_multi"]:
+            result["config"][f"inprocess_multi_{b['stages']}_stages_{b['sequences']}_seq_aggregate_tokens_per_s"] = round(b["aggregate_tokens_per_s"], 1)
+        result["config"]["inprocess_multi_sequence0_equal_single_stream"] = all(b["sequence0_tokens_equal_single_stream"] for b in result["inprocess_pipeline_multi"])
     if isinstance(result.get("batched_sequences"), list):
         for b in result["batched_sequences"]:
             result["config"][f"batched_sequences_aggregate_tokens_per_s_{b['sequences']}_seq"] = round(b["aggregate_tokens_per_s"], 1)

@@ -177,6 +177,16 @@ int llamahip_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past,
                            int32_t n_steps, int32_t *out_tokens, float *logits_last,
                            char *err, size_t err_cap);
 
+/* Greedy decode of n_seqs INDEPENDENT sequences at once (beyond the reference's surface, whose bridge holds one conversation; SURVEY.md section 8e:
+ * "throughput scales only with independent sequences in flight").  Sequence i lives in KV slot i of the handle (llamahip_opts.n_seq >= n_seqs; its
+ * context was evaluated with llamahip_set_seq(i) + llamahip_eval / llamahip_eval_chunks), continues at position n_past[i] with first_tokens[i], and
+ * gets out_tokens[i * n_steps + t], t < n_steps: bit for bit the tokens of llamahip_decode_greedy on that sequence alone.  The slots are stepped in
+ * groups of up to 16 as sets (llamahip_stage_step_set: the weights are streamed once per step for a whole group); on a pipeline handle
+ * (n_devices > 1) the groups -- at least one per stage -- are additionally pipelined over the stages: in steady state every stage (GPU) works on a
+ * different group, rows and picks move between stages as stream-ordered copies.  The native form of the schedule bench.py --gpus N runs over RCCL. */
+int llamahip_decode_greedy_multi(llamahip_model *m, int32_t n_threads, int32_t n_seqs, const int32_t *n_past, const int32_t *first_tokens,
+                                 int32_t n_steps, int32_t *out_tokens, char *err, size_t err_cap);
+
 /* llamahip_eval + every token's logits (n_tokens * n_vocab) and, for dump_layer >= 0, that layer's
  * 17 intermediates in the order documented in DESIGN.md ("debug dump order").  Parity tooling. */
 int llamahip_eval_debug(llamahip_model *m, int32_t n_threads, int32_t n_past,

@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
     L.llamahip_sample_top_p_top_k.argtypes = [vp, vp, vp, C.c_double, i32, C.c_double, C.c_double]
     L.llamahip_sample_top_p_top_k.restype = i32
     L.llamahip_decode_greedy.argtypes = [vp, i32, i32, i32, i32, vp, vp, cp, sz]
+    L.llamahip_decode_greedy_multi.argtypes = [vp, i32, i32, vp, vp, i32, vp, cp, sz]
     L.llamahip_eval_debug.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, C.c_int64, vp, cp, sz]
     L.llamahip_eval_stage.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, cp, sz]
     L.llamahip_stage_bind.argtypes = [vp, i32, i32, vp, vp, vp, vp, cp, sz]
@@ -370,6 +371,16 @@ class Model:
         rc = lib().llamahip_decode_greedy(self._h, n_threads, n_past, int(first_token), n_steps, _ptr(out), _ptr(logits), err, len(err))
         _check(rc, err)
         return (out, logits) if want_logits else out
+
+    def decode_greedy_multi(self, first_tokens, n_past, n_steps: int, n_threads: int = 8) -> np.ndarray:
+        """llamahip_decode_greedy_multi: sequences in KV slots 0 .. len(first_tokens) - 1 decoded together; returns [n_seqs][n_steps]."""
+        ft = np.ascontiguousarray(first_tokens, np.int32)
+        npast = np.ascontiguousarray(n_past, np.int32)
+        out = np.empty((ft.size, n_steps), np.int32)
+        err = C.create_string_buffer(1024)
+        rc = lib().llamahip_decode_greedy_multi(self._h, n_threads, ft.size, _ptr(npast), _ptr(ft), n_steps, _ptr(out), err, len(err))
+        _check(rc, err)
+        return out
 
     def kv(self, il: int, n_pos: int):
         k = np.empty((n_pos, self.n_embd), np.float32)

@@ -222,6 +222,10 @@ struct llamahip_model {
     float *pipe_hout = nullptr;          // decode steps: the row this stage hands on, [n_embd]
     int32_t *pipe_tok = nullptr;         // decode steps: first stage token_in / last stage token_out
     hipEvent_t pipe_ev = nullptr;        // recorded on this stage's stream behind its hand-off
+    // llamahip_decode_greedy_multi (any handle; on the stages of a pipeline handle): per-slot rows in / out and token words, one event per group of slots
+    float *mq_in = nullptr, *mq_out = nullptr;     // [n_seq][n_embd]
+    int32_t *mq_tok = nullptr;                     // [n_seq]
+    std::vector<hipEvent_t> mq_ev;
     int pipe_hand_off = 0;               // (front) llamahip_stats.hand_off
 
     ~llamahip_model();
@@ -279,6 +283,8 @@ llamahip_model::~llamahip_model() {
     free_dev(d_slot_state); free_dev(d_slot_trace);
     free_dev(attn_ws.S); free_dev(attn_ws.pmax); free_dev(attn_ws.inv); free_dev(attn_ws.part);
     free_dev(pipe_in); free_dev(pipe_hout); free_dev(pipe_tok);
+    free_dev(mq_in); free_dev(mq_out); free_dev(mq_tok);
+    for (hipEvent_t e : mq_ev) (void) hipEventDestroy(e);
     if (pipe_ev) (void) hipEventDestroy(pipe_ev);
     if (stream) (void) hipStreamDestroy(stream);
 }
@@ -1081,6 +1087,8 @@ static int pipe_load(const char *path, int32_t n_ctx, const llamahip_opts *opts,
 static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t N, int32_t chunk, float *logits_out, char *err, size_t err_cap);
 static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_past, int32_t first_token, int32_t n_steps, int32_t *out_tokens, float *logits_last,
                               char *err, size_t err_cap);
+static int decode_greedy_multi_impl(llamahip_model *m, int32_t n_threads, int32_t n_seqs, const int32_t *n_past, const int32_t *first_tokens, int32_t n_steps,
+                                    int32_t *out_tokens, char *err, size_t err_cap);
 #define PIPE_REFUSE(m, what) do { if ((m) && !(m)->stages.empty()) { set_err(err, err_cap, what " is not available on a multi-device pipeline handle (llamahip_opts.n_devices / LLAMAHIP_DEVICES): load a stage handle with layer_begin / layer_end"); return LLAMAHIP_ERR_PREDICT; } } while (0)
 
 // No C++ exception may cross the C ABI (std::bad_alloc on a corrupt header would abort the host process).
@@ -1977,6 +1985,117 @@ static int pipe_decode_greedy(llamahip_model *m, int32_t n_threads, int32_t n_pa
     m->n_evals += n_steps;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// llamahip_decode_greedy_multi: n_seqs independent greedy streams at once -- the micro-batched schedule of the layer pipeline (SURVEY.md 8e:
+// "throughput scales only with independent sequences in flight"), native, behind the C ABI.  The slots are cut into G >= n_stages groups of
+// consecutive slots; a stage steps a group as ONE set (llamahip_stage_step_set: its weights streamed once for the group) and hands the group's
+// residual rows to the next stage with one stream-ordered copy + event while it goes on with the next group -- so in steady state every stage
+// (every GPU of a pipeline handle) works on a different group; the last stage's picks go back to the first stage's token words the same way.
+// Host order (step, group, stage): every wait refers to an event recorded by work enqueued before it, so nothing here blocks but the first
+// capture of a set's graph.  A plain handle is the one-stage case: its groups are stepped one after the other, no copies.
+// ------------------------------------------------------------------------------------------------
+static int multi_prepare(llamahip_model *st, int n_groups, char *err, size_t err_cap) {
+    HIP_TRY(hipSetDevice(st->device), LLAMAHIP_ERR_PREDICT);
+    const size_t d = st->hp.n_embd;
+    if (!st->mq_tok) {
+        HIP_TRY(hipMalloc((void **) &st->mq_tok, (size_t) st->n_seq * 4 + 64), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMemset(st->mq_tok, 0, (size_t) st->n_seq * 4 + 64), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMalloc((void **) &st->mq_in, (size_t) st->n_seq * d * 4), LLAMAHIP_ERR_PREDICT);
+        HIP_TRY(hipMalloc((void **) &st->mq_out, (size_t) st->n_seq * d * 4), LLAMAHIP_ERR_PREDICT);
+    }
+    while ((int) st->mq_ev.size() < n_groups) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), LLAMAHIP_ERR_PREDICT);
+        st->mq_ev.push_back(e);
+    }
+    return 0;
+}
+
+static int decode_greedy_multi_impl(llamahip_model *m, int32_t n_threads, int32_t n_seqs, const int32_t *n_past, const int32_t *first_tokens, int32_t n_steps,
+                                    int32_t *out_tokens, char *err, size_t err_cap) {
+    if (!m) { set_err(err, err_cap, "null model"); return LLAMAHIP_ERR_PREDICT; }
+    std::vector<llamahip_model *> stages = m->stages.empty() ? std::vector<llamahip_model *>{ m } : m->stages;
+    const int S = (int) stages.size();
+    llamahip_model *first = stages[0], *last = stages[S - 1];
+    if (first->host_only) { set_err(err, err_cap, "model was loaded with LLAMAHIP_FLAG_HOST_ONLY: no device state, cannot evaluate"); return LLAMAHIP_ERR_PREDICT; }
+    if (!first->first_stage || !last->last_stage) { set_err(err, err_cap, "llamahip_decode_greedy_multi needs a whole-model or a pipeline handle"); return LLAMAHIP_ERR_PREDICT; }
+    if (!n_past || !first_tokens || !out_tokens || n_seqs < 1 || n_steps < 1) { set_err(err, err_cap, "llamahip_decode_greedy_multi: bad arguments"); return LLAMAHIP_ERR_PREDICT; }
+    if (n_seqs > first->n_seq) { set_err(err, err_cap, "llamahip_decode_greedy_multi: %d sequences on a handle with %d KV slots (llamahip_opts.n_seq)", n_seqs, first->n_seq); return LLAMAHIP_ERR_PREDICT; }
+    for (int i = 0; i < n_seqs; i++) {
+        int rc = check_eval_args(first, n_past[i], first_tokens + i, 1, true, err, err_cap);
+        if (rc) return rc;
+        if (n_past[i] + n_steps > m->hp.n_ctx) { set_err(err, err_cap, "context overflow: n_past (%d) + n_steps (%d) > n_ctx (%d)", n_past[i], n_steps, m->hp.n_ctx); return LLAMAHIP_ERR_PREDICT; }
+    }
+    const double t0 = now_ms();
+    const size_t d = m->hp.n_embd;
+    // groups of consecutive slots: at least one per stage (so that every stage has a group to work on), at most SET_MAX slots each
+    const int G = std::min(n_seqs, std::max(S, (n_seqs + SET_MAX - 1) / SET_MAX));
+    std::vector<int> g0(G + 1, 0);
+    for (int g = 0; g < G; g++) g0[g + 1] = g0[g] + n_seqs / G + (g < n_seqs % G ? 1 : 0);
+    int rc = 0;
+    for (llamahip_model *st : stages) if ((rc = multi_prepare(st, G, err, err_cap)) != 0) return rc;
+    HIP_TRY(hipSetDevice(first->device), LLAMAHIP_ERR_PREDICT);
+    HIP_TRY(hipMemcpy(first->mq_tok, first_tokens, (size_t) n_seqs * 4, hipMemcpyHostToDevice), LLAMAHIP_ERR_PREDICT);
+    for (int s = 0; s < S; s++) {
+        llamahip_model *st = stages[s];
+        for (int i = 0; i < n_seqs; i++) {
+            // (one stage: the pick goes straight back into the slot's token word, as the whole-model stage step allows)
+            if ((rc = llamahip_stage_bind(st, i, n_past[i], s == 0 ? first->mq_tok + i : nullptr, s ? st->mq_in + (size_t) i * d : nullptr,
+                                          s + 1 < S ? st->mq_out + (size_t) i * d : nullptr, s + 1 == S ? (S == 1 ? first->mq_tok + i : last->mq_tok + i) : nullptr, err, err_cap)) != 0) return rc;
+        }
+    }
+    std::vector<int32_t> slots(n_seqs);
+    for (int i = 0; i < n_seqs; i++) slots[i] = i;
+    for (int t = 0; t < n_steps && rc == 0; t++) {
+        for (int g = 0; g < G && rc == 0; g++) {
+            const int gn = g0[g + 1] - g0[g];
+            for (int s = 0; s < S && rc == 0; s++) {
+                llamahip_model *st = stages[s];
+                HIP_TRY(hipSetDevice(st->device), LLAMAHIP_ERR_PREDICT);
+                if (s > 0) HIP_TRY(hipStreamWaitEvent(st->stream, stages[s - 1]->mq_ev[g], 0), LLAMAHIP_ERR_PREDICT);
+                else if (S > 1 && t > 0) HIP_TRY(hipStreamWaitEvent(st->stream, last->mq_ev[g], 0), LLAMAHIP_ERR_PREDICT);
+                if (gn >= 2 && llamahip_stage_set_applies(st, gn, n_threads)) rc = llamahip_stage_step_set(st, slots.data() + g0[g], gn, n_threads, st->stream, err, err_cap);
+                else for (int i = g0[g]; i < g0[g + 1] && rc == 0; i++) rc = llamahip_stage_step(st, i, n_threads, st->stream, err, err_cap);
+                if (rc || S == 1) continue;
+                // hand the group on: its rows to the next stage, or (last stage) its picks to the first stage's token words
+                llamahip_model *to = s + 1 < S ? stages[s + 1] : first;
+                void *dst = s + 1 < S ? (void *) (to->mq_in + (size_t) g0[g] * d) : (void *) (first->mq_tok + g0[g]);
+                const void *src = s + 1 < S ? (const void *) (st->mq_out + (size_t) g0[g] * d) : (const void *) (last->mq_tok + g0[g]);
+                const size_t bytes = s + 1 < S ? (size_t) gn * d * 4 : (size_t) gn * 4;
+                if (s + 1 == S && t + 1 == n_steps) continue;                  // (nobody waits for the last picks: the trace holds them)
+                if (st->device == to->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st->stream), LLAMAHIP_ERR_PREDICT);
+                else HIP_TRY(hipMemcpyPeerAsync(dst, to->device, src, st->device, bytes, st->stream), LLAMAHIP_ERR_PREDICT);
+                HIP_TRY(hipEventRecord(st->mq_ev[g], st->stream), LLAMAHIP_ERR_PREDICT);
+            }
+        }
+    }
+    // wait for every stage, collect their fault words
+    int rc_sync = 0;
+    for (int s = S - 1; s >= 0; s--) {
+        llamahip_model *st = stages[s];
+        if (hipSetDevice(st->device) != hipSuccess || hipStreamSynchronize(st->stream) != hipSuccess) { if (!rc) set_err(err, err_cap, "HIP error while waiting for stage %d", s); rc_sync = LLAMAHIP_ERR_PREDICT; continue; }
+        const int r = check_sync_timeout(st, rc ? nullptr : err, rc ? 0 : err_cap);
+        if (r) rc_sync = r;
+    }
+    if (rc) return rc;
+    if (rc_sync) return rc_sync;
+    for (int i = 0; i < n_seqs; i++) {
+        int32_t pos = 0;
+        const int n = llamahip_stage_trace(last, i, &pos, out_tokens + (size_t) i * n_steps, n_steps, err, err_cap);
+        if (n < 0) return n;
+        if (n != n_steps || pos != n_past[i] + n_steps) { set_err(err, err_cap, "multi-sequence decode: sequence %d recorded %d of %d steps, position %d", i, n, n_steps, pos); return LLAMAHIP_ERR_PREDICT; }
+    }
+    m->n_evals += (int64_t) n_seqs * n_steps;
+    m->t_eval_ms += now_ms() - t0;
+    if (!m->stages.empty()) m->pipe_hand_off = 1;
+    return LLAMAHIP_OK;
+}
+
+int llamahip_decode_greedy_multi(llamahip_model *m, int32_t n_threads, int32_t n_seqs, const int32_t *n_past, const int32_t *first_tokens, int32_t n_steps,
+                                 int32_t *out_tokens, char *err, size_t err_cap) {
+    return decode_greedy_multi_impl(m, n_threads, n_seqs, n_past, first_tokens, n_steps, out_tokens, err, err_cap);
 }
 
 int llamahip_set_seq(llamahip_model *m, int32_t seq, char *err, size_t err_cap) {

@@ -181,3 +181,65 @@ def test_runner_event_stream_through_the_pipeline_with_no_change_to_the_caller(t
     assert res["plain"]["True"]["states"] == ["notStarted", "initializing", "generatingOutput", "completed"]
     assert res["pipe"] == res["plain"] and res["pipe_count"] == res["plain"]
     assert len(res["plain"]["False"]["toks"]) == len(res["plain"]["True"]["toks"])
+
+
+_MULTI = {
+    "plain_handle_5_sequences": ("small", None, 5, 8),                 # one stage: a single group, picks fed back in place
+    "plain_handle_20_sequences": ("small", None, 20, 3),               # ... two groups of 10 stepped one after the other
+    "3_stages_7_sequences": ("small", [0, 0, 0], 7, 3),                # groups of 3 + 2 + 2, one per stage
+    "2_stages_40_sequences": ("small", [0, 0], 40, 8),                 # more than 16 per stage: three groups of 14 / 13 / 13
+    "7b_width_2_stages_16_sequences": ("7b_width", [0, 0], 16, 8),     # two sets of 8: the pipeline bench's default set size
+    "65b_width_2_stages_9_sequences": ("65b_width", [0, 0], 9, 5),     # 5 + 4 rows
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(_MULTI))
+def test_multi_sequence_greedy_decode_equals_one_stream_per_sequence_on_the_oracle(L, oracle, tmp_path, case):
+    """llamahip_decode_greedy_multi: the micro-batched pipeline schedule behind the C ABI -- groups of sequences stepped as sets, the groups
+    pipelined over the stages of a pipeline handle.  Every sequence (its own prompt length, its own KV slot) must produce bit for bit the
+    tokens one llama_eval per token gives it on the oracle, through two consecutive calls (graphs replayed, slots re-bound), and leave the
+    oracle's KV rows behind."""
+    shape, devices, S, nth = _MULTI[case]
+    kw = {"small": dict(n_vocab=160, n_embd=512, n_mult=256, n_head=4, n_layer=5),
+          "7b_width": dict(n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=2),
+          "65b_width": dict(n_vocab=512, n_embd=8192, n_mult=256, n_head=64, n_layer=2, parts=8)}[shape]
+    hp = synth.HParams(**{k: v for k, v in kw.items() if k != "parts"})
+    path = synth_tool(tmp_path / "m.bin", seed=47, **kw)
+    n_ctx, K1, K2 = 64, 7, 5
+    prompts = [synth.synth_prompt(3 + (5 * i) % 23, hp.n_vocab, seed=70 + i) for i in range(S)]
+    with L.Model(path, n_ctx=n_ctx, devices=devices, n_seq=S) as pm:
+        firsts = []
+        for i in range(S):
+            pm.set_seq(i)
+            firsts.append(int(np.argmax(pm.eval(prompts[i], 0, nth))))
+        pm.set_seq(0)
+        n_past = [len(p) for p in prompts]
+        a = pm.decode_greedy_multi(firsts, n_past, K1, nth)
+        b = pm.decode_greedy_multi(a[:, -1], [n + K1 for n in n_past], K2, nth)
+        got = np.concatenate([a, b[:, :]], axis=1)
+        assert got.shape == (S, K1 + K2)
+        check = range(S) if S <= 9 else sorted(set([0, 1, S // 2, S - 2, S - 1, 13, 14, 15, 16]) & set(range(S)))      # (every group's edges; all of them when few)
+        for i in check:
+            om = oracle.load(path, n_ctx)
+            lo = om.eval(prompts[i], 0, nth)["logits"]
+            t = int(np.argmax(lo))
+            assert t == firsts[i]
+            want = [t]
+            for k in range(K1 + K2):
+                lo = om.eval(np.array([want[-1]], np.int32), n_past[i] + k, nth)["logits"]
+                want.append(int(np.argmax(lo)))
+            # (the second call is fed the first call's last pick at the position behind it: b continues a)
+            assert a[i].tolist() == want[1:K1 + 1], f"sequence {i}: {a[i].tolist()} vs {want[1:K1 + 1]}"
+            assert b[i].tolist() == want[K1 + 1:K1 + K2 + 1], f"sequence {i}, second call: {b[i].tolist()} vs {want[K1 + 1:]}"
+            pm.set_seq(i)
+            for il in (0, hp.n_layer - 1):
+                gk, gv = pm.kv(il, n_past[i] + K1 + K2)
+                ok, ov = om.kv(il, n_past[i] + K1 + K2)
+                assert same(gk, ok) and same(gv, ov), f"sequence {i}: KV cache layer {il}"
+            om.close()
+        with pytest.raises(L.LlamaHipError, match="context overflow"):
+            pm.decode_greedy_multi(firsts, [n_ctx - 2] * S, 3, nth)
+    with L.Model(path, n_ctx=n_ctx, devices=devices, n_seq=2) as small:
+        with pytest.raises(L.LlamaHipError, match="KV slots"):
+            small.decode_greedy_multi([1, 2, 3], [0, 0, 0], 2, nth)
