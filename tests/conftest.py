@@ -74,6 +74,22 @@ def _ensure_built():
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
 
 
+@pytest.fixture(autouse=True)
+def _free_big_files_after_the_test(tmp_path):
+    """A test's tmp_path lives until the session ends; the GPU suite writes ~1 GB synthetic model files (13B / 65B widths) in dozens of tests and
+    in every nested variant run, three of those at a time -- next to the 52 GB of full-size models that filled the GPU box's /tmp once
+    (round 6: 'No space left on device' -> a truncated part file -> 'corrupt tensor header').  Model files are deleted when their test is done."""
+    yield
+    for root, _, files in os.walk(str(tmp_path)):
+        for f in files:
+            fp = os.path.join(root, f)
+            try:
+                if os.path.getsize(fp) > (8 << 20):
+                    os.remove(fp)
+            except OSError:
+                pass
+
+
 @pytest.fixture(scope="session")
 def built():
     _ensure_built()
