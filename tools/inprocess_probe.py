@@ -25,7 +25,7 @@ prompt[0] = 1
 ref = None
 for S in stages:
     t0 = time.perf_counter()
-    m = L.Model(path, n_ctx=512, devices=[0] * S if S > 1 else None)
+    m = L.Model(path, n_ctx=512, devices=[0] * S if S > 1 else None, flags=int(os.environ.get("PROBE_FLAGS", "0")))      # PROBE_FLAGS=1: eager launches instead of captured graphs
     t_load = time.perf_counter() - t0
     m.eval(np.array([0, 1, 2, 3], np.int32), 0, 8)
     t0 = time.perf_counter()
