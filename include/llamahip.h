@@ -71,6 +71,7 @@ typedef struct llamahip_opts {
  * replacement bridge, with the environment variable LLAMAHIP_DEVICES="0,1,...,7" (or a count: "8" = devices 0 .. 7) -- holds one stage per
  * device; llamahip_eval / llamahip_eval_chunks / llamahip_eval_topk / llamahip_decode_greedy / llamahip_kv_read / llamahip_get_stats and the
  * llama_runner_* driver work on it unchanged, the residual stream (.mm:563-564, 687-690) crosses devices as stream-ordered peer copies.
+ * Waiting for a stage is bounded: LLAMAHIP_PIPE_WATCHDOG_S seconds (default 600) without the stage's stream completing is LLAMAHIP_ERR_PREDICT, not a hang.
  * Results are bit for bit the single-device handle's.  The stage-level entry points (llamahip_eval_stage, llamahip_stage_*) and
  * llamahip_eval_debug's dumps refuse such a handle.  LLAMAHIP_DEVICES never applies to a handle loaded with an explicit device, layer range
  * or LLAMAHIP_FLAG_HOST_ONLY. */

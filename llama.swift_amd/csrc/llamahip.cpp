@@ -1904,18 +1904,39 @@ static int pipe_hand_off(llamahip_model *a, llamahip_model *b, void *dst, const 
     HIP_TRY(hipStreamWaitEvent(b->stream, a->pipe_ev, 0), LLAMAHIP_ERR_PREDICT);
     return 0;
 }
+// Waiting for a stage is bounded (the watchdog the Python pipeline keeps around its collectives, here behind the C ABI): a stage whose GPU stops
+// making progress -- a hung device, a lost xGMI link under a peer copy -- turns into LLAMAHIP_ERR_PREDICT after LLAMAHIP_PIPE_WATCHDOG_S seconds
+// (default 600; the longest legitimate wait is a 2 048-token eval of a 65B stage, well under a second) instead of blocking the caller's thread for
+// ever.  Spins on hipStreamQuery for the first milliseconds (token steps), then yields 100 us per look.
+static int pipe_wait_stage(llamahip_model *st, int s, char *err, size_t err_cap) {
+    static const double limit_ms = (getenv("LLAMAHIP_PIPE_WATCHDOG_S") ? atof(getenv("LLAMAHIP_PIPE_WATCHDOG_S")) : 600.0) * 1e3;
+    HIP_TRY(hipSetDevice(st->device), LLAMAHIP_ERR_PREDICT);
+    const double t0 = now_ms();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st->stream);
+        if (e == hipSuccess) return 0;
+        (void) hipGetLastError();
+        if (e != hipErrorNotReady) { set_err(err, err_cap, "HIP error: %s while waiting for pipeline stage %d (device %d)", hipGetErrorString(e), s, st->device); return LLAMAHIP_ERR_PREDICT; }
+        const double waited = now_ms() - t0;
+        if (waited > limit_ms) {
+            set_err(err, err_cap, "pipeline stage %d (device %d, layers [%d, %d)) did not finish within %.3g s (LLAMAHIP_PIPE_WATCHDOG_S): results are invalid", s, st->device, st->l0, st->l1, limit_ms / 1e3);
+            return LLAMAHIP_ERR_PREDICT;
+        }
+        if (waited > 5.0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
 // wait for every stage and collect their fault words (a hand-off that timed out inside a launch of ANY stage invalidates the result)
-static int pipe_sync(llamahip_model *m, char *err, size_t err_cap) {
+static int pipe_sync_stages(const std::vector<llamahip_model *> &stages, char *err, size_t err_cap) {
     int rc = 0;
-    for (int s = (int) m->stages.size() - 1; s >= 0; s--) {
-        llamahip_model *st = m->stages[s];
-        HIP_TRY(hipSetDevice(st->device), LLAMAHIP_ERR_PREDICT);
-        HIP_TRY(hipStreamSynchronize(st->stream), LLAMAHIP_ERR_PREDICT);
-        const int r = check_sync_timeout(st, err, err_cap);
-        if (r) rc = r;
+    for (int s = (int) stages.size() - 1; s >= 0; s--) {
+        llamahip_model *st = stages[s];
+        int r = pipe_wait_stage(st, s, rc ? nullptr : err, rc ? 0 : err_cap);
+        if (!r) r = check_sync_timeout(st, rc ? nullptr : err, rc ? 0 : err_cap);
+        if (r && !rc) rc = r;
     }
     return rc;
 }
+static int pipe_sync(llamahip_model *m, char *err, size_t err_cap) { return pipe_sync_stages(m->stages, err, err_cap); }
 
 static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const int32_t *tokens, int32_t N, int32_t chunk, float *logits_out, char *err, size_t err_cap) {
     const int S = (int) m->stages.size();
@@ -2071,14 +2092,8 @@ static int decode_greedy_multi_impl(llamahip_model *m, int32_t n_threads, int32_
             }
         }
     }
-    // wait for every stage, collect their fault words
-    int rc_sync = 0;
-    for (int s = S - 1; s >= 0; s--) {
-        llamahip_model *st = stages[s];
-        if (hipSetDevice(st->device) != hipSuccess || hipStreamSynchronize(st->stream) != hipSuccess) { if (!rc) set_err(err, err_cap, "HIP error while waiting for stage %d", s); rc_sync = LLAMAHIP_ERR_PREDICT; continue; }
-        const int r = check_sync_timeout(st, rc ? nullptr : err, rc ? 0 : err_cap);
-        if (r) rc_sync = r;
-    }
+    // wait for every stage (bounded: pipe_wait_stage), collect their fault words
+    const int rc_sync = pipe_sync_stages(stages, rc ? nullptr : err, rc ? 0 : err_cap);
     if (rc) return rc;
     if (rc_sync) return rc_sync;
     for (int i = 0; i < n_seqs; i++) {

@@ -243,3 +243,22 @@ def test_multi_sequence_greedy_decode_equals_one_stream_per_sequence_on_the_orac
     with L.Model(path, n_ctx=n_ctx, devices=devices, n_seq=2) as small:
         with pytest.raises(L.LlamaHipError, match="KV slots"):
             small.decode_greedy_multi([1, 2, 3], [0, 0, 0], 2, nth)
+
+
+@pytest.mark.gpu
+def test_pipeline_stage_wait_timeout_is_an_error_not_a_hang(tmp_path):
+    """Waiting for a stage of a pipeline handle is bounded (LLAMAHIP_PIPE_WATCHDOG_S, default 600 s): with the bound set to a microsecond a
+    600-token eval over four stages cannot have finished at the first look, and the call returns PredictionFailed naming the stage instead
+    of blocking (the bound is read once per process: subprocess)."""
+    kw = dict(n_vocab=512, n_embd=4096, n_mult=256, n_head=32, n_layer=4)
+    path = synth_tool(tmp_path / "m.bin", seed=43, **kw)
+    code = ("import sys, numpy as np, llama_swift_amd as L\n"
+            "m = L.Model(sys.argv[1], n_ctx=640, devices=[0, 0, 0, 0])\n"
+            "p = (np.arange(600) % 500 + 3).astype(np.int32)\n"
+            "try:\n"
+            "    m.eval(p, 0, 8); print('NO ERROR')\n"
+            "except L.LlamaHipError as e:\n"
+            "    print('ERR', e.code, str(e))\n")
+    r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, PYTHONPATH=ROOT, LLAMAHIP_PIPE_WATCHDOG_S="0.000001"), capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert "ERR -1001" in r.stdout and "did not finish within" in r.stdout and "pipeline stage" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
