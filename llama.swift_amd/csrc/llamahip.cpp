@@ -1951,10 +1951,12 @@ static int pipe_eval(llamahip_model *m, int32_t n_threads, int32_t n_past, const
         if ((rc = eval_stage_enqueue(st, n_threads, n_past, tokens, N, s ? st->pipe_in : nullptr, st->dense ? 0 : chunk, err, err_cap)) != 0) { (void) pipe_sync(m, nullptr, 0); return rc; }
         if (s + 1 < S && (rc = pipe_hand_off(st, m->stages[s + 1], m->stages[s + 1]->pipe_in, st->x, (size_t) N * d * 4, err, err_cap)) != 0) { (void) pipe_sync(m, nullptr, 0); return rc; }
     }
+    // (the bounded wait first, the copy of the logits row behind it: a device-to-host copy into the caller's pageable buffer blocks inside the
+    //  runtime until the stream has drained, without a bound)
+    if ((rc = pipe_sync(m, err, err_cap)) != 0) return rc;
     llamahip_model *last = m->stages[S - 1];
     HIP_TRY(hipSetDevice(last->device), LLAMAHIP_ERR_PREDICT);
-    if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, last->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost, last->stream), LLAMAHIP_ERR_PREDICT);
-    if ((rc = pipe_sync(m, err, err_cap)) != 0) return rc;
+    if (logits_out) HIP_TRY(hipMemcpy(logits_out, last->logits + (size_t) (N - 1) * V, V * 4, hipMemcpyDeviceToHost), LLAMAHIP_ERR_PREDICT);
     m->n_evals++;
     m->t_eval_ms += now_ms() - t0;
     return LLAMAHIP_OK;
